@@ -1,0 +1,165 @@
+/*
+ * pdmp3_hip.h -- C-ABI of the MI355X (gfx950) transform engine.
+ *
+ * This is the drop-in boundary for the ONE data-parallel hot path of
+ * technosaurus/PDMP3: everything `Decode_L3` (pdmp3.c:1024-1060) does to one
+ * parsed frame, plus `Convert_Frame_S16` (pdmp3.c:2307-2345):
+ *
+ *   L3_Requantize (P:1829) -> L3_Reorder (P:1786) -> L3_Stereo (P:1911) ->
+ *   L3_Antialias (P:1706) -> L3_Hybrid_Synthesis/IMDCT_Win (P:1752/P:1649) ->
+ *   L3_Frequency_Inversion (P:1738) -> L3_Subband_Synthesis (P:1978) ->
+ *   interleaved int16 PCM.
+ *
+ * Plain C: pointers, sizes, PODs.  No C++/torch types.  Device pointers are
+ * ordinary `void*` HIP device addresses; `stream` is a `hipStream_t` passed as
+ * `void*` (NULL = the default stream).  All entry points return 0 on success
+ * or a negative PDMP3_HIP_E* code; pdmp3_hip_last_error() gives the text.
+ *
+ * "P:n" = /root/reference/pdmp3.c line n.
+ */
+#ifndef PDMP3_HIP_H
+#define PDMP3_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDMP3_HIP_OK        0
+#define PDMP3_HIP_EINVAL   -1   /* bad argument */
+#define PDMP3_HIP_EDEVICE  -2   /* HIP runtime error (see pdmp3_hip_last_error) */
+#define PDMP3_HIP_ENOMEM   -3
+
+/* ------------------------------------------------------------------------
+ * The record the device needs per granule-channel ("gc").
+ *
+ * It replaces the reference's in-handle structs t_mpeg1_side_info (P:71-95),
+ * t_mpeg1_main_data (P:96-101) and the three header fields the hot path reads
+ * (mode, mode_extension, sampling_frequency; P:56-70).
+ *
+ * Spectra travel separately as int16 (the reference keeps Huffman integers in
+ * `float is[2][2][576]`, P:99; |value| <= 8206 = 15 + 2^13 - 1, P:1637).
+ * Contract (what the reference's own Read_Huffman guarantees, P:2107-2111):
+ * spectra[n] == 0 for n >= count1.
+ * ---------------------------------------------------------------------- */
+
+/* flags */
+#define PDMP3_GC_SCALEFAC_SCALE  0x01u  /* P:92 */
+#define PDMP3_GC_PREFLAG         0x02u  /* P:91 */
+#define PDMP3_GC_WIN_SWITCH      0x04u  /* P:80 */
+#define PDMP3_GC_BLOCK_TYPE_SHIFT 3     /* 2 bits, P:82 (0 when win_switch==0, P:1191) */
+#define PDMP3_GC_BLOCK_TYPE_MASK 0x18u
+#define PDMP3_GC_MIXED           0x20u  /* P:83 */
+
+/* frame byte (identical in all gc records of one frame) */
+#define PDMP3_FR_SFREQ_MASK      0x03u  /* sampling_frequency index: 0=44100 1=48000 2=32000 (P:529) */
+#define PDMP3_FR_MODE_SHIFT      2      /* 2 bits: 0 stereo 1 joint 2 dual 3 mono (P:49-55) */
+#define PDMP3_FR_MODE_MASK       0x0Cu
+#define PDMP3_FR_MODEEXT_SHIFT   4      /* 2 bits: bit1 = MS, bit0 = intensity (P:1918,1932) */
+#define PDMP3_FR_MODEEXT_MASK    0x30u
+#define PDMP3_FR_RESET           0x40u  /* zero overlap + polyphase FIFO before this frame
+                                           (what hsynth_init/synth_init do after
+                                           pdmp3_open_feed, P:1757-1766, P:1996-2003) */
+
+/* scalefac_s[12][w] marker: "the reference reads the float bits of
+ * is[0][0][w] here" (granule 1 / channel 1 aliases the previous
+ * granule's synthesis output).  Resolved on the device. */
+#define PDMP3_SF_PEEK            0xFFu
+
+typedef struct pdmp3_gc_side {
+  uint16_t count1;            /* P:93; 0..576; first line of the rzero region      */
+  uint8_t  global_gain;       /* P:77                                              */
+  uint8_t  flags;             /* PDMP3_GC_*                                        */
+  uint8_t  subblock_gain[3];  /* P:85                                              */
+  uint8_t  frame;             /* PDMP3_FR_*                                        */
+  uint8_t  scalefac_l[22];    /* P:97; [21] = value the reference's out-of-bounds
+                                 read yields, resolved by the host     */
+  uint8_t  scalefac_s[13][3]; /* P:98; [12][w] = out-of-bounds value
+                                 or PDMP3_SF_PEEK                                  */
+  uint8_t  reserved[59];      /* must be zero                                      */
+} pdmp3_gc_side;              /* 128 bytes                                         */
+
+#define PDMP3_GC_LINES          576
+#define PDMP3_FRAME_GCS         4                 /* [gr][ch] = 2 x 2                */
+#define PDMP3_FRAME_SPECTRA_BYTES (4 * 576 * 2)   /* int16 [2][2][576]               */
+#define PDMP3_FRAME_SIDE_BYTES  (4 * 128)
+#define PDMP3_FRAME_PCM_BYTES   (1152 * 2 * 2)    /* stereo; mono uses the first half */
+
+typedef struct pdmp3_hip_ctx pdmp3_hip_ctx;
+
+/* Create an engine on HIP device `device` (uploads the constant tables:
+ * P:572-870 literals + the libm-derived pow/cos tables of P:979, P:1992,
+ * P:2127-2128, P:2144-2146, generated on the host with the same expressions). */
+int pdmp3_hip_create(int device, pdmp3_hip_ctx** out);
+void pdmp3_hip_destroy(pdmp3_hip_ctx* ctx);
+const char* pdmp3_hip_last_error(void);
+
+/* Bytes of one stream's carried synthesis state (replaces the function-static
+ * `store[2][32][18]` P:1755 and `v_vec[2][1024]` P:1983; opaque layout). */
+size_t pdmp3_hip_state_bytes(void);
+
+/*
+ * Decode `n_frames` consecutive frames of ONE stream: replaces n calls of
+ * Decode_L3 (P:1024) + Convert_Frame_S16 (P:2307).
+ *
+ *   d_spectra  device, int16 [n_frames][2 gr][2 ch][576]
+ *   d_side     device, pdmp3_gc_side [n_frames][2][2]
+ *   d_pcm      device, int16; frame f occupies bytes [f*4608, f*4608+4608)
+ *              (mono frames: the first 2304 bytes are used)
+ *   d_state    device, pdmp3_hip_state_bytes() bytes, read before the first
+ *              frame and written after the last one; NULL = start from the
+ *              zero state and discard the final state
+ *   chunk_frames  frames per workgroup chunk (the engine re-derives the state
+ *              at chunk boundaries from a halo of preceding frames, SURVEY
+ *              8e); 0 = choose automatically
+ *
+ * Asynchronous on `stream`.
+ */
+int pdmp3_hip_decode_frames(pdmp3_hip_ctx* ctx,
+                            const int16_t* d_spectra,
+                            const pdmp3_gc_side* d_side,
+                            int n_frames,
+                            void* d_state,
+                            int16_t* d_pcm,
+                            int chunk_frames,
+                            void* stream);
+
+/* Same, additionally dumping float32 stage outputs for parity tests
+ * (d_stages: float [n_frames][2][2][4][576]; stage 0 = after requantize +
+ * reorder, 1 = after stereo, 2 = after antialias, 3 = after hybrid synthesis
+ * + frequency inversion).  Single-workgroup, slow; test use only. */
+int pdmp3_hip_decode_frames_stages(pdmp3_hip_ctx* ctx,
+                                   const int16_t* d_spectra,
+                                   const pdmp3_gc_side* d_side,
+                                   int n_frames,
+                                   void* d_state,
+                                   int16_t* d_pcm,
+                                   float* d_stages,
+                                   void* stream);
+
+/*
+ * Synthetic-workload generator of SURVEY 8d (C2 / C5), counter-based
+ * splitmix64 so every GPU can generate its own shard on device:
+ * frames [first_frame, first_frame + n_frames) of the stream `seed`.
+ * The same integer-only generator exists on the host in the oracle
+ * (oracle/pdmp3_oracle.c: orc_generate_frames); tests check they agree.
+ */
+int pdmp3_hip_generate_frames(pdmp3_hip_ctx* ctx,
+                              uint64_t seed,
+                              int64_t first_frame,
+                              int n_frames,
+                              int16_t* d_spectra,
+                              pdmp3_gc_side* d_side,
+                              void* stream);
+
+/* Host-side twin of the generator (fills host buffers); used to build
+ * identical inputs for the CPU baseline without a device round trip. */
+int pdmp3_host_generate_frames(uint64_t seed, int64_t first_frame, int n_frames,
+                               int16_t* spectra, pdmp3_gc_side* side);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDMP3_HIP_H */

@@ -1,0 +1,159 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so) and, when present,
+the compiled reference (oracle/_ref/libpdmp3_ref.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (pdmp3_amd/) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SIDE_DTYPE = np.dtype([
+    ("count1", "<u2"), ("global_gain", "u1"), ("flags", "u1"),
+    ("subblock_gain", "u1", (3,)), ("frame", "u1"),
+    ("scalefac_l", "u1", (22,)), ("scalefac_s", "u1", (13, 3)),
+    ("reserved", "u1", (59,)),
+])
+assert SIDE_DTYPE.itemsize == 128
+
+GC_SCALEFAC_SCALE, GC_PREFLAG, GC_WIN_SWITCH, GC_MIXED = 0x01, 0x02, 0x04, 0x20
+GC_BLOCK_TYPE_SHIFT = 3
+FR_MODE_SHIFT, FR_MODEEXT_SHIFT, FR_RESET = 2, 4, 0x40
+SF_PEEK = 0xFF
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref when /root/reference is present)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(so)
+            for f in ("pdmp3_oracle.c", "pdmp3_oracle_stream.c", "pdmp3_oracle.h", "oracle_tables.h")):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/pdmp3.c"):
+        ref = os.path.join(_HERE, "_ref", "libpdmp3_ref.so")
+        if force or not os.path.exists(ref) or \
+                os.path.getmtime(os.path.join(_HERE, "ref_harness.c")) > os.path.getmtime(ref):
+            subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_p = C.c_void_p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_p) if a is not None else None
+
+
+class Oracle:
+    def __init__(self):
+        build()
+        self.lib = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        L = self.lib
+        L.orc_decode_frames.argtypes = [_p, _p, _p, C.c_int, _p, _p]
+        L.orc_generate_frames.argtypes = [C.c_uint64, C.c_int64, C.c_int, _p, _p]
+        L.orc_table_pow43.restype = C.POINTER(C.c_float)
+        L.orc_table_nwin.restype = C.POINTER(C.c_float)
+        L.orc_decode_buffer_like_cli.restype = C.c_size_t
+        L.orc_decode_buffer_like_cli.argtypes = [_p, C.c_size_t, _p, C.c_size_t, _p]
+        L.orc_time_decode.restype = C.c_double
+        L.orc_time_decode.argtypes = [_p, _p, C.c_int, C.c_int]
+
+    def new_state(self):
+        return np.zeros(2 * 32 * 18 + 2 * 1024, dtype=np.float32)
+
+    def generate(self, seed, first_frame, n_frames):
+        spectra = np.zeros((n_frames, 2, 2, 576), dtype=np.int16)
+        side = np.zeros((n_frames, 2, 2), dtype=SIDE_DTYPE)
+        self.lib.orc_generate_frames(seed, first_frame, n_frames, _ptr(spectra), _ptr(side))
+        return spectra, side
+
+    def decode(self, spectra, side, state=None, stages=False):
+        n = spectra.shape[0]
+        spectra = np.ascontiguousarray(spectra, dtype=np.int16)
+        side = np.ascontiguousarray(side)
+        if state is None:
+            state = self.new_state()
+        pcm = np.zeros((n, 2304), dtype=np.int16)
+        stg = np.zeros((n, 2, 2, 4, 576), dtype=np.float32) if stages else None
+        self.lib.orc_decode_frames(_ptr(state), _ptr(spectra), _ptr(side), n, _ptr(pcm), _ptr(stg))
+        return (pcm, stg) if stages else pcm
+
+    def time_decode(self, spectra, side, reps=1):
+        n = spectra.shape[0]
+        return self.lib.orc_time_decode(_ptr(spectra), _ptr(side), n, reps)
+
+    def pow43(self):
+        return np.ctypeslib.as_array(self.lib.orc_table_pow43(), shape=(8207,)).copy()
+
+    def nwin(self):
+        return np.ctypeslib.as_array(self.lib.orc_table_nwin(), shape=(64, 32)).copy()
+
+    def decode_buffer_like_cli(self, mp3: bytes, tap_frames=0):
+        buf = np.frombuffer(mp3, dtype=np.uint8)
+        cap = (len(mp3) // 96 + 8) * 4608
+        pcm = np.zeros(cap, dtype=np.uint8)
+
+        class Tap(C.Structure):
+            _fields_ = [("spectra", _p), ("side", _p), ("cap", C.c_int), ("n", C.c_int)]
+        tap = None
+        if tap_frames:
+            sp = np.zeros((tap_frames, 2, 2, 576), dtype=np.int16)
+            sd = np.zeros((tap_frames, 2, 2), dtype=SIDE_DTYPE)
+            tap = Tap(_ptr(sp), _ptr(sd), tap_frames, 0)
+        n = self.lib.orc_decode_buffer_like_cli(_ptr(buf), len(mp3), _ptr(pcm), cap,
+                                                C.byref(tap) if tap else None)
+        out = pcm[:n].tobytes()
+        if tap_frames:
+            k = min(tap.n, tap_frames)
+            return out, sp[:k], sd[:k]
+        return out
+
+
+def have_ref():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libpdmp3_ref.so"))
+
+
+class Reference:
+    """The real reference decoder (oracle/_ref/libpdmp3_ref.so).  Its synthesis
+    state is process-global: one stream at a time."""
+
+    def __init__(self):
+        self.lib = C.CDLL(os.path.join(_HERE, "_ref", "libpdmp3_ref.so"))
+        L = self.lib
+        L.ref_new.restype = _p
+        L.ref_delete.argtypes = [_p]
+        L.ref_decode_frames.argtypes = [_p, _p, _p, C.c_int, _p, _p]
+        L.ref_time_decode.restype = C.c_double
+        L.ref_time_decode.argtypes = [_p, _p, _p, C.c_int, C.c_int]
+        L.ref_decode_buffer_like_cli.restype = C.c_size_t
+        L.ref_decode_buffer_like_cli.argtypes = [_p, C.c_size_t, _p, C.c_size_t, _p, _p, C.c_int, _p]
+        self.h = L.ref_new()
+
+    def decode(self, spectra, side, stages=False):
+        n = spectra.shape[0]
+        spectra = np.ascontiguousarray(spectra, dtype=np.int16)
+        side = np.ascontiguousarray(side)
+        pcm = np.zeros((n, 2304), dtype=np.int16)
+        stg = np.zeros((n, 2, 2, 4, 576), dtype=np.float32) if stages else None
+        self.lib.ref_decode_frames(self.h, _ptr(spectra), _ptr(side), n, _ptr(pcm), _ptr(stg))
+        return (pcm, stg) if stages else pcm
+
+    def time_decode(self, spectra, side, reps=1):
+        return self.lib.ref_time_decode(self.h, _ptr(spectra), _ptr(side), spectra.shape[0], reps)
+
+    def decode_buffer_like_cli(self, mp3: bytes, tap_frames=0):
+        buf = np.frombuffer(mp3, dtype=np.uint8)
+        cap = (len(mp3) // 96 + 8) * 4608
+        pcm = np.zeros(cap, dtype=np.uint8)
+        if tap_frames:
+            sp = np.zeros((tap_frames, 2, 2, 576), dtype=np.int16)
+            sd = np.zeros((tap_frames, 2, 2), dtype=SIDE_DTYPE)
+            nt = C.c_int(0)
+            n = self.lib.ref_decode_buffer_like_cli(_ptr(buf), len(mp3), _ptr(pcm), cap,
+                                                    _ptr(sp), _ptr(sd), tap_frames, C.byref(nt))
+            k = min(nt.value, tap_frames)
+            return pcm[:n].tobytes(), sp[:k], sd[:k]
+        n = self.lib.ref_decode_buffer_like_cli(_ptr(buf), len(mp3), _ptr(pcm), cap, None, None, 0, None)
+        return pcm[:n].tobytes()
