@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Layer-III transform hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path (pdmp3_hip_decode_frames: requantize ->
+reorder -> stereo -> antialias -> IMDCT/overlap -> frequency inversion ->
+polyphase -> int16 PCM) over one batch of synthetic input that is already
+resident in HBM.  Workload at N = 1 is BASELINE.json configs[1] (SURVEY 8d
+"C2"): one stream of 2048 stereo 44.1 kHz frames = 4096 pre-Huffman-decoded
+granules (x 2 channels), integer-only generator, seed 0x5EED0000C2.  At N > 1
+the stream is N x 2048 frames long and rank r decodes frames [2048 r, 2048 (r+1))
+from a 2-frame halo: no data-path collective, weak scaling.  The
+one exchange of the path -- the final PCM gather to rank 0 over RCCL -- runs
+once after the timed region and is reported as `gather_ms`.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED_C2 = 0x5EED0000C2
+FRAMES_PER_GPU = 2048                 # C2: 4096 granules
+ALGO_BYTES_PER_FRAME = 9728           # 4 gc x (1152 B spectra + 128 B side + 1152 B PCM)
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
+RT_FRAMES_PER_S = 44100.0 / 1152.0
+
+
+def cpu_baseline(sample_frames, target_seconds):
+    """The reference CPU path on this box's host cores (rank 0, N = 1 only).
+    kind "reference": the real pdmp3.c Decode_L3 from oracle/_ref (prebuilt in
+    the build container); falls back to the oracle port when _ref is absent."""
+    from oracle import oracle as orc
+    o = orc.Oracle()
+    sp, sd = o.generate(SEED_C2, 0, sample_frames)
+    if orc.have_ref():
+        dec, kind = orc.Reference(), "reference"
+    else:
+        dec, kind = o, "port"
+    t1 = dec.time_decode(sp, sd, 1)
+    reps = max(1, int(target_seconds / max(t1, 1e-6)))
+    t = dec.time_decode(sp, sd, reps)
+    fps = sample_frames * reps / t
+    return {
+        "value": round(fps, 1), "unit": "frames/s", "cores": 1, "kind": kind,
+        "sample": "%d passes of Decode_L3 over the same %d C2 frames (%.1f s, 1 thread; "
+                  "the reference is single-threaded with process-global state)" % (reps, sample_frames, t),
+        "x_realtime": round(fps / RT_FRAMES_PER_S, 1),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--chunk", type=int, default=0, help="frames per workgroup chunk (0 = engine default)")
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--big", type=int, default=131072, help="frames of the extra large-batch roofline probe (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import pdmp3_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    eng = pdmp3_amd.Engine(local_rank)
+    n = args.frames
+    halo = 2 if rank > 0 else 0
+    first = rank * n - halo
+    spectra, side, pcm = eng.alloc_frames(n + halo)
+    eng.generate(SEED_C2, first, n + halo, spectra, side)
+    torch.cuda.synchronize()
+
+    def step():
+        eng.decode(spectra, side, pcm, chunk_frames=args.chunk)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        # the path's one exchange: final PCM gather to rank 0 (RCCL over xGMI), outside the timed region
+        mine = pcm[halo:].contiguous()
+        bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        dist.gather(mine, bufs, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+    else:
+        gather_ms = None
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_frames = n * world * args.steps
+    fps = total_frames / dt
+    launch_bytes = (n + halo) * ALGO_BYTES_PER_FRAME
+    achieved = launch_bytes / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": "MP3 frames/sec (44.1 kHz stereo 320 kbps), transforms-only hot path",
+        "value": round(fps, 1),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "C2 (BASELINE configs[1]): %d stereo frames = %d granules per GPU per step, "
+                        "pre-Huffman-decoded spectra resident in HBM, one stream sharded by frame range "
+                        "with a 2-frame halo" % (n, 2 * n),
+            "frames_per_gpu": n, "granules_per_gpu": 2 * n, "seed": hex(SEED_C2),
+            "chunk_frames": args.chunk or "auto", "sharding": "frame-range x%d, no data-path collective" % world,
+        },
+        "x_realtime": round(fps / RT_FRAMES_PER_S, 1),
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "kernel": "k_decode<false>", "avg_launch_ms": round(kern_ms, 5),
+            "algorithmic_bytes_per_launch": launch_bytes,
+        },
+    }
+    if gather_ms is not None:
+        out["gather_ms"] = round(gather_ms, 3)
+
+    if args.big and world == 1:
+        # kernel quality at throughput size (SURVEY 8d C5 shard scale), outside the timed region
+        nb = args.big
+        sp2, sd2, pcm2 = eng.alloc_frames(nb)
+        eng.generate(0x5EED0000C5, 0, nb, sp2, sd2)
+        for _ in range(2):
+            eng.decode(sp2, sd2, pcm2, chunk_frames=args.chunk)
+        torch.cuda.synchronize()
+        reps = 5
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            eng.decode(sp2, sd2, pcm2, chunk_frames=args.chunk)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        ach = nb * ALGO_BYTES_PER_FRAME / (ms * 1e-3) / 1e9
+        out["roofline_large_batch"] = {
+            "frames": nb, "avg_launch_ms": round(ms, 4), "frames_per_s": round(nb / (ms * 1e-3), 1),
+            "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+        }
+        del sp2, sd2, pcm2
+
+    if world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(FRAMES_PER_GPU, args.cpu_seconds)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

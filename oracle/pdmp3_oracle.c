@@ -488,7 +488,8 @@ void orc_generate_frames(uint64_t seed, int64_t first_frame, int n_frames,
     for (unsigned wn = 0; wn < 3; wn++) sd[0 * 2 + 1].scalefac_s[12][wn] = sd[1 * 2 + 0].scalefac_s[0][wn];
     sd[1 * 2 + 1].scalefac_l[21] = sd[0].scalefac_s[0][0];
     for (unsigned wn = 0; wn < 3; wn++) sd[1 * 2 + 1].scalefac_s[12][wn] = PDMP3_SF_PEEK;
-    if (frame == 0) sd[0].frame |= PDMP3_FR_RESET;
+    if (frame == 0)
+      for (unsigned k = 0; k < 4; k++) sd[k].frame |= PDMP3_FR_RESET;   /* frame byte is per frame */
   }
 }
 

@@ -1,0 +1,168 @@
+// engine.hip -- gfx950 kernels + the C-ABI of include/pdmp3_hip.h.
+//
+// Launch geometry: one 64-lane workgroup (= one wavefront) per chunk of
+// `chunk_frames` frames; a launch of N frames makes ceil(N/chunk) workgroups,
+// so at throughput sizes (>= 10^5 frames) the grid is >> 256 CUs x 8 XCDs and
+// consecutive workgroups (which the dispatcher round-robins over the XCDs)
+// stream disjoint, contiguous spans of the spectra / PCM buffers.  There is no
+// inter-workgroup communication: chunk boundaries are re-derived from a
+// 3-granule halo (decode_core.h).
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "decode_core.h"
+#include "gen_core.h"
+#include "host_tables.h"
+
+using namespace pdmp3;
+
+#ifndef PDMP3_WAVES_PER_EU
+#define PDMP3_WAVES_PER_EU 2
+#endif
+
+__constant__ ConstBank c_bank;
+
+template <bool DUMP>
+__global__ __launch_bounds__(64, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a, GlobalTables T) {
+  __shared__ WaveLds L;
+  run_chunk<DUMP>(a, T, (BankPtr)&c_bank, (int)blockIdx.x, L);
+}
+
+__global__ __launch_bounds__(64) void k_generate(uint64_t seed, int64_t first, int16_t* spectra, pdmp3_gc_side* side) {
+  const int64_t gc = blockIdx.x;           // (frame_local*4 + gr*2 + ch)
+  const int64_t f = gc >> 2;
+  gen_gc(seed, first + f, (unsigned)((gc >> 1) & 1), (unsigned)(gc & 1), (int)threadIdx.x,
+         spectra + gc * 576, side + gc);
+}
+
+struct pdmp3_hip_ctx {
+  int device;
+  float* d_pow43;
+  uint8_t* d_band;
+  uint16_t* d_src_idx;
+  float* d_state_tmp;
+};
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char* what, hipError_t e) {
+  snprintf(g_err, sizeof g_err, "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));
+  return code;
+}
+
+#define HIP_TRY(call, what)                                   \
+  do {                                                        \
+    hipError_t e_ = (call);                                   \
+    if (e_ != hipSuccess) return fail(PDMP3_HIP_EDEVICE, what, e_); \
+  } while (0)
+
+extern "C" const char* pdmp3_hip_last_error(void) { return g_err; }
+
+extern "C" size_t pdmp3_hip_state_bytes(void) { return (size_t)kStateFloats * sizeof(float); }
+
+extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
+  if (!out) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_create: out is NULL", hipSuccess);
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(device), "hipSetDevice");
+  HostTables H;
+  build_host_tables(H);
+  pdmp3_hip_ctx* c = (pdmp3_hip_ctx*)calloc(1, sizeof *c);
+  if (!c) return fail(PDMP3_HIP_ENOMEM, "calloc", hipSuccess);
+  c->device = device;
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_bank), &H.cb, sizeof(ConstBank)), "upload const bank");
+  HIP_TRY(hipMalloc(&c->d_pow43, H.pow43.size() * sizeof(float)), "hipMalloc pow43");
+  HIP_TRY(hipMalloc(&c->d_band, H.band.size()), "hipMalloc band");
+  HIP_TRY(hipMalloc(&c->d_src_idx, H.src_idx.size() * sizeof(uint16_t)), "hipMalloc src_idx");
+  HIP_TRY(hipMalloc(&c->d_state_tmp, pdmp3_hip_state_bytes()), "hipMalloc state");
+  HIP_TRY(hipMemcpy(c->d_pow43, H.pow43.data(), H.pow43.size() * sizeof(float), hipMemcpyHostToDevice), "upload pow43");
+  HIP_TRY(hipMemcpy(c->d_band, H.band.data(), H.band.size(), hipMemcpyHostToDevice), "upload band");
+  HIP_TRY(hipMemcpy(c->d_src_idx, H.src_idx.data(), H.src_idx.size() * sizeof(uint16_t), hipMemcpyHostToDevice), "upload src_idx");
+  HIP_TRY(hipDeviceSynchronize(), "sync after uploads");
+  *out = c;
+  return PDMP3_HIP_OK;
+}
+
+extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipFree(c->d_pow43);
+  (void)hipFree(c->d_band);
+  (void)hipFree(c->d_src_idx);
+  (void)hipFree(c->d_state_tmp);
+  free(c);
+}
+
+static int auto_chunk(int n_frames) {
+  // enough chunks to put >= 8 waves on each of the 256 CUs, but keep the
+  // 3-granule halo a small fraction of the chunk when the batch allows it.
+  int L = n_frames / 2048;
+  if (L < 4) L = 4;
+  if (L > 32) L = 32;
+  return L;
+}
+
+static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3_gc_side* d_side, int n_frames,
+                         void* d_state, int16_t* d_pcm, float* d_stages, int chunk_frames, void* stream) {
+  if (!c || !d_spectra || !d_side || !d_pcm || n_frames < 0)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: bad argument", hipSuccess);
+  if (((uintptr_t)d_spectra | (uintptr_t)d_side | (uintptr_t)d_pcm) & 15)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: buffers must be 16-byte aligned", hipSuccess);
+  if (n_frames == 0) return PDMP3_HIP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (chunk_frames <= 0) chunk_frames = auto_chunk(n_frames);
+  if (chunk_frames < 2) chunk_frames = 2;      // the halo reaches 3 granules back
+  if (d_stages || chunk_frames > n_frames) chunk_frames = n_frames < 2 ? 2 : n_frames;
+  const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
+  DecodeArgs a;
+  a.spectra = d_spectra;
+  a.side = d_side;
+  a.pcm = d_pcm;
+  a.state_in = (const float*)d_state;
+  a.state_out = d_state ? c->d_state_tmp : nullptr;
+  a.stages = d_stages;
+  a.n_frames = n_frames;
+  a.chunk_frames = chunk_frames;
+  GlobalTables T{c->d_pow43, c->d_band, c->d_src_idx};
+  if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T);
+  else hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), 0, s, a, T);
+  HIP_TRY(hipGetLastError(), "launch k_decode");
+  if (d_state)
+    HIP_TRY(hipMemcpyAsync(d_state, c->d_state_tmp, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, s), "state copy");
+  return PDMP3_HIP_OK;
+}
+
+extern "C" int pdmp3_hip_decode_frames(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,
+                                       int n_frames, void* d_state, int16_t* d_pcm, int chunk_frames, void* stream) {
+  return launch_decode(ctx, d_spectra, d_side, n_frames, d_state, d_pcm, nullptr, chunk_frames, stream);
+}
+
+extern "C" int pdmp3_hip_decode_frames_stages(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,
+                                              int n_frames, void* d_state, int16_t* d_pcm, float* d_stages, void* stream) {
+  if (!d_stages) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames_stages: d_stages is NULL", hipSuccess);
+  return launch_decode(ctx, d_spectra, d_side, n_frames, d_state, d_pcm, d_stages, 0, stream);
+}
+
+extern "C" int pdmp3_hip_generate_frames(pdmp3_hip_ctx* ctx, uint64_t seed, int64_t first_frame, int n_frames,
+                                         int16_t* d_spectra, pdmp3_gc_side* d_side, void* stream) {
+  if (!ctx || !d_spectra || !d_side || n_frames < 0)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_generate_frames: bad argument", hipSuccess);
+  if (n_frames == 0) return PDMP3_HIP_OK;
+  hipLaunchKernelGGL(k_generate, dim3((unsigned)n_frames * 4u), dim3(64), 0, (hipStream_t)stream, seed, first_frame,
+                     d_spectra, d_side);
+  HIP_TRY(hipGetLastError(), "launch k_generate");
+  return PDMP3_HIP_OK;
+}
+
+extern "C" int pdmp3_host_generate_frames(uint64_t seed, int64_t first_frame, int n_frames, int16_t* spectra,
+                                          pdmp3_gc_side* side) {
+  if (!spectra || !side || n_frames < 0) return fail(PDMP3_HIP_EINVAL, "pdmp3_host_generate_frames: bad argument", hipSuccess);
+  for (int f = 0; f < n_frames; ++f)
+    for (int gc = 0; gc < 4; ++gc)
+      for (int lane = 0; lane < 64; ++lane)
+        gen_gc(seed, first_frame + f, (unsigned)(gc >> 1), (unsigned)(gc & 1), lane,
+               spectra + ((size_t)f * 4 + gc) * 576, side + (size_t)f * 4 + gc);
+  return PDMP3_HIP_OK;
+}

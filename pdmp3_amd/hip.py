@@ -1,0 +1,147 @@
+"""ctypes mirror of include/pdmp3_hip.h.
+
+Every method maps 1:1 to a C-ABI entry point; tensors are used only as owners
+of device memory (`tensor.data_ptr()`), and the launch goes onto torch's
+current HIP stream so that torch.cuda.Event timing brackets it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SIDE_DTYPE = np.dtype([
+    ("count1", "<u2"), ("global_gain", "u1"), ("flags", "u1"),
+    ("subblock_gain", "u1", (3,)), ("frame", "u1"),
+    ("scalefac_l", "u1", (22,)), ("scalefac_s", "u1", (13, 3)),
+    ("reserved", "u1", (59,)),
+])
+FRAME_SPECTRA_INT16 = 4 * 576
+FRAME_PCM_INT16 = 2304
+FRAME_SIDE_BYTES = 512
+
+EXPORTS = [
+    "pdmp3_hip_create", "pdmp3_hip_destroy", "pdmp3_hip_last_error", "pdmp3_hip_state_bytes",
+    "pdmp3_hip_decode_frames", "pdmp3_hip_decode_frames_stages", "pdmp3_hip_generate_frames",
+    "pdmp3_host_generate_frames",
+]
+
+
+def library_path():
+    return os.path.join(_HERE, "libpdmp3_hip.so")
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(library_path()):
+        os.remove(library_path())
+    subprocess.check_call(["make", "-C", src_dir], stdout=subprocess.DEVNULL)
+    return library_path()
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "pdmp3_amd: %s is missing -- build it with __graft_entry__.build() or "
+            "`make -C pdmp3_amd/csrc`; there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
+    lib.pdmp3_hip_create.argtypes = [i32, C.POINTER(vp)]
+    lib.pdmp3_hip_destroy.argtypes = [vp]
+    lib.pdmp3_hip_last_error.restype = C.c_char_p
+    lib.pdmp3_hip_state_bytes.restype = C.c_size_t
+    lib.pdmp3_hip_decode_frames.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp]
+    lib.pdmp3_hip_decode_frames_stages.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.pdmp3_hip_generate_frames.argtypes = [vp, u64, i64, i32, vp, vp, vp]
+    lib.pdmp3_host_generate_frames.argtypes = [u64, i64, i32, vp, vp]
+    _LIB = lib
+    return lib
+
+
+def host_generate(seed, first_frame, n_frames):
+    """pdmp3_host_generate_frames: the SURVEY 8d generator on the host (no GPU needed)."""
+    lib = load_library()
+    spectra = np.zeros((n_frames, 2, 2, 576), dtype=np.int16)
+    side = np.zeros((n_frames, 2, 2), dtype=SIDE_DTYPE)
+    rc = lib.pdmp3_host_generate_frames(seed, first_frame, n_frames,
+                                        spectra.ctypes.data_as(C.c_void_p), side.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError(lib.pdmp3_hip_last_error().decode())
+    return spectra, side
+
+
+class Engine:
+    """One pdmp3_hip_ctx on one GPU."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("pdmp3_amd.Engine needs a HIP device; there is no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        self.device = int(device)
+        h = C.c_void_p()
+        self._check(self.lib.pdmp3_hip_create(self.device, C.byref(h)))
+        self.h = h
+        self.tdev = torch.device("cuda", self.device)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("pdmp3_hip error %d: %s" % (rc, self.lib.pdmp3_hip_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pdmp3_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.tdev).cuda_stream)
+
+    # -- device buffers ----------------------------------------------------
+    def alloc_frames(self, n_frames):
+        t = self.torch
+        spectra = t.empty((n_frames, 2, 2, 576), dtype=t.int16, device=self.tdev)
+        side = t.zeros((n_frames, 4, 128), dtype=t.uint8, device=self.tdev)
+        pcm = t.empty((n_frames, FRAME_PCM_INT16), dtype=t.int16, device=self.tdev)
+        return spectra, side, pcm
+
+    def new_state(self):
+        t = self.torch
+        return t.zeros(self.lib.pdmp3_hip_state_bytes() // 4, dtype=t.float32, device=self.tdev)
+
+    def upload(self, spectra_np, side_np):
+        t = self.torch
+        sp = t.from_numpy(np.ascontiguousarray(spectra_np, dtype=np.int16)).to(self.tdev)
+        sd = t.from_numpy(np.ascontiguousarray(side_np).view(np.uint8).reshape(-1, 4, 128).copy()).to(self.tdev)
+        return sp, sd
+
+    # -- C-ABI calls ---------------------------------------------------------
+    def generate(self, seed, first_frame, n_frames, spectra, side):
+        self._check(self.lib.pdmp3_hip_generate_frames(self.h, seed, first_frame, n_frames,
+                                                       spectra.data_ptr(), side.data_ptr(), self._stream()))
+
+    def decode(self, spectra, side, pcm, n_frames=None, state=None, chunk_frames=0):
+        n = int(spectra.shape[0]) if n_frames is None else int(n_frames)
+        self._check(self.lib.pdmp3_hip_decode_frames(
+            self.h, spectra.data_ptr(), side.data_ptr(), n,
+            state.data_ptr() if state is not None else None, pcm.data_ptr(), int(chunk_frames), self._stream()))
+
+    def decode_stages(self, spectra, side, pcm, stages, state=None):
+        n = int(spectra.shape[0])
+        self._check(self.lib.pdmp3_hip_decode_frames_stages(
+            self.h, spectra.data_ptr(), side.data_ptr(), n,
+            state.data_ptr() if state is not None else None, pcm.data_ptr(), stages.data_ptr(), self._stream()))

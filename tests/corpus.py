@@ -1,0 +1,109 @@
+"""Synthetic gc-record corpora for the parity tests.
+
+Deterministic (numpy's legacy MT19937 RandomState) so that the committed golden
+fixtures (tests/golden/, made by tools/make_golden.py from the compiled
+reference) can be re-derived from (name, seed) alone.
+
+Records obey the boundary contract of include/pdmp3_hip.h: spectra are zero at
+and above count1 (what the reference's Read_Huffman guarantees) and the two
+out-of-bounds scalefactor slots carry what the reference's memory layout would
+yield, via resolve_aliases().
+"""
+import numpy as np
+
+from oracle.oracle import (SIDE_DTYPE, GC_SCALEFAC_SCALE, GC_PREFLAG, GC_WIN_SWITCH, GC_MIXED,
+                           GC_BLOCK_TYPE_SHIFT, FR_MODE_SHIFT, FR_MODEEXT_SHIFT, FR_RESET, SF_PEEK)
+
+MODE_STEREO, MODE_JOINT, MODE_DUAL, MODE_MONO = 0, 1, 2, 3
+
+
+def resolve_aliases(side):
+    """side: array [n][2][2] of SIDE_DTYPE with scalefac_l[:21], scalefac_s[:12] filled."""
+    for f in range(side.shape[0]):
+        s = side[f]
+        for g in range(2):
+            s[g, 0]["scalefac_l"][21] = s[g, 1]["scalefac_l"][0]
+            s[g, 0]["scalefac_s"][12] = s[g, 1]["scalefac_s"][0]
+        s[0, 1]["scalefac_l"][21] = s[1, 0]["scalefac_l"][0]
+        s[0, 1]["scalefac_s"][12] = s[1, 0]["scalefac_s"][0]
+        s[1, 1]["scalefac_l"][21] = s[0, 0]["scalefac_s"][0][0]
+        s[1, 1]["scalefac_s"][12] = SF_PEEK
+    return side
+
+
+def make_frames(n, seed, mode=MODE_JOINT, mode_ext=2, sfreq=0, block_mix=(70, 10, 10, 10),
+                mixed_prob=0.5, count1_range=(0, 576), gain_range=(120, 170), big_prob=1 / 200.0,
+                max_small=15, sf_max=8, reset_every=0, zero_gc_prob=0.05, is_pos_max=8):
+    """Random frames.  block_mix = percentages of block types 0,1,2,3."""
+    rs = np.random.RandomState(seed)
+    spectra = np.zeros((n, 2, 2, 576), dtype=np.int16)
+    side = np.zeros((n, 2, 2), dtype=SIDE_DTYPE)
+    cum = np.cumsum(block_mix)
+    for f in range(n):
+        fr = (sfreq & 3) | (mode << FR_MODE_SHIFT) | (mode_ext << FR_MODEEXT_SHIFT)
+        if f == 0 or (reset_every and f % reset_every == 0):
+            fr |= FR_RESET
+        for g in range(2):
+            for c in range(2):
+                s = side[f, g, c]
+                s["frame"] = fr
+                lo, hi = count1_range
+                count1 = int(rs.randint(lo, hi + 1))
+                count1 -= count1 % 2
+                if rs.rand() < zero_gc_prob:
+                    count1 = 0 if rs.rand() < 0.5 else count1
+                s["count1"] = count1
+                s["global_gain"] = rs.randint(gain_range[0], gain_range[1] + 1)
+                fl = 0
+                if rs.rand() < 0.5:
+                    fl |= GC_SCALEFAC_SCALE
+                if rs.rand() < 0.5:
+                    fl |= GC_PREFLAG
+                pct = rs.randint(0, 100)
+                bt = int(np.searchsorted(cum, pct, side="right"))
+                bt = min(bt, 3)
+                if bt:
+                    fl |= GC_WIN_SWITCH | (bt << GC_BLOCK_TYPE_SHIFT)
+                    if bt == 2 and rs.rand() < mixed_prob:
+                        fl |= GC_MIXED
+                s["flags"] = fl
+                s["subblock_gain"] = rs.randint(0, 8, size=3)
+                s["scalefac_l"][:21] = rs.randint(0, sf_max, size=21)
+                s["scalefac_s"][:12] = rs.randint(0, min(sf_max, is_pos_max), size=(12, 3))
+                mags = rs.randint(0, max_small + 1, size=576)
+                big = rs.rand(576) < big_prob
+                mags[big] = rs.randint(0, 8207, size=int(big.sum()))
+                sign = rs.randint(0, 2, size=576) * 2 - 1
+                v = (mags * sign).astype(np.int16)
+                v[count1:] = 0
+                spectra[f, g, c] = v
+        if mode == MODE_MONO:
+            spectra[f, :, 1] = 0
+    resolve_aliases(side)
+    return spectra, side
+
+
+# name -> kwargs; every entry is a golden fixture (tools/make_golden.py) and a parity case
+CASES = {
+    "ms_long_441": dict(mode=MODE_JOINT, mode_ext=2, sfreq=0, block_mix=(100, 0, 0, 0)),
+    "ms_mixed_blocks_441": dict(mode=MODE_JOINT, mode_ext=2, sfreq=0, block_mix=(40, 15, 30, 15)),
+    "ms_short_heavy_480": dict(mode=MODE_JOINT, mode_ext=2, sfreq=1, block_mix=(10, 10, 70, 10), count1_range=(380, 576)),
+    "stereo_plain_320": dict(mode=MODE_STEREO, mode_ext=0, sfreq=2, block_mix=(50, 15, 20, 15)),
+    "dual_480": dict(mode=MODE_DUAL, mode_ext=2, sfreq=1, block_mix=(60, 10, 20, 10)),
+    "mono_441": dict(mode=MODE_MONO, mode_ext=0, sfreq=0, block_mix=(50, 15, 20, 15)),
+    "mono_320": dict(mode=MODE_MONO, mode_ext=2, sfreq=2, block_mix=(30, 10, 50, 10)),
+    "ms_count1_skew": dict(mode=MODE_JOINT, mode_ext=2, sfreq=0, count1_range=(0, 576), zero_gc_prob=0.3),
+    "ms_loud_clip": dict(mode=MODE_JOINT, mode_ext=2, sfreq=0, gain_range=(170, 215), big_prob=0.02),
+    "ms_sf15": dict(mode=MODE_JOINT, mode_ext=2, sfreq=0, block_mix=(40, 15, 30, 15), sf_max=16),
+    "ms_resets": dict(mode=MODE_JOINT, mode_ext=2, sfreq=0, block_mix=(40, 15, 30, 15), reset_every=3),
+    # intensity stereo, long blocks only and is_pos <= 7 (the part of H3 that is well defined)
+    "is_long_441": dict(mode=MODE_JOINT, mode_ext=1, sfreq=0, block_mix=(100, 0, 0, 0), count1_range=(100, 500), sf_max=8),
+    "ms_is_long_480": dict(mode=MODE_JOINT, mode_ext=3, sfreq=1, block_mix=(100, 0, 0, 0), count1_range=(100, 500), sf_max=8),
+}
+
+
+def case(name, n=6, seed=None):
+    kw = CASES[name]
+    if seed is None:
+        seed = (sum(ord(ch) * (i + 1) for i, ch in enumerate(name)) * 2654435761) & 0x7FFFFFFF
+    return make_frames(n, seed, **kw)

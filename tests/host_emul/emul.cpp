@@ -1,0 +1,52 @@
+// emul.cpp -- CPU build of pdmp3_amd/csrc/decode_core.h for the test-suite.
+//
+// TEST INFRASTRUCTURE.  Runs the device pipeline's phase functions lane by
+// lane on the host so that `pytest -m "not gpu"` can check the kernel's
+// indexing, table construction and chunk/halo logic against the oracle in a
+// container without a GPU.  Never loaded by the product (pdmp3_amd/).
+#include "../../pdmp3_amd/csrc/decode_core.h"
+#include "../../pdmp3_amd/csrc/host_tables.h"
+#include "../../pdmp3_amd/csrc/gen_core.h"
+
+#include <memory>
+
+using namespace pdmp3;
+
+extern "C" int emul_decode_frames(const int16_t* spectra, const pdmp3_gc_side* side, int n_frames,
+                                  float* state, int16_t* pcm, float* stages, int chunk_frames) {
+  static HostTables H;
+  static bool ready = false;
+  if (!ready) { build_host_tables(H); ready = true; }
+  GlobalTables T{H.pow43.data(), H.band.data(), H.src_idx.data()};
+  if (chunk_frames <= 0) chunk_frames = n_frames;
+  if (stages) chunk_frames = n_frames;
+  DecodeArgs a{spectra, side, pcm, state, state, stages, n_frames, chunk_frames};
+  const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
+  auto L = std::make_unique<WaveLds>();
+  // the final state is written by the last chunk; the first reads it: run the
+  // first chunk before the last one overwrites it (same order as on the device
+  // where chunk 0 reads `state` in its prologue -- see engine.hip for the
+  // double-buffered state there).
+  for (int c = 0; c < nchunks; ++c) {
+    if (stages) run_chunk<true>(a, T, &H.cb, c, *L);
+    else run_chunk<false>(a, T, &H.cb, c, *L);
+  }
+  return 0;
+}
+
+extern "C" size_t emul_state_floats() { return kStateFloats; }
+
+extern "C" void emul_generate_frames(uint64_t seed, int64_t first, int n, int16_t* spectra, pdmp3_gc_side* side) {
+  for (int f = 0; f < n; ++f)
+    for (int gc = 0; gc < 4; ++gc)
+      for (int lane = 0; lane < 64; ++lane)
+        gen_gc(seed, first + f, gc >> 1, gc & 1, lane, spectra + ((size_t)f * 4 + gc) * 576, side + (size_t)f * 4 + gc);
+}
+
+extern "C" void emul_tables(float* pow43, float* t1, float* t2) {
+  static HostTables H;
+  build_host_tables(H);
+  memcpy(pow43, H.pow43.data(), 8207 * 4);
+  memcpy(t1, H.cb.t1, sizeof H.cb.t1);
+  memcpy(t2, H.cb.t2, sizeof H.cb.t2);
+}

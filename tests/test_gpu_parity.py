@@ -1,0 +1,154 @@
+"""Parity tests proper: the HIP engine, called through the C-ABI
+(include/pdmp3_hip.h via pdmp3_amd.hip), against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures of the reference, and --
+at BASELINE.json's full sizes -- through size-independent properties.
+
+Bars: int16 PCM within +-1 LSB (north_star); float stage dumps within 1e-5
+absolute relative to the stage amplitude (stages 0-2 are expected bit-exact:
+they only use separately rounded mul/add like the reference).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import corpus
+from conftest import C2_SEED
+from util import assert_pcm_close, nch_of, pcm_tolerance, sha
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gpu_decode(engine, sp, sd, chunk=0, state=None, stages=False):
+    import torch
+    dsp, dsd = engine.upload(sp, sd)
+    n = sp.shape[0]
+    pcm = torch.zeros((n, 2304), dtype=torch.int16, device=engine.tdev)
+    if stages:
+        stg = torch.zeros((n, 2, 2, 4, 576), dtype=torch.float32, device=engine.tdev)
+        engine.decode_stages(dsp, dsd, pcm, stg, state=state)
+        torch.cuda.synchronize()
+        return pcm.cpu().numpy(), stg.cpu().numpy()
+    engine.decode(dsp, dsd, pcm, state=state, chunk_frames=chunk)
+    torch.cuda.synchronize()
+    return pcm.cpu().numpy()
+
+
+def test_native_library_is_loaded(engine):
+    import pdmp3_amd
+    maps = open("/proc/self/maps").read()
+    assert os.path.basename(pdmp3_amd.library_path()) in maps
+
+
+@pytest.mark.parametrize("name", list(corpus.CASES))
+def test_gpu_vs_oracle_and_golden(engine, oracle, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    n = g["pcm"].shape[0]
+    sp, sd = corpus.case(name, n=n)
+    want, ws = oracle.decode(sp, sd, stages=True)
+    assert np.array_equal(want, g["pcm"]), "oracle drifted from the reference fixture"
+    got, gs = gpu_decode(engine, sp, sd, stages=True)
+    nch = nch_of(sd)
+    for k in range(3):
+        assert np.array_equal(ws[:, :, :nch, k].view(np.uint32), gs[:, :, :nch, k].view(np.uint32)), \
+            "stage %d not bit-exact" % k
+    amp = max(1.0, float(np.abs(ws[:, :, :nch, 3]).max()))
+    err = float(np.abs(ws[:, :, :nch, 3] - gs[:, :, :nch, 3]).max())
+    assert err <= 1e-5 * amp, "hybrid output differs by %g (amplitude %g)" % (err, amp)
+    tol = pcm_tolerance(ws[:, :, :, 3])
+    assert_pcm_close(got, g["pcm"], tol, name + " vs reference fixture")
+    # the normal (non-dump) kernel, chunked
+    got2 = gpu_decode(engine, sp, sd, chunk=2)
+    assert_pcm_close(got2, g["pcm"], tol, name + " chunked")
+
+
+def test_gpu_generator_matches_oracle(engine, oracle):
+    import torch
+    n = 300
+    spectra, side, _ = engine.alloc_frames(n)
+    engine.generate(C2_SEED, 1000, n, spectra, side)
+    torch.cuda.synchronize()
+    sp, sd = oracle.generate(C2_SEED, 1000, n)
+    assert np.array_equal(spectra.cpu().numpy(), sp)
+    assert np.array_equal(side.cpu().numpy(), sd.view(np.uint8).reshape(n, 4, 128))
+
+
+def test_gpu_c2_prefix_vs_reference_fixture(engine, oracle):
+    g = np.load(os.path.join(GOLD, "c2_prefix.npz"))
+    sp, sd = oracle.generate(C2_SEED, 0, 32)
+    got = gpu_decode(engine, sp, sd, chunk=4)
+    assert_pcm_close(got, g["pcm_head"], 1, "C2 prefix")
+
+
+def test_gpu_c2_full_size(engine, oracle):
+    """BASELINE configs[1]: 2048 frames = 4096 granules, one stream.  Oracle
+    finishes this in <1 s, so compare everything; plus chunking invariance."""
+    import torch
+    n = 2048
+    spectra, side, pcm = engine.alloc_frames(n)
+    engine.generate(C2_SEED, 0, n, spectra, side)
+    engine.decode(spectra, side, pcm, chunk_frames=0)
+    torch.cuda.synchronize()
+    got = pcm.cpu().numpy()
+    sp, sd = oracle.generate(C2_SEED, 0, n)
+    want = oracle.decode(sp, sd)
+    g = np.load(os.path.join(GOLD, "c2_prefix.npz"))
+    assert sha(want) == str(g["pcm_sha_2048"][0])
+    dmax, ndiff = assert_pcm_close(got, want, 1, "C2 full")
+    assert ndiff < 0.02 * got.size
+    for chunk in (2, 7, 64, 2048):
+        pcm2 = torch.zeros_like(pcm)
+        engine.decode(spectra, side, pcm2, chunk_frames=chunk)
+        torch.cuda.synchronize()
+        assert torch.equal(pcm, pcm2), "chunk=%d changes the PCM" % chunk
+
+
+def test_gpu_state_handoff(engine, oracle):
+    import torch
+    sp, sd = oracle.generate(C2_SEED, 0, 50)
+    whole = gpu_decode(engine, sp, sd, chunk=50)
+    st = engine.new_state()
+    a = gpu_decode(engine, sp[:13], sd[:13], chunk=0, state=st)
+    b = gpu_decode(engine, sp[13:], sd[13:], chunk=5, state=st)
+    assert np.array_equal(np.concatenate([a, b]), whole)
+
+
+def test_gpu_shard_with_halo_equals_whole(engine, oracle):
+    """Multi-GPU rule: a shard decoded from 2 halo frames earlier,
+    halo output discarded, equals the same range of the whole stream."""
+    sp, sd = oracle.generate(C2_SEED, 0, 96)
+    whole = gpu_decode(engine, sp, sd, chunk=8)
+    lo = 40
+    part = gpu_decode(engine, sp[lo - 2:], sd[lo - 2:], chunk=8)[2:]
+    assert np.array_equal(part, whole[lo:])
+
+
+def test_gpu_ragged_and_tiny(engine, oracle):
+    sp, sd = oracle.generate(C2_SEED, 0, 9)
+    want = oracle.decode(sp, sd)
+    for n in (1, 2, 3, 9):
+        got = gpu_decode(engine, sp[:n], sd[:n], chunk=4)
+        assert_pcm_close(got, want[:n], 1, "n=%d" % n)
+    engine.decode(*engine.upload(sp[:0], sd[:0]), engine.alloc_frames(1)[2], n_frames=0)
+
+
+def test_gpu_large_synthetic_properties(engine):
+    """C5-style size (65536 frames on one GPU): determinism, chunk invariance,
+    and equality of a prefix with an independent small run."""
+    import torch
+    n = 65536
+    spectra, side, pcm = engine.alloc_frames(n)
+    seed = 0x5EED0000C5
+    engine.generate(seed, 0, n, spectra, side)
+    engine.decode(spectra, side, pcm, chunk_frames=32)
+    pcm2 = torch.empty_like(pcm)
+    engine.decode(spectra, side, pcm2, chunk_frames=16)
+    torch.cuda.synchronize()
+    assert torch.equal(pcm, pcm2)
+    sp3, sd3, pcm3 = engine.alloc_frames(128)
+    engine.generate(seed, 0, 128, sp3, sd3)
+    engine.decode(sp3, sd3, pcm3, chunk_frames=128)
+    torch.cuda.synchronize()
+    assert torch.equal(pcm[:128], pcm3)
+    assert int(pcm.abs().max()) > 1000

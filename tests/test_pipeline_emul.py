@@ -1,0 +1,59 @@
+"""Host build of the device pipeline (pdmp3_amd/csrc/decode_core.h compiled by
+g++, tests/host_emul) against the oracle: validates the kernel's indexing,
+tables, chunk/halo logic and state hand-off without a GPU.  The real parity
+tests (through the C-ABI, on the GPU) are in test_gpu_parity.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import corpus
+from conftest import C2_SEED
+from util import assert_pcm_close, nch_of, pcm_tolerance
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def emul_decode(emul, sp, sd, chunk=0, state=None, stages=False):
+    n = sp.shape[0]
+    pcm = np.zeros((n, 2304), np.int16)
+    stg = np.zeros((n, 2, 2, 4, 576), np.float32) if stages else None
+    emul.emul_decode_frames(_p(sp), _p(sd), n, _p(state), _p(pcm), _p(stg), chunk)
+    return (pcm, stg) if stages else pcm
+
+
+@pytest.mark.parametrize("name", list(corpus.CASES))
+def test_emul_vs_oracle(oracle, emul, name):
+    sp, sd = corpus.case(name, n=8)
+    want, ws = oracle.decode(sp, sd, stages=True)
+    got, gs = emul_decode(emul, sp, sd, stages=True)
+    nch = nch_of(sd)
+    for k in range(4):   # host build has no FMA contraction: every stage is bit-exact
+        assert np.array_equal(ws[:, :, :nch, k].view(np.uint32), gs[:, :, :nch, k].view(np.uint32)), "stage %d" % k
+    assert_pcm_close(got, want, pcm_tolerance(ws[:, :, :, 3]), name)
+
+
+@pytest.mark.parametrize("chunk", [2, 3, 5, 16])
+def test_emul_chunking_is_invisible(oracle, emul, chunk):
+    sp, sd = oracle.generate(C2_SEED, 0, 40)
+    whole = emul_decode(emul, sp, sd, 0)
+    assert np.array_equal(emul_decode(emul, sp, sd, chunk), whole)
+
+
+def test_emul_state_handoff(oracle, emul):
+    sp, sd = oracle.generate(C2_SEED, 0, 30)
+    whole = emul_decode(emul, sp, sd, 0)
+    st = np.zeros(emul.emul_state_floats(), np.float32)
+    a = emul_decode(emul, sp[:11], sd[:11], 0, st)
+    b = emul_decode(emul, sp[11:], sd[11:], 4, st)
+    assert np.array_equal(np.concatenate([a, b]), whole)
+
+
+def test_emul_generator(oracle, emul):
+    sp, sd = oracle.generate(C2_SEED, 3, 9)
+    sp2 = np.zeros_like(sp)
+    sd2 = np.zeros_like(sd)
+    emul.emul_generate_frames(C.c_uint64(C2_SEED), C.c_int64(3), 9, _p(sp2), _p(sd2))
+    assert np.array_equal(sp, sp2) and np.array_equal(sd.view(np.uint8), sd2.view(np.uint8))

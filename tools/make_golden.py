@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the REAL reference (oracle/_ref, compiled from
+/root/reference by oracle/Makefile).  Run in the build container only.
+
+Fixtures are data: expected outputs of the reference for inputs that the tests
+re-derive from (case name, seed) -- tests/corpus.py -- or from the integer-only
+C2 generator.  Nothing of the reference's source is stored.
+
+  tests/golden/<case>.npz       pcm int16 [n][2304]; stage3 float32 of the first 2 frames;
+                                sha256 of each of the 4 stage dumps (all frames)
+  tests/golden/c2_prefix.npz    PCM of the first 32 frames of the C2 stream + sha256 of the
+                                PCM of all 2048 frames
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import corpus  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+N_FRAMES = 6
+C2_SEED = 0x5EED0000C2
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    orc.build()
+    ref = orc.Reference()
+    o = orc.Oracle()
+    gold = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(gold, exist_ok=True)
+    for name in corpus.CASES:
+        sp, sd = corpus.case(name, n=N_FRAMES)
+        pcm, stg = ref.decode(sp, sd, stages=True)
+        nch = 1 if ((int(sd["frame"][0, 0, 0]) >> 2) & 3) == 3 else 2
+        np.savez_compressed(
+            os.path.join(gold, name + ".npz"),
+            pcm=pcm, stage3_head=stg[:2, :, :, 3],
+            stage_sha=np.array([sha(stg[:, :, :nch, k]) for k in range(4)]),
+            input_sha=np.array([sha(sp), sha(sd)]))
+        print("%-24s pcm sha %s" % (name, sha(pcm)[:16]))
+    sp, sd = o.generate(C2_SEED, 0, 2048)
+    pcm = ref.decode(sp, sd)
+    np.savez_compressed(os.path.join(gold, "c2_prefix.npz"), pcm_head=pcm[:32],
+                        pcm_sha_2048=np.array([sha(pcm)]), input_sha=np.array([sha(sp), sha(sd)]))
+    print("c2 2048-frame pcm sha", sha(pcm)[:16])
+
+
+if __name__ == "__main__":
+    main()
