@@ -1,2 +1,543 @@
+/*
+ * pdmp3_oracle_stream.c -- CPU ORACLE, bitstream front end + streaming API.
+ * TEST INFRASTRUCTURE ONLY (see pdmp3_oracle.h).
+ *
+ * Restates the reference's sequential host stage -- input ring, header sync,
+ * side info, bit reservoir, scalefactors, bit-serial Huffman tree walk -- and
+ * the libmpg123-style API bodies, then hands each parsed frame to the transform
+ * oracle (orc_decode_frames) as gc records.  The reference's out-of-bounds
+ * scalefactor reads are made explicit here by the layout rule
+ * instead of by memory aliasing; tests/test_stream_oracle.py pins this against
+ * the compiled reference (oracle/_ref), records and PCM, bit for bit.
+ *
+ * "P:n" = /root/reference/pdmp3.c line n.
+ */
 #include "pdmp3_oracle.h"
-size_t orc_decode_buffer_like_cli(const unsigned char* mp3, size_t n, unsigned char* pcm, size_t pcm_cap, orc_tap* tap) { return 0; }
+#include "oracle_tables.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define INBUF 16384u                 /* P:123 */
+#define O_EOF 0xffffffffu            /* P:165 */
+#define ENC_SIGNED_16 0xD0           /* P:121 */
+
+struct orc_stream {
+  size_t processed;                  /* P:126 */
+  unsigned istart, iend, ostart;
+  unsigned char in[INBUF];
+  int16_t frame_pcm[2304];           /* id->out[2][576] after Convert, interleaved */
+  /* header, P:56-70 */
+  unsigned h_id, h_layer, h_protection, h_bitrate_index, h_sfreq, h_padding, h_mode, h_mode_ext;
+  /* side info, P:71-95 */
+  unsigned main_data_begin, scfsi[2][4];
+  unsigned part2_3_length[2][2], big_values[2][2], global_gain[2][2], scalefac_compress[2][2];
+  unsigned win_switch_flag[2][2], block_type[2][2], mixed_block_flag[2][2];
+  unsigned table_select[2][2][3], subblock_gain[2][2][3], region0_count[2][2], region1_count[2][2];
+  unsigned preflag[2][2], scalefac_scale[2][2], count1table_select[2][2], count1[2][2];
+  /* main data, P:96-101 */
+  unsigned scalefac_l[2][2][21], scalefac_s[2][2][12][3];
+  int is[2][2][576];
+  unsigned hsynth_init, synth_init;
+  unsigned main_vec[2048 + 8];       /* P:137: one byte per unsigned */
+  unsigned main_ptr, main_idx, main_top;
+  unsigned side_vec[36 + 8];
+  unsigned side_ptr, side_idx;
+  int new_header;
+  orc_synth synth;
+  orc_tap* tap;
+};
+
+orc_stream* orc_stream_new(void) { return (orc_stream*)calloc(1, sizeof(orc_stream)); }
+void orc_stream_delete(orc_stream* s) { free(s); }
+void orc_stream_set_tap(orc_stream* s, orc_tap* tap) { s->tap = tap; }
+
+/* P:2369-2384 */
+int orc_stream_open_feed(orc_stream* s) {
+  if (!s) return ORC_ERR;
+  s->ostart = 0; s->istart = 0; s->iend = 0; s->processed = 0; s->new_header = 0;
+  s->hsynth_init = 1; s->synth_init = 1; s->main_top = 0;
+  return ORC_OK;
+}
+
+/* P:1062-1068 */
+static unsigned inbuf_filled(const orc_stream* s) {
+  return (s->istart <= s->iend) ? (s->iend - s->istart) : (INBUF - s->istart + s->iend);
+}
+static unsigned inbuf_free(const orc_stream* s) {
+  return (s->iend < s->istart) ? (s->istart - s->iend) : (INBUF - s->iend + s->istart);
+}
+
+/* P:1464-1474 */
+static unsigned get_byte(orc_stream* s) {
+  unsigned val = O_EOF;
+  if (s->istart != s->iend) {
+    val = s->in[s->istart++];
+    if (s->istart == INBUF) s->istart = 0;
+    s->processed++;
+  }
+  return val;
+}
+
+/* P:1076-1086: stops at the first EOF, leaving the rest of data_vec untouched */
+static int get_bytes(orc_stream* s, unsigned n, unsigned* vec) {
+  for (unsigned i = 0; i < n; i++) {
+    unsigned v = get_byte(s);
+    if (v == O_EOF) return (int)O_EOF;
+    vec[i] = v;
+  }
+  return ORC_OK;
+}
+
+/* P:2391-2423 */
+int orc_stream_feed(orc_stream* s, const unsigned char* in, size_t size) {
+  if (!(s && in && size)) return ORC_ERR;
+  int fre = (int)inbuf_free(s);
+  if (!(size <= (size_t)fre)) return ORC_NO_SPACE;
+  size_t res;
+  if (s->iend < s->istart) {
+    res = s->istart - s->iend;
+    if (size < res) res = size;
+    memcpy(s->in + s->iend, in, res);
+    s->iend += (unsigned)res;
+  } else {
+    res = INBUF - s->iend;
+    if (size < res) res = size;
+    if (res) { memcpy(s->in + s->iend, in, res); s->iend += (unsigned)res; size -= res; }
+    if (size) { memcpy(s->in, in + res, size); s->iend = (unsigned)size; }
+  }
+  return ORC_OK;
+}
+
+/* P:1252-1320 */
+static int read_header(orc_stream* s) {
+  unsigned b1 = get_byte(s), b2 = get_byte(s), b3 = get_byte(s), b4 = get_byte(s);
+  if (b1 == O_EOF || b2 == O_EOF || b3 == O_EOF || b4 == O_EOF) return ORC_ERR;
+  unsigned header = (b1 << 24) | (b2 << 16) | (b3 << 8) | b4;
+  while ((header & 0xfff00000u) != 0xfff00000u) {
+    b1 = b2; b2 = b3; b3 = b4;
+    b4 = get_byte(s);
+    if (b4 == O_EOF) return ORC_ERR;
+    header = (b1 << 24) | (b2 << 16) | (b3 << 8) | b4;
+  }
+  s->h_id = (header & 0x00080000u) >> 19;
+  s->h_layer = (header & 0x00060000u) >> 17;
+  s->h_protection = (header & 0x00010000u) >> 16;
+  s->h_bitrate_index = (header & 0x0000f000u) >> 12;
+  s->h_sfreq = (header & 0x00000c00u) >> 10;
+  s->h_padding = (header & 0x00000200u) >> 9;
+  s->h_mode = (header & 0x000000c0u) >> 6;
+  s->h_mode_ext = (header & 0x00000030u) >> 4;
+  if (s->h_id != 1) return ORC_ERR;
+  if (s->h_bitrate_index == 0) return ORC_ERR;
+  if (s->h_bitrate_index == 15) return ORC_ERR;
+  if (s->h_sfreq == 3) return ORC_ERR;
+  if (s->h_layer == 0) return ORC_ERR;
+  s->h_layer = 4 - s->h_layer;
+  if (!s->new_header) s->new_header = 1;
+  return ORC_OK;
+}
+
+/* P:1322-1340 */
+static int search_header(orc_stream* s) {
+  size_t pos = s->processed;
+  unsigned mark = s->istart;
+  int res = ORC_NEED_MORE, cnt = 0;
+  while (inbuf_filled(s) > 4) {
+    res = read_header(s);
+    if (s->h_layer == 3) {
+      if (res == ORC_OK || res == ORC_NEW_FORMAT) break;
+    }
+    if (++mark == INBUF) mark = 0;
+    s->istart = mark;
+    s->processed = pos;
+    if (++cnt > (2 * 576)) return ORC_ERR;
+  }
+  return res;
+}
+
+/* P:1547-1561 */
+static unsigned side_bits(orc_stream* s, unsigned n) {
+  const unsigned* p = &s->side_vec[s->side_ptr];
+  unsigned tmp = (p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3];
+  tmp = tmp << s->side_idx;
+  tmp = tmp >> (32 - n);
+  s->side_ptr += (s->side_idx + n) >> 3;
+  s->side_idx = (s->side_idx + n) & 7;
+  return tmp;
+}
+
+static unsigned frame_size(const orc_stream* s) {   /* P:1135-1138 */
+  return (144 * ot_bitrates[(s->h_layer - 1) * 15 + s->h_bitrate_index]) / ot_sfreq[s->h_sfreq] + s->h_padding;
+}
+
+/* P:1129-1200 */
+static int read_audio_l3(orc_stream* s) {
+  unsigned nch = (s->h_mode == 3) ? 1 : 2;
+  unsigned framesize = frame_size(s);
+  if (framesize > 2000) return ORC_ERR;
+  unsigned sideinfo_size = (nch == 1) ? 17 : 32;
+  /* P:1576-1586 Get_Sideinfo: pointers are reset only when all bytes arrived */
+  if (get_bytes(s, sideinfo_size, s->side_vec) == ORC_OK) { s->side_ptr = 0; s->side_idx = 0; }
+  s->main_data_begin = side_bits(s, 9);
+  (void)side_bits(s, (s->h_mode == 3) ? 5 : 3);
+  for (unsigned ch = 0; ch < nch; ch++)
+    for (unsigned b = 0; b < 4; b++) s->scfsi[ch][b] = side_bits(s, 1);
+  for (unsigned gr = 0; gr < 2; gr++)
+    for (unsigned ch = 0; ch < nch; ch++) {
+      s->part2_3_length[gr][ch] = side_bits(s, 12);
+      s->big_values[gr][ch] = side_bits(s, 9);
+      s->global_gain[gr][ch] = side_bits(s, 8);
+      s->scalefac_compress[gr][ch] = side_bits(s, 4);
+      s->win_switch_flag[gr][ch] = side_bits(s, 1);
+      if (s->win_switch_flag[gr][ch] == 1) {
+        s->block_type[gr][ch] = side_bits(s, 2);
+        s->mixed_block_flag[gr][ch] = side_bits(s, 1);
+        for (unsigned r = 0; r < 2; r++) s->table_select[gr][ch][r] = side_bits(s, 5);
+        for (unsigned w = 0; w < 3; w++) s->subblock_gain[gr][ch][w] = side_bits(s, 3);
+        s->region0_count[gr][ch] = (s->block_type[gr][ch] == 2 && s->mixed_block_flag[gr][ch] == 0) ? 8 : 7;
+        s->region1_count[gr][ch] = 20 - s->region0_count[gr][ch];
+      } else {
+        for (unsigned r = 0; r < 3; r++) s->table_select[gr][ch][r] = side_bits(s, 5);
+        s->region0_count[gr][ch] = side_bits(s, 4);
+        s->region1_count[gr][ch] = side_bits(s, 3);
+        s->block_type[gr][ch] = 0;
+      }
+      s->preflag[gr][ch] = side_bits(s, 1);
+      s->scalefac_scale[gr][ch] = side_bits(s, 1);
+      s->count1table_select[gr][ch] = side_bits(s, 1);
+    }
+  return ORC_OK;
+}
+
+/* P:1096-1122 */
+static int get_main_data(orc_stream* s, unsigned size, unsigned begin) {
+  if (begin > s->main_top) {
+    (void)get_bytes(s, size, &s->main_vec[s->main_top]);
+    s->main_ptr = 0; s->main_idx = 0;
+    s->main_top += size;
+    return ORC_NEED_MORE;
+  }
+  for (unsigned i = 0; i < begin; i++) s->main_vec[i] = s->main_vec[s->main_top - begin + i];
+  (void)get_bytes(s, size, &s->main_vec[begin]);
+  s->main_ptr = 0; s->main_idx = 0;
+  s->main_top = begin + size;
+  return ORC_OK;
+}
+
+/* P:1489-1497 */
+static unsigned main_bit(orc_stream* s) {
+  unsigned tmp = (s->main_vec[s->main_ptr] >> (7 - s->main_idx)) & 1;
+  s->main_ptr += (s->main_idx + 1) >> 3;
+  s->main_idx = (s->main_idx + 1) & 7;
+  return tmp;
+}
+
+/* P:1504-1527 */
+static unsigned main_bits(orc_stream* s, unsigned n) {
+  if (n == 0) return 0;
+  const unsigned* p = &s->main_vec[s->main_ptr];
+  unsigned tmp = (p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3];
+  tmp = tmp << s->main_idx;
+  tmp = tmp >> (32 - n);
+  s->main_ptr += (s->main_idx + n) >> 3;
+  s->main_idx = (s->main_idx + n) & 7;
+  return tmp;
+}
+
+static unsigned main_pos(const orc_stream* s) { return s->main_ptr * 8 + s->main_idx; }   /* P:1533-1541 */
+static void set_main_pos(orc_stream* s, unsigned bit) { s->main_ptr = bit >> 3; s->main_idx = bit & 7; }  /* P:1448 */
+
+/* P:1593-1643 */
+static int huffman_decode(orc_stream* s, unsigned table, int* x, int* y, int* v, int* w) {
+  unsigned point = 0, error = 1, bitsleft = 32;
+  unsigned treelen = (unsigned)ot_huff_main[table].treelen, linbits = (unsigned)ot_huff_main[table].linbits;
+  if (treelen == 0) { *x = *y = *v = *w = 0; return ORC_OK; }
+  const uint16_t* ht = &ot_huff_nodes[ot_huff_main[table].off];
+  do {
+    if ((ht[point] & 0xff00) == 0) {
+      error = 0;
+      *x = (ht[point] >> 4) & 0xf;
+      *y = ht[point] & 0xf;
+      break;
+    }
+    if (main_bit(s)) {
+      while ((ht[point] & 0xff) >= 250) point += ht[point] & 0xff;
+      point += ht[point] & 0xff;
+    } else {
+      while ((ht[point] >> 8) >= 250) point += ht[point] >> 8;
+      point += ht[point] >> 8;
+    }
+  } while ((--bitsleft > 0) && (point < treelen));
+  if (error) { *x = *y = 0; }
+  if (table > 31) {
+    *v = (*y >> 3) & 1; *w = (*y >> 2) & 1; *x = (*y >> 1) & 1; *y = *y & 1;
+    if ((*v > 0) && (main_bit(s) == 1)) *v = -*v;
+    if ((*w > 0) && (main_bit(s) == 1)) *w = -*w;
+    if ((*x > 0) && (main_bit(s) == 1)) *x = -*x;
+    if ((*y > 0) && (main_bit(s) == 1)) *y = -*y;
+  } else {
+    if ((linbits > 0) && (*x == 15)) *x += (int)main_bits(s, linbits);
+    if ((*x > 0) && (main_bit(s) == 1)) *x = -*x;
+    if ((linbits > 0) && (*y == 15)) *y += (int)main_bits(s, linbits);
+    if ((*y > 0) && (main_bit(s) == 1)) *y = -*y;
+  }
+  return error ? ORC_ERR : ORC_OK;
+}
+
+/* P:2051-2115.  Writes beyond line 575 (big_values > 288, H8) are dropped
+ * here; the reference corrupts its neighbours -- excluded from corpora. */
+static void read_huffman(orc_stream* s, unsigned part_2_start, unsigned gr, unsigned ch) {
+  int x, y, v, w;
+  unsigned table, is_pos, bit_pos_end, r1, r2;
+  int* is = s->is[gr][ch];
+#define PUT(pos, val) do { if ((pos) < 576) is[(pos)] = (val); } while (0)
+  if (s->part2_3_length[gr][ch] == 0) {
+    for (is_pos = 0; is_pos < 576; is_pos++) is[is_pos] = 0;
+    return;                                              /* count1 stays stale (H6) */
+  }
+  bit_pos_end = part_2_start + s->part2_3_length[gr][ch] - 1;
+  if (s->win_switch_flag[gr][ch] == 1 && s->block_type[gr][ch] == 2) { r1 = 36; r2 = 576; }
+  else {
+    r1 = ot_sfb[s->h_sfreq * 37 + s->region0_count[gr][ch] + 1];
+    r2 = ot_sfb[s->h_sfreq * 37 + s->region0_count[gr][ch] + s->region1_count[gr][ch] + 2];   /* H7 */
+  }
+  for (is_pos = 0; is_pos < s->big_values[gr][ch] * 2; is_pos++) {
+    if (is_pos < r1) table = s->table_select[gr][ch][0];
+    else if (is_pos < r2) table = s->table_select[gr][ch][1];
+    else table = s->table_select[gr][ch][2];
+    (void)huffman_decode(s, table, &x, &y, &v, &w);
+    PUT(is_pos, x); is_pos++;
+    PUT(is_pos, y);
+  }
+  table = s->count1table_select[gr][ch] + 32;
+  for (is_pos = s->big_values[gr][ch] * 2; (is_pos <= 572) && (main_pos(s) <= bit_pos_end); is_pos++) {
+    (void)huffman_decode(s, table, &x, &y, &v, &w);
+    PUT(is_pos, v); is_pos++;
+    if (is_pos >= 576) break;
+    PUT(is_pos, w); is_pos++;
+    if (is_pos >= 576) break;
+    PUT(is_pos, x); is_pos++;
+    if (is_pos >= 576) break;
+    PUT(is_pos, y);
+  }
+  if (main_pos(s) > (bit_pos_end + 1)) is_pos -= 4;
+  s->count1[gr][ch] = is_pos;
+  for (; is_pos < 576; is_pos++) is[is_pos] = 0;
+  set_main_pos(s, bit_pos_end + 1);
+#undef PUT
+}
+
+/* P:1346-1442 */
+static int read_main_l3(orc_stream* s) {
+  unsigned nch = (s->h_mode == 3) ? 1 : 2;
+  unsigned framesize = frame_size(s);
+  if (framesize > 2000) return ORC_ERR;
+  unsigned sideinfo_size = (nch == 1) ? 17 : 32;
+  unsigned main_data_size = framesize - sideinfo_size - 4;
+  if (s->h_protection == 0) main_data_size -= 2;
+  int res = get_main_data(s, main_data_size, s->main_data_begin);
+  if (res != ORC_OK) return res;
+  for (unsigned gr = 0; gr < 2; gr++)
+    for (unsigned ch = 0; ch < nch; ch++) {
+      unsigned part_2_start = main_pos(s);
+      unsigned slen1 = ot_slen[s->scalefac_compress[gr][ch] * 2], slen2 = ot_slen[s->scalefac_compress[gr][ch] * 2 + 1];
+      unsigned sfb, win;
+      if (s->win_switch_flag[gr][ch] != 0 && s->block_type[gr][ch] == 2) {
+        if (s->mixed_block_flag[gr][ch] != 0) {
+          for (sfb = 0; sfb < 8; sfb++) s->scalefac_l[gr][ch][sfb] = main_bits(s, slen1);
+          for (sfb = 3; sfb < 12; sfb++) {
+            unsigned nb = (sfb < 6) ? slen1 : slen2;
+            for (win = 0; win < 3; win++) s->scalefac_s[gr][ch][sfb][win] = main_bits(s, nb);
+          }
+        } else {
+          for (sfb = 0; sfb < 12; sfb++) {
+            unsigned nb = (sfb < 6) ? slen1 : slen2;
+            for (win = 0; win < 3; win++) s->scalefac_s[gr][ch][sfb][win] = main_bits(s, nb);
+          }
+        }
+      } else {
+        static const unsigned lo[4] = {0, 6, 11, 16}, hi[4] = {6, 11, 16, 21};
+        for (unsigned b = 0; b < 4; b++) {
+          unsigned nb = (b < 2) ? slen1 : slen2;
+          if (s->scfsi[ch][b] == 0 || gr == 0) {
+            for (sfb = lo[b]; sfb < hi[b]; sfb++) s->scalefac_l[gr][ch][sfb] = main_bits(s, nb);
+          } else if (s->scfsi[ch][b] == 1 && gr == 1) {
+            for (sfb = lo[b]; sfb < hi[b]; sfb++) s->scalefac_l[1][ch][sfb] = s->scalefac_l[0][ch][sfb];
+          }
+        }
+      }
+      read_huffman(s, part_2_start, gr, ch);
+    }
+  return ORC_OK;
+}
+
+/* P:1217-1244 */
+static int read_frame(orc_stream* s) {
+  if (search_header(s) != ORC_OK) return ORC_ERR;
+  if (s->h_protection == 0) {                     /* P:1206-1210: two bytes skipped, never an error */
+    if (get_byte(s) != O_EOF) (void)get_byte(s);
+  }
+  if (s->h_layer == 3) {
+    (void)read_audio_l3(s);                       /* status ignored (H18) */
+    return read_main_l3(s);
+  }
+  return ORC_ERR;
+}
+
+/* The parsed frame as gc records: what the transforms are about to read,
+ * with the reference's two out-of-bounds scalefactor reads spelled out by its
+ * memory-layout rule: scalefac_l[gr][ch][21] is the next
+ * array element in [gr][ch] order, running on into scalefac_s[0][0][0][0];
+ * scalefac_s[gr][ch][12][w] likewise, running on into the bits of is[0][0][w]. */
+static void frame_to_records(const orc_stream* s, int16_t* spectra, pdmp3_gc_side* sd, int reset) {
+  memset(sd, 0, 4 * sizeof *sd);
+  unsigned nch = (s->h_mode == 3) ? 1 : 2;
+  for (unsigned gr = 0; gr < 2; gr++)
+    for (unsigned ch = 0; ch < 2; ch++) {
+      pdmp3_gc_side* r = &sd[gr * 2 + ch];
+      int16_t* sp = spectra + (gr * 2 + ch) * 576;
+      r->frame = (uint8_t)((s->h_sfreq & 3) | ((s->h_mode & 3) << PDMP3_FR_MODE_SHIFT) |
+                           ((s->h_mode_ext & 3) << PDMP3_FR_MODEEXT_SHIFT) | (reset ? PDMP3_FR_RESET : 0));
+      memset(sp, 0, 576 * sizeof *sp);
+      if (ch >= nch) continue;
+      for (unsigned i = 0; i < 576; i++) sp[i] = (int16_t)s->is[gr][ch][i];
+      r->count1 = (uint16_t)s->count1[gr][ch];
+      r->global_gain = (uint8_t)s->global_gain[gr][ch];
+      unsigned fl = 0;
+      if (s->scalefac_scale[gr][ch]) fl |= PDMP3_GC_SCALEFAC_SCALE;
+      if (s->preflag[gr][ch]) fl |= PDMP3_GC_PREFLAG;
+      if (s->win_switch_flag[gr][ch]) {
+        fl |= PDMP3_GC_WIN_SWITCH;
+        if (s->mixed_block_flag[gr][ch]) fl |= PDMP3_GC_MIXED;
+      }
+      fl |= (s->block_type[gr][ch] & 3) << PDMP3_GC_BLOCK_TYPE_SHIFT;
+      r->flags = (uint8_t)fl;
+      for (unsigned k = 0; k < 3; k++) r->subblock_gain[k] = (uint8_t)s->subblock_gain[gr][ch][k];
+      for (unsigned k = 0; k < 21; k++) r->scalefac_l[k] = (uint8_t)s->scalefac_l[gr][ch][k];
+      for (unsigned k = 0; k < 12; k++)
+        for (unsigned w = 0; w < 3; w++) r->scalefac_s[k][w] = (uint8_t)s->scalefac_s[gr][ch][k][w];
+      unsigned g = gr * 2 + ch;
+      if (g < 3) {
+        r->scalefac_l[21] = (uint8_t)s->scalefac_l[(g + 1) >> 1][(g + 1) & 1][0];
+        for (unsigned w = 0; w < 3; w++) r->scalefac_s[12][w] = (uint8_t)s->scalefac_s[(g + 1) >> 1][(g + 1) & 1][0][w];
+      } else {
+        r->scalefac_l[21] = (uint8_t)s->scalefac_s[0][0][0][0];
+        for (unsigned w = 0; w < 3; w++) r->scalefac_s[12][w] = PDMP3_SF_PEEK;
+      }
+    }
+}
+
+/* P:1024 Decode_L3 for the frame just parsed, via the record boundary */
+static void decode_current_frame(orc_stream* s) {
+  int16_t spectra[2304];
+  pdmp3_gc_side sd[4];
+  int reset = (s->hsynth_init || s->synth_init);
+  s->hsynth_init = 0; s->synth_init = 0;
+  frame_to_records(s, spectra, sd, reset);
+  if (s->tap) {
+    if (s->tap->n_frames < s->tap->cap_frames) {
+      memcpy(s->tap->spectra + (size_t)s->tap->n_frames * 2304, spectra, sizeof spectra);
+      memcpy(s->tap->side + (size_t)s->tap->n_frames * 4, sd, sizeof sd);
+    }
+    s->tap->n_frames++;
+  }
+  orc_decode_frames(&s->synth, spectra, sd, 1, s->frame_pcm, NULL);
+}
+
+/* P:2307-2345 */
+static void convert_frame_s16(orc_stream* s, unsigned char* outbuf, size_t buflen, size_t* done) {
+  unsigned nch = (s->h_mode == 3) ? 1 : 2;
+  unsigned framesz = 2 * nch;
+  size_t nsamps = buflen / framesz;
+  if (nsamps > (2 * 576 - s->ostart)) nsamps = 2 * 576 - s->ostart;
+  *done = nsamps * framesz;
+  memcpy(outbuf, (const unsigned char*)s->frame_pcm + (size_t)s->ostart * framesz, nsamps * framesz);
+  s->ostart += (unsigned)nsamps;
+  if (s->ostart == 2 * 576) s->ostart = 0;
+}
+
+/* P:2431-2481 */
+int orc_stream_read(orc_stream* s, unsigned char* out, size_t outsize, size_t* done) {
+  if (!(s && out && outsize && done)) return ORC_ERR;
+  *done = 0;
+  int res = ORC_ERR;
+  if (s->ostart) {
+    convert_frame_s16(s, out, outsize, done);
+    out += *done; outsize -= *done;
+    res = ORC_OK;
+  }
+  while (outsize) {
+    if (inbuf_filled(s) >= 2 * 576) {
+      size_t pos = s->processed;
+      unsigned mark = s->istart;
+      res = read_frame(s);
+      if (res == ORC_OK || res == ORC_NEW_FORMAT) {
+        size_t batch;
+        decode_current_frame(s);
+        convert_frame_s16(s, out, outsize, &batch);
+        out += batch; outsize -= batch; *done += batch;
+      } else {
+        s->processed = pos; s->istart = mark;
+        break;
+      }
+    } else { res = ORC_NEED_MORE; break; }
+  }
+  if (s->new_header == 1 && res == ORC_OK) res = ORC_NEW_FORMAT;
+  return res;
+}
+
+/* P:2491-2520 */
+int orc_stream_decode(orc_stream* s, const unsigned char* in, size_t insize, unsigned char* out, size_t outsize, size_t* done) {
+  int fre = (int)inbuf_free(s);
+  *done = 0;
+  if ((size_t)fre > insize) fre = (int)insize;
+  int res = orc_stream_feed(s, in, (size_t)fre);
+  if (res == ORC_OK) {
+    size_t avail;
+    if (out && outsize) {
+      res = orc_stream_read(s, out, outsize, &avail);
+      *done = avail;
+    } else if (s->processed == 0) {
+      size_t pos = s->processed;
+      unsigned mark = s->istart;
+      res = search_header(s);
+      s->processed = pos; s->istart = mark;
+      if (s->new_header == 1) res = ORC_NEW_FORMAT;
+    }
+  }
+  return res;
+}
+
+/* P:2526-2535 */
+int orc_stream_getformat(orc_stream* s, long* rate, int* channels, int* enc) {
+  if (!(s && rate && channels && enc)) return ORC_ERR;
+  *enc = ENC_SIGNED_16;
+  *rate = (long)ot_sfreq[s->h_sfreq];
+  *channels = (s->h_mode == 3) ? 1 : 2;
+  s->new_header = -1;
+  return ORC_OK;
+}
+
+/* P:2552-2587: the CLI driver's loop over a memory buffer */
+size_t orc_decode_buffer_like_cli(const unsigned char* mp3, size_t n, unsigned char* pcm, size_t pcm_cap, orc_tap* tap) {
+  orc_stream* s = orc_stream_new();
+  unsigned char out[INBUF];
+  size_t done, total = 0, pos = 0;
+  int res;
+  if (tap) { tap->n_frames = 0; s->tap = tap; }
+  orc_stream_open_feed(s);
+  while ((res = orc_stream_read(s, out, INBUF, &done)) != ORC_ERR) {
+    if (total + done <= pcm_cap) memcpy(pcm + total, out, done);
+    total += done;
+    if (res == ORC_NEED_MORE) {
+      size_t k = n - pos;
+      if (k > 4096) k = 4096;
+      if (!k) break;
+      (void)orc_stream_feed(s, mp3 + pos, k);
+      pos += k;
+    }
+  }
+  orc_stream_delete(s);
+  return total;
+}

@@ -5,20 +5,21 @@
 //   * IMDCT overlap (the reference's `store[2][32][18]`, pdmp3.c:1755) in the
 //     VGPRs of the lane that owns (channel, subband),
 //   * the polyphase history (the reference's 1024-float V FIFO per channel,
-//     pdmp3.c:1983,2006) as 15 slots of 32 DCT coefficients per channel in LDS.
+//     pdmp3.c:1983,2006) as the 2 x 15 DCT coefficients each lane will need
+//     again, also in VGPRs.
 // Stages per granule (reference stage it replaces, "P:n" = pdmp3.c line n):
-//   ph_load     global -> LDS copy of 2304 B int16 spectra + 2 side records
+//   ph_commit   prefetched 2304 B int16 spectra + 2 side records -> LDS
 //   ph_scales   per-band requantisation scale 2^-(sfm*sf) * 2^(gain/4)   P:2127-2128, P:2144-2146
 //   ph_requant  |is|^(4/3) * scale, short-block reorder as a gather,
 //               MS / intensity stereo                                     P:1829, P:1786, P:1911
-//   ph_imdct    alias reduction fused into the operand fetch, 18->36 (or
-//               3 x 6->12) IMDCT with scalar-broadcast coefficients,
-//               window, overlap-add, frequency inversion                  P:1706, P:1649, P:1752, P:1738
+//   ph_fetch    alias reduction fused into the IMDCT operand fetch        P:1706
+//   ph_imdct    18->36 (or 3 x 6->12) IMDCT with scalar-broadcast
+//               coefficients, window, overlap-add, frequency inversion    P:1649, P:1752, P:1738
 //   ph_dct32    32-point DCT-II (Lee) per time slot = the 64x32 matrixing
 //               folded by its cosine symmetries                           P:2010-2014
 //   ph_window   512-tap D window as 16 FMAs per sample against the slot
 //               history, float -> int16 exactly as P:2028-2031
-//   ph_store    coalesced PCM store, history shift
+//   ph_store    coalesced PCM store
 //
 // The file is plain C++ that compiles for the device with hipcc AND for the
 // host with g++ (tests/host_emul): the host build runs each phase for lanes
@@ -26,6 +27,7 @@
 // without a GPU.  It is not a product path.
 #pragma once
 
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 #include "../../include/pdmp3_hip.h"
@@ -34,43 +36,46 @@
 #if defined(__HIPCC__)
 #define PD_FN __device__ __forceinline__
 #define PD_MFN __device__ __forceinline__
-#define PD_MUL(a, b) __fmul_rn((a), (b))
-#define PD_ADD(a, b) __fadd_rn((a), (b))
-#define PD_SUB(a, b) __fsub_rn((a), (b))
+#define PD_HD __host__ __device__ __forceinline__
+// Built with -ffp-contract=off: a*b+c stays two roundings (as in the reference's
+// x86-64 build) unless PD_FMA is written out.
 #define PD_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#define PD_CLOCK() __builtin_amdgcn_s_memtime()
+#define PD_UNROLL _Pragma("unroll")
+#define PD_NOUNROLL _Pragma("nounroll")
 #define PD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// pins a VGPR value at this program point (keeps IR passes from sinking the
+// arithmetic that produced it past the scheduling fences)
+#define PD_PIN(x) asm volatile("" : "+v"(x))
 #else
 #define PD_FN static inline
 #define PD_MFN inline
-#define PD_MUL(a, b) ((a) * (b))
-#define PD_ADD(a, b) ((a) + (b))
-#define PD_SUB(a, b) ((a) - (b))
+#define PD_HD static inline
 #define PD_FMA(a, b, c) ((a) * (b) + (c))
+#define PD_CLOCK() 0ull
+#define PD_UNROLL
+#define PD_NOUNROLL
 #define PD_SCHED_FENCE() ((void)0)
+#define PD_PIN(x) ((void)0)
 #endif
 
 namespace pdmp3 {
 
 constexpr int kHaloGranules = 3;      // (f-2,gr1) (f-1,gr0) (f-1,gr1): SURVEY 8e incl. the H5 corner
 constexpr int kHistSlots = 15;        // polyphase history depth (P:2015-2019 reaches 15 slots back)
-constexpr int kT1Size = 304;          // 2^(-n/2), n = 0..303 (beyond: 0 as binary32)
-constexpr int kT2Size = 312;          // 2^((k-266)/4), k = 0..311
+constexpr int kPow43Small = 128;      // |is| below this come from the LDS copy of the table
 
 // Small tables; lives in __constant__ memory on the device so that
 // wave-uniform indices become scalar loads.
 struct ConstBank {
-  float c36t[36][18];   // cos_N36 (P:620-729) transposed to [p][m]
-  float c12t[12][6];    // cos_N12 (P:606-619) transposed to [p][m]
-  float win[4][36];     // g_imdct_win (P:577-603)
-  float cs[8], ca[8];   // P:573-574
-  float isr_l[16];      // is_ratio_l for is_pos 0..6 (P:2166-2172); [7] unused;
-  float isr_r[16];      // [8..15]: the reference reads past is_ratios[] (H3) -> defined as t = 0
-  float dwin[512];      // g_synth_dtbl (P:740-870)
-  float t1[kT1Size];    // (float)pow(2.0, -0.5*n)   covers P:2127, P:2144
-  float t2[kT2Size];    // (float)pow(2.0, 0.25*(k-266)) covers P:2128, P:2145
+  float c36p[18][18][2];  // cos_N36 (P:620-729) as [m][q][{p = q, p = q + 18}]
+  float c12t[12][6];      // cos_N12 (P:606-619) transposed to [p][m]
+  float cs[8], ca[8];     // P:573-574
+  float isr_l[16];        // is_ratio_l for is_pos 0..6 (P:2166-2172); [7] unused;
+  float isr_r[16];        // [8..15]: the reference reads past is_ratios[] (H3) -> defined as t = 0
+  float dwin[512];        // g_synth_dtbl (P:740-870)
   uint16_t sfb_l[3][24];  // g_sf_band_indices[].l (P:879-892), padded
   uint16_t sfb_s[3][16];  // g_sf_band_indices[].s
-  uint8_t pretab[24];   // P:2123 (+ [21] = 0, H4)
 };
 
 // Pointer to the bank.  On the device it is address-space-4 (constant) typed so
@@ -86,18 +91,19 @@ typedef const ConstBank* BankPtr;
 #define PD_LAUNDER(p) ((void)0)
 #endif
 
-// Large tables in global memory.
+// Large tables in global memory (L2-resident; copied to LDS per chunk where hot).
 struct GlobalTables {
   const float* pow43;       // [8207] (float)pow((float)i, 4.0/3.0), P:979
-  const uint8_t* band;      // [3 sfreq][3 kind][576]: scale-table index of SOURCE line n;
-                            //   kind 0 long: sfb; 1 short: 22+sfb*3+win; 2 mixed
-  const uint16_t* src_idx;  // [3 sfreq][2 (short, mixed)][576]: reordered line d <- source line (P:1786-1823)
+  const uint16_t* linetab;  // [3 sfreq][3 kind][576]: for REORDERED line d: source line (10 bits) |
+                            //   scale-table index of that source line << 10.
+                            //   kind 0 long, 1 short, 2 mixed; index 0..21 long sfb, 22+sfb*3+win short
+  const float* win;         // [4][36] g_imdct_win (P:577-603)
 };
 
-// LDS per wave (~7.9 KB).  Buffers whose lifetimes do not overlap share storage:
-//   spec (ph_load .. ph_requant)            | pcm  (ph_window .. ph_store)
-//   xr   (ph_requant .. ph_fetch)           | hyb  (ph_imdct .. ph_dct32) | vnew (ph_dct32 .. ph_window)
-// hyb/vnew rows are [slot t][33]: the DCT lane that owns slot t transforms its row in place.
+// LDS per wave (~12.3 KB).  Buffers whose lifetimes do not overlap share storage:
+//   spec (ph_commit .. ph_requant)          | pcm  (ph_window .. ph_store)
+//   xr   (ph_requant .. ph_fetch)           | hyb  (ph_imdct .. ph_window)
+// hyb rows are [slot t][33]: the DCT lane that owns slot t transforms its row in place.
 struct WaveLds {
   union {
     alignas(16) int16_t spec[2][576];
@@ -109,8 +115,13 @@ struct WaveLds {
     float xr[2][576];
     float hyb[2][18][33];
   };
+  alignas(16) float win[4][36];
+  float pow43s[kPow43Small];
+  alignas(16) uint16_t ltab[3][576];
   float peek[4];
 };
+
+typedef uint32_t Chunk16 __attribute__((vector_size(16)));   // one 16-byte global/LDS access
 
 struct LaneRegs {
   float ovl[18];     // IMDCT overlap of (ch = lane>>5, sb = lane&31): the reference's store[ch][sb][] (P:1755)
@@ -119,46 +130,55 @@ struct LaneRegs {
   float he[15];      // polyphase history: coefficient idx_e of the last 15 slots (oldest first)
   float ho[15];      // same for idx_o   (together = what the lane needs of v_vec[ch][], P:1983)
   float in[18];      // scratch: this granule's antialiased IMDCT input
+  Chunk16 pf0, pf1, pf2, pf3;   // next granule's spectra / side records in flight
   int idx_e, idx_o;  // which DCT coefficient the lane reads from even-/odd-aged slots
 };
 
 // Uniform per-granule facts, decoded from the side records in LDS.
 struct GranuleInfo {
   int nch, sfreq, mode, mode_ext;
-  int count1[2], flags[2];
+  int count1_0, count1_1, flags0, flags1;
+  PD_MFN int flags(int ch) const { return ch ? flags1 : flags0; }
   PD_MFN bool is_short(int ch) const {
-    return (flags[ch] & PDMP3_GC_WIN_SWITCH) && ((flags[ch] & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
+    const int f = flags(ch);
+    return (f & PDMP3_GC_WIN_SWITCH) && ((f & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
   }
-  PD_MFN bool is_mixed(int ch) const { return (flags[ch] & PDMP3_GC_MIXED) != 0; }
-  PD_MFN int block_type(int ch) const { return (flags[ch] & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT; }
+  PD_MFN bool is_mixed(int ch) const { return (flags(ch) & PDMP3_GC_MIXED) != 0; }
+  PD_MFN int block_type(int ch) const { return (flags(ch) & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT; }
+  PD_MFN int kind(int ch) const { return is_short(ch) ? (is_mixed(ch) ? 2 : 1) : 0; }
 };
 
 PD_FN GranuleInfo granule_info(const WaveLds& L) {
   GranuleInfo g;
-  int fr = L.side[0][7];
+  const int fr = L.side[0][7];
   g.sfreq = fr & PDMP3_FR_SFREQ_MASK;
   if (g.sfreq > 2) g.sfreq = 2;
   g.mode = (fr & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT;
   g.mode_ext = (fr & PDMP3_FR_MODEEXT_MASK) >> PDMP3_FR_MODEEXT_SHIFT;
   g.nch = (g.mode == 3) ? 1 : 2;
-  for (int ch = 0; ch < 2; ch++) {
-    g.count1[ch] = L.side[ch][0] | (L.side[ch][1] << 8);
-    g.flags[ch] = L.side[ch][3];
-  }
+  g.count1_0 = L.side[0][0] | (L.side[0][1] << 8);
+  g.count1_1 = L.side[1][0] | (L.side[1][1] << 8);
+  g.flags0 = L.side[0][3];
+  g.flags1 = L.side[1][3];
   return g;
 }
 
-PD_FN uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+PD_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 // ---------------------------------------------------------------------------
-// chunk prologue: per-lane constants
+// chunk prologue: per-lane constants, LDS copies of hot tables
 // ---------------------------------------------------------------------------
-PD_FN void state_zero(int lane, LaneRegs& R);
-PD_FN void lane_init(int lane, LaneRegs& R, BankPtr cb) {
+PD_FN void state_zero(int lane, LaneRegs& R) {
+  (void)lane;
+  for (int m = 0; m < 18; m++) R.ovl[m] = 0.0f;
+  for (int s = 0; s < kHistSlots; s++) { R.he[s] = 0.0f; R.ho[s] = 0.0f; }
+}
+
+PD_FN void lane_init(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTables& T) {
   const int i = lane & 31;
   // v[i] = C[16+i] (i<16), 0 (i==16), -C[48-i] (i>16);  v[32+i] = -C[16-i] (i<=16), -C[i-16] (i>16)
   // where C = 32-point DCT-II of the slot (derivation: DESIGN.md "polyphase").
-  float sgn_e = (i < 16) ? 1.0f : ((i == 16) ? 0.0f : -1.0f);
+  const float sgn_e = (i < 16) ? 1.0f : ((i == 16) ? 0.0f : -1.0f);
   R.idx_e = (i < 16) ? 16 + i : ((i == 16) ? 0 : 48 - i);
   R.idx_o = (i <= 16) ? 16 - i : i - 16;
   for (int k = 0; k < 8; k++) {
@@ -166,15 +186,20 @@ PD_FN void lane_init(int lane, LaneRegs& R, BankPtr cb) {
     R.wo[k] = -cb->dwin[64 * k + 32 + i];
   }
   state_zero(lane, R);
+  L.pow43s[lane] = T.pow43[lane];
+  L.pow43s[lane + 64] = T.pow43[lane + 64];
+  for (int k = lane; k < 144; k += 64) (&L.win[0][0])[k] = T.win[k];
+  if (lane < 4) L.peek[lane] = 1.0f;
 }
 
-PD_FN void state_zero(int lane, LaneRegs& R) {
-  (void)lane;
-  for (int m = 0; m < 18; m++) R.ovl[m] = 0.0f;
-  for (int s = 0; s < kHistSlots; s++) { R.he[s] = 0.0f; R.ho[s] = 0.0f; }
+// the line tables of one sampling frequency (3 kinds x 576 u16 = 216 x 16 B)
+PD_FN void load_linetab(int lane, WaveLds& L, const GlobalTables& T, int sfreq) {
+  const Chunk16* src = reinterpret_cast<const Chunk16*>(T.linetab + (size_t)sfreq * 3 * 576);
+  Chunk16* dst = reinterpret_cast<Chunk16*>(&L.ltab[0][0]);
+  for (int k = lane; k < 216; k += 64) dst[k] = src[k];
 }
 
-// state layout (opaque to callers): float ovl[64 lanes][18]; float he[64][15]; float ho[64][15]
+// state layout (opaque to callers): float ovl[18][64 lanes]; float he[15][64]; float ho[15][64]
 constexpr int kStateFloats = 64 * (18 + 2 * kHistSlots);
 
 PD_FN void state_load(int lane, LaneRegs& R, const float* st) {
@@ -194,135 +219,181 @@ PD_FN void state_store(int lane, const LaneRegs& R, float* st) {
 }
 
 // ---------------------------------------------------------------------------
-// ph_load: 2304 B spectra + 256 B side, 16 B per lane per access
+// ph_prefetch / ph_commit: 2304 B spectra + 256 B side of one granule,
+// 16 B per lane per access, issued one granule ahead of its use
 // ---------------------------------------------------------------------------
-struct Chunk16 { uint32_t x, y, z, w; };
-
-PD_FN void ph_load(int lane, WaveLds& L, const int16_t* spectra_g, const pdmp3_gc_side* side_g) {
+PD_FN void ph_prefetch(int lane, LaneRegs& R, const int16_t* spectra_g, const pdmp3_gc_side* side_g) {
   const Chunk16* src = reinterpret_cast<const Chunk16*>(spectra_g);
-  Chunk16* dst = reinterpret_cast<Chunk16*>(&L.spec[0][0]);
-  dst[lane] = src[lane];
-  dst[lane + 64] = src[lane + 64];
+  R.pf0 = src[lane];
+  R.pf1 = src[lane + 64];
   if (lane < 16) {
-    dst[lane + 128] = src[lane + 128];
-    reinterpret_cast<Chunk16*>(&L.side[0][0])[lane] = reinterpret_cast<const Chunk16*>(side_g)[lane];
+    R.pf2 = src[lane + 128];
+    R.pf3 = reinterpret_cast<const Chunk16*>(side_g)[lane];
+  }
+}
+
+PD_FN void ph_commit(int lane, WaveLds& L, const LaneRegs& R) {
+  Chunk16* dst = reinterpret_cast<Chunk16*>(&L.spec[0][0]);
+  dst[lane] = R.pf0;
+  dst[lane + 64] = R.pf1;
+  if (lane < 16) {
+    dst[lane + 128] = R.pf2;
+    reinterpret_cast<Chunk16*>(&L.side[0][0])[lane] = R.pf3;
   }
 }
 
 // ---------------------------------------------------------------------------
-// ph_scales: scale[ch][e], e = 0..21 long sfb, 22+sfb*3+win short
+// ph_scales: scale[ch][e], e = 0..21 long sfb, 22+sfb*3+win short.
+//   t1 = (float)pow(2.0, -(sfm*(sf+pre)))  = {1, 2^-1/2}[n&1] * 2^-(n>>1), n = sf+pre (or twice that)
+//   t2 = (float)pow(2.0, 0.25*k)           = {2^(j/4)}[k&3] * 2^(k>>2)
+// Power-of-two scaling of a binary32 is exact, so both equal the reference's
+// libm values bit for bit (host_tables.h re-checks this against pow() for the
+// whole index range when the engine is created).
 // ---------------------------------------------------------------------------
-PD_FN void ph_scales(int lane, WaveLds& L, BankPtr cb) {
+PD_HD float pow2_quarter(int k) {        // 2^(k/4), k in [-266, 45]
+  const int j = k & 3;
+  const float base = (j == 0) ? 1.0f : (j == 1) ? 0x1.306fe0p+0f : (j == 2) ? 0x1.6a09e6p+0f : 0x1.ae89fap+0f;
+  return ldexpf(base, k >> 2);
+}
+PD_HD float pow2_neg_half(uint32_t n) {  // 2^(-n/2); 0 from n = 300 on (binary32 underflow)
+  if (n >= 300u) return 0.0f;
+  return ldexpf((n & 1) ? 0x1.6a09e6p-1f : 1.0f, -(int)(n >> 1));
+}
+
+PD_FN void ph_scales(int lane, WaveLds& L) {
   if (lane >= 61) return;
+  PD_UNROLL
   for (int ch = 0; ch < 2; ch++) {
     const uint8_t* s = L.side[ch];
     const int gg = s[2], flags = s[3];
     const bool sfscale = flags & PDMP3_GC_SCALEFAC_SCALE;
     float t1, t2;
     if (lane < 22) {
-      int x = s[8 + lane] + ((flags & PDMP3_GC_PREFLAG) ? cb->pretab[lane] : 0);
-      int n = sfscale ? 2 * x : x;
-      t1 = cb->t1[n];
-      t2 = cb->t2[gg + 56];
+      // pretab P:2123 (+ [21] = 0, H4), 2 bits per entry
+      const int pre = (int)((0x2fe95400000ull >> (2 * lane)) & 3);
+      const uint32_t x = (uint32_t)s[8 + lane] + ((flags & PDMP3_GC_PREFLAG) ? pre : 0);
+      t1 = pow2_neg_half(sfscale ? 2 * x : x);
+      t2 = pow2_quarter(gg - 210);
     } else {
       const int q = lane - 22, sfb = q / 3, win = q - 3 * sfb;
       uint32_t sf = s[30 + q];
       if (sfb == 12 && s[30 + 36] == PDMP3_SF_PEEK) sf = f2u(L.peek[win]);   // H5
       if (sf > 400u) sf = 400u;
-      uint32_t n = sfscale ? 2 * sf : sf;
-      t1 = (n < (uint32_t)kT1Size) ? cb->t1[n] : 0.0f;
-      t2 = cb->t2[gg + 56 - 8 * s[4 + win]];
+      t1 = pow2_neg_half(sfscale ? 2 * sf : sf);
+      t2 = pow2_quarter(gg - 210 - 8 * (int)s[4 + win]);
     }
-    L.scale[ch][lane] = PD_MUL(t1, t2);
+    L.scale[ch][lane] = t1 * t2;
   }
 }
 
 // ---------------------------------------------------------------------------
-// ph_requant: requantise + reorder (gather) + stereo, in reordered line order
+// ph_requant: requantise + reorder (gather) + stereo.  Lane l owns the
+// REORDERED lines 9l .. 9l+8 of both channels.
 // ---------------------------------------------------------------------------
 template <bool DUMP>
-PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T,
-                      float* dump0, float* dump1) {
+PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, float* dump0, float* dump1) {
   const GranuleInfo g = granule_info(L);
   const bool joint = (g.nch == 2) && (g.mode == 1) && (g.mode_ext != 0);
   const bool ms = joint && (g.mode_ext & 2);
   const bool is = joint && (g.mode_ext & 1);
-  const int cmin = (g.count1[0] > g.count1[1]) ? g.count1[1] : g.count1[0];   // P:1920 (H2)
-  int kind[2];
-  for (int ch = 0; ch < 2; ch++) kind[ch] = g.is_short(ch) ? (g.is_mixed(ch) ? 2 : 1) : 0;
-  const uint8_t* bandL = T.band + (g.sfreq * 3 + 0) * 576;
-  const uint8_t* bandS = T.band + (g.sfreq * 3 + 1) * 576;
-
-  for (int r = 0; r < 2; r++) {
-    const int base = 512 * r + 8 * lane;
-    if (base >= 576) break;
-    for (int e = 0; e < 8; e++) {
-      const int d = base + e;
-      float x[2] = {0.0f, 0.0f};
-      for (int ch = 0; ch < g.nch; ch++) {
-        const int k = kind[ch];
-        const int sidx = (k == 0) ? d : T.src_idx[(g.sfreq * 2 + (k - 1)) * 576 + d];
-        const int v = L.spec[ch][sidx];
-        const int a = v < 0 ? -v : v;
-        const float p = T.pow43[a > 8206 ? 8206 : a];
-        const float t3 = v < 0 ? -p : p;
-        const int b = T.band[(g.sfreq * 3 + k) * 576 + sidx];
-        x[ch] = PD_MUL(L.scale[ch][b], t3);
+  const int cmin = (g.count1_0 > g.count1_1) ? g.count1_1 : g.count1_0;   // P:1920 (H2)
+  const int kind0 = g.kind(0), kind1 = g.kind(1);
+  const int d0 = 9 * lane;
+  float x0[9], x1[9];
+  {
+    unsigned e0[9], e1[9];
+    PD_UNROLL for (int i = 0; i < 9; i++) e0[i] = L.ltab[kind0][d0 + i];
+    PD_UNROLL for (int i = 0; i < 9; i++) e1[i] = L.ltab[kind1][d0 + i];
+    int v0[9], v1[9];
+    float s0[9], s1[9];
+    PD_UNROLL for (int i = 0; i < 9; i++) { v0[i] = L.spec[0][e0[i] & 1023]; s0[i] = L.scale[0][e0[i] >> 10]; }
+    PD_UNROLL for (int i = 0; i < 9; i++) { v1[i] = L.spec[1][e1[i] & 1023]; s1[i] = L.scale[1][e1[i] >> 10]; }
+    PD_UNROLL for (int i = 0; i < 9; i++) {
+      const int a = v0[i] < 0 ? -v0[i] : v0[i];
+      float p = L.pow43s[a & (kPow43Small - 1)];
+      if (a >= kPow43Small) p = T.pow43[a > 8206 ? 8206 : a];
+      x0[i] = s0[i] * (v0[i] < 0 ? -p : p);                 // (t1*t2)*t3, P:2132
+    }
+    PD_UNROLL for (int i = 0; i < 9; i++) {
+      const int a = v1[i] < 0 ? -v1[i] : v1[i];
+      float p = L.pow43s[a & (kPow43Small - 1)];
+      if (a >= kPow43Small) p = T.pow43[a > 8206 ? 8206 : a];
+      x1[i] = (g.nch == 2) ? s1[i] * (v1[i] < 0 ? -p : p) : 0.0f;
+    }
+  }
+  if (DUMP) {
+    PD_UNROLL for (int i = 0; i < 9; i++) {
+      dump0[d0 + i] = x0[i];
+      if (g.nch == 2) dump0[4 * 576 + d0 + i] = x1[i];
+    }
+  }
+  if (ms) {   // P:1921-1928
+    PD_UNROLL for (int i = 0; i < 9; i++) {
+      if (d0 + i < cmin) {
+        const float sum = x0[i] + x1[i], dif = x0[i] - x1[i];
+        x0[i] = (float)((double)sum * 0.70710678118654752440);
+        x1[i] = (float)((double)dif * 0.70710678118654752440);
       }
-      if (DUMP) {
-        for (int ch = 0; ch < g.nch; ch++) dump0[ch * 4 * 576 + d] = x[ch];
-      }
-      if (ms && d < cmin) {   // P:1921-1928
-        const float sum = PD_ADD(x[0], x[1]), dif = PD_SUB(x[0], x[1]);
-        x[0] = (float)((double)sum * 0.70710678118654752440);
-        x[1] = (float)((double)dif * 0.70710678118654752440);
-      }
-      if (is) {               // P:1932-1971; block shape taken from channel 0
-        const uint8_t* s0 = L.side[0];
-        const int c1 = g.count1[1];
-        bool do_long = false, do_short = false;
-        int sfb = 0, win = 0;
-        if (kind[0] == 0) {
-          sfb = bandL[d];
-          do_long = (sfb < 21);
-        } else if (kind[0] == 2 && d < 36) {
-          sfb = bandL[d];
-          do_long = (sfb < 8);
-        } else {
-          const int q = bandS[d] - 22;
-          sfb = q / 3; win = q - 3 * sfb;
-          do_short = (sfb < 12) && (kind[0] == 1 || sfb >= 3);
+    }
+  }
+  if (is) {   // P:1932-1971; block shape taken from channel 0.  Rare (no common encoder emits it).
+    const uint8_t* sd0 = L.side[0];
+    const int c1 = g.count1_1;
+    PD_NOUNROLL for (int i = 0; i < 9; i++) {
+      const int d = d0 + i;
+      float a0 = 0.0f, a1 = 0.0f;
+      PD_UNROLL for (int k = 0; k < 9; k++) if (k == i) { a0 = x0[k]; a1 = x1[k]; }
+      bool do_long = false, do_short = false;
+      int sfb = 0, win = 0;
+      if (kind0 == 0) {
+        sfb = L.ltab[0][d] >> 10;
+        do_long = (sfb < 21);
+      } else if (kind0 == 2 && d < 36) {
+        sfb = L.ltab[0][d] >> 10;
+        do_long = (sfb < 8);
+      } else {
+        // band of POSITION d in the un-reordered [win][j] layout (P:2203)
+        PD_NOUNROLL for (int b = 0; b < 13; b++) {
+          const int lo = 3 * cb->sfb_s[g.sfreq][b], hi = 3 * cb->sfb_s[g.sfreq][b + 1];
+          if (d >= lo && d < hi) { sfb = b; win = (d - lo) / ((hi - lo) / 3); }
         }
-        if (do_long && (int)cb->sfb_l[g.sfreq][sfb] >= c1) {
-          const int is_pos = s0[8 + sfb];
-          if (is_pos != 7) {
-            const float l = PD_MUL(cb->isr_l[is_pos & 15], x[0]);
-            const float rr = PD_MUL(cb->isr_r[is_pos & 15], x[0]);
-            x[0] = l;
-            x[1] = rr;
-          }
-        }
-        if (do_short && 3 * (int)cb->sfb_s[g.sfreq][sfb] >= c1) {
-          const int is_pos = s0[30 + sfb * 3 + win];
-          if (is_pos != 7) {   // H3: sample forced through `unsigned` (x86-64 conversion semantics)
-            const float xv = x[0];
-            long long t = (xv >= 9.2233720368547758e18f || xv < -9.2233720368547758e18f || xv != xv)
-                              ? (long long)0x8000000000000000ull : (long long)xv;
-            const float vv = (float)(uint32_t)(unsigned long long)t;
-            x[0] = vv; x[1] = vv;
-          }
+        do_short = (sfb < 12) && (kind0 == 1 || sfb >= 3);
+      }
+      if (do_long && (int)cb->sfb_l[g.sfreq][sfb] >= c1) {
+        const int is_pos = sd0[8 + sfb];
+        if (is_pos != 7) {
+          const float l = cb->isr_l[is_pos & 15] * a0;
+          const float r = cb->isr_r[is_pos & 15] * a0;
+          a0 = l; a1 = r;
         }
       }
-      for (int ch = 0; ch < g.nch; ch++) L.xr[ch][d] = x[ch];
-      if (DUMP) {
-        for (int ch = 0; ch < g.nch; ch++) dump1[ch * 4 * 576 + d] = x[ch];
+      if (do_short && 3 * (int)cb->sfb_s[g.sfreq][sfb] >= c1) {
+        const int is_pos = sd0[30 + sfb * 3 + win];
+        if (is_pos != 7) {   // H3: sample forced through `unsigned` (x86-64 conversion semantics)
+          const float xv = a0;
+          long long t = (xv >= 9.2233720368547758e18f || xv < -9.2233720368547758e18f || xv != xv)
+                            ? (long long)0x8000000000000000ull : (long long)xv;
+          const float vv = (float)(uint32_t)(unsigned long long)t;
+          a0 = vv; a1 = vv;
+        }
       }
+      PD_UNROLL for (int k = 0; k < 9; k++) if (k == i) { x0[k] = a0; x1[k] = a1; }
+    }
+  }
+  PD_UNROLL for (int i = 0; i < 9; i++) {
+    L.xr[0][d0 + i] = x0[i];
+    if (g.nch == 2) L.xr[1][d0 + i] = x1[i];
+  }
+  if (DUMP) {
+    PD_UNROLL for (int i = 0; i < 9; i++) {
+      dump1[d0 + i] = x0[i];
+      if (g.nch == 2) dump1[4 * 576 + d0 + i] = x1[i];
     }
   }
 }
 
 // ---------------------------------------------------------------------------
-// ph_imdct: antialias (fused) + IMDCT + window + overlap-add + freq inversion
+// ph_fetch: IMDCT operand fetch with the alias-reduction butterflies folded in
 // ---------------------------------------------------------------------------
 template <bool DUMP>
 PD_FN void ph_fetch(int lane, const WaveLds& L, LaneRegs& R, BankPtr cb, float* dump2) {
@@ -332,69 +403,99 @@ PD_FN void ph_fetch(int lane, const WaveLds& L, LaneRegs& R, BankPtr cb, float* 
   const bool shrt = g.is_short(ch), mixed = g.is_mixed(ch);
   const float* x = L.xr[ch];
   float* in = R.in;
-  for (int m = 0; m < 18; m++) in[m] = x[18 * sb + m];
+  PD_UNROLL for (int m = 0; m < 18; m++) in[m] = x[18 * sb + m];
   // P:1706-1732: butterflies across the boundary below (index sb) and above (sb+1)
   const bool aa_lo = (sb >= 1) && (!shrt || (mixed && sb == 1));
   const bool aa_hi = (sb <= 30) && (!shrt || (mixed && sb == 0));
   if (aa_lo) {
-    for (int i = 0; i < 8; i++) {
+    PD_UNROLL for (int i = 0; i < 8; i++) {
       const float lo = x[18 * sb - 1 - i];
-      in[i] = PD_ADD(PD_MUL(in[i], cb->cs[i]), PD_MUL(lo, cb->ca[i]));           // ub, P:1726
+      in[i] = in[i] * cb->cs[i] + lo * cb->ca[i];                 // ub, P:1726
     }
   }
   if (aa_hi) {
-    for (int i = 0; i < 8; i++) {
+    PD_UNROLL for (int i = 0; i < 8; i++) {
       const float up = x[18 * (sb + 1) + i];
-      in[17 - i] = PD_SUB(PD_MUL(in[17 - i], cb->cs[i]), PD_MUL(up, cb->ca[i]));  // lb, P:1725
+      in[17 - i] = in[17 - i] * cb->cs[i] - up * cb->ca[i];       // lb, P:1725
     }
   }
   if (DUMP) {
-    for (int m = 0; m < 18; m++) dump2[ch * 4 * 576 + 18 * sb + m] = in[m];
+    PD_UNROLL for (int m = 0; m < 18; m++) dump2[ch * 4 * 576 + 18 * sb + m] = in[m];
   }
 }
 
+// ---------------------------------------------------------------------------
+// ph_imdct: 18 -> 36 IMDCT (or 3 x 6 -> 12), window, overlap-add, freq inversion
+// ---------------------------------------------------------------------------
 template <bool DUMP>
 PD_FN void ph_imdct(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, float* dump3) {
   const GranuleInfo g = granule_info(L);
   const int ch = lane >> 5, sb = lane & 31;
-  if (ch >= g.nch) return;
+  const bool active = ch < g.nch;
   const bool mixed = g.is_mixed(ch);
-  const bool wsf = (g.flags[ch] & PDMP3_GC_WIN_SWITCH) != 0;
+  const bool wsf = (g.flags(ch) & PDMP3_GC_WIN_SWITCH) != 0;
   const float* in = R.in;
   const int bt = (wsf && mixed && sb < 2) ? 0 : g.block_type(ch);   // P:1769-1771
   const bool odd_sb = sb & 1;
-  float res[18];
-  if (bt != 2) {
-    // out[p] = (sum_m in[m] cos_N36[m][p]) * win[bt][p]  (P:1689-1698); the 18
-    // coefficients of one p are wave-uniform => scalar operands.
-    for (int p = 0; p < 18; p++) {
-      float sa = 0.0f, sb2 = 0.0f;
-      for (int m = 0; m < 18; m++) {
-        sa = PD_FMA(in[m], cb->c36t[p][m], sa);
-        sb2 = PD_FMA(in[m], cb->c36t[p + 18][m], sb2);
+  float res[18], nov[18];
+  {
+    // Long transform, executed by every lane in straight-line code (lanes of a
+    // short-block channel discard it below): out[p] = (sum_m in[m] cos_N36[m][p]) * win[bt][p]
+    // (P:1689-1698), all 36 sums advance together, m ascending as in the
+    // reference.  The coefficients of one m are wave-uniform => scalar operands,
+    // fetched one unit (9 output pairs) ahead of their use; the fences keep the
+    // scheduler from clustering all 648 scalar loads up front (SGPR spills).
+    float lo[18], hi[18];
+    PD_UNROLL for (int q = 0; q < 18; q++) { lo[q] = 0.0f; hi[q] = 0.0f; }
+    float ca[18], cn[18];
+    const auto* cflat = &cb->c36p[0][0][0];
+    PD_UNROLL for (int k = 0; k < 18; k++) ca[k] = cflat[k];
+    PD_UNROLL for (int u = 0; u < 36; u += 2) {
+      const int m = u >> 1;
+      PD_UNROLL for (int k = 0; k < 18; k++) cn[k] = cflat[(u + 1) * 18 + k];
+      PD_UNROLL for (int q = 0; q < 9; q++) {
+        lo[q] = PD_FMA(in[m], ca[2 * q], lo[q]);
+        hi[q] = PD_FMA(in[m], ca[2 * q + 1], hi[q]);
       }
-      const float w0 = (bt == 0) ? cb->win[0][p] : ((bt == 1) ? cb->win[1][p] : cb->win[3][p]);
-      const float w1 = (bt == 0) ? cb->win[0][p + 18] : ((bt == 1) ? cb->win[1][p + 18] : cb->win[3][p + 18]);
-      res[p] = sa * w0 + R.ovl[p];                                             // P:1775
-      R.ovl[p] = sb2 * w1;                                                     // P:1776
-      if ((p & 1) == 1) PD_SCHED_FENCE();
+      PD_UNROLL for (int q = 0; q < 9; q++) { PD_PIN(lo[q]); PD_PIN(hi[q]); }
+      PD_SCHED_FENCE();
+      if (u + 2 < 36) {
+        PD_UNROLL for (int k = 0; k < 18; k++) ca[k] = cflat[(u + 2) * 18 + k];
+      }
+      PD_UNROLL for (int q = 0; q < 9; q++) {
+        lo[9 + q] = PD_FMA(in[m], cn[2 * q], lo[9 + q]);
+        hi[9 + q] = PD_FMA(in[m], cn[2 * q + 1], hi[9 + q]);
+      }
+      PD_UNROLL for (int q = 0; q < 9; q++) { PD_PIN(lo[9 + q]); PD_PIN(hi[9 + q]); }
+      PD_SCHED_FENCE();
     }
-  } else {
-    float raw[36];
-    for (int p = 0; p < 36; p++) raw[p] = 0.0f;
-    for (int wn = 0; wn < 3; wn++)                                             // P:1675-1685
-      for (int p = 0; p < 12; p++) {
-        float sum = 0.0f;
-        for (int m = 0; m < 6; m++) sum = PD_FMA(in[wn + 3 * m], cb->c12t[p][m], sum);
-        raw[6 * wn + p + 6] += sum * cb->win[2][p];
-      }
-    for (int p = 0; p < 18; p++) { res[p] = raw[p] + R.ovl[p]; R.ovl[p] = raw[p + 18]; }
+    const float* w = L.win[bt == 2 ? 0 : bt];
+    PD_UNROLL for (int q = 0; q < 18; q++) {
+      res[q] = lo[q] * w[q] + R.ovl[q];                                        // P:1775
+      nov[q] = hi[q] * w[q + 18];                                              // P:1776
+    }
   }
-  for (int p = 0; p < 18; p++) {
+  if (g.is_short(0) || g.is_short(1)) {      // wave-uniform: some lanes need the 3 x 12-point transform
+    if (bt == 2) {
+      float raw[36];
+      PD_UNROLL for (int p = 0; p < 36; p++) raw[p] = 0.0f;
+      PD_UNROLL for (int wn = 0; wn < 3; wn++)                                 // P:1675-1685
+        PD_UNROLL for (int p = 0; p < 12; p++) {
+          float sum = 0.0f;
+          PD_UNROLL for (int m = 0; m < 6; m++) sum = PD_FMA(in[wn + 3 * m], cb->c12t[p][m], sum);
+          raw[6 * wn + p + 6] += sum * L.win[2][p];
+        }
+      PD_UNROLL for (int p = 0; p < 18; p++) { res[p] = raw[p] + R.ovl[p]; nov[p] = raw[p + 18]; }
+    }
+  }
+  // lanes of the unused channel of a mono frame keep their overlap (the state of
+  // channel 1 survives mono frames, as in the reference) and write a dead hyb row
+  PD_UNROLL for (int p = 0; p < 18; p++) {
+    R.ovl[p] = active ? nov[p] : R.ovl[p];
     float y = res[p];
     if (odd_sb && (p & 1)) y = -y;                                             // P:1738-1746
     L.hyb[ch][p][sb] = y;
-    if (DUMP) dump3[ch * 4 * 576 + 18 * sb + p] = y;
+    if (DUMP) { if (active) dump3[ch * 4 * 576 + 18 * sb + p] = y; }
     if (lane == 0 && p < 3) L.peek[p] = y;                                     // H5 source
   }
 }
@@ -415,13 +516,13 @@ PD_FN void dct2_lee(const float* in, float* out) {
     out[0] = in[0];
   } else {
     float a[N / 2], b[N / 2], A[N / 2], B[N / 2];
-    for (int n = 0; n < N / 2; n++) {
+    PD_UNROLL for (int n = 0; n < N / 2; n++) {
       a[n] = in[n] + in[N - 1 - n];
       b[n] = (in[n] - in[N - 1 - n]) * LeeC<N>::v[n];
     }
     dct2_lee<N / 2>(a, A);
     dct2_lee<N / 2>(b, B);
-    for (int k = 0; k < N / 2; k++) {
+    PD_UNROLL for (int k = 0; k < N / 2; k++) {
       out[2 * k] = A[k];
       out[2 * k + 1] = (k + 1 < N / 2) ? B[k] + B[k + 1] : B[k];
     }
@@ -433,9 +534,9 @@ PD_FN void ph_dct32(int lane, WaveLds& L) {
   if (lane >= 18 * g.nch) return;
   const int ch = lane / 18, t = lane - 18 * ch;
   float x[32], c[32];
-  for (int j = 0; j < 32; j++) x[j] = L.hyb[ch][t][j];
+  PD_UNROLL for (int j = 0; j < 32; j++) x[j] = L.hyb[ch][t][j];
   dct2_lee<32>(x, c);
-  for (int n = 0; n < 32; n++) L.hyb[ch][t][n] = c[n];   // in place: the row now holds the slot's C[0..31]
+  PD_UNROLL for (int n = 0; n < 32; n++) L.hyb[ch][t][n] = c[n];   // in place: the row now holds the slot's C[0..31]
 }
 
 // float -> int16 exactly as P:2028-2031 on x86-64 (cvttsd2si: out of range => INT32_MIN)
@@ -455,23 +556,23 @@ PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R) {
   if (ch >= g.nch) return;
   // E[s], O[s]: the lane's two coefficients of slot s; s = 0..14 history, 15..32 this granule
   float E[kHistSlots + 18], O[kHistSlots + 18];
-  for (int s = 0; s < kHistSlots; s++) { E[s] = R.he[s]; O[s] = R.ho[s]; }
-  for (int t = 0; t < 18; t++) {
+  PD_UNROLL for (int s = 0; s < kHistSlots; s++) { E[s] = R.he[s]; O[s] = R.ho[s]; }
+  PD_UNROLL for (int t = 0; t < 18; t++) {
     E[kHistSlots + t] = L.hyb[ch][t][R.idx_e];
     O[kHistSlots + t] = L.hyb[ch][t][R.idx_o];
   }
   int16_t out[18];
-  for (int t = 0; t < 18; t++) {
+  PD_UNROLL for (int t = 0; t < 18; t++) {
     float sum = 0.0f;
-    for (int k = 0; k < 8; k++) {     // P:2021-2026: u[32j+i], j = 2k (age 2k), 2k+1 (age 2k+1)
+    PD_UNROLL for (int k = 0; k < 8; k++) {     // P:2021-2026: u[32j+i], j = 2k (age 2k), 2k+1 (age 2k+1)
       sum = PD_FMA(R.we[k], E[kHistSlots + t - 2 * k], sum);
       sum = PD_FMA(R.wo[k], O[kHistSlots + t - 2 * k - 1], sum);
     }
     out[t] = (int16_t)pcm_from_sum(sum);
   }
-  for (int s = 0; s < kHistSlots; s++) { R.he[s] = E[18 + s]; R.ho[s] = O[18 + s]; }
+  PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = E[18 + s]; R.ho[s] = O[18 + s]; }
   // pcm aliases spec, which is dead since ph_requant; hyb reads above are done
-  for (int t = 0; t < 18; t++) L.pcm[(t * 32 + i) * g.nch + ch] = out[t];
+  PD_UNROLL for (int t = 0; t < 18; t++) L.pcm[(t * 32 + i) * g.nch + ch] = out[t];
 }
 
 // PCM: granule = 576 sample-frames = 1152*nch bytes
@@ -500,7 +601,10 @@ struct DecodeArgs {
   float* stages;                 // [n_frames][2][2][4][576] or null (DUMP builds)
   int n_frames;
   int chunk_frames;
+  unsigned long long* prof;      // PROF builds: [n_chunks][kProfSlots] shader-clock ticks per phase
 };
+
+constexpr int kProfSlots = 10;
 
 #if defined(__HIPCC__)
 #define PD_NLANES 1
@@ -522,7 +626,7 @@ struct DecodeArgs {
   }
 #endif
 
-template <bool DUMP>
+template <bool DUMP, bool PROF = false>
 PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveLds& L) {
   LaneRegs Rs[PD_NLANES];
   const int f0 = chunk * a.chunk_frames;
@@ -531,29 +635,63 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   const int g_begin = 2 * f0, g_end = 2 * f1;
   const int g_start = (chunk == 0) ? 0 : g_begin - kHaloGranules;
   const bool last = (f1 == a.n_frames);
+  int cur_sfreq = -1;
 
   PD_PHASE(
-    lane_init(lane, R, cb);
+    ph_prefetch(lane, R, a.spectra + (size_t)g_start * 1152, a.side + (size_t)g_start * 2);
+    lane_init(lane, L, R, cb, T);
     if (chunk == 0 && a.state_in) state_load(lane, R, a.state_in);
-    if (lane < 4) L.peek[lane] = 1.0f;
   )
+  unsigned long long acc[kProfSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = PD_CLOCK();
+#define PD_TICK(k) if (PROF) { const unsigned long long tn_ = PD_CLOCK(); acc[k] += tn_ - tprev; tprev = tn_; }
   for (int g = g_start; g < g_end; ++g) {
     const int f = g >> 1, gr = g & 1;
     PD_LAUNDER(cb);
-    PD_PHASE(ph_load(lane, L, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2))
+    PD_PHASE(ph_commit(lane, L, R))
+    {
+      int sf = L.side[0][7] & PDMP3_FR_SFREQ_MASK;
+      if (sf > 2) sf = 2;
+      if (sf != cur_sfreq) {          // wave-uniform: first granule, or the stream changed sampling rate
+        PD_PHASE(load_linetab(lane, L, T, sf))
+        cur_sfreq = sf;
+      }
+    }
+    PD_TICK(0)
     PD_PHASE(
       if (gr == 0 && (L.side[0][7] & PDMP3_FR_RESET)) state_zero(lane, R);
-      ph_scales(lane, L, cb);
+      ph_scales(lane, L);
     )
+    PD_TICK(1)
     float* dmp = DUMP ? a.stages + ((size_t)f * 16 + gr * 8) * 576 : nullptr;
     PD_PHASE(ph_requant<DUMP>(lane, L, cb, T, dmp, dmp + 576))
-    PD_PHASE(ph_fetch<DUMP>(lane, L, R, cb, dmp + 2 * 576))
+    PD_TICK(2)
+    PD_PHASE(
+      // the next granule's HBM reads fly during this granule's transforms
+      if (g + 1 < g_end) ph_prefetch(lane, R, a.spectra + (size_t)(g + 1) * 1152, a.side + (size_t)(g + 1) * 2);
+      ph_fetch<DUMP>(lane, L, R, cb, dmp + 2 * 576);
+    )
+    PD_TICK(3)
     PD_PHASE(ph_imdct<DUMP>(lane, L, R, cb, dmp + 3 * 576))
+    PD_TICK(4)
     PD_PHASE(ph_dct32(lane, L))
+    PD_TICK(5)
     PD_PHASE(ph_window(lane, L, R))
+    PD_TICK(6)
     PD_PHASE(
       const int nch = ((L.side[0][7] & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
       ph_store(lane, L, a.pcm + (size_t)f * 2304 + gr * 576 * nch, g >= g_begin);
+    )
+    PD_TICK(7)
+  }
+#undef PD_TICK
+  if (PROF) {
+    PD_PHASE(
+      if (lane == 0) {
+        for (int k = 0; k < 8; k++) a.prof[(size_t)chunk * kProfSlots + k] = acc[k];
+        a.prof[(size_t)chunk * kProfSlots + 8] = (unsigned long long)(g_end - g_start);
+        a.prof[(size_t)chunk * kProfSlots + 9] = PD_CLOCK();
+      }
     )
   }
   if (last && a.state_out) {

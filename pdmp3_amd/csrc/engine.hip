@@ -31,6 +31,12 @@ __global__ __launch_bounds__(64, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a,
   run_chunk<DUMP>(a, T, (BankPtr)&c_bank, (int)blockIdx.x, L);
 }
 
+// same kernel with shader-clock stamps after every phase (tools/phase_profile.py)
+__global__ __launch_bounds__(64, PDMP3_WAVES_PER_EU) void k_decode_prof(DecodeArgs a, GlobalTables T) {
+  __shared__ WaveLds L;
+  run_chunk<false, true>(a, T, (BankPtr)&c_bank, (int)blockIdx.x, L);
+}
+
 __global__ __launch_bounds__(64) void k_generate(uint64_t seed, int64_t first, int16_t* spectra, pdmp3_gc_side* side) {
   const int64_t gc = blockIdx.x;           // (frame_local*4 + gr*2 + ch)
   const int64_t f = gc >> 2;
@@ -41,8 +47,8 @@ __global__ __launch_bounds__(64) void k_generate(uint64_t seed, int64_t first, i
 struct pdmp3_hip_ctx {
   int device;
   float* d_pow43;
-  uint8_t* d_band;
-  uint16_t* d_src_idx;
+  uint16_t* d_linetab;
+  float* d_win;
   float* d_state_tmp;
 };
 
@@ -73,13 +79,17 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
   if (!c) return fail(PDMP3_HIP_ENOMEM, "calloc", hipSuccess);
   c->device = device;
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_bank), &H.cb, sizeof(ConstBank)), "upload const bank");
+  if (!H.ldexp_forms_exact) {
+    free(c);
+    return fail(PDMP3_HIP_EDEVICE, "this host's libm pow() disagrees with the device's ldexp forms of 2^(k/4), 2^(-n/2)", hipSuccess);
+  }
   HIP_TRY(hipMalloc(&c->d_pow43, H.pow43.size() * sizeof(float)), "hipMalloc pow43");
-  HIP_TRY(hipMalloc(&c->d_band, H.band.size()), "hipMalloc band");
-  HIP_TRY(hipMalloc(&c->d_src_idx, H.src_idx.size() * sizeof(uint16_t)), "hipMalloc src_idx");
+  HIP_TRY(hipMalloc(&c->d_linetab, H.linetab.size() * sizeof(uint16_t)), "hipMalloc linetab");
+  HIP_TRY(hipMalloc(&c->d_win, H.win.size() * sizeof(float)), "hipMalloc win");
   HIP_TRY(hipMalloc(&c->d_state_tmp, pdmp3_hip_state_bytes()), "hipMalloc state");
   HIP_TRY(hipMemcpy(c->d_pow43, H.pow43.data(), H.pow43.size() * sizeof(float), hipMemcpyHostToDevice), "upload pow43");
-  HIP_TRY(hipMemcpy(c->d_band, H.band.data(), H.band.size(), hipMemcpyHostToDevice), "upload band");
-  HIP_TRY(hipMemcpy(c->d_src_idx, H.src_idx.data(), H.src_idx.size() * sizeof(uint16_t), hipMemcpyHostToDevice), "upload src_idx");
+  HIP_TRY(hipMemcpy(c->d_linetab, H.linetab.data(), H.linetab.size() * sizeof(uint16_t), hipMemcpyHostToDevice), "upload linetab");
+  HIP_TRY(hipMemcpy(c->d_win, H.win.data(), H.win.size() * sizeof(float), hipMemcpyHostToDevice), "upload win");
   HIP_TRY(hipDeviceSynchronize(), "sync after uploads");
   *out = c;
   return PDMP3_HIP_OK;
@@ -89,8 +99,8 @@ extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_pow43);
-  (void)hipFree(c->d_band);
-  (void)hipFree(c->d_src_idx);
+  (void)hipFree(c->d_linetab);
+  (void)hipFree(c->d_win);
   (void)hipFree(c->d_state_tmp);
   free(c);
 }
@@ -105,9 +115,12 @@ static int auto_chunk(int n_frames) {
 }
 
 static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3_gc_side* d_side, int n_frames,
-                         void* d_state, int16_t* d_pcm, float* d_stages, int chunk_frames, void* stream) {
-  if (!c || !d_spectra || !d_side || !d_pcm || n_frames < 0)
-    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: bad argument", hipSuccess);
+                         void* d_state, int16_t* d_pcm, float* d_stages, int chunk_frames, void* stream,
+                         unsigned long long* d_prof = nullptr) {
+  if (!c || n_frames < 0) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: bad argument", hipSuccess);
+  if (n_frames == 0) return PDMP3_HIP_OK;
+  if (!d_spectra || !d_side || !d_pcm)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: NULL buffer", hipSuccess);
   if (((uintptr_t)d_spectra | (uintptr_t)d_side | (uintptr_t)d_pcm) & 15)
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: buffers must be 16-byte aligned", hipSuccess);
   if (n_frames == 0) return PDMP3_HIP_OK;
@@ -125,8 +138,10 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.stages = d_stages;
   a.n_frames = n_frames;
   a.chunk_frames = chunk_frames;
-  GlobalTables T{c->d_pow43, c->d_band, c->d_src_idx};
-  if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T);
+  a.prof = d_prof;
+  GlobalTables T{c->d_pow43, c->d_linetab, c->d_win};
+  if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
+  else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T);
   else hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), 0, s, a, T);
   HIP_TRY(hipGetLastError(), "launch k_decode");
   if (d_state)
@@ -165,4 +180,13 @@ extern "C" int pdmp3_host_generate_frames(uint64_t seed, int64_t first_frame, in
         gen_gc(seed, first_frame + f, (unsigned)(gc >> 1), (unsigned)(gc & 1), lane,
                spectra + ((size_t)f * 4 + gc) * 576, side + (size_t)f * 4 + gc);
   return PDMP3_HIP_OK;
+}
+
+// Debug/profiling entry (not part of the product boundary): per-chunk shader-clock
+// ticks spent in each pipeline phase.  d_prof: uint64 [n_chunks][10].
+extern "C" int pdmp3_hip_debug_profile_phases(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,
+                                              int n_frames, int16_t* d_pcm, int chunk_frames,
+                                              unsigned long long* d_prof, void* stream) {
+  if (!d_prof) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_debug_profile_phases: d_prof is NULL", hipSuccess);
+  return launch_decode(ctx, d_spectra, d_side, n_frames, nullptr, d_pcm, nullptr, chunk_frames, stream, d_prof);
 }

@@ -47,6 +47,9 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own HIP runtime; import it first so that both share ONE
+    # runtime instance in this process (a second copy does not see the device).
+    import torch  # noqa: F401
     path = library_path()
     if not os.path.exists(path):
         raise RuntimeError(

@@ -17,10 +17,10 @@ extern "C" int emul_decode_frames(const int16_t* spectra, const pdmp3_gc_side* s
   static HostTables H;
   static bool ready = false;
   if (!ready) { build_host_tables(H); ready = true; }
-  GlobalTables T{H.pow43.data(), H.band.data(), H.src_idx.data()};
+  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data()};
   if (chunk_frames <= 0) chunk_frames = n_frames;
   if (stages) chunk_frames = n_frames;
-  DecodeArgs a{spectra, side, pcm, state, state, stages, n_frames, chunk_frames};
+  DecodeArgs a{spectra, side, pcm, state, state, stages, n_frames, chunk_frames, nullptr};
   const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
   auto L = std::make_unique<WaveLds>();
   // the final state is written by the last chunk; the first reads it: run the
@@ -43,10 +43,12 @@ extern "C" void emul_generate_frames(uint64_t seed, int64_t first, int n, int16_
         gen_gc(seed, first + f, gc >> 1, gc & 1, lane, spectra + ((size_t)f * 4 + gc) * 576, side + (size_t)f * 4 + gc);
 }
 
+extern "C" int emul_ldexp_forms_exact() { static HostTables H; build_host_tables(H); return H.ldexp_forms_exact ? 1 : 0; }
+
 extern "C" void emul_tables(float* pow43, float* t1, float* t2) {
   static HostTables H;
   build_host_tables(H);
   memcpy(pow43, H.pow43.data(), 8207 * 4);
-  memcpy(t1, H.cb.t1, sizeof H.cb.t1);
-  memcpy(t2, H.cb.t2, sizeof H.cb.t2);
+  memcpy(t1, H.t1.data(), kT1Size * 4);
+  memcpy(t2, H.t2.data(), kT2Size * 4);
 }

@@ -45,3 +45,4 @@ def test_libm_tables(oracle, emul):
     assert zlib.crc32(t2.tobytes()) & 0xFFFFFFFF == 0x34D802C9       # 2^(k/4), k = -266..45
     assert zlib.crc32(t1[:37].tobytes()) & 0xFFFFFFFF == 0xE8D0EE70  # 2^(-n/2), n = 0..36
     assert t1[299] > 0 and t1[300] == 0                               # binary32 underflow point
+    assert emul.emul_ldexp_forms_exact() == 1                        # device ldexp forms == libm pow, whole range

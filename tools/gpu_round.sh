@@ -23,5 +23,5 @@ d = json.loads(sys.stdin.read())
 print('chunk', '$c', 'fps', d['value'], 'ms/step', d['ms_per_step'], 'frac', d['roofline']['frac'], 'big', d.get('roofline_large_batch'))
 "; done 2>&1 | tee $OUT/chunk_sweep.txt
 echo "== rocprof"
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu --big 131072 > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu --big 131072 > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"
 find $OUT/prof -name "*stats*" | head; for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do cat $f; done
