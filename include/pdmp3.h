@@ -1,0 +1,58 @@
+/*
+ * pdmp3.h -- the libmpg123-style streaming API of technosaurus/PDMP3
+ * (pdmp3.c:115-157), implemented by pdmp3_amd/libpdmp3.so with the Layer-III
+ * transforms running on an MI355X through include/pdmp3_hip.h.
+ *
+ * Same names, argument meaning, return codes and error behaviour as the
+ * reference so that its `main.c` (and any libmpg123-feed-style caller) links
+ * against this library unchanged:
+ *
+ *   pdmp3_new        pdmp3.c:2351     pdmp3_delete     pdmp3.c:2360
+ *   pdmp3_open_feed  pdmp3.c:2369     pdmp3_feed       pdmp3.c:2391
+ *   pdmp3_read       pdmp3.c:2431     pdmp3_decode     pdmp3.c:2491
+ *   pdmp3_getformat  pdmp3.c:2526     pdmp3            pdmp3.c:2540
+ *
+ * Differences by design: the handle is opaque (the reference exposes its
+ * struct, pdmp3.c:124-148, but no caller touches it); synthesis state is per
+ * handle instead of process-global; the handle starts zeroed
+ * (H13).  There is no CPU decode path: pdmp3_new() returns NULL (and sets
+ * *error when given) if no HIP device / engine library is available.
+ */
+#ifndef PDMP3_H
+#define PDMP3_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDMP3_OK           0
+#define PDMP3_ERR         -1
+#define PDMP3_NEED_MORE  -10
+#define PDMP3_NEW_FORMAT -11
+#define PDMP3_NO_SPACE     7
+
+#define PDMP3_ENC_SIGNED_16 (0x080|0x040|0x10)
+
+typedef struct pdmp3_handle pdmp3_handle;
+
+pdmp3_handle* pdmp3_new(const char* decoder, int* error);
+void pdmp3_delete(pdmp3_handle* id);
+int pdmp3_open_feed(pdmp3_handle* id);
+int pdmp3_feed(pdmp3_handle* id, const unsigned char* in, size_t size);
+int pdmp3_read(pdmp3_handle* id, unsigned char* outmemory, size_t outsize, size_t* done);
+int pdmp3_decode(pdmp3_handle* id, const unsigned char* in, size_t insize,
+                 unsigned char* out, size_t outsize, size_t* done);
+int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding);
+
+/* CLI driver: NULL-terminated list of .mp3 paths ("-" = stdin); writes
+ * <first file>.raw (interleaved native-endian int16), as the reference's
+ * OUTPUT_RAW build does (pdmp3.c:2236-2257).  A leading "/dev/dsp*" argument
+ * is accepted and ignored (OSS playback is out of scope). */
+void pdmp3(char* const* mp3s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

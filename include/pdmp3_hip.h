@@ -154,6 +154,27 @@ int pdmp3_hip_generate_frames(pdmp3_hip_ctx* ctx,
                               pdmp3_gc_side* d_side,
                               void* stream);
 
+/* ------------------------------------------------------------------------
+ * Host-buffer streaming helper: what the libmpg123-style API (include/pdmp3.h,
+ * pdmp3_read) drives.  One pdmp3_hip_stream = one decoder handle's device
+ * state (overlap + polyphase history), a HIP stream and pinned, library-owned
+ * staging buffers; the sequential Huffman stage on the host fills gc records,
+ * this call moves them with hipMemcpyAsync, runs the transforms and brings the
+ * PCM back.  Replaces `Decode_L3(id)` at pdmp3.c:2453 for a batch of frames.
+ * ---------------------------------------------------------------------- */
+typedef struct pdmp3_hip_stream pdmp3_hip_stream;
+
+int pdmp3_hip_stream_create(pdmp3_hip_ctx* ctx, int max_frames, pdmp3_hip_stream** out);
+void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs);
+/* zero the carried synthesis state (pdmp3_open_feed, pdmp3.c:2377-2378) */
+int pdmp3_hip_stream_reset(pdmp3_hip_stream* hs);
+/* pinned staging buffers to fill / read: capacity max_frames frames each */
+int16_t* pdmp3_hip_stream_spectra(pdmp3_hip_stream* hs);
+pdmp3_gc_side* pdmp3_hip_stream_side(pdmp3_hip_stream* hs);
+const int16_t* pdmp3_hip_stream_pcm(pdmp3_hip_stream* hs);
+/* decode frames [0, n_frames) of the staging buffers; synchronous */
+int pdmp3_hip_stream_decode(pdmp3_hip_stream* hs, int n_frames);
+
 /* Host-side twin of the generator (fills host buffers); used to build
  * identical inputs for the CPU baseline without a device round trip. */
 int pdmp3_host_generate_frames(uint64_t seed, int64_t first_frame, int n_frames,

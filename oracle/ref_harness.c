@@ -135,7 +135,8 @@ static void ref_tap_frame(pdmp3_handle* id, int16_t* spectra, pdmp3_gc_side* sd)
       int16_t* sp = spectra + (gr * 2 + ch) * 576;
       s->frame = (uint8_t)((id->g_frame_header.sampling_frequency & 3) |
                            ((id->g_frame_header.mode & 3) << PDMP3_FR_MODE_SHIFT) |
-                           ((id->g_frame_header.mode_extension & 3) << PDMP3_FR_MODEEXT_SHIFT));
+                           ((id->g_frame_header.mode_extension & 3) << PDMP3_FR_MODEEXT_SHIFT) |
+                           ((id->hsynth_init || id->synth_init) ? PDMP3_FR_RESET : 0));
       if (ch >= nch) continue;
       for (unsigned i = 0; i < 576; i++) sp[i] = (int16_t)id->g_main_data.is[gr][ch][i];
       s->count1 = (uint16_t)id->g_side_info.count1[gr][ch];

@@ -1,0 +1,148 @@
+"""ctypes mirror of include/pdmp3.h (pdmp3_amd/libpdmp3.so): the reference's
+libmpg123-style streaming API, names and semantics unchanged.  Used by tests
+and examples; the library itself is plain C."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .hip import SIDE_DTYPE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PDMP3_OK, PDMP3_ERR, PDMP3_NEED_MORE, PDMP3_NEW_FORMAT, PDMP3_NO_SPACE = 0, -1, -10, -11, 7
+PDMP3_ENC_SIGNED_16 = 0xD0
+_LIB = None
+
+API_EXPORTS = ["pdmp3_new", "pdmp3_delete", "pdmp3_open_feed", "pdmp3_feed", "pdmp3_read",
+               "pdmp3_decode", "pdmp3_getformat", "pdmp3"]
+
+
+def library_path():
+    return os.path.join(_HERE, "libpdmp3.so")
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    import torch  # noqa: F401  (one HIP runtime per process: torch's, loaded first)
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError("pdmp3_amd: %s is missing -- run __graft_entry__.build()" % path)
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.pdmp3_new.restype = vp
+    lib.pdmp3_new.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    lib.pdmp3_delete.argtypes = [vp]
+    lib.pdmp3_open_feed.argtypes = [vp]
+    lib.pdmp3_feed.argtypes = [vp, vp, C.c_size_t]
+    lib.pdmp3_read.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.pdmp3_decode.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.pdmp3_getformat.argtypes = [vp, C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.pdmp3_amd_new_parse_only.restype = vp
+    lib.pdmp3_amd_set_tap.argtypes = [vp, vp, vp, C.c_int]
+    lib.pdmp3_amd_tap_count.argtypes = [vp]
+    lib.pdmp3_amd_parse_available.argtypes = [vp]
+    _LIB = lib
+    return lib
+
+
+class Decoder:
+    """pdmp3_handle wrapper.  parse_only=True gives the GPU-less test handle."""
+
+    def __init__(self, parse_only=False):
+        self.lib = load_library()
+        if parse_only:
+            self.h = self.lib.pdmp3_amd_new_parse_only()
+        else:
+            err = C.c_int(0)
+            self.h = self.lib.pdmp3_new(None, C.byref(err))
+        if not self.h:
+            raise RuntimeError("pdmp3_new failed (no MI355X transform engine; there is no CPU fallback)")
+        self.lib.pdmp3_open_feed(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.pdmp3_delete(self.h)
+            self.h = None
+
+    def open_feed(self):
+        return self.lib.pdmp3_open_feed(self.h)
+
+    def feed(self, data: bytes):
+        buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+        return self.lib.pdmp3_feed(self.h, buf, len(data))
+
+    def read(self, outsize):
+        out = (C.c_ubyte * outsize)()
+        done = C.c_size_t(0)
+        rc = self.lib.pdmp3_read(self.h, out, outsize, C.byref(done))
+        return rc, bytes(out[:done.value])
+
+    def decode(self, data: bytes, outsize):
+        buf = (C.c_ubyte * max(1, len(data))).from_buffer_copy(data or b"\0")
+        out = (C.c_ubyte * outsize)() if outsize else None
+        done = C.c_size_t(0)
+        rc = self.lib.pdmp3_decode(self.h, buf, len(data), out, outsize, C.byref(done))
+        return rc, bytes(out[:done.value]) if outsize else b""
+
+    def getformat(self):
+        rate, ch, enc = C.c_long(0), C.c_int(0), C.c_int(0)
+        rc = self.lib.pdmp3_getformat(self.h, C.byref(rate), C.byref(ch), C.byref(enc))
+        return rc, rate.value, ch.value, enc.value
+
+    def set_tap(self, cap_frames):
+        self._tap_sp = np.zeros((cap_frames, 2, 2, 576), dtype=np.int16)
+        self._tap_sd = np.zeros((cap_frames, 2, 2), dtype=SIDE_DTYPE)
+        self.lib.pdmp3_amd_set_tap(self.h, self._tap_sp.ctypes.data_as(C.c_void_p),
+                                   self._tap_sd.ctypes.data_as(C.c_void_p), cap_frames)
+
+    def tap(self):
+        n = min(self.lib.pdmp3_amd_tap_count(self.h), self._tap_sp.shape[0])
+        return self._tap_sp[:n], self._tap_sd[:n]
+
+    def parse_available(self):
+        return self.lib.pdmp3_amd_parse_available(self.h)
+
+
+def decode_like_cli(mp3: bytes, dec: "Decoder" = None):
+    """The CLI driver loop pdmp3() (pdmp3.c:2552-2587) over a memory buffer."""
+    own = dec is None
+    if own:
+        dec = Decoder()
+    dec.open_feed()
+    out, pos = [], 0
+    while True:
+        rc, pcm = dec.read(16384)
+        if rc == PDMP3_ERR:
+            break
+        out.append(pcm)
+        if rc == PDMP3_NEED_MORE:
+            chunk = mp3[pos:pos + 4096]
+            if not chunk:
+                break
+            dec.feed(chunk)
+            pos += len(chunk)
+    if own:
+        dec.close()
+    return b"".join(out)
+
+
+def parse_like_cli(mp3: bytes, cap_frames):
+    """Host stage only (no GPU): records the host parser emits when driven with
+    the CLI's feed cadence."""
+    dec = Decoder(parse_only=True)
+    dec.set_tap(cap_frames)
+    pos = 0
+    while True:
+        rc = dec.parse_available()
+        if rc == PDMP3_ERR:
+            break
+        chunk = mp3[pos:pos + 4096]
+        if not chunk:
+            break
+        dec.feed(chunk)
+        pos += len(chunk)
+    sp, sd = dec.tap()
+    dec.close()
+    return sp.copy(), sd.copy()

@@ -106,10 +106,12 @@ extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
 }
 
 static int auto_chunk(int n_frames) {
-  // enough chunks to put >= 8 waves on each of the 256 CUs, but keep the
-  // 3-granule halo a small fraction of the chunk when the batch allows it.
-  int L = n_frames / 2048;
-  if (L < 4) L = 4;
+  // One wave per chunk: aim for >= 1024 chunks (4 waves on each of the 256 CUs)
+  // before growing the chunk; measured on MI355X (profiles/): a 2048-frame batch
+  // is fastest at 2 frames per chunk despite the 3-granule halo, 10^5+ frames
+  // at 16-32.
+  int L = n_frames / 1024;
+  if (L < 2) L = 2;
   if (L > 32) L = 32;
   return L;
 }
@@ -158,6 +160,79 @@ extern "C" int pdmp3_hip_decode_frames_stages(pdmp3_hip_ctx* ctx, const int16_t*
                                               int n_frames, void* d_state, int16_t* d_pcm, float* d_stages, void* stream) {
   if (!d_stages) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames_stages: d_stages is NULL", hipSuccess);
   return launch_decode(ctx, d_spectra, d_side, n_frames, d_state, d_pcm, d_stages, 0, stream);
+}
+
+// ---------------------------------------------------------------------------
+// host-buffer streaming helper (pinned staging, hipMemcpyAsync both ways)
+// ---------------------------------------------------------------------------
+struct pdmp3_hip_stream {
+  pdmp3_hip_ctx* ctx;
+  int max_frames;
+  hipStream_t stream;
+  int16_t* h_spectra; pdmp3_gc_side* h_side; int16_t* h_pcm;     // pinned
+  int16_t* d_spectra; pdmp3_gc_side* d_side; int16_t* d_pcm;
+  float* d_state;
+};
+
+extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
+  if (!hs) return;
+  (void)hipSetDevice(hs->ctx->device);
+  if (hs->stream) (void)hipStreamDestroy(hs->stream);
+  (void)hipHostFree(hs->h_spectra); (void)hipHostFree(hs->h_side); (void)hipHostFree(hs->h_pcm);
+  (void)hipFree(hs->d_spectra); (void)hipFree(hs->d_side); (void)hipFree(hs->d_pcm); (void)hipFree(hs->d_state);
+  free(hs);
+}
+
+extern "C" int pdmp3_hip_stream_create(pdmp3_hip_ctx* ctx, int max_frames, pdmp3_hip_stream** out) {
+  if (!ctx || !out || max_frames < 1) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_create: bad argument", hipSuccess);
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+  pdmp3_hip_stream* hs = (pdmp3_hip_stream*)calloc(1, sizeof *hs);
+  if (!hs) return fail(PDMP3_HIP_ENOMEM, "calloc", hipSuccess);
+  hs->ctx = ctx;
+  hs->max_frames = max_frames;
+  const size_t n = (size_t)max_frames;
+#define HS_TRY(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { pdmp3_hip_stream_destroy(hs); return fail(PDMP3_HIP_EDEVICE, what, e_); } } while (0)
+  HS_TRY(hipStreamCreateWithFlags(&hs->stream, hipStreamNonBlocking), "hipStreamCreate");
+  HS_TRY(hipHostMalloc((void**)&hs->h_spectra, n * PDMP3_FRAME_SPECTRA_BYTES, hipHostMallocDefault), "hipHostMalloc spectra");
+  HS_TRY(hipHostMalloc((void**)&hs->h_side, n * PDMP3_FRAME_SIDE_BYTES, hipHostMallocDefault), "hipHostMalloc side");
+  HS_TRY(hipHostMalloc((void**)&hs->h_pcm, n * PDMP3_FRAME_PCM_BYTES, hipHostMallocDefault), "hipHostMalloc pcm");
+  HS_TRY(hipMalloc((void**)&hs->d_spectra, n * PDMP3_FRAME_SPECTRA_BYTES), "hipMalloc spectra");
+  HS_TRY(hipMalloc((void**)&hs->d_side, n * PDMP3_FRAME_SIDE_BYTES), "hipMalloc side");
+  HS_TRY(hipMalloc((void**)&hs->d_pcm, n * PDMP3_FRAME_PCM_BYTES), "hipMalloc pcm");
+  HS_TRY(hipMalloc((void**)&hs->d_state, pdmp3_hip_state_bytes()), "hipMalloc state");
+  HS_TRY(hipMemsetAsync(hs->d_state, 0, pdmp3_hip_state_bytes(), hs->stream), "memset state");
+  HS_TRY(hipStreamSynchronize(hs->stream), "sync");
+#undef HS_TRY
+  *out = hs;
+  return PDMP3_HIP_OK;
+}
+
+extern "C" int pdmp3_hip_stream_reset(pdmp3_hip_stream* hs) {
+  if (!hs) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_reset: NULL", hipSuccess);
+  HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
+  HIP_TRY(hipMemsetAsync(hs->d_state, 0, pdmp3_hip_state_bytes(), hs->stream), "memset state");
+  HIP_TRY(hipStreamSynchronize(hs->stream), "sync");
+  return PDMP3_HIP_OK;
+}
+
+extern "C" int16_t* pdmp3_hip_stream_spectra(pdmp3_hip_stream* hs) { return hs ? hs->h_spectra : nullptr; }
+extern "C" pdmp3_gc_side* pdmp3_hip_stream_side(pdmp3_hip_stream* hs) { return hs ? hs->h_side : nullptr; }
+extern "C" const int16_t* pdmp3_hip_stream_pcm(pdmp3_hip_stream* hs) { return hs ? hs->h_pcm : nullptr; }
+
+extern "C" int pdmp3_hip_stream_decode(pdmp3_hip_stream* hs, int n_frames) {
+  if (!hs || n_frames < 0 || n_frames > hs->max_frames)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_decode: bad argument", hipSuccess);
+  if (n_frames == 0) return PDMP3_HIP_OK;
+  HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
+  const size_t n = (size_t)n_frames;
+  HIP_TRY(hipMemcpyAsync(hs->d_spectra, hs->h_spectra, n * PDMP3_FRAME_SPECTRA_BYTES, hipMemcpyHostToDevice, hs->stream), "H2D spectra");
+  HIP_TRY(hipMemcpyAsync(hs->d_side, hs->h_side, n * PDMP3_FRAME_SIDE_BYTES, hipMemcpyHostToDevice, hs->stream), "H2D side");
+  int rc = launch_decode(hs->ctx, hs->d_spectra, hs->d_side, n_frames, hs->d_state, hs->d_pcm, nullptr, 0, hs->stream);
+  if (rc != PDMP3_HIP_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(hs->h_pcm, hs->d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDeviceToHost, hs->stream), "D2H pcm");
+  HIP_TRY(hipStreamSynchronize(hs->stream), "stream sync");
+  return PDMP3_HIP_OK;
 }
 
 extern "C" int pdmp3_hip_generate_frames(pdmp3_hip_ctx* ctx, uint64_t seed, int64_t first_frame, int n_frames,

@@ -27,6 +27,8 @@ EXPORTS = [
     "pdmp3_hip_create", "pdmp3_hip_destroy", "pdmp3_hip_last_error", "pdmp3_hip_state_bytes",
     "pdmp3_hip_decode_frames", "pdmp3_hip_decode_frames_stages", "pdmp3_hip_generate_frames",
     "pdmp3_host_generate_frames",
+    "pdmp3_hip_stream_create", "pdmp3_hip_stream_destroy", "pdmp3_hip_stream_reset", "pdmp3_hip_stream_spectra",
+    "pdmp3_hip_stream_side", "pdmp3_hip_stream_pcm", "pdmp3_hip_stream_decode",
 ]
 
 

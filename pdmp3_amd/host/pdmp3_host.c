@@ -1,0 +1,706 @@
+/*
+ * pdmp3_host.c -- libpdmp3.so: the libmpg123-style streaming API of PDMP3
+ * (include/pdmp3.h) over the MI355X transform engine (include/pdmp3_hip.h).
+ *
+ * Host stage (plain C, runs on the box's host cores, as BASELINE north_star
+ * asks): input ring, header sync, side info, bit reservoir, scalefactors and a
+ * table-driven Huffman decoder.  Each parsed frame becomes four granule-channel
+ * records (pdmp3_gc_side + int16 spectra) written straight into the engine's
+ * pinned staging buffers; pdmp3_read() parses as many frames as its output
+ * buffer can take, decodes them as ONE batch on the GPU
+ * (pdmp3_hip_stream_decode: hipMemcpyAsync H2D -> k_decode -> D2H) and then
+ * hands the PCM out with the reference's partial-frame cursor semantics.
+ *
+ * Behavioural contract = the reference's (file:line cited at each function,
+ * "P:n" = /root/reference/pdmp3.c line n), including the quirks SURVEY.md
+ * lists as H1, H6, H7, H9, H10, H16-H18.  The code is written from that
+ * contract, not from the reference's source: e.g. Huffman decoding is a
+ * two-level lookup built from code books (tables_data.h) instead of the
+ * reference's bit-serial tree walk.
+ *
+ * There is no CPU fallback for the transforms: without the engine library or
+ * a HIP device pdmp3_new() fails.
+ */
+#include "../../include/pdmp3.h"
+#include "../../include/pdmp3_hip.h"
+#include "../csrc/tables_data.h"
+
+#include <fcntl.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#define INBUF_SIZE 16384u            /* P:123 */
+#define BATCH_MAX 16                 /* frames per GPU batch: > 16 KiB / 1152 B frames */
+#define BYTE_EOF 0xffffffffu
+
+/* ------------------------------------------------------------------------ */
+/* Huffman code books -> two-level lookup tables                             */
+/* ------------------------------------------------------------------------ */
+#define HL_BITS 10
+typedef struct {
+  uint16_t first[1 << HL_BITS];   /* len<<8 | val   or   0x8000 | subtable index */
+  uint16_t* sub;                  /* subtables of 1 << sub_bits entries: len<<8 | val (len = bits beyond HL_BITS) */
+  int sub_bits;
+} huff_lut;
+
+static huff_lut g_lut[PDMP3_NUM_HUFF_BOOKS];
+static pthread_once_t g_lut_once = PTHREAD_ONCE_INIT;
+
+static void build_luts(void) {
+  for (int b = 0; b < PDMP3_NUM_HUFF_BOOKS; b++) {
+    huff_lut* L = &g_lut[b];
+    const pdmp3_hcode* codes = kHuffBooks[b];
+    const int n = kHuffBookSize[b];
+    int maxlen = 0;
+    for (int i = 0; i < n; i++) if (codes[i].len > maxlen) maxlen = codes[i].len;
+    L->sub_bits = maxlen > HL_BITS ? maxlen - HL_BITS : 0;
+    int nsub = 0;
+    memset(L->first, 0, sizeof L->first);
+    for (int i = 0; i < n; i++) {
+      if (codes[i].len > HL_BITS) {
+        uint32_t prefix = codes[i].code >> (codes[i].len - HL_BITS);
+        if (!(L->first[prefix] & 0x8000)) L->first[prefix] = (uint16_t)(0x8000 | nsub++);
+      }
+    }
+    L->sub = nsub ? (uint16_t*)calloc((size_t)nsub << L->sub_bits, sizeof(uint16_t)) : NULL;
+    for (int i = 0; i < n; i++) {
+      const int len = codes[i].len;
+      const uint16_t val = codes[i].err ? 0 : codes[i].val;
+      if (len <= HL_BITS) {
+        const uint32_t base = codes[i].code << (HL_BITS - len);
+        for (uint32_t k = 0; k < (1u << (HL_BITS - len)); k++) L->first[base + k] = (uint16_t)((len << 8) | val);
+      } else {
+        const uint32_t prefix = codes[i].code >> (len - HL_BITS);
+        const int si = L->first[prefix] & 0x7fff;
+        const int extra = len - HL_BITS;
+        const uint32_t rest = codes[i].code & ((1u << extra) - 1);
+        const uint32_t base = rest << (L->sub_bits - extra);
+        for (uint32_t k = 0; k < (1u << (L->sub_bits - extra)); k++)
+          L->sub[((size_t)si << L->sub_bits) + base + k] = (uint16_t)((extra << 8) | val);
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* handle                                                                    */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  unsigned id, layer, protection, bitrate_index, sfreq, padding, mode, mode_ext;
+} frame_header;
+
+typedef struct {
+  unsigned main_data_begin, scfsi[2][4];
+  unsigned part2_3_length[2][2], big_values[2][2], global_gain[2][2], scalefac_compress[2][2];
+  unsigned win_switch[2][2], block_type[2][2], mixed[2][2], table_select[2][2][3], subblock_gain[2][2][3];
+  unsigned region0_count[2][2], region1_count[2][2], preflag[2][2], scalefac_scale[2][2], count1table_select[2][2];
+} side_info;
+
+struct pdmp3_handle {
+  /* input ring, P:126-128 */
+  size_t processed;
+  unsigned istart, iend;
+  unsigned char in[INBUF_SIZE];
+  /* output cursor into the last decoded frame, P:127 (ostart), P:129 (out) */
+  unsigned ostart;
+  int16_t last_pcm[2304];
+  unsigned last_nch;
+  /* parse state that survives frames (the reference never clears it) */
+  frame_header hdr;
+  side_info si;
+  uint8_t scalefac_l[2][2][21];
+  uint8_t scalefac_s[2][2][12][3];
+  uint16_t count1[2][2];
+  int16_t is[2][2][576];
+  uint8_t main_vec[2048 + 16];     /* bit reservoir, P:137 */
+  unsigned main_top;
+  unsigned bitpos;                 /* read position in main_vec, in bits */
+  unsigned side_vec[36 + 8];
+  unsigned side_ptr, side_idx;
+  int new_header;                  /* P:147 */
+  int need_reset;                  /* hsynth_init / synth_init, P:134-135 */
+  /* engine */
+  pdmp3_hip_stream* hs;
+  int host_only;                   /* test hook: parse without an engine (no decode possible) */
+  /* record tap for tests (host logic without GPU) */
+  int16_t* tap_spectra; pdmp3_gc_side* tap_side; int tap_cap, tap_n;
+};
+
+static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
+static pdmp3_hip_ctx* g_ctx = NULL;
+
+static pdmp3_hip_ctx* shared_ctx(void) {
+  pthread_mutex_lock(&g_ctx_lock);
+  if (!g_ctx) {
+    int dev = 0;
+    const char* e = getenv("PDMP3_DEVICE");
+    if (e) dev = atoi(e);
+    if (pdmp3_hip_create(dev, &g_ctx) != PDMP3_HIP_OK) g_ctx = NULL;
+  }
+  pthread_mutex_unlock(&g_ctx_lock);
+  return g_ctx;
+}
+
+/* P:2351: pdmp3_new(decoder, error) -- `decoder` is ignored like in the reference */
+pdmp3_handle* pdmp3_new(const char* decoder, int* error) {
+  (void)decoder;
+  pthread_once(&g_lut_once, build_luts);
+  pdmp3_handle* id = (pdmp3_handle*)calloc(1, sizeof *id);
+  if (!id) { if (error) *error = PDMP3_ERR; return NULL; }
+  pdmp3_hip_ctx* ctx = shared_ctx();
+  if (!ctx || pdmp3_hip_stream_create(ctx, BATCH_MAX, &id->hs) != PDMP3_HIP_OK) {
+    fprintf(stderr, "pdmp3: no MI355X transform engine: %s\n", pdmp3_hip_last_error());
+    free(id);
+    if (error) *error = PDMP3_ERR;
+    return NULL;
+  }
+  if (error) *error = PDMP3_OK;
+  return id;
+}
+
+/* Test hook (host-logic tests on machines without a GPU): a handle that can
+ * parse and tap records but not decode.  Not part of the reference API. */
+pdmp3_handle* pdmp3_amd_new_parse_only(void) {
+  pthread_once(&g_lut_once, build_luts);
+  pdmp3_handle* id = (pdmp3_handle*)calloc(1, sizeof *id);
+  if (id) id->host_only = 1;
+  return id;
+}
+
+void pdmp3_amd_set_tap(pdmp3_handle* id, int16_t* spectra, pdmp3_gc_side* side, int cap_frames) {
+  id->tap_spectra = spectra; id->tap_side = side; id->tap_cap = cap_frames; id->tap_n = 0;
+}
+int pdmp3_amd_tap_count(const pdmp3_handle* id) { return id->tap_n; }
+
+/* P:2360 */
+void pdmp3_delete(pdmp3_handle* id) {
+  if (!id) return;
+  if (id->hs) pdmp3_hip_stream_destroy(id->hs);
+  free(id);
+}
+
+/* P:2369-2384 */
+int pdmp3_open_feed(pdmp3_handle* id) {
+  if (!id) return PDMP3_ERR;
+  id->ostart = 0; id->istart = 0; id->iend = 0; id->processed = 0; id->new_header = 0;
+  id->need_reset = 1;
+  id->main_top = 0;
+  return PDMP3_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* input ring (P:1062-1086, P:1464-1474)                                     */
+/* ------------------------------------------------------------------------ */
+static unsigned ring_filled(const pdmp3_handle* id) {
+  return (id->istart <= id->iend) ? (id->iend - id->istart) : (INBUF_SIZE - id->istart + id->iend);
+}
+static unsigned ring_free(const pdmp3_handle* id) {
+  return (id->iend < id->istart) ? (id->istart - id->iend) : (INBUF_SIZE - id->iend + id->istart);
+}
+static inline unsigned ring_byte(pdmp3_handle* id) {
+  if (id->istart == id->iend) return BYTE_EOF;
+  unsigned v = id->in[id->istart++];
+  if (id->istart == INBUF_SIZE) id->istart = 0;
+  id->processed++;
+  return v;
+}
+
+/* P:2391-2423: all-or-nothing copy into the ring */
+int pdmp3_feed(pdmp3_handle* id, const unsigned char* in, size_t size) {
+  if (!(id && in && size)) return PDMP3_ERR;
+  if (size > (size_t)ring_free(id)) return PDMP3_NO_SPACE;
+  size_t first;
+  if (id->iend < id->istart) {
+    first = id->istart - id->iend;
+    if (size < first) first = size;
+    memcpy(id->in + id->iend, in, first);
+    id->iend += (unsigned)first;
+  } else {
+    first = INBUF_SIZE - id->iend;
+    if (size < first) first = size;
+    if (first) { memcpy(id->in + id->iend, in, first); id->iend += (unsigned)first; size -= first; }
+    if (size) { memcpy(id->in, in + first, size); id->iend = (unsigned)size; }
+  }
+  return PDMP3_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* header sync (P:1252-1340)                                                 */
+/* ------------------------------------------------------------------------ */
+static int read_header(pdmp3_handle* id) {
+  unsigned b[4];
+  for (int i = 0; i < 4; i++) b[i] = ring_byte(id);
+  if (b[0] == BYTE_EOF || b[1] == BYTE_EOF || b[2] == BYTE_EOF || b[3] == BYTE_EOF) return PDMP3_ERR;
+  uint32_t h = (b[0] << 24) | (b[1] << 16) | (b[2] << 8) | b[3];
+  while ((h & 0xfff00000u) != 0xfff00000u) {     /* byte-aligned 12-bit sync */
+    unsigned nb = ring_byte(id);
+    if (nb == BYTE_EOF) return PDMP3_ERR;
+    h = (h << 8) | nb;
+  }
+  frame_header* H = &id->hdr;
+  H->id = (h >> 19) & 1; H->layer = (h >> 17) & 3; H->protection = (h >> 16) & 1;
+  H->bitrate_index = (h >> 12) & 15; H->sfreq = (h >> 10) & 3; H->padding = (h >> 9) & 1;
+  H->mode = (h >> 6) & 3; H->mode_ext = (h >> 4) & 3;
+  /* MPEG-1 only; free format, index 15, sfreq 3 and layer 0 rejected (P:1293-1315) */
+  if (H->id != 1 || H->bitrate_index == 0 || H->bitrate_index == 15 || H->sfreq == 3 || H->layer == 0)
+    return PDMP3_ERR;
+  H->layer = 4 - H->layer;
+  if (!id->new_header) id->new_header = 1;
+  return PDMP3_OK;
+}
+
+/* P:1322-1340: retry from the next byte after the mark; give up after 1152 tries */
+static int search_header(pdmp3_handle* id) {
+  const size_t pos = id->processed;
+  unsigned mark = id->istart;
+  int res = PDMP3_NEED_MORE, tries = 0;
+  while (ring_filled(id) > 4) {
+    res = read_header(id);
+    if (id->hdr.layer == 3 && (res == PDMP3_OK || res == PDMP3_NEW_FORMAT)) break;
+    if (++mark == INBUF_SIZE) mark = 0;
+    id->istart = mark;
+    id->processed = pos;
+    if (++tries > 1152) return PDMP3_ERR;
+  }
+  return res;
+}
+
+/* ------------------------------------------------------------------------ */
+/* side info (P:1129-1200)                                                   */
+/* ------------------------------------------------------------------------ */
+static unsigned side_bits(pdmp3_handle* id, unsigned n) {
+  const unsigned* p = &id->side_vec[id->side_ptr];
+  uint32_t w = (p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3];
+  w <<= id->side_idx;
+  w >>= (32 - n);
+  id->side_ptr += (id->side_idx + n) >> 3;
+  id->side_idx = (id->side_idx + n) & 7;
+  return w;
+}
+
+static unsigned frame_bytes(const frame_header* H) {   /* P:1135-1138 */
+  return 144u * kBitratesL3[H->bitrate_index] / kSampleRates[H->sfreq] + H->padding;
+}
+
+static void read_side_info(pdmp3_handle* id) {
+  const unsigned nch = id->hdr.mode == 3 ? 1 : 2, nbytes = nch == 1 ? 17 : 32;
+  unsigned got = 0;
+  for (; got < nbytes; got++) {
+    unsigned v = ring_byte(id);
+    if (v == BYTE_EOF) break;
+    id->side_vec[got] = v;
+  }
+  if (got == nbytes) { id->side_ptr = 0; id->side_idx = 0; }   /* pointers move only on a full read (P:1576-1586) */
+  side_info* S = &id->si;
+  S->main_data_begin = side_bits(id, 9);
+  (void)side_bits(id, nch == 1 ? 5 : 3);
+  for (unsigned ch = 0; ch < nch; ch++)
+    for (unsigned b = 0; b < 4; b++) S->scfsi[ch][b] = side_bits(id, 1);
+  for (unsigned gr = 0; gr < 2; gr++)
+    for (unsigned ch = 0; ch < nch; ch++) {
+      S->part2_3_length[gr][ch] = side_bits(id, 12);
+      S->big_values[gr][ch] = side_bits(id, 9);
+      S->global_gain[gr][ch] = side_bits(id, 8);
+      S->scalefac_compress[gr][ch] = side_bits(id, 4);
+      S->win_switch[gr][ch] = side_bits(id, 1);
+      if (S->win_switch[gr][ch]) {
+        S->block_type[gr][ch] = side_bits(id, 2);
+        S->mixed[gr][ch] = side_bits(id, 1);
+        S->table_select[gr][ch][0] = side_bits(id, 5);
+        S->table_select[gr][ch][1] = side_bits(id, 5);
+        for (unsigned w = 0; w < 3; w++) S->subblock_gain[gr][ch][w] = side_bits(id, 3);
+        S->region0_count[gr][ch] = (S->block_type[gr][ch] == 2 && !S->mixed[gr][ch]) ? 8 : 7;   /* implicit */
+        S->region1_count[gr][ch] = 20 - S->region0_count[gr][ch];
+      } else {
+        for (unsigned r = 0; r < 3; r++) S->table_select[gr][ch][r] = side_bits(id, 5);
+        S->region0_count[gr][ch] = side_bits(id, 4);
+        S->region1_count[gr][ch] = side_bits(id, 3);
+        S->block_type[gr][ch] = 0;             /* mixed / subblock_gain stay stale (H20) */
+      }
+      S->preflag[gr][ch] = side_bits(id, 1);
+      S->scalefac_scale[gr][ch] = side_bits(id, 1);
+      S->count1table_select[gr][ch] = side_bits(id, 1);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* bit reservoir (P:1096-1122) and main-data bit reader                      */
+/* ------------------------------------------------------------------------ */
+static int fill_reservoir(pdmp3_handle* id, unsigned size, unsigned begin) {
+  uint8_t* dst;
+  int ok = begin <= id->main_top;
+  if (ok) {
+    memmove(id->main_vec, id->main_vec + id->main_top - begin, begin);
+    dst = id->main_vec + begin;
+    id->main_top = begin + size;
+  } else {            /* not enough history: keep the bytes for later frames, skip this one (H9) */
+    dst = id->main_vec + id->main_top;
+    id->main_top += size;
+  }
+  for (unsigned i = 0; i < size; i++) {
+    if ((size_t)(dst - id->main_vec) + i >= sizeof id->main_vec) break;
+    unsigned v = ring_byte(id);
+    if (v == BYTE_EOF) break;                  /* short read ignored (H18) */
+    dst[i] = (uint8_t)v;
+  }
+  id->bitpos = 0;
+  return ok ? PDMP3_OK : PDMP3_NEED_MORE;
+}
+
+static inline uint32_t peek32(const pdmp3_handle* id) {   /* next 25+ valid bits, MSB first */
+  const unsigned byte = id->bitpos >> 3;
+  const uint8_t* p = id->main_vec + (byte < sizeof id->main_vec - 5 ? byte : sizeof id->main_vec - 5);
+  uint64_t w = ((uint64_t)p[0] << 32) | ((uint64_t)p[1] << 24) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 8) | p[4];
+  return (uint32_t)(w >> (8 - (id->bitpos & 7)));
+}
+static inline unsigned get_bits(pdmp3_handle* id, unsigned n) {
+  if (!n) return 0;
+  unsigned v = peek32(id) >> (32 - n);
+  id->bitpos += n;
+  return v;
+}
+
+/* one code word of `book`: returns the leaf value (x<<4 | y) */
+static inline unsigned huff_symbol(pdmp3_handle* id, int book) {
+  const huff_lut* L = &g_lut[book];
+  const uint32_t w = peek32(id);
+  unsigned e = L->first[w >> (32 - HL_BITS)];
+  if (e & 0x8000) {
+    const unsigned rest = (w << HL_BITS) >> (32 - L->sub_bits);
+    const unsigned e2 = L->sub[((size_t)(e & 0x7fff) << L->sub_bits) + rest];
+    id->bitpos += HL_BITS + (e2 >> 8);
+    return e2 & 0xff;
+  }
+  id->bitpos += e >> 8;
+  return e & 0xff;
+}
+
+/* P:2051-2115 */
+static void read_huffman(pdmp3_handle* id, unsigned part2_start, unsigned gr, unsigned ch) {
+  const side_info* S = &id->si;
+  int16_t* is = id->is[gr][ch];
+  if (S->part2_3_length[gr][ch] == 0) {           /* all zero; count1 keeps its old value (H6) */
+    memset(is, 0, 576 * sizeof *is);
+    return;
+  }
+  const unsigned end = part2_start + S->part2_3_length[gr][ch] - 1;   /* last bit of this part */
+  unsigned r1, r2;
+  if (S->win_switch[gr][ch] && S->block_type[gr][ch] == 2) { r1 = 36; r2 = 576; }
+  else {
+    /* l[23] s[14] are contiguous in the reference: indices 23, 24 read s[0], s[1] (H7) */
+    const uint16_t* l = id->hdr.sfreq == 0 ? kSfbLong0 : id->hdr.sfreq == 1 ? kSfbLong1 : kSfbLong2;
+    const uint16_t* s = id->hdr.sfreq == 0 ? kSfbShort0 : id->hdr.sfreq == 1 ? kSfbShort1 : kSfbShort2;
+    const unsigned i1 = S->region0_count[gr][ch] + 1, i2 = S->region0_count[gr][ch] + S->region1_count[gr][ch] + 2;
+    r1 = i1 < 23 ? l[i1] : s[i1 - 23];
+    r2 = i2 < 23 ? l[i2] : s[i2 - 23];
+  }
+  const unsigned nbig = S->big_values[gr][ch] * 2;
+  unsigned pos = 0;
+  for (; pos < nbig; pos += 2) {
+    const unsigned tn = pos < r1 ? S->table_select[gr][ch][0] : pos < r2 ? S->table_select[gr][ch][1] : S->table_select[gr][ch][2];
+    int x = 0, y = 0;
+    const int book = kHuffBookOfTable[tn];
+    if (book >= 0) {
+      const unsigned leaf = huff_symbol(id, book), linbits = kHuffLinbits[tn];
+      x = leaf >> 4; y = leaf & 15;
+      if (linbits && x == 15) x += (int)get_bits(id, linbits);
+      if (x > 0 && get_bits(id, 1)) x = -x;
+      if (linbits && y == 15) y += (int)get_bits(id, linbits);
+      if (y > 0 && get_bits(id, 1)) y = -y;
+    }
+    if (pos < 576) is[pos] = (int16_t)x;           /* big_values > 288 is not checked by the reference (H8) */
+    if (pos + 1 < 576) is[pos + 1] = (int16_t)y;
+  }
+  /* count1 region: table 32, or the reference's mis-pointed table 33 (H1) */
+  const int qbook = kHuffBookOfTable[32 + S->count1table_select[gr][ch]];
+  pos = nbig;
+  while (pos <= 572 && id->bitpos <= end) {
+    const unsigned leaf = huff_symbol(id, qbook);
+    int q[4] = {(int)(leaf >> 3) & 1, (int)(leaf >> 2) & 1, (int)(leaf >> 1) & 1, (int)leaf & 1};   /* v w x y */
+    for (int k = 0; k < 4; k++) if (q[k] && get_bits(id, 1)) q[k] = -1;
+    int stop = 0;
+    for (int k = 0; k < 4; k++) {
+      is[pos] = (int16_t)q[k];
+      if (k < 3) { pos++; if (pos >= 576) { stop = 1; break; } }
+    }
+    if (stop) break;
+    pos++;
+  }
+  if (id->bitpos > end + 1) pos -= 4;              /* overshoot: drop the last quad */
+  if (pos > 576) pos = 576;                        /* (unsigned wrap of the reference on pos < 4: corrupt input) */
+  id->count1[gr][ch] = (uint16_t)pos;
+  for (; pos < 576; pos++) is[pos] = 0;
+  id->bitpos = end + 1;
+}
+
+/* P:1346-1442 */
+static int read_main_data(pdmp3_handle* id) {
+  const unsigned nch = id->hdr.mode == 3 ? 1 : 2;
+  const unsigned fb = frame_bytes(&id->hdr);
+  if (fb > 2000) return PDMP3_ERR;
+  unsigned size = fb - (nch == 1 ? 17 : 32) - 4;
+  if (id->hdr.protection == 0) size -= 2;
+  const int res = fill_reservoir(id, size, id->si.main_data_begin);
+  if (res != PDMP3_OK) return res;
+  const side_info* S = &id->si;
+  for (unsigned gr = 0; gr < 2; gr++)
+    for (unsigned ch = 0; ch < nch; ch++) {
+      const unsigned part2_start = id->bitpos;
+      const unsigned slen1 = kSlen[S->scalefac_compress[gr][ch] * 2], slen2 = kSlen[S->scalefac_compress[gr][ch] * 2 + 1];
+      if (S->win_switch[gr][ch] && S->block_type[gr][ch] == 2) {
+        unsigned first_short = 0;
+        if (S->mixed[gr][ch]) {
+          for (unsigned sfb = 0; sfb < 8; sfb++) id->scalefac_l[gr][ch][sfb] = (uint8_t)get_bits(id, slen1);
+          first_short = 3;
+        }
+        for (unsigned sfb = first_short; sfb < 12; sfb++)
+          for (unsigned w = 0; w < 3; w++) id->scalefac_s[gr][ch][sfb][w] = (uint8_t)get_bits(id, sfb < 6 ? slen1 : slen2);
+      } else {
+        static const uint8_t lo[5] = {0, 6, 11, 16, 21};
+        for (unsigned b = 0; b < 4; b++) {
+          const unsigned nb = b < 2 ? slen1 : slen2;
+          if (gr == 1 && S->scfsi[ch][b]) {        /* reuse granule 0's factors */
+            for (unsigned sfb = lo[b]; sfb < lo[b + 1]; sfb++) id->scalefac_l[1][ch][sfb] = id->scalefac_l[0][ch][sfb];
+          } else {
+            for (unsigned sfb = lo[b]; sfb < lo[b + 1]; sfb++) id->scalefac_l[gr][ch][sfb] = (uint8_t)get_bits(id, nb);
+          }
+        }
+      }
+      read_huffman(id, part2_start, gr, ch);
+    }
+  return PDMP3_OK;
+}
+
+/* P:1217-1244 */
+static int read_frame(pdmp3_handle* id) {
+  if (search_header(id) != PDMP3_OK) return PDMP3_ERR;
+  if (id->hdr.protection == 0) {                   /* CRC is skipped, never checked (P:1206-1210) */
+    if (ring_byte(id) != BYTE_EOF) (void)ring_byte(id);
+  }
+  if (id->hdr.layer != 3) return PDMP3_ERR;
+  if (frame_bytes(&id->hdr) <= 2000) read_side_info(id);
+  return read_main_data(id);
+}
+
+/* ------------------------------------------------------------------------ */
+/* parsed frame -> 4 gc records (the engine boundary)                        */
+/* ------------------------------------------------------------------------ */
+static void emit_records(pdmp3_handle* id, int16_t* spectra, pdmp3_gc_side* sd) {
+  const unsigned nch = id->hdr.mode == 3 ? 1 : 2;
+  const side_info* S = &id->si;
+  memset(sd, 0, 4 * sizeof *sd);
+  const uint8_t fr = (uint8_t)((id->hdr.sfreq & 3) | (id->hdr.mode << PDMP3_FR_MODE_SHIFT) |
+                               (id->hdr.mode_ext << PDMP3_FR_MODEEXT_SHIFT) | (id->need_reset ? PDMP3_FR_RESET : 0));
+  id->need_reset = 0;
+  for (unsigned g = 0; g < 4; g++) {
+    const unsigned gr = g >> 1, ch = g & 1;
+    pdmp3_gc_side* r = &sd[g];
+    r->frame = fr;
+    if (ch >= nch) { memset(spectra + g * 576, 0, 576 * sizeof(int16_t)); continue; }
+    memcpy(spectra + g * 576, id->is[gr][ch], 576 * sizeof(int16_t));
+    r->count1 = id->count1[gr][ch];
+    r->global_gain = (uint8_t)S->global_gain[gr][ch];
+    r->flags = (uint8_t)((S->scalefac_scale[gr][ch] ? PDMP3_GC_SCALEFAC_SCALE : 0) |
+                         (S->preflag[gr][ch] ? PDMP3_GC_PREFLAG : 0) |
+                         (S->win_switch[gr][ch] ? PDMP3_GC_WIN_SWITCH : 0) |
+                         ((S->block_type[gr][ch] & 3) << PDMP3_GC_BLOCK_TYPE_SHIFT) |
+                         ((S->win_switch[gr][ch] && S->mixed[gr][ch]) ? PDMP3_GC_MIXED : 0));
+    for (unsigned w = 0; w < 3; w++) r->subblock_gain[w] = (uint8_t)S->subblock_gain[gr][ch][w];
+    memcpy(r->scalefac_l, id->scalefac_l[gr][ch], 21);
+    memcpy(r->scalefac_s, id->scalefac_s[gr][ch], 36);
+    /* What the reference reads one element past each array:
+     * the first element of the NEXT [gr][ch] block, and for the last block
+     * the start of the following member (scalefac_s, resp. the float bits of
+     * is[0][0][w], which only the device knows). */
+    if (g < 3) {
+      r->scalefac_l[21] = id->scalefac_l[(g + 1) >> 1][(g + 1) & 1][0];
+      memcpy(r->scalefac_s[12], id->scalefac_s[(g + 1) >> 1][(g + 1) & 1][0], 3);
+    } else {
+      r->scalefac_l[21] = id->scalefac_s[0][0][0][0];
+      r->scalefac_s[12][0] = r->scalefac_s[12][1] = r->scalefac_s[12][2] = PDMP3_SF_PEEK;
+    }
+  }
+  if (id->tap_side) {
+    if (id->tap_n < id->tap_cap) {
+      memcpy(id->tap_spectra + (size_t)id->tap_n * 2304, spectra, 2304 * sizeof(int16_t));
+      memcpy(id->tap_side + (size_t)id->tap_n * 4, sd, 4 * sizeof *sd);
+    }
+    id->tap_n++;
+  }
+}
+
+/* P:2307-2345: hand out up to buflen bytes of the frame under the cursor */
+static size_t drain_frame(pdmp3_handle* id, unsigned char* out, size_t buflen) {
+  const unsigned nch = id->hdr.mode == 3 ? 1 : 2;          /* the CURRENT header's channel count, as in the reference */
+  const unsigned bps = 2 * nch;
+  size_t n = buflen / bps;
+  if (n > 1152u - id->ostart) n = 1152u - id->ostart;
+  memcpy(out, (const unsigned char*)id->last_pcm + (size_t)id->ostart * bps, n * bps);
+  id->ostart += (unsigned)n;
+  if (id->ostart == 1152) id->ostart = 0;
+  return n * bps;
+}
+
+/* ------------------------------------------------------------------------ */
+/* pdmp3_read (P:2431-2481), batched                                         */
+/* ------------------------------------------------------------------------ */
+int pdmp3_read(pdmp3_handle* id, unsigned char* outmemory, size_t outsize, size_t* done) {
+  if (!(id && outmemory && outsize && done)) return PDMP3_ERR;
+  *done = 0;
+  int res = PDMP3_ERR;
+  if (id->ostart) {                               /* rest of the frame a previous call could not fit */
+    const size_t n = drain_frame(id, outmemory, outsize);
+    *done = n; outmemory += n; outsize -= n;
+    res = PDMP3_OK;
+  }
+  while (outsize) {
+    /* 1. host stage: parse as many frames as the caller's buffer will take
+     *    (one frame needs >= 1152 buffered bytes to be attempted, H10) */
+    int16_t* spectra = id->hs ? pdmp3_hip_stream_spectra(id->hs) : NULL;
+    pdmp3_gc_side* side = id->hs ? pdmp3_hip_stream_side(id->hs) : NULL;
+    int16_t scratch_sp[2304];
+    pdmp3_gc_side scratch_sd[4];
+    unsigned nchs[BATCH_MAX];
+    int nb = 0, stop = 0;
+    size_t budget = outsize;
+    while (budget && nb < BATCH_MAX) {
+      if (ring_filled(id) < 1152) { res = PDMP3_NEED_MORE; stop = 1; break; }
+      const size_t pos = id->processed;
+      const unsigned mark = id->istart;
+      res = read_frame(id);
+      if (res != PDMP3_OK && res != PDMP3_NEW_FORMAT) {   /* failed: rewind to the frame start (P:2459-2462) */
+        id->processed = pos; id->istart = mark;
+        stop = 1;
+        break;
+      }
+      emit_records(id, spectra ? spectra + (size_t)nb * 2304 : scratch_sp, side ? side + (size_t)nb * 4 : scratch_sd);
+      nchs[nb] = id->hdr.mode == 3 ? 1 : 2;
+      const size_t fbytes = 2304u * nchs[nb];
+      budget -= budget < fbytes ? budget : fbytes;
+      nb++;
+    }
+    /* 2. transforms on the GPU, one batch */
+    if (nb) {
+      if (!id->hs) return PDMP3_ERR;              /* parse-only handle: cannot decode */
+      if (pdmp3_hip_stream_decode(id->hs, nb) != PDMP3_HIP_OK) {
+        fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
+        return PDMP3_ERR;
+      }
+      const int16_t* pcm = pdmp3_hip_stream_pcm(id->hs);
+      for (int k = 0; k < nb; k++) {
+        const size_t fbytes = 2304u * nchs[k];
+        if (outsize >= fbytes && k < nb - 1) {    /* whole frame fits: copy straight through */
+          memcpy(outmemory, pcm + (size_t)k * 2304, fbytes);
+          outmemory += fbytes; outsize -= fbytes; *done += fbytes;
+        } else {                                  /* last frame of the batch: may be partial */
+          memcpy(id->last_pcm, pcm + (size_t)k * 2304, fbytes);
+          id->last_nch = nchs[k];
+          id->ostart = 0;
+          const size_t n = drain_frame(id, outmemory, outsize);
+          outmemory += n; outsize -= n; *done += n;
+        }
+      }
+    }
+    if (stop) break;
+  }
+  if (id->new_header == 1 && res == PDMP3_OK) res = PDMP3_NEW_FORMAT;
+  return res;
+}
+
+/* parse-only variant of the read loop for host-logic tests: parses every frame
+ * the ring allows, taps records, produces no PCM */
+int pdmp3_amd_parse_available(pdmp3_handle* id) {
+  int16_t sp[2304];
+  pdmp3_gc_side sd[4];
+  int res = PDMP3_NEED_MORE;
+  while (ring_filled(id) >= 1152) {
+    const size_t pos = id->processed;
+    const unsigned mark = id->istart;
+    res = read_frame(id);
+    if (res != PDMP3_OK && res != PDMP3_NEW_FORMAT) { id->processed = pos; id->istart = mark; return res; }
+    emit_records(id, sp, sd);
+  }
+  return PDMP3_NEED_MORE;
+}
+
+/* P:2491-2520 */
+int pdmp3_decode(pdmp3_handle* id, const unsigned char* in, size_t insize, unsigned char* out, size_t outsize, size_t* done) {
+  size_t take = ring_free(id);
+  *done = 0;
+  if (take > insize) take = insize;               /* the surplus is silently dropped (H16) */
+  int res = pdmp3_feed(id, in, take);
+  if (res != PDMP3_OK) return res;
+  if (out && outsize) {
+    size_t got;
+    res = pdmp3_read(id, out, outsize, &got);
+    *done = got;
+  } else if (id->processed == 0) {                /* probe: peek at the first header, then rewind */
+    const size_t pos = id->processed;
+    const unsigned mark = id->istart;
+    res = search_header(id);
+    id->processed = pos; id->istart = mark;
+    if (id->new_header == 1) res = PDMP3_NEW_FORMAT;
+  }
+  return res;
+}
+
+/* P:2526-2535 */
+int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) {
+  if (!(id && rate && channels && encoding)) return PDMP3_ERR;
+  *encoding = PDMP3_ENC_SIGNED_16;
+  *rate = (long)kSampleRates[id->hdr.sfreq];
+  *channels = id->hdr.mode == 3 ? 1 : 2;
+  id->new_header = -1;
+  return PDMP3_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CLI driver (P:2540-2589) with the raw sink (P:2236-2257)                   */
+/* ------------------------------------------------------------------------ */
+static void write_raw(const char* filename, const unsigned char* data, size_t nbytes) {
+  static int fd = -2;                             /* opened once, for the FIRST file name only, like the reference */
+  if (fd == -2) {
+    if (strcmp(filename, "-")) {
+      char name[1024];
+      snprintf(name, sizeof name, "%s.raw", filename);
+      fd = open(name, O_WRONLY | O_CREAT, 0666);  /* no O_TRUNC, like the reference */
+      if (fd == -1) { perror(name); exit(-1); }
+    } else fd = 1;
+  }
+  size_t off = 0;
+  while (off < nbytes) {
+    ssize_t w = write(fd, data + off, nbytes - off);
+    if (w <= 0) { fputs("Unable to write raw data\n", stderr); exit(-1); }
+    off += (size_t)w;
+  }
+}
+
+void pdmp3(char* const* mp3s) {
+  unsigned char out[INBUF_SIZE];
+  if (*mp3s && !strncmp("/dev/dsp", *mp3s, 8)) mp3s++;      /* OSS device argument accepted, playback not supported */
+  pdmp3_handle* id = pdmp3_new(NULL, NULL);
+  if (!id) { fputs("Cannot open stream API (no transform engine)\n", stderr); exit(0); }
+  for (; *mp3s; mp3s++) {
+    const char* filename = *mp3s;
+    FILE* fp = strcmp(filename, "-") ? fopen(filename, "r") : stdin;
+    if (!fp) { fputs("Cannot open file\n", stderr); exit(0); }
+    pdmp3_open_feed(id);
+    size_t done;
+    int res;
+    while ((res = pdmp3_read(id, out, INBUF_SIZE, &done)) != PDMP3_ERR) {
+      write_raw(filename, out, done);
+      if (res == PDMP3_NEED_MORE) {
+        unsigned char in[4096];
+        const size_t n = fread(in, 1, sizeof in, fp);
+        if (!n) break;
+        (void)pdmp3_feed(id, in, n);
+      }
+    }
+    if (fp != stdin) fclose(fp);
+  }
+  pdmp3_delete(id);
+}

@@ -1,0 +1,107 @@
+"""Host stage of the product (pdmp3_amd/host/pdmp3_host.c: ring, header sync,
+side info, bit reservoir, scalefactors, table-driven Huffman, record
+emission) against the oracle's bitstream front end, on the real clip and on
+packer-made streams (tools/packer).  No GPU involved: the parse-only handle
+taps the gc records the engine would be given.  Bar: records bit-identical.
+
+Where oracle/_ref is present the same streams also pin the ORACLE front end to
+the reference (records + PCM bit-identical).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tools.packer import packer
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+STREAMS = {
+    "cbr320_js_441": dict(n_frames=120, seed=11, sfreq=0, mode=1, mode_ext=2, bitrate_index=14),
+    "cbr128_js_441": dict(n_frames=120, seed=12, sfreq=0, mode=1, mode_ext=2, bitrate_index=9),
+    "mono_32k_96": dict(n_frames=100, seed=13, sfreq=2, mode=3, mode_ext=0, bitrate_index=7),
+    "vbr_48k_stereo_crc_tab33": dict(n_frames=150, seed=14, sfreq=1, mode=0, mode_ext=0, vbr=True, crc=True, table33_pct=15),
+    "short_heavy_dual": dict(n_frames=100, seed=15, sfreq=0, mode=2, mode_ext=0, bitrate_index=12, block_pct=(10, 10, 70, 10)),
+    "no_reservoir_js": dict(n_frames=80, seed=16, reservoir=False, bitrate_index=11),
+    "vbr_mono_441": dict(n_frames=120, seed=17, sfreq=0, mode=3, vbr=True, vbr_lo=3, vbr_hi=14),
+    "js_32k_256": dict(n_frames=80, seed=18, sfreq=2, mode=1, mode_ext=2, bitrate_index=13),   # 1152-byte frames (H10 limit)
+    "linbits_heavy": dict(n_frames=60, seed=19, big_pct=200, gain=(100, 140)),
+}
+
+
+def _records_equal(a, b):
+    return a[0].shape == b[0].shape and np.array_equal(a[0], b[0]) and \
+        np.array_equal(a[1].view(np.uint8), b[1].view(np.uint8))
+
+
+@pytest.mark.parametrize("name", list(STREAMS))
+def test_host_parser_matches_oracle(oracle, name):
+    from pdmp3_amd import api
+    mp3 = packer.generate(**STREAMS[name])
+    _, sp_o, sd_o = oracle.decode_buffer_like_cli(mp3, tap_frames=400)
+    got = api.parse_like_cli(mp3, 400)
+    assert sp_o.shape[0] >= STREAMS[name]["n_frames"] - 3      # tail drop (H10) only
+    assert _records_equal(got, (sp_o, sd_o))
+
+
+def test_host_parser_clip(oracle):
+    from pdmp3_amd import api
+    mp3 = open(os.path.join(GOLD, "clip_invalid_keypress.mp3"), "rb").read()
+    _, sp_o, sd_o = oracle.decode_buffer_like_cli(mp3, tap_frames=64)
+    assert _records_equal(api.parse_like_cli(mp3, 64), (sp_o, sd_o))
+
+
+def test_host_parser_garbage_and_resync(oracle):
+    """leading junk (< 1152 bytes), junk between frames, truncated tail"""
+    from pdmp3_amd import api
+    rs = np.random.RandomState(5)
+    body = packer.generate(n_frames=40, seed=21, bitrate_index=9)
+    junk = bytes(rs.randint(0, 255, size=700).astype(np.uint8).tolist()).replace(b"\xff", b"\x00")
+    mp3 = junk + body[:9000] + junk[:333] + body[9000:-517]
+    _, sp_o, sd_o = oracle.decode_buffer_like_cli(mp3, tap_frames=100)
+    assert _records_equal(api.parse_like_cli(mp3, 100), (sp_o, sd_o))
+    # a tag longer than the 1152-byte search window stops the decoder (H17)
+    mp3b = bytes(2000) + body
+    _, sp_b, _ = oracle.decode_buffer_like_cli(mp3b, tap_frames=100)
+    got_b = api.parse_like_cli(mp3b, 100)
+    assert sp_b.shape[0] == got_b[0].shape[0]
+
+
+def test_api_argument_errors():
+    """NULL / zero-size arguments: same codes as the reference (P:2391, P:2431, P:2526)"""
+    import ctypes as C
+    from pdmp3_amd import api
+    lib = api.load_library()
+    d = api.Decoder(parse_only=True)
+    assert lib.pdmp3_open_feed(None) == api.PDMP3_ERR
+    assert lib.pdmp3_feed(d.h, None, 10) == api.PDMP3_ERR
+    assert d.feed(b"") == api.PDMP3_ERR
+    assert d.feed(bytes(16384)) == api.PDMP3_OK                # exactly the free space
+    assert d.feed(b"x") == api.PDMP3_NO_SPACE                  # nothing copied when it does not fit
+    done = C.c_size_t(0)
+    assert lib.pdmp3_read(d.h, None, 16, C.byref(done)) == api.PDMP3_ERR
+    assert lib.pdmp3_getformat(d.h, None, None, None) == api.PDMP3_ERR
+    rc, rate, ch, enc = d.getformat()
+    assert rc == api.PDMP3_OK and enc == api.PDMP3_ENC_SIGNED_16 and rate == 44100 and ch == 2
+    d.close()
+
+
+def test_api_library_exports():
+    from pdmp3_amd import api
+    lib = api.load_library()
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "pdmp3.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(pdmp3[a-z0-9_]*)\s*\(", src)))
+    assert set(api.API_EXPORTS) <= set(names)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+@pytest.mark.parametrize("name", ["cbr320_js_441", "vbr_48k_stereo_crc_tab33", "mono_32k_96", "short_heavy_dual"])
+def test_oracle_front_end_vs_reference(oracle, reference, name):
+    mp3 = packer.generate(**STREAMS[name])
+    p_ref, sp_r, sd_r = reference.decode_buffer_like_cli(mp3, tap_frames=400)
+    p_orc, sp_o, sd_o = oracle.decode_buffer_like_cli(mp3, tap_frames=400)
+    assert p_ref == p_orc
+    assert _records_equal((sp_r, sd_r), (sp_o, sd_o))

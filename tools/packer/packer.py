@@ -1,0 +1,42 @@
+"""ctypes wrapper of the synthetic Layer-III bitstream generator (test tool)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Cfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("sfreq", C.c_int), ("mode", C.c_int), ("mode_ext", C.c_int),
+                ("bitrate_index", C.c_int), ("vbr", C.c_int), ("vbr_lo", C.c_int), ("vbr_hi", C.c_int),
+                ("crc", C.c_int), ("block_pct", C.c_int * 4), ("mixed_pct", C.c_int), ("reservoir", C.c_int),
+                ("table33_pct", C.c_int), ("fill_pct", C.c_int), ("big_pct", C.c_int),
+                ("gain_lo", C.c_int), ("gain_hi", C.c_int)]
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+        _lib = C.CDLL(os.path.join(_HERE, "libpacker.so"))
+        _lib.pk_generate.restype = C.c_size_t
+        _lib.pk_generate.argtypes = [C.POINTER(Cfg), C.c_int, C.c_void_p, C.c_size_t]
+    return _lib
+
+
+def generate(n_frames, seed=1, sfreq=0, mode=1, mode_ext=2, bitrate_index=14, vbr=False, vbr_lo=5, vbr_hi=14,
+             crc=False, block_pct=(70, 10, 10, 10), mixed_pct=50, reservoir=True, table33_pct=0, fill_pct=92,
+             big_pct=5, gain=(120, 170)) -> bytes:
+    """bitrate_index 14 = 320 kbps, 9 = 128 kbps (Layer III)."""
+    cfg = Cfg(seed, sfreq, mode, mode_ext, bitrate_index, int(vbr), vbr_lo, vbr_hi, int(crc),
+              (C.c_int * 4)(*block_pct), mixed_pct, int(reservoir), table33_pct, fill_pct, big_pct, gain[0], gain[1])
+    cap = n_frames * 1500 + 4096
+    buf = np.zeros(cap, dtype=np.uint8)
+    n = _load().pk_generate(C.byref(cfg), n_frames, buf.ctypes.data_as(C.c_void_p), cap)
+    assert n > 0
+    return buf[:n].tobytes()
