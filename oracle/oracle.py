@@ -111,6 +111,43 @@ class Oracle:
         return out
 
 
+class OracleStream:
+    """The oracle's restatement of the streaming API (orc_stream_*), driven like
+    pdmp3_amd.api.Decoder so that call sequences can be replayed on both."""
+
+    def __init__(self, oracle):
+        self.L = oracle.lib
+        self.L.orc_stream_new.restype = C.c_void_p
+        self.L.orc_stream_open_feed.argtypes = [_p]
+        self.L.orc_stream_feed.argtypes = [_p, _p, C.c_size_t]
+        self.L.orc_stream_read.argtypes = [_p, _p, C.c_size_t, C.POINTER(C.c_size_t)]
+        self.L.orc_stream_delete.argtypes = [_p]
+        self.s = self.L.orc_stream_new()
+        self.L.orc_stream_open_feed(self.s)
+
+    def close(self):
+        self.L.orc_stream_delete(self.s)
+
+    def decode_like_cli(self, mp3: bytes):
+        self.L.orc_stream_open_feed(self.s)
+        out, pos = [], 0
+        buf = (C.c_ubyte * 16384)()
+        done = C.c_size_t(0)
+        while True:
+            rc = self.L.orc_stream_read(self.s, buf, 16384, C.byref(done))
+            if rc == -1:
+                break
+            out.append(bytes(buf[:done.value]))
+            if rc == -10:
+                chunk = mp3[pos:pos + 4096]
+                if not chunk:
+                    break
+                cb = (C.c_ubyte * len(chunk)).from_buffer_copy(chunk)
+                self.L.orc_stream_feed(self.s, cb, len(chunk))
+                pos += len(chunk)
+        return b"".join(out)
+
+
 def have_ref():
     return os.path.exists(os.path.join(_HERE, "_ref", "libpdmp3_ref.so"))
 

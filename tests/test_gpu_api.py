@@ -71,7 +71,8 @@ def test_c1_pdmp3_decode_128k(oracle):
         if not chunk and rc != 0:
             break
     want = b"".join(want)
-    assert len(got) == len(want) and len(got) > 250 * 4608
+    # pdmp3_decode silently drops input beyond the ring's free space (H16): fewer than 300 frames come out, identically
+    assert len(got) == len(want) and len(got) > 100 * 4608
     assert_pcm_close(_as16(got), _as16(want), 1, "C1")
 
 
@@ -91,15 +92,22 @@ def test_feed_read_streaming(oracle, kw):
 
 
 def test_two_handles_do_not_share_state(oracle):
-    """per-handle synthesis state (the reference's is process-global)"""
+    """per-handle synthesis state (the reference's is process-global); a
+    handle re-opened with pdmp3_open_feed keeps its parse state (stale count1 /
+    scalefactors, H4-H6) exactly like the reference -- replayed on the oracle."""
+    from oracle.oracle import OracleStream
     from pdmp3_amd import api
     a = packer.generate(n_frames=60, seed=201)
     b = packer.generate(n_frames=60, seed=202, sfreq=1)
     da, db = api.Decoder(), api.Decoder()
+    oa, ob = OracleStream(oracle), OracleStream(oracle)
     pa = api.decode_like_cli(a, da)
-    pb = api.decode_like_cli(b, db)
-    pa2 = api.decode_like_cli(a, da)                  # open_feed resets the stream
+    pb = api.decode_like_cli(b, db)                   # interleaved use of a second handle
+    pa2 = api.decode_like_cli(b, da)                  # handle a re-opened on another stream
+    pb2 = api.decode_like_cli(a, db)
     da.close(); db.close()
-    assert pa == pa2
-    assert_pcm_close(_as16(pa), _as16(oracle.decode_buffer_like_cli(a)), 1, "a")
-    assert_pcm_close(_as16(pb), _as16(oracle.decode_buffer_like_cli(b)), 1, "b")
+    for got, want, what in ((pa, oa.decode_like_cli(a), "a"), (pb, ob.decode_like_cli(b), "b"),
+                            (pa2, oa.decode_like_cli(b), "a reopened"), (pb2, ob.decode_like_cli(a), "b reopened")):
+        assert len(got) == len(want)
+        assert_pcm_close(_as16(got), _as16(want), 1, what)
+    oa.close(); ob.close()
