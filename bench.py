@@ -122,7 +122,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # the path's one exchange: final PCM gather to rank 0 (RCCL over xGMI), outside the timed region
-        mine = pcm[halo:].contiguous()
+        mine = pcm[halo:].contiguous().view(torch.uint8)   # RCCL has no int16: gather the PCM as bytes
         bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
         torch.cuda.synchronize()
         dist.barrier()
