@@ -1,0 +1,90 @@
+"""Stream-level BASELINE configs on the GPU box:
+
+  configs[2] (C3)  feed/read streaming of a long 44.1 kHz stereo 320 kbps CBR stream, host Huffman +
+                   GPU transforms (default: 20 000 frames ~ 8.7 min of audio; PDMP3_FULL_C3=1 runs the
+                   full hour, 137 813 frames, ~144 MB)
+  configs[3] (C4)  mixed corpus: mono / stereo / joint-MS x 32 / 44.1 / 48 kHz x CBR+VBR x long /
+                   start-short-stop / mixed blocks, files dealt to ranks largest-first
+  CLI             pdmp3_cli (the reference's main.c contract) writing <file>.raw
+
+Oracle = bit-exact restatement of the reference, on the same bytes; bar +-1 LSB.
+"""
+import hashlib
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from tools.packer import packer
+from util import assert_pcm_close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _as16(b):
+    return np.frombuffer(b, dtype=np.int16)
+
+
+def test_c3_long_stream(oracle):
+    from pdmp3_amd import api
+    n = 137813 if os.environ.get("PDMP3_FULL_C3") else 20000
+    mp3 = packer.generate(n_frames=n, seed=0xC3, sfreq=0, mode=1, mode_ext=2, bitrate_index=14)
+    assert abs(len(mp3) / n - 1044.9) < 0.2                     # 320 kbps CBR with ISO padding
+    t0 = time.time()
+    got = api.decode_like_cli(mp3)
+    dt = time.time() - t0
+    want = oracle.decode_buffer_like_cli(mp3)
+    assert len(got) == len(want) >= (n - 3) * 4608
+    dmax, ndiff = assert_pcm_close(_as16(got), _as16(want), 1, "C3")
+    fps = (len(got) / 4608) / dt
+    print("C3: %d frames in %.2f s = %.0f frames/s = %.0fx real time (python ctypes loop included); "
+          "max diff %d LSB in %.3f%% of samples" % (len(got) // 4608, dt, fps, fps / 38.28125, dmax, 100.0 * ndiff / (len(got) // 2)))
+    assert fps / 38.28125 >= 50, "north_star: >= 50x real time"
+
+
+def test_c4_mixed_corpus(oracle):
+    from pdmp3_amd import api
+    from pdmp3_amd.sharding import assign_files
+    files = []
+    seed = 400
+    for mode, mext in ((3, 0), (0, 0), (1, 2)):
+        for sfreq in (0, 1, 2):
+            for vbr in (False, True):
+                for blocks in ((100, 0, 0, 0), (40, 20, 20, 20), (20, 10, 60, 10)):
+                    seed += 1
+                    hi = 13 if sfreq == 2 else 14                # 32 kHz <= 256 kbps (H10)
+                    files.append(packer.generate(n_frames=40 + seed % 50, seed=seed, sfreq=sfreq, mode=mode, mode_ext=mext,
+                                                 vbr=vbr, vbr_lo=4, vbr_hi=hi, bitrate_index=min(12, hi), block_pct=blocks,
+                                                 mixed_pct=50 if blocks[2] else 0))
+    assert len(files) == 54
+    plan = assign_files([len(f) for f in files], 8)
+    assert sorted(sum(plan, [])) == list(range(len(files)))
+    dec = [api.Decoder() for _ in range(2)]                     # two live handles, interleaved
+    worst = 0
+    for r, idxs in enumerate(plan):
+        for i in idxs:
+            d = api.Decoder()                                   # fresh handle per file = fresh parse state, like the oracle
+            got = api.decode_like_cli(files[i], d)
+            d.close()
+            want = oracle.decode_buffer_like_cli(files[i])
+            assert len(got) == len(want)
+            dmax, _ = assert_pcm_close(_as16(got), _as16(want), 1, "file %d" % i)
+            worst = max(worst, dmax)
+    for d in dec:
+        d.close()
+    assert worst <= 1
+
+
+def test_cli_writes_raw(oracle, tmp_path):
+    mp3 = packer.generate(n_frames=200, seed=0xC1, sfreq=0, mode=1, mode_ext=2, bitrate_index=9)
+    path = tmp_path / "c1_128k.mp3"
+    path.write_bytes(mp3)
+    cli = os.path.join(ROOT, "pdmp3_amd", "pdmp3_cli")
+    subprocess.check_call([cli, str(path)], timeout=120)
+    got = (tmp_path / "c1_128k.mp3.raw").read_bytes()
+    want = oracle.decode_buffer_like_cli(mp3)
+    assert len(got) == len(want)
+    assert_pcm_close(_as16(got), _as16(want), 1, "CLI")

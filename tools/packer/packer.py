@@ -31,7 +31,7 @@ def _load():
 
 def generate(n_frames, seed=1, sfreq=0, mode=1, mode_ext=2, bitrate_index=14, vbr=False, vbr_lo=5, vbr_hi=14,
              crc=False, block_pct=(70, 10, 10, 10), mixed_pct=50, reservoir=True, table33_pct=0, fill_pct=92,
-             big_pct=5, gain=(120, 170)) -> bytes:
+             big_pct=5, gain=(110, 150)) -> bytes:
     """bitrate_index 14 = 320 kbps, 9 = 128 kbps (Layer III)."""
     cfg = Cfg(seed, sfreq, mode, mode_ext, bitrate_index, int(vbr), vbr_lo, vbr_hi, int(crc),
               (C.c_int * 4)(*block_pct), mixed_pct, int(reservoir), table33_pct, fill_pct, big_pct, gain[0], gain[1])
