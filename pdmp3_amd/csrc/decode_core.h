@@ -59,7 +59,21 @@
 #define PD_PIN(x) ((void)0)
 #endif
 
+// IMDCT and the polyphase matrixing on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32)
+// in the device build; the host (index-logic) build keeps the VALU formulation.
+#if defined(__HIPCC__) && !defined(PDMP3_NO_MFMA)
+#define PD_MFMA 1
+#else
+#define PD_MFMA 0
+#endif
+
 namespace pdmp3 {
+
+#if PD_MFMA
+constexpr int kOvlRegs = 32;          // overlap kept in MFMA C/D layout: [ch][h][r] for t = j, and for t = 16 + j
+#else
+constexpr int kOvlRegs = 18;          // overlap of (ch, sb) in the lane that owns it
+#endif
 
 constexpr int kHaloGranules = 3;      // (f-2,gr1) (f-1,gr0) (f-1,gr1): SURVEY 8e incl. the H5 corner
 constexpr int kHistSlots = 15;        // polyphase history depth (P:2015-2019 reaches 15 slots back)
@@ -98,6 +112,10 @@ struct GlobalTables {
                             //   scale-table index of that source line << 10.
                             //   kind 0 long, 1 short, 2 mixed; index 0..21 long sfb, 22+sfb*3+win short
   const float* win;         // [4][36] g_imdct_win (P:577-603)
+  // MFMA B-operand fragments, lane-indexed [fragment][64 lanes] (host_tables.h: build_fragments)
+  const float* frag_long;   // [5 kk][3 nt]   cos_N36 columns {p=j | 18+j | 16,17,34,35}
+  const float* frag_short;  // [5 kk][3 nt]   3 x 12-point IMDCT with win[2] folded in, same column map
+  const float* frag_mat;    // [8 (h,r)][2 nt'] 32-point DCT-II rows in the order the IMDCT leaves them in registers
 };
 
 // LDS per wave (~12.3 KB).  Buffers whose lifetimes do not overlap share storage:
@@ -124,7 +142,9 @@ struct WaveLds {
 typedef uint32_t Chunk16 __attribute__((vector_size(16)));   // one 16-byte global/LDS access
 
 struct LaneRegs {
-  float ovl[18];     // IMDCT overlap of (ch = lane>>5, sb = lane&31): the reference's store[ch][sb][] (P:1755)
+  float ovl[kOvlRegs];  // IMDCT overlap, the reference's store[ch][sb][] (P:1755)
+  float bi[15];      // MFMA build: B fragments of the long IMDCT matrix
+  float bm[16];      // MFMA build: B fragments of the matrixing DCT
   float we[8];       // window coefficients of (ch, i = lane&31): even taps, sign folded
   float wo[8];       // odd taps
   float he[15];      // polyphase history: coefficient idx_e of the last 15 slots (oldest first)
@@ -170,7 +190,7 @@ PD_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 // ---------------------------------------------------------------------------
 PD_FN void state_zero(int lane, LaneRegs& R) {
   (void)lane;
-  for (int m = 0; m < 18; m++) R.ovl[m] = 0.0f;
+  for (int m = 0; m < kOvlRegs; m++) R.ovl[m] = 0.0f;
   for (int s = 0; s < kHistSlots; s++) { R.he[s] = 0.0f; R.ho[s] = 0.0f; }
 }
 
@@ -190,6 +210,10 @@ PD_FN void lane_init(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const Global
   L.pow43s[lane + 64] = T.pow43[lane + 64];
   for (int k = lane; k < 144; k += 64) (&L.win[0][0])[k] = T.win[k];
   if (lane < 4) L.peek[lane] = 1.0f;
+#if PD_MFMA
+  for (int k = 0; k < 15; k++) R.bi[k] = T.frag_long[k * 64 + lane];
+  for (int k = 0; k < 16; k++) R.bm[k] = T.frag_mat[k * 64 + lane];
+#endif
 }
 
 // the line tables of one sampling frequency (3 kinds x 576 u16 = 216 x 16 B)
@@ -199,22 +223,22 @@ PD_FN void load_linetab(int lane, WaveLds& L, const GlobalTables& T, int sfreq) 
   for (int k = lane; k < 216; k += 64) dst[k] = src[k];
 }
 
-// state layout (opaque to callers): float ovl[18][64 lanes]; float he[15][64]; float ho[15][64]
-constexpr int kStateFloats = 64 * (18 + 2 * kHistSlots);
+// state layout (opaque to callers): float ovl[kOvlRegs][64 lanes]; float he[15][64]; float ho[15][64]
+constexpr int kStateFloats = 64 * (kOvlRegs + 2 * kHistSlots);
 
 PD_FN void state_load(int lane, LaneRegs& R, const float* st) {
-  for (int m = 0; m < 18; m++) R.ovl[m] = st[m * 64 + lane];
+  for (int m = 0; m < kOvlRegs; m++) R.ovl[m] = st[m * 64 + lane];
   for (int s = 0; s < kHistSlots; s++) {
-    R.he[s] = st[(18 + s) * 64 + lane];
-    R.ho[s] = st[(18 + kHistSlots + s) * 64 + lane];
+    R.he[s] = st[(kOvlRegs + s) * 64 + lane];
+    R.ho[s] = st[(kOvlRegs + kHistSlots + s) * 64 + lane];
   }
 }
 
 PD_FN void state_store(int lane, const LaneRegs& R, float* st) {
-  for (int m = 0; m < 18; m++) st[m * 64 + lane] = R.ovl[m];
+  for (int m = 0; m < kOvlRegs; m++) st[m * 64 + lane] = R.ovl[m];
   for (int s = 0; s < kHistSlots; s++) {
-    st[(18 + s) * 64 + lane] = R.he[s];
-    st[(18 + kHistSlots + s) * 64 + lane] = R.ho[s];
+    st[(kOvlRegs + s) * 64 + lane] = R.he[s];
+    st[(kOvlRegs + kHistSlots + s) * 64 + lane] = R.ho[s];
   }
 }
 
@@ -256,39 +280,38 @@ PD_HD float pow2_quarter(int k) {        // 2^(k/4), k in [-266, 45]
   return ldexpf(base, k >> 2);
 }
 PD_HD float pow2_neg_half(uint32_t n) {  // 2^(-n/2); 0 from n = 300 on (binary32 underflow)
-  if (n >= 300u) return 0.0f;
-  return ldexpf((n & 1) ? 0x1.6a09e6p-1f : 1.0f, -(int)(n >> 1));
+  const float v = ldexpf((n & 1) ? 0x1.6a09e6p-1f : 1.0f, -(int)((n < 300u ? n : 300u) >> 1));
+  return n >= 300u ? 0.0f : v;
 }
 
+// straight-line (select-only) so that the LDS reads of both channels are in flight together
 PD_FN void ph_scales(int lane, WaveLds& L) {
-  if (lane >= 61) return;
-  PD_UNROLL
-  for (int ch = 0; ch < 2; ch++) {
+  const bool is_long = lane < 22;
+  const int ll = is_long ? lane : 21;
+  const int q = is_long ? 0 : (lane < 61 ? lane - 22 : 38);
+  const int sfb = q / 3, win = q - 3 * sfb;
+  const int pre = (int)((0x2fe95400000ull >> (2 * ll)) & 3);     // pretab P:2123 (+ [21] = 0, H4), 2 bits per entry
+  const float pk = L.peek[win];
+  float res[2];
+  PD_UNROLL for (int ch = 0; ch < 2; ch++) {
     const uint8_t* s = L.side[ch];
     const int gg = s[2], flags = s[3];
+    const uint32_t sl = s[8 + ll], ss = s[30 + q], mark = s[30 + 36], sbg = s[4 + win];
     const bool sfscale = flags & PDMP3_GC_SCALEFAC_SCALE;
-    float t1, t2;
-    if (lane < 22) {
-      // pretab P:2123 (+ [21] = 0, H4), 2 bits per entry
-      const int pre = (int)((0x2fe95400000ull >> (2 * lane)) & 3);
-      const uint32_t x = (uint32_t)s[8 + lane] + ((flags & PDMP3_GC_PREFLAG) ? pre : 0);
-      t1 = pow2_neg_half(sfscale ? 2 * x : x);
-      t2 = pow2_quarter(gg - 210);
-    } else {
-      const int q = lane - 22, sfb = q / 3, win = q - 3 * sfb;
-      uint32_t sf = s[30 + q];
-      if (sfb == 12 && s[30 + 36] == PDMP3_SF_PEEK) sf = f2u(L.peek[win]);   // H5
-      if (sf > 400u) sf = 400u;
-      t1 = pow2_neg_half(sfscale ? 2 * sf : sf);
-      t2 = pow2_quarter(gg - 210 - 8 * (int)s[4 + win]);
-    }
-    L.scale[ch][lane] = t1 * t2;
+    uint32_t sf_short = (sfb == 12 && mark == PDMP3_SF_PEEK) ? f2u(pk) : ss;                 // H5
+    sf_short = sf_short > 400u ? 400u : sf_short;
+    const uint32_t x = is_long ? sl + ((flags & PDMP3_GC_PREFLAG) ? (uint32_t)pre : 0u) : sf_short;
+    const float t1 = pow2_neg_half(sfscale ? 2 * x : x);
+    const float t2 = pow2_quarter(gg - 210 - (is_long ? 0 : 8 * (int)sbg));
+    res[ch] = t1 * t2;
   }
+  if (lane < 61) { L.scale[0][lane] = res[0]; L.scale[1][lane] = res[1]; }
 }
 
 // ---------------------------------------------------------------------------
 // ph_requant: requantise + reorder (gather) + stereo.  Lane l owns the
-// REORDERED lines 9l .. 9l+8 of both channels.
+// REORDERED lines l, l + 64, ..., l + 512 of both channels (consecutive lanes
+// touch consecutive LDS words: no bank conflicts on the int16 / u16 tables).
 // ---------------------------------------------------------------------------
 template <bool DUMP>
 PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, float* dump0, float* dump1) {
@@ -298,49 +321,57 @@ PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, f
   const bool is = joint && (g.mode_ext & 1);
   const int cmin = (g.count1_0 > g.count1_1) ? g.count1_1 : g.count1_0;   // P:1920 (H2)
   const int kind0 = g.kind(0), kind1 = g.kind(1);
-  const int d0 = 9 * lane;
   float x0[9], x1[9];
+#define PD_LINE(i) (lane + 64 * (i))
   {
     unsigned e0[9], e1[9];
-    PD_UNROLL for (int i = 0; i < 9; i++) e0[i] = L.ltab[kind0][d0 + i];
-    PD_UNROLL for (int i = 0; i < 9; i++) e1[i] = L.ltab[kind1][d0 + i];
+    PD_UNROLL for (int i = 0; i < 9; i++) e0[i] = L.ltab[kind0][PD_LINE(i)];
+    PD_UNROLL for (int i = 0; i < 9; i++) e1[i] = L.ltab[kind1][PD_LINE(i)];
     int v0[9], v1[9];
     float s0[9], s1[9];
     PD_UNROLL for (int i = 0; i < 9; i++) { v0[i] = L.spec[0][e0[i] & 1023]; s0[i] = L.scale[0][e0[i] >> 10]; }
     PD_UNROLL for (int i = 0; i < 9; i++) { v1[i] = L.spec[1][e1[i] & 1023]; s1[i] = L.scale[1][e1[i] >> 10]; }
+    // |is|^(4/3): LDS copy for magnitudes < 128; for the rare larger ones every lane issues an
+    // unconditional gather from the full table (index 0 when not needed, i.e. one shared line), all
+    // 18 in flight together with the LDS lookups -- no per-value branch, one wait.
+    int a0[9], a1[9];
+    float pg0[9], pg1[9], ps0[9], ps1[9];
+    PD_UNROLL for (int i = 0; i < 9; i++) { a0[i] = v0[i] < 0 ? -v0[i] : v0[i]; a1[i] = v1[i] < 0 ? -v1[i] : v1[i]; }
     PD_UNROLL for (int i = 0; i < 9; i++) {
-      const int a = v0[i] < 0 ? -v0[i] : v0[i];
-      float p = L.pow43s[a & (kPow43Small - 1)];
-      if (a >= kPow43Small) p = T.pow43[a > 8206 ? 8206 : a];
+      pg0[i] = T.pow43[a0[i] >= kPow43Small ? (a0[i] > 8206 ? 8206 : a0[i]) : 0];
+      pg1[i] = T.pow43[a1[i] >= kPow43Small ? (a1[i] > 8206 ? 8206 : a1[i]) : 0];
+    }
+    PD_UNROLL for (int i = 0; i < 9; i++) { ps0[i] = L.pow43s[a0[i] & (kPow43Small - 1)]; ps1[i] = L.pow43s[a1[i] & (kPow43Small - 1)]; }
+    PD_UNROLL for (int i = 0; i < 9; i++) {
+      const float p = a0[i] >= kPow43Small ? pg0[i] : ps0[i];
       x0[i] = s0[i] * (v0[i] < 0 ? -p : p);                 // (t1*t2)*t3, P:2132
     }
     PD_UNROLL for (int i = 0; i < 9; i++) {
-      const int a = v1[i] < 0 ? -v1[i] : v1[i];
-      float p = L.pow43s[a & (kPow43Small - 1)];
-      if (a >= kPow43Small) p = T.pow43[a > 8206 ? 8206 : a];
+      const float p = a1[i] >= kPow43Small ? pg1[i] : ps1[i];
       x1[i] = (g.nch == 2) ? s1[i] * (v1[i] < 0 ? -p : p) : 0.0f;
     }
   }
   if (DUMP) {
     PD_UNROLL for (int i = 0; i < 9; i++) {
-      dump0[d0 + i] = x0[i];
-      if (g.nch == 2) dump0[4 * 576 + d0 + i] = x1[i];
+      dump0[PD_LINE(i)] = x0[i];
+      if (g.nch == 2) dump0[4 * 576 + PD_LINE(i)] = x1[i];
     }
   }
   if (ms) {   // P:1921-1928
     PD_UNROLL for (int i = 0; i < 9; i++) {
-      if (d0 + i < cmin) {
-        const float sum = x0[i] + x1[i], dif = x0[i] - x1[i];
-        x0[i] = (float)((double)sum * 0.70710678118654752440);
-        x1[i] = (float)((double)dif * 0.70710678118654752440);
-      }
+      const float sum = x0[i] + x1[i], dif = x0[i] - x1[i];
+      const float l = (float)((double)sum * 0.70710678118654752440);
+      const float r = (float)((double)dif * 0.70710678118654752440);
+      const bool in = PD_LINE(i) < cmin;
+      x0[i] = in ? l : x0[i];
+      x1[i] = in ? r : x1[i];
     }
   }
   if (is) {   // P:1932-1971; block shape taken from channel 0.  Rare (no common encoder emits it).
     const uint8_t* sd0 = L.side[0];
     const int c1 = g.count1_1;
     PD_NOUNROLL for (int i = 0; i < 9; i++) {
-      const int d = d0 + i;
+      const int d = PD_LINE(i);
       float a0 = 0.0f, a1 = 0.0f;
       PD_UNROLL for (int k = 0; k < 9; k++) if (k == i) { a0 = x0[k]; a1 = x1[k]; }
       bool do_long = false, do_short = false;
@@ -381,15 +412,16 @@ PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, f
     }
   }
   PD_UNROLL for (int i = 0; i < 9; i++) {
-    L.xr[0][d0 + i] = x0[i];
-    if (g.nch == 2) L.xr[1][d0 + i] = x1[i];
+    L.xr[0][PD_LINE(i)] = x0[i];
+    if (g.nch == 2) L.xr[1][PD_LINE(i)] = x1[i];
   }
   if (DUMP) {
     PD_UNROLL for (int i = 0; i < 9; i++) {
-      dump1[d0 + i] = x0[i];
-      if (g.nch == 2) dump1[4 * 576 + d0 + i] = x1[i];
+      dump1[PD_LINE(i)] = x0[i];
+      if (g.nch == 2) dump1[4 * 576 + PD_LINE(i)] = x1[i];
     }
   }
+#undef PD_LINE
 }
 
 // ---------------------------------------------------------------------------
@@ -499,6 +531,145 @@ PD_FN void ph_imdct(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, float* dump3)
     if (lane == 0 && p < 3) L.peek[p] = y;                                     // H5 source
   }
 }
+
+#if PD_MFMA
+// ---------------------------------------------------------------------------
+// MFMA formulation of IMDCT + matrixing (device build)
+//
+// v_mfma_f32_16x16x4_f32: lane l = (j = l & 15, kq = l >> 4) holds A[row j][k = kq], B[k = kq][col j] and
+// D[row 4 kq + r][col j], r = 0..3; the result is a k-ordered fmaf chain, i.e. the same arithmetic as the
+// scalar formulation's PD_FMA chain.
+//
+//   IMDCT      D[(ch, sb)][p] = sum_k xr[ch][18 sb + k] * cos_N36[k][p]; 4 row tiles (ch, h: sb = 16 h + ..),
+//              3 column tiles {p = j | p = 18 + j | p = 16, 17, 34, 35}, 5 k-steps (k = 18, 19 are zero)
+//   epilogue   window, overlap-add (overlap stays in D layout), frequency inversion -- in registers
+//   matrixing  C[(ch, t)][n] = sum_sb hyb[ch][sb][t] * cos((2 sb + 1) n pi / 64): the epilogue's registers ARE the
+//              A fragments (row = t = j; the contraction index sb = 16 h + 4 kq + r arrives as 8 k-steps (h, r)),
+//              so the hybrid output never goes through LDS; the B rows are permuted to match (frag_mat)
+// ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+PD_FN f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// alias reduction in place (P:1706-1732): lane (ch, sb) owns the boundary below subband sb
+PD_FN void ph_antialias(int lane, WaveLds& L, BankPtr cb) {
+  const GranuleInfo g = granule_info(L);
+  const int ch = lane >> 5, sb = lane & 31;
+  if (ch >= g.nch || sb == 0) return;
+  const bool shrt = g.is_short(ch), mixed = g.is_mixed(ch);
+  if (shrt && !(mixed && sb == 1)) return;
+  float* x = L.xr[ch];
+  float lo[8], up[8];
+  PD_UNROLL for (int i = 0; i < 8; i++) { lo[i] = x[18 * sb - 1 - i]; up[i] = x[18 * sb + i]; }
+  PD_UNROLL for (int i = 0; i < 8; i++) {
+    x[18 * sb - 1 - i] = lo[i] * cb->cs[i] - up[i] * cb->ca[i];   // lb, P:1725
+    x[18 * sb + i] = up[i] * cb->cs[i] + lo[i] * cb->ca[i];       // ub, P:1726
+  }
+}
+
+template <bool DUMP>
+PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, const GlobalTables& T, float* dump2, float* dump3) {
+  const GranuleInfo g = granule_info(L);
+  const int j = lane & 15, kq = lane >> 4;
+  if (DUMP) {   // stage 2 = lines after alias reduction
+    PD_UNROLL for (int i = 0; i < 9; i++) {
+      dump2[lane + 64 * i] = L.xr[0][lane + 64 * i];
+      if (g.nch == 2) dump2[4 * 576 + lane + 64 * i] = L.xr[1][lane + 64 * i];
+    }
+  }
+  float out2[2][8];                      // [ch][h*4+r]: hybrid output of t = 16 + j (lanes j < 2)
+  PD_UNROLL for (int k = 0; k < 8; k++) { out2[0][k] = 0.0f; out2[1][k] = 0.0f; }
+  // channel 1 first: its matrixing output overwrites xr[1][18..] and nothing of xr[0];
+  // channel 0's output then overwrites xr[0] and xr[1][0..17], both consumed by then.
+  PD_UNROLL for (int cc = 0; cc < 2; cc++) {
+    const int ch = 1 - cc;
+    if (ch < g.nch) {                    // wave-uniform
+      const bool shrt = g.is_short(ch);
+      const bool wsf = (g.flags(ch) & PDMP3_GC_WIN_SWITCH) != 0;
+      const bool mixrows = wsf && g.is_mixed(ch);        // subbands 0, 1 use window/transform 0 (P:1769-1771)
+      const int bt = g.block_type(ch);
+      float bfr[15];
+      if (shrt) { PD_UNROLL for (int k = 0; k < 15; k++) bfr[k] = T.frag_short[k * 64 + lane]; }
+      else { PD_UNROLL for (int k = 0; k < 15; k++) bfr[k] = R.bi[k]; }
+      f32x4 acc[2][3];
+      PD_UNROLL for (int h = 0; h < 2; h++) PD_UNROLL for (int nt = 0; nt < 3; nt++) acc[h][nt] = (f32x4){0, 0, 0, 0};
+      float afr[2][5];
+      PD_UNROLL for (int h = 0; h < 2; h++)
+        PD_UNROLL for (int kk = 0; kk < 5; kk++) {
+          const int k = 4 * kk + kq;
+          afr[h][kk] = L.xr[ch][18 * (16 * h + j) + (k < 18 ? k : 0)];
+          if (k >= 18) afr[h][kk] = 0.0f;
+        }
+      PD_UNROLL for (int kk = 0; kk < 5; kk++)
+        PD_UNROLL for (int h = 0; h < 2; h++)
+          PD_UNROLL for (int nt = 0; nt < 3; nt++) acc[h][nt] = mfma16(afr[h][kk], bfr[kk * 3 + nt], acc[h][nt]);
+      f32x4 accl[3];
+      PD_UNROLL for (int nt = 0; nt < 3; nt++) accl[nt] = acc[0][nt];
+      if (shrt && mixrows) {             // wave-uniform: rows sb 0, 1 of the first tile take the long transform
+        PD_UNROLL for (int nt = 0; nt < 3; nt++) accl[nt] = (f32x4){0, 0, 0, 0};
+        PD_UNROLL for (int kk = 0; kk < 5; kk++)
+          PD_UNROLL for (int nt = 0; nt < 3; nt++) accl[nt] = mfma16(afr[0][kk], R.bi[kk * 3 + nt], accl[nt]);
+      }
+      // window factors of this lane's columns: t = j, p = 18 + j, and t = 16 + j / p = 34 + (j - 2)
+      const int zc = (j < 2) ? 16 + j : ((j < 4) ? 32 + j : 0);
+      const float* wb = L.win[bt];
+      const float* w0 = L.win[0];
+      const float wb1 = wb[j], wb2 = wb[18 + j], wbz = wb[zc];
+      const float w01 = w0[j], w02 = w0[18 + j], w0z = w0[zc];
+      float outa[8];
+      PD_UNROLL for (int h = 0; h < 2; h++)
+        PD_UNROLL for (int r = 0; r < 4; r++) {
+          const bool lowrow = mixrows && h == 0 && kq == 0 && r < 2;      // sb = 16 h + 4 kq + r < 2
+          float y1 = acc[h][0][r], y2 = acc[h][1][r], z = acc[h][2][r];
+          if (h == 0 && lowrow) { y1 = accl[0][r]; y2 = accl[1][r]; z = accl[2][r]; }
+          const bool win_folded = shrt && !lowrow;                        // short transform: window is in the matrix
+          const float f1 = lowrow ? w01 : wb1, f2 = lowrow ? w02 : wb2, fz = lowrow ? w0z : wbz;
+          if (!win_folded) { y1 = y1 * f1; y2 = y2 * f2; z = z * fz; }
+          const int oi = ch * 8 + h * 4 + r;
+          float o = y1 + R.ovl[oi];                                       // P:1775
+          R.ovl[oi] = y2;                                                 // P:1776
+          const float znext = __shfl(z, lane + 2);                        // p = 34 + j sits two columns to the right
+          float o2 = z + R.ovl[16 + oi];
+          R.ovl[16 + oi] = znext;
+          if ((r & 1) && (j & 1)) { o = -o; o2 = -o2; }                   // P:1738-1746: odd subband, odd sample
+          outa[h * 4 + r] = o;
+          out2[ch][h * 4 + r] = o2;
+          if (DUMP) {
+            const int sb = 16 * h + 4 * kq + r;
+            dump3[ch * 4 * 576 + 18 * sb + j] = o;
+            if (j < 2) dump3[ch * 4 * 576 + 18 * sb + 16 + j] = o2;
+          }
+          if (ch == 0 && h == 0 && r == 0 && kq == 0 && j < 3) L.peek[j] = o;   // H5 source: (ch 0, sb 0, t 0..2)
+        }
+      // matrixing of time slots t = j (rows) of this channel: k-steps in (h, r) order
+      f32x4 m0 = (f32x4){0, 0, 0, 0}, m1 = (f32x4){0, 0, 0, 0};
+      PD_UNROLL for (int k = 0; k < 8; k++) {
+        m0 = mfma16(outa[k], R.bm[2 * k], m0);
+        m1 = mfma16(outa[k], R.bm[2 * k + 1], m1);
+      }
+      PD_UNROLL for (int r = 0; r < 4; r++) {      // D rows = time slot 4 kq + r, cols n = j, 16 + j
+        L.hyb[ch][4 * kq + r][j] = m0[r];
+        L.hyb[ch][4 * kq + r][16 + j] = m1[r];
+      }
+    }
+  }
+  // the four left-over time slots (ch 0: t = 16, 17; ch 1: t = 16, 17) as one more row tile
+  {
+    f32x4 m0 = (f32x4){0, 0, 0, 0}, m1 = (f32x4){0, 0, 0, 0};
+    PD_UNROLL for (int k = 0; k < 8; k++) {
+      const float from1 = __shfl(out2[1][k], lane - 2);                   // rows 2, 3 <- channel 1's columns 0, 1
+      const float a = (j < 2) ? out2[0][k] : ((j < 4) ? from1 : 0.0f);
+      m0 = mfma16(a, R.bm[2 * k], m0);
+      m1 = mfma16(a, R.bm[2 * k + 1], m1);
+    }
+    if (kq == 0) {
+      PD_UNROLL for (int r = 0; r < 4; r++) {
+        const int ch = r >> 1, t = 16 + (r & 1);
+        if (ch < g.nch) { L.hyb[ch][t][j] = m0[r]; L.hyb[ch][t][16 + j] = m1[r]; }
+      }
+    }
+  }
+}
+#endif  // PD_MFMA
 
 // ---------------------------------------------------------------------------
 // 32-point DCT-II, Lee's recursion:  X[k] = sum_n x[n] cos(pi (2n+1) k / 2N)
@@ -666,6 +837,17 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     float* dmp = DUMP ? a.stages + ((size_t)f * 16 + gr * 8) * 576 : nullptr;
     PD_PHASE(ph_requant<DUMP>(lane, L, cb, T, dmp, dmp + 576))
     PD_TICK(2)
+#if PD_MFMA
+    PD_PHASE(
+      // the next granule's HBM reads fly during this granule's transforms
+      if (g + 1 < g_end) ph_prefetch(lane, R, a.spectra + (size_t)(g + 1) * 1152, a.side + (size_t)(g + 1) * 2);
+      ph_antialias(lane, L, cb);
+    )
+    PD_TICK(3)
+    PD_PHASE(ph_mfma<DUMP>(lane, L, R, T, dmp + 2 * 576, dmp + 3 * 576))
+    PD_TICK(4)
+    PD_TICK(5)
+#else
     PD_PHASE(
       // the next granule's HBM reads fly during this granule's transforms
       if (g + 1 < g_end) ph_prefetch(lane, R, a.spectra + (size_t)(g + 1) * 1152, a.side + (size_t)(g + 1) * 2);
@@ -676,6 +858,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     PD_TICK(4)
     PD_PHASE(ph_dct32(lane, L))
     PD_TICK(5)
+#endif
     PD_PHASE(ph_window(lane, L, R))
     PD_TICK(6)
     PD_PHASE(

@@ -29,6 +29,7 @@ struct HostTables {
   std::vector<float> pow43;        // 8207
   std::vector<uint16_t> linetab;   // 3*3*576: source line | scale index << 10, per reordered line
   std::vector<float> win;          // 4*36
+  std::vector<float> frag_long, frag_short, frag_mat;   // MFMA B fragments, [fragment][64 lanes]
   // the reference's libm expressions, kept to verify the device's ldexp forms
   // (decode_core.h: pow2_neg_half / pow2_quarter) over their whole index range
   std::vector<float> t1, t2;
@@ -97,6 +98,46 @@ inline void build_host_tables(HostTables& H) {
     }
     for (int n = 0; n < 576; n++) tm[n] = (n < 36) ? tl[n] : ts[n];   // mixed: 2 long subbands, then short from sfb 3
   }
+
+  // ---- MFMA B-operand fragments (decode_core.h: ph_mfma).  Lane l = (j = l & 15, kq = l >> 4)
+  // holds B[k = 4 kk + kq][column map(nt, j)].
+  auto col_of = [](int nt, int j) -> int {          // IMDCT output index p of tile column j; -1 = unused
+    if (nt == 0) return j;
+    if (nt == 1) return 18 + j;
+    if (j < 2) return 16 + j;
+    if (j < 4) return 32 + j;                       // 34, 35 sit two columns right of 16, 17
+    return -1;
+  };
+  // short transform as one 18 x 36 matrix, window folded in: out[6 w + p + 6] += in[w + 3 m] cos_N12[m][p] win[2][p]
+  float bs[18][36];
+  memset(bs, 0, sizeof bs);
+  for (int w = 0; w < 3; w++)
+    for (int m = 0; m < 6; m++)
+      for (int p = 0; p < 12; p++) bs[w + 3 * m][6 * w + p + 6] = kCosN12[m * 12 + p] * kImdctWin[2 * 36 + p];
+  H.frag_long.assign(15 * 64, 0.0f);
+  H.frag_short.assign(15 * 64, 0.0f);
+  for (int kk = 0; kk < 5; kk++)
+    for (int nt = 0; nt < 3; nt++)
+      for (int l = 0; l < 64; l++) {
+        const int j = l & 15, k = 4 * kk + (l >> 4), p = col_of(nt, j);
+        if (k < 18 && p >= 0) {
+          H.frag_long[(kk * 3 + nt) * 64 + l] = kCosN36[k * 36 + p];
+          H.frag_short[(kk * 3 + nt) * 64 + l] = bs[k][p];
+        }
+      }
+  // matrixing: C[n] = sum_sb s[sb] cos((2 sb + 1) n pi / 64), n = 0..31, taken from the reference's own matrix
+  // N[i][sb] = (float)cos((float)((16 + i) (2 sb + 1)) * (pi / 64)) (pdmp3.c:1992):  C[n] = v[n - 16] (n >= 16),
+  // C[n] = -v[48 - n] (n < 16).
+  H.frag_mat.assign(16 * 64, 0.0f);
+  for (int h = 0; h < 2; h++)
+    for (int r = 0; r < 4; r++)
+      for (int ntp = 0; ntp < 2; ntp++)
+        for (int l = 0; l < 64; l++) {
+          const int j = l & 15, sb = 16 * h + 4 * (l >> 4) + r, n = 16 * ntp + j;
+          const int i = n >= 16 ? n - 16 : 48 - n;
+          const float nref = (float)cos(((float)(16 + i) * (2 * sb + 1)) * (3.14159265358979323846 / 64.0));
+          H.frag_mat[((h * 4 + r) * 2 + ntp) * 64 + l] = n >= 16 ? nref : -nref;
+        }
 }
 
 }  // namespace pdmp3

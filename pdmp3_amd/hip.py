@@ -33,7 +33,8 @@ EXPORTS = [
 
 
 def library_path():
-    return os.path.join(_HERE, "libpdmp3_hip.so")
+    # PDMP3_HIP_LIB: alternative build of the engine library (A/B experiments)
+    return os.environ.get("PDMP3_HIP_LIB") or os.path.join(_HERE, "libpdmp3_hip.so")
 
 
 def build_library(force=False):

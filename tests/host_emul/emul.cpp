@@ -17,7 +17,7 @@ extern "C" int emul_decode_frames(const int16_t* spectra, const pdmp3_gc_side* s
   static HostTables H;
   static bool ready = false;
   if (!ready) { build_host_tables(H); ready = true; }
-  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data()};
+  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data()};
   if (chunk_frames <= 0) chunk_frames = n_frames;
   if (stages) chunk_frames = n_frames;
   DecodeArgs a{spectra, side, pcm, state, state, stages, n_frames, chunk_frames, nullptr};
