@@ -40,6 +40,7 @@
 // Built with -ffp-contract=off: a*b+c stays two roundings (as in the reference's
 // x86-64 build) unless PD_FMA is written out.
 #define PD_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#define PD_FMA_EXACT(a, b, c) __builtin_fmaf((a), (b), (c))
 #define PD_CLOCK() __builtin_amdgcn_s_memtime()
 #define PD_UNROLL _Pragma("unroll")
 #define PD_NOUNROLL _Pragma("nounroll")
@@ -52,6 +53,7 @@
 #define PD_MFN inline
 #define PD_HD static inline
 #define PD_FMA(a, b, c) ((a) * (b) + (c))
+#define PD_FMA_EXACT(a, b, c) fmaf((a), (b), (c))   /* a true fused multiply-add is required */
 #define PD_CLOCK() 0ull
 #define PD_UNROLL
 #define PD_NOUNROLL
@@ -75,7 +77,9 @@ constexpr int kOvlRegs = 32;          // overlap kept in MFMA C/D layout: [ch][h
 constexpr int kOvlRegs = 18;          // overlap of (ch, sb) in the lane that owns it
 #endif
 
-constexpr int kHaloGranules = 3;      // (f-2,gr1) (f-1,gr0) (f-1,gr1): SURVEY 8e incl. the H5 corner
+constexpr int kHaloGranules = 2;      // (f-1,gr0) (f-1,gr1): overlap depth 1, polyphase history 15 slots
+constexpr int kHaloGranulesH5 = 3;    // + (f-2,gr1) when (f-1,gr1,ch1) is a short block: its requantisation peeks at
+                                      //   (f-1,gr0)'s synthesis output, which needs one more granule of overlap
 constexpr int kHistSlots = 15;        // polyphase history depth (P:2015-2019 reaches 15 slots back)
 constexpr int kPow43Small = 128;      // |is| below this come from the LDS copy of the table
 
@@ -591,7 +595,6 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, const GlobalTables& T, flo
       if (shrt) { PD_UNROLL for (int k = 0; k < 15; k++) bfr[k] = T.frag_short[k * 64 + lane]; }
       else { PD_UNROLL for (int k = 0; k < 15; k++) bfr[k] = R.bi[k]; }
       f32x4 acc[2][3];
-      PD_UNROLL for (int h = 0; h < 2; h++) PD_UNROLL for (int nt = 0; nt < 3; nt++) acc[h][nt] = (f32x4){0, 0, 0, 0};
       float afr[2][5];
       PD_UNROLL for (int h = 0; h < 2; h++)
         PD_UNROLL for (int kk = 0; kk < 5; kk++) {
@@ -599,14 +602,16 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, const GlobalTables& T, flo
           afr[h][kk] = L.xr[ch][18 * (16 * h + j) + (k < 18 ? k : 0)];
           if (k >= 18) afr[h][kk] = 0.0f;
         }
-      PD_UNROLL for (int kk = 0; kk < 5; kk++)
+      PD_UNROLL for (int h = 0; h < 2; h++)
+        PD_UNROLL for (int nt = 0; nt < 3; nt++) acc[h][nt] = mfma16(afr[h][0], bfr[nt], (f32x4){0, 0, 0, 0});
+      PD_UNROLL for (int kk = 1; kk < 5; kk++)
         PD_UNROLL for (int h = 0; h < 2; h++)
           PD_UNROLL for (int nt = 0; nt < 3; nt++) acc[h][nt] = mfma16(afr[h][kk], bfr[kk * 3 + nt], acc[h][nt]);
       f32x4 accl[3];
       PD_UNROLL for (int nt = 0; nt < 3; nt++) accl[nt] = acc[0][nt];
       if (shrt && mixrows) {             // wave-uniform: rows sb 0, 1 of the first tile take the long transform
-        PD_UNROLL for (int nt = 0; nt < 3; nt++) accl[nt] = (f32x4){0, 0, 0, 0};
-        PD_UNROLL for (int kk = 0; kk < 5; kk++)
+        PD_UNROLL for (int nt = 0; nt < 3; nt++) accl[nt] = mfma16(afr[0][0], R.bi[nt], (f32x4){0, 0, 0, 0});
+        PD_UNROLL for (int kk = 1; kk < 5; kk++)
           PD_UNROLL for (int nt = 0; nt < 3; nt++) accl[nt] = mfma16(afr[0][kk], R.bi[kk * 3 + nt], accl[nt]);
       }
       // window factors of this lane's columns: t = j, p = 18 + j, and t = 16 + j / p = 34 + (j - 2)
@@ -641,8 +646,8 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, const GlobalTables& T, flo
           if (ch == 0 && h == 0 && r == 0 && kq == 0 && j < 3) L.peek[j] = o;   // H5 source: (ch 0, sb 0, t 0..2)
         }
       // matrixing of time slots t = j (rows) of this channel: k-steps in (h, r) order
-      f32x4 m0 = (f32x4){0, 0, 0, 0}, m1 = (f32x4){0, 0, 0, 0};
-      PD_UNROLL for (int k = 0; k < 8; k++) {
+      f32x4 m0 = mfma16(outa[0], R.bm[0], (f32x4){0, 0, 0, 0}), m1 = mfma16(outa[0], R.bm[1], (f32x4){0, 0, 0, 0});
+      PD_UNROLL for (int k = 1; k < 8; k++) {
         m0 = mfma16(outa[k], R.bm[2 * k], m0);
         m1 = mfma16(outa[k], R.bm[2 * k + 1], m1);
       }
@@ -710,7 +715,8 @@ PD_FN void ph_dct32(int lane, WaveLds& L) {
   PD_UNROLL for (int n = 0; n < 32; n++) L.hyb[ch][t][n] = c[n];   // in place: the row now holds the slot's C[0..31]
 }
 
-// float -> int16 exactly as P:2028-2031 on x86-64 (cvttsd2si: out of range => INT32_MIN)
+// float -> int16 exactly as P:2028-2031 on x86-64 (cvttsd2si: out of range / NaN => INT32_MIN);
+// the f64 product of a binary32 and 32767 is exact, so this is bit-for-bit the reference's conversion
 PD_FN int pcm_from_sum(float sum) {
   const double d = (double)sum * 32767.0;
   int s;
@@ -779,6 +785,11 @@ constexpr int kProfSlots = 10;
 
 #if defined(__HIPCC__)
 #define PD_NLANES 1
+// A workgroup is ONE wavefront: LDS operations of a wave execute in order, so the
+// phase hand-offs through LDS need no s_barrier and -- unlike __syncthreads() -- no
+// drain of the vector-memory counter: the next granule's prefetch loads and this
+// granule's PCM stores stay in flight across phases.  The wave barrier only stops
+// the compiler from moving memory operations across the phase boundary.
 #define PD_PHASE(...)                                   \
   {                                                     \
     const int lane = threadIdx.x;                       \
@@ -786,7 +797,9 @@ constexpr int kProfSlots = 10;
     (void)R; (void)lane;                                \
     __VA_ARGS__;                                        \
   }                                                     \
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+  __builtin_amdgcn_wave_barrier();                      \
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #else
 #define PD_NLANES 64
 #define PD_PHASE(...)                                   \
@@ -804,14 +817,22 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   int f1 = f0 + a.chunk_frames;
   if (f1 > a.n_frames) f1 = a.n_frames;
   const int g_begin = 2 * f0, g_end = 2 * f1;
-  const int g_start = (chunk == 0) ? 0 : g_begin - kHaloGranules;
+  int g_start = 0;
+  if (g_begin > 0) {
+    // channel 1 of the granule just before the chunk: flags byte of its side record (wave-uniform)
+    const uint8_t fl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(g_begin - 1) * 2 + 1)[3];
+    const bool shrt = (fl & PDMP3_GC_WIN_SWITCH) && ((fl & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
+    g_start = g_begin - (shrt ? kHaloGranulesH5 : kHaloGranules);
+    if (g_start < 0) g_start = 0;
+  }
+  const bool from_stream_start = (g_start == 0);     // exact state: the caller's (or zero), no halo needed
   const bool last = (f1 == a.n_frames);
   int cur_sfreq = -1;
 
   PD_PHASE(
     ph_prefetch(lane, R, a.spectra + (size_t)g_start * 1152, a.side + (size_t)g_start * 2);
     lane_init(lane, L, R, cb, T);
-    if (chunk == 0 && a.state_in) state_load(lane, R, a.state_in);
+    if (from_stream_start && a.state_in) state_load(lane, R, a.state_in);
   )
   unsigned long long acc[kProfSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = PD_CLOCK();

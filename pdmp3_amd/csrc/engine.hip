@@ -116,8 +116,8 @@ static int auto_chunk(int n_frames) {
   // before growing the chunk; measured on MI355X (profiles/): a 2048-frame batch
   // is fastest at 2 frames per chunk despite the 3-granule halo, 10^5+ frames
   // at 16-32.
-  int L = n_frames / 1024;
-  if (L < 2) L = 2;
+  int L = n_frames / 2048;
+  if (L < 1) L = 1;
   if (L > 32) L = 32;
   return L;
 }
@@ -134,8 +134,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   if (n_frames == 0) return PDMP3_HIP_OK;
   hipStream_t s = (hipStream_t)stream;
   if (chunk_frames <= 0) chunk_frames = auto_chunk(n_frames);
-  if (chunk_frames < 2) chunk_frames = 2;      // the halo reaches 3 granules back
-  if (d_stages || chunk_frames > n_frames) chunk_frames = n_frames < 2 ? 2 : n_frames;
+  if (d_stages || chunk_frames > n_frames) chunk_frames = n_frames;
   const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
   DecodeArgs a;
   a.spectra = d_spectra;

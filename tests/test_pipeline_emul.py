@@ -35,7 +35,7 @@ def test_emul_vs_oracle(oracle, emul, name):
     assert_pcm_close(got, want, pcm_tolerance(ws[:, :, :, 3]), name)
 
 
-@pytest.mark.parametrize("chunk", [2, 3, 5, 16])
+@pytest.mark.parametrize("chunk", [1, 2, 3, 5, 16])
 def test_emul_chunking_is_invisible(oracle, emul, chunk):
     sp, sd = oracle.generate(C2_SEED, 0, 40)
     whole = emul_decode(emul, sp, sd, 0)
