@@ -57,6 +57,25 @@ def cpu_baseline(sample_frames, target_seconds):
     }
 
 
+def measured_traffic(frames, n_halo):
+    """HBM bytes per launch of k_decode from the committed PMC passes
+    (profiles/*_pmc_summary.json; separate rocprofv3 --pmc runs of this same
+    command, tools/gpu_profile.sh).  gfx950 correction per MI355X_MICROARCH.md
+    (HBM): FETCH_SIZE reports half of a wide coalesced read stream -> x2;
+    WRITE_SIZE matched the known PCM byte count exactly in calibration."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files or frames != FRAMES_PER_GPU or n_halo:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        fetch_kb = d["fetch"]["per_dispatch"]["FETCH_SIZE"]
+        write_kb = d["write"]["per_dispatch"]["WRITE_SIZE"]
+        return int((2.0 * fetch_kb + write_kb) * 1024), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,19 +122,22 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream (torch's current stream = the one handed to the C-ABI) bracket the K
+    # back-to-back launches: mean launch duration = elapsed / K (the stream never idles: the host enqueues a
+    # step in a few microseconds, a step runs ~50).
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()
+    ev0.record()
+    for _ in range(args.steps):
         step()
-        b.record()
+    ev1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
 
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -141,6 +163,7 @@ def main():
     total_frames = n * world * args.steps
     fps = total_frames / dt
     launch_bytes = (n + halo) * ALGO_BYTES_PER_FRAME
+    traffic, traffic_src = measured_traffic(n, halo)
     achieved = launch_bytes / (kern_ms * 1e-3) / 1e9
     out = {
         "metric": "MP3 frames/sec (44.1 kHz stereo 320 kbps), transforms-only hot path",
@@ -165,7 +188,7 @@ def main():
         "x_realtime": round(fps / RT_FRAMES_PER_S, 1),
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "k_decode<false>", "avg_launch_ms": round(kern_ms, 5),
             "algorithmic_bytes_per_launch": launch_bytes,
         },

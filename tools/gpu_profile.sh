@@ -1,0 +1,36 @@
+#!/bin/bash
+# Profiles that get committed under profiles/ (run on the GPU box via gpurun):
+#   1. rocprofv3 --kernel-trace --stats of the default bench workload (C2 launches only)
+#   2. PMC passes (separate runs) on the same workload: FETCH_SIZE, WRITE_SIZE, SQ mix
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu --big 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats.log; echo "stats rc=$?"
+cat $OUT/stats/bench_kernel_stats.csv
+pmc() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 bench.py --steps 20 --warmup 2 --no-cpu --big 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
+pmc fetch FETCH_SIZE
+pmc write WRITE_SIZE
+pmc sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
+pmc sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+pmc sq3 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32
+# the same for a C5-shard-sized launch
+pmcb() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 tools/pmc_target.py 131072 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
+pmcb big_fetch FETCH_SIZE
+pmcb big_write WRITE_SIZE
+python3 - "$OUT" <<'PY'
+import csv, glob, json, os, sys, collections
+out = sys.argv[1]
+summary = {}
+for d in sorted(glob.glob(os.path.join(out, "*", "p_counter_collection.csv"))):
+    name = d.split("/")[-2]
+    rows = list(csv.DictReader(open(d)))
+    agg = collections.defaultdict(float); disp = set()
+    for r in rows:
+        if "k_decode" not in r.get("Kernel_Name", ""): continue
+        agg[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
+    n = max(1, len(disp))
+    summary[name] = {"dispatches": n, "per_dispatch": {k: v / n for k, v in sorted(agg.items())}}
+json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
+PY
