@@ -119,7 +119,7 @@ struct GlobalTables {
   // MFMA B-operand fragments, lane-indexed [fragment][64 lanes] (host_tables.h: build_fragments)
   const float* frag_long;   // [5 kk][3 nt]   cos_N36 columns {p=j | 18+j | 16,17,34,35}
   const float* frag_short;  // [5 kk][3 nt]   3 x 12-point IMDCT with win[2] folded in, same column map
-  const float* frag_mat;    // [8 (h,r)][2 nt'] 32-point DCT-II rows in the order the IMDCT leaves them in registers
+  const float* frag_mat;    // [2 even/odd][4 k-steps]: 16 x 16 halves of the 32-point DCT-II, rows in register order
 };
 
 // LDS per wave (~12.3 KB).  Buffers whose lifetimes do not overlap share storage:
@@ -148,7 +148,7 @@ typedef uint32_t Chunk16 __attribute__((vector_size(16)));   // one 16-byte glob
 struct LaneRegs {
   float ovl[kOvlRegs];  // IMDCT overlap, the reference's store[ch][sb][] (P:1755)
   float bi[15];      // MFMA build: B fragments of the long IMDCT matrix
-  float bm[16];      // MFMA build: B fragments of the matrixing DCT
+  float bm[8];       // MFMA build: B fragments of the matrixing (even / odd 16 x 16 halves of the 32-point DCT-II)
   float we[8];       // window coefficients of (ch, i = lane&31): even taps, sign folded
   float wo[8];       // odd taps
   float he[15];      // polyphase history: coefficient idx_e of the last 15 slots (oldest first)
@@ -216,7 +216,7 @@ PD_FN void lane_init(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const Global
   if (lane < 4) L.peek[lane] = 1.0f;
 #if PD_MFMA
   for (int k = 0; k < 15; k++) R.bi[k] = T.frag_long[k * 64 + lane];
-  for (int k = 0; k < 16; k++) R.bm[k] = T.frag_mat[k * 64 + lane];
+  for (int k = 0; k < 8; k++) R.bm[k] = T.frag_mat[k * 64 + lane];
 #endif
 }
 
@@ -547,9 +547,12 @@ PD_FN void ph_imdct(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, float* dump3)
 //   IMDCT      D[(ch, sb)][p] = sum_k xr[ch][18 sb + k] * cos_N36[k][p]; 4 row tiles (ch, h: sb = 16 h + ..),
 //              3 column tiles {p = j | p = 18 + j | p = 16, 17, 34, 35}, 5 k-steps (k = 18, 19 are zero)
 //   epilogue   window, overlap-add (overlap stays in D layout), frequency inversion -- in registers
-//   matrixing  C[(ch, t)][n] = sum_sb hyb[ch][sb][t] * cos((2 sb + 1) n pi / 64): the epilogue's registers ARE the
-//              A fragments (row = t = j; the contraction index sb = 16 h + 4 kq + r arrives as 8 k-steps (h, r)),
-//              so the hybrid output never goes through LDS; the B rows are permuted to match (frag_mat)
+//   matrixing  C[(ch, t)][n] = sum_sb hyb[ch][sb][t] * cos((2 sb + 1) n pi / 64), folded once more:
+//              C[2m] = sum_{k<16} (x[k] + x[31-k]) cos((2k+1) 2m pi/64),  C[2m+1] = sum_{k<16} (x[k] - x[31-k]) cos((2k+1)(2m+1) pi/64).
+//              The second IMDCT row tile of a channel holds its subbands REVERSED (row i = subband 31 - i), so x[k]
+//              and x[31-k] sit in the same lane and register: the butterflies are lane-local adds and the epilogue's
+//              registers ARE the A fragments (row = t = j, k = 4 kq + r arrives as k-step r) -- the hybrid output
+//              never goes through LDS and the matrixing costs 8 instead of 16 MFMAs per row tile.
 // ---------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 PD_FN f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -599,7 +602,7 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, const GlobalTables& T, flo
       PD_UNROLL for (int h = 0; h < 2; h++)
         PD_UNROLL for (int kk = 0; kk < 5; kk++) {
           const int k = 4 * kk + kq;
-          afr[h][kk] = L.xr[ch][18 * (16 * h + j) + (k < 18 ? k : 0)];
+          afr[h][kk] = L.xr[ch][18 * (h ? 31 - j : j) + (k < 18 ? k : 0)];
           if (k >= 18) afr[h][kk] = 0.0f;
         }
       PD_UNROLL for (int h = 0; h < 2; h++)
@@ -623,7 +626,7 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, const GlobalTables& T, flo
       float outa[8];
       PD_UNROLL for (int h = 0; h < 2; h++)
         PD_UNROLL for (int r = 0; r < 4; r++) {
-          const bool lowrow = mixrows && h == 0 && kq == 0 && r < 2;      // sb = 16 h + 4 kq + r < 2
+          const bool lowrow = mixrows && h == 0 && kq == 0 && r < 2;      // subbands 0, 1 (first tile, rows 0, 1)
           float y1 = acc[h][0][r], y2 = acc[h][1][r], z = acc[h][2][r];
           if (h == 0 && lowrow) { y1 = accl[0][r]; y2 = accl[1][r]; z = accl[2][r]; }
           const bool win_folded = shrt && !lowrow;                        // short transform: window is in the matrix
@@ -635,41 +638,45 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, const GlobalTables& T, flo
           const float znext = __shfl(z, lane + 2);                        // p = 34 + j sits two columns to the right
           float o2 = z + R.ovl[16 + oi];
           R.ovl[16 + oi] = znext;
-          if ((r & 1) && (j & 1)) { o = -o; o2 = -o2; }                   // P:1738-1746: odd subband, odd sample
+          const int sb = h ? 31 - (4 * kq + r) : 4 * kq + r;              // subband of this row (tile 1 is reversed)
+          if ((sb & 1) && (j & 1)) { o = -o; o2 = -o2; }                  // P:1738-1746: odd subband, odd sample
           outa[h * 4 + r] = o;
           out2[ch][h * 4 + r] = o2;
           if (DUMP) {
-            const int sb = 16 * h + 4 * kq + r;
             dump3[ch * 4 * 576 + 18 * sb + j] = o;
             if (j < 2) dump3[ch * 4 * 576 + 18 * sb + 16 + j] = o2;
           }
           if (ch == 0 && h == 0 && r == 0 && kq == 0 && j < 3) L.peek[j] = o;   // H5 source: (ch 0, sb 0, t 0..2)
         }
-      // matrixing of time slots t = j (rows) of this channel: k-steps in (h, r) order
-      f32x4 m0 = mfma16(outa[0], R.bm[0], (f32x4){0, 0, 0, 0}), m1 = mfma16(outa[0], R.bm[1], (f32x4){0, 0, 0, 0});
-      PD_UNROLL for (int k = 1; k < 8; k++) {
-        m0 = mfma16(outa[k], R.bm[2 * k], m0);
-        m1 = mfma16(outa[k], R.bm[2 * k + 1], m1);
+      // matrixing of time slots t = j (rows) of this channel: butterflies, then even / odd 16 x 16 products
+      f32x4 me = (f32x4){0, 0, 0, 0}, mo = (f32x4){0, 0, 0, 0};
+      PD_UNROLL for (int r = 0; r < 4; r++) {
+        const float a = outa[r] + outa[4 + r], b = outa[r] - outa[4 + r];   // x[k] +- x[31 - k], k = 4 kq + r
+        me = mfma16(a, R.bm[r], me);
+        mo = mfma16(b, R.bm[4 + r], mo);
       }
-      PD_UNROLL for (int r = 0; r < 4; r++) {      // D rows = time slot 4 kq + r, cols n = j, 16 + j
-        L.hyb[ch][4 * kq + r][j] = m0[r];
-        L.hyb[ch][4 * kq + r][16 + j] = m1[r];
+      PD_UNROLL for (int r = 0; r < 4; r++) {      // D rows = time slot 4 kq + r, cols: C[2 j] and C[2 j + 1]
+        L.hyb[ch][4 * kq + r][2 * j] = me[r];
+        L.hyb[ch][4 * kq + r][2 * j + 1] = mo[r];
       }
     }
   }
   // the four left-over time slots (ch 0: t = 16, 17; ch 1: t = 16, 17) as one more row tile
   {
-    f32x4 m0 = (f32x4){0, 0, 0, 0}, m1 = (f32x4){0, 0, 0, 0};
-    PD_UNROLL for (int k = 0; k < 8; k++) {
-      const float from1 = __shfl(out2[1][k], lane - 2);                   // rows 2, 3 <- channel 1's columns 0, 1
-      const float a = (j < 2) ? out2[0][k] : ((j < 4) ? from1 : 0.0f);
-      m0 = mfma16(a, R.bm[2 * k], m0);
-      m1 = mfma16(a, R.bm[2 * k + 1], m1);
+    f32x4 me = (f32x4){0, 0, 0, 0}, mo = (f32x4){0, 0, 0, 0};
+    PD_UNROLL for (int r = 0; r < 4; r++) {
+      const float a0 = out2[0][r] + out2[0][4 + r], b0 = out2[0][r] - out2[0][4 + r];
+      const float a1 = out2[1][r] + out2[1][4 + r], b1 = out2[1][r] - out2[1][4 + r];
+      const float a1s = __shfl(a1, lane - 2), b1s = __shfl(b1, lane - 2);   // rows 2, 3 <- channel 1's columns 0, 1
+      const float a = (j < 2) ? a0 : ((j < 4) ? a1s : 0.0f);
+      const float b = (j < 2) ? b0 : ((j < 4) ? b1s : 0.0f);
+      me = mfma16(a, R.bm[r], me);
+      mo = mfma16(b, R.bm[4 + r], mo);
     }
     if (kq == 0) {
       PD_UNROLL for (int r = 0; r < 4; r++) {
         const int ch = r >> 1, t = 16 + (r & 1);
-        if (ch < g.nch) { L.hyb[ch][t][j] = m0[r]; L.hyb[ch][t][16 + j] = m1[r]; }
+        if (ch < g.nch) { L.hyb[ch][t][2 * j] = me[r]; L.hyb[ch][t][2 * j + 1] = mo[r]; }
       }
     }
   }

@@ -127,17 +127,18 @@ inline void build_host_tables(HostTables& H) {
       }
   // matrixing: C[n] = sum_sb s[sb] cos((2 sb + 1) n pi / 64), n = 0..31, taken from the reference's own matrix
   // N[i][sb] = (float)cos((float)((16 + i) (2 sb + 1)) * (pi / 64)) (pdmp3.c:1992):  C[n] = v[n - 16] (n >= 16),
-  // C[n] = -v[48 - n] (n < 16).
-  H.frag_mat.assign(16 * 64, 0.0f);
-  for (int h = 0; h < 2; h++)
+  // C[n] = -v[48 - n] (n < 16); folded into the even / odd halves
+  //   C[2m]   = sum_{k<16} (s[k] + s[31-k]) cos((2k+1) 2m pi/64),  C[2m+1] = sum_{k<16} (s[k] - s[31-k]) cos((2k+1)(2m+1) pi/64).
+  // Fragment (eo, step r): lane (j, kq) holds the coefficient of k = 4 kq + r for output n = 2 j + eo.
+  H.frag_mat.assign(8 * 64, 0.0f);
+  for (int eo = 0; eo < 2; eo++)
     for (int r = 0; r < 4; r++)
-      for (int ntp = 0; ntp < 2; ntp++)
-        for (int l = 0; l < 64; l++) {
-          const int j = l & 15, sb = 16 * h + 4 * (l >> 4) + r, n = 16 * ntp + j;
-          const int i = n >= 16 ? n - 16 : 48 - n;
-          const float nref = (float)cos(((float)(16 + i) * (2 * sb + 1)) * (3.14159265358979323846 / 64.0));
-          H.frag_mat[((h * 4 + r) * 2 + ntp) * 64 + l] = n >= 16 ? nref : -nref;
-        }
+      for (int l = 0; l < 64; l++) {
+        const int j = l & 15, k = 4 * (l >> 4) + r, n = 2 * j + eo;
+        const int i = n >= 16 ? n - 16 : 48 - n;
+        const float nref = (float)cos(((float)(16 + i) * (2 * k + 1)) * (3.14159265358979323846 / 64.0));
+        H.frag_mat[(eo * 4 + r) * 64 + l] = n >= 16 ? nref : -nref;
+      }
 }
 
 }  // namespace pdmp3
