@@ -72,7 +72,7 @@
 namespace pdmp3 {
 
 #if PD_MFMA
-constexpr int kOvlRegs = 32;          // overlap kept in MFMA C/D layout: [ch][h][r] for t = j, and for t = 16 + j
+constexpr int kOvlRegs = 18;          // overlap: [ch][h][r] in MFMA C/D layout for p = 18 + j, plus p = 34, 35 of the lane's own (ch, sb)
 #else
 constexpr int kOvlRegs = 18;          // overlap of (ch, sb) in the lane that owns it
 #endif
@@ -88,6 +88,8 @@ constexpr int kPow43Small = 128;      // |is| below this come from the LDS copy 
 struct ConstBank {
   float c36p[18][18][2];  // cos_N36 (P:620-729) as [m][q][{p = q, p = q + 18}]
   float c12t[12][6];      // cos_N12 (P:606-619) transposed to [p][m]
+  float c36x[4][18];      // cos_N36 columns p = 16, 17, 34, 35 as [q][m]   (MFMA build: the columns left to the VALU)
+  float s36x[4][18];      // the same columns of the short-block matrix (3 x 12-point IMDCT, win[2] folded in)
   float cs[8], ca[8];     // P:573-574
   float isr_l[16];        // is_ratio_l for is_pos 0..6 (P:2166-2172); [7] unused;
   float isr_r[16];        // [8..15]: the reference reads past is_ratios[] (H3) -> defined as t = 0
@@ -117,8 +119,8 @@ struct GlobalTables {
                             //   kind 0 long, 1 short, 2 mixed; index 0..21 long sfb, 22+sfb*3+win short
   const float* win;         // [4][36] g_imdct_win (P:577-603)
   // MFMA B-operand fragments, lane-indexed [fragment][64 lanes] (host_tables.h: build_fragments)
-  const float* frag_long;   // [5 kk][3 nt]   cos_N36 columns {p=j | 18+j | 16,17,34,35}
-  const float* frag_short;  // [5 kk][3 nt]   3 x 12-point IMDCT with win[2] folded in, same column map
+  const float* frag_long;   // [5 kk][2 nt]   cos_N36 columns {p = j | p = 18 + j}
+  const float* frag_short;  // [5 kk][2 nt]   3 x 12-point IMDCT with win[2] folded in, same column map
   const float* frag_mat;    // [2 even/odd][4 k-steps]: 16 x 16 halves of the 32-point DCT-II, rows in register order
 };
 
@@ -141,13 +143,14 @@ struct WaveLds {
   float pow43s[kPow43Small];
   alignas(16) uint16_t ltab[3][576];
   float peek[4];
+  float lo[2][4][16];       // MFMA build: even / odd folded time slots 16, 17: [a|b][2 ch + (t - 16)][k]
 };
 
 typedef uint32_t Chunk16 __attribute__((vector_size(16)));   // one 16-byte global/LDS access
 
 struct LaneRegs {
   float ovl[kOvlRegs];  // IMDCT overlap, the reference's store[ch][sb][] (P:1755)
-  float bi[15];      // MFMA build: B fragments of the long IMDCT matrix
+  float bi[10];      // MFMA build: B fragments of the long IMDCT matrix
   float bm[8];       // MFMA build: B fragments of the matrixing (even / odd 16 x 16 halves of the 32-point DCT-II)
   float we[8];       // window coefficients of (ch, i = lane&31): even taps, sign folded
   float wo[8];       // odd taps
@@ -215,7 +218,7 @@ PD_FN void lane_init(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const Global
   for (int k = lane; k < 144; k += 64) (&L.win[0][0])[k] = T.win[k];
   if (lane < 4) L.peek[lane] = 1.0f;
 #if PD_MFMA
-  for (int k = 0; k < 15; k++) R.bi[k] = T.frag_long[k * 64 + lane];
+  for (int k = 0; k < 10; k++) R.bi[k] = T.frag_long[k * 64 + lane];
   for (int k = 0; k < 8; k++) R.bm[k] = T.frag_mat[k * 64 + lane];
 #endif
 }
@@ -573,8 +576,13 @@ PD_FN void ph_antialias(int lane, WaveLds& L, BankPtr cb) {
   }
 }
 
+#define PD_WAVE_SYNC()                                       \
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+  __builtin_amdgcn_wave_barrier();                          \
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
+
 template <bool DUMP>
-PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, const GlobalTables& T, float* dump2, float* dump3) {
+PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTables& T, float* dump2, float* dump3) {
   const GranuleInfo g = granule_info(L);
   const int j = lane & 15, kq = lane >> 4;
   if (DUMP) {   // stage 2 = lines after alias reduction
@@ -583,9 +591,43 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, const GlobalTables& T, flo
       if (g.nch == 2) dump2[4 * 576 + lane + 64 * i] = L.xr[1][lane + 64 * i];
     }
   }
-  float out2[2][8];                      // [ch][h*4+r]: hybrid output of t = 16 + j (lanes j < 2)
-  PD_UNROLL for (int k = 0; k < 8; k++) { out2[0][k] = 0.0f; out2[1][k] = 0.0f; }
-  // channel 1 first: its matrixing output overwrites xr[1][18..] and nothing of xr[0];
+  const bool any_short = g.is_short(0) || (g.nch == 2 && g.is_short(1));
+  // ---- IMDCT outputs p = 16, 17, 34, 35 on the VALU: lane = (cl, sb), scalar-broadcast coefficients.
+  // (As a third MFMA column tile they would fill 4 of 16 columns.)  Must precede the hyb writes below:
+  // hyb aliases xr.
+  {
+    const int cl = lane >> 5, sb = lane & 31;
+    const bool act = cl < g.nch;
+    const bool lwsf = (g.flags(cl) & PDMP3_GC_WIN_SWITCH) != 0;
+    const bool llow = lwsf && g.is_mixed(cl) && sb < 2;
+    const bool lshort = g.is_short(cl) && !llow;
+    const float* x = &L.xr[cl][18 * sb];
+    float in[18];
+    PD_UNROLL for (int m = 0; m < 18; m++) in[m] = x[m];
+    float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    PD_UNROLL for (int m = 0; m < 18; m++)
+      PD_UNROLL for (int q = 0; q < 4; q++) y[q] = PD_FMA(in[m], cb->c36x[q][m], y[q]);
+    const float* w = L.win[llow ? 0 : g.block_type(cl)];
+    y[0] = y[0] * w[16]; y[1] = y[1] * w[17]; y[2] = y[2] * w[34]; y[3] = y[3] * w[35];
+    if (any_short) {                      // wave-uniform
+      float ys[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      PD_UNROLL for (int m = 0; m < 18; m++)
+        PD_UNROLL for (int q = 0; q < 4; q++) ys[q] = PD_FMA(in[m], cb->s36x[q][m], ys[q]);
+      PD_UNROLL for (int q = 0; q < 4; q++) y[q] = lshort ? ys[q] : y[q];
+    }
+    float o16 = y[0] + R.ovl[16], o17 = y[1] + R.ovl[17];                 // P:1775
+    R.ovl[16] = act ? y[2] : R.ovl[16];                                   // P:1776
+    R.ovl[17] = act ? y[3] : R.ovl[17];
+    if (sb & 1) o17 = -o17;                                               // P:1738-1746
+    if (DUMP) { if (act) { dump3[cl * 4 * 576 + 18 * sb + 16] = o16; dump3[cl * 4 * 576 + 18 * sb + 17] = o17; } }
+    // matrixing fold: x[k] +- x[31 - k]; subband 31 - sb of the same channel is lane ^ 31
+    const float p16 = __shfl_xor(o16, 31), p17 = __shfl_xor(o17, 31);
+    if (sb < 16) {
+      L.lo[0][2 * cl + 0][sb] = o16 + p16; L.lo[1][2 * cl + 0][sb] = o16 - p16;
+      L.lo[0][2 * cl + 1][sb] = o17 + p17; L.lo[1][2 * cl + 1][sb] = o17 - p17;
+    }
+  }
+  // ---- channel 1 first: its matrixing output overwrites xr[1][18..] and nothing of xr[0];
   // channel 0's output then overwrites xr[0] and xr[1][0..17], both consumed by then.
   PD_UNROLL for (int cc = 0; cc < 2; cc++) {
     const int ch = 1 - cc;
@@ -594,58 +636,50 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, const GlobalTables& T, flo
       const bool wsf = (g.flags(ch) & PDMP3_GC_WIN_SWITCH) != 0;
       const bool mixrows = wsf && g.is_mixed(ch);        // subbands 0, 1 use window/transform 0 (P:1769-1771)
       const int bt = g.block_type(ch);
-      float bfr[15];
-      if (shrt) { PD_UNROLL for (int k = 0; k < 15; k++) bfr[k] = T.frag_short[k * 64 + lane]; }
-      else { PD_UNROLL for (int k = 0; k < 15; k++) bfr[k] = R.bi[k]; }
-      f32x4 acc[2][3];
+      float bfr[10];
+      if (shrt) { PD_UNROLL for (int k = 0; k < 10; k++) bfr[k] = T.frag_short[k * 64 + lane]; }
+      else { PD_UNROLL for (int k = 0; k < 10; k++) bfr[k] = R.bi[k]; }
+      f32x4 acc[2][2];
       float afr[2][5];
       PD_UNROLL for (int h = 0; h < 2; h++)
         PD_UNROLL for (int kk = 0; kk < 5; kk++) {
           const int k = 4 * kk + kq;
-          afr[h][kk] = L.xr[ch][18 * (h ? 31 - j : j) + (k < 18 ? k : 0)];
+          afr[h][kk] = L.xr[ch][18 * (h ? 31 - j : j) + (k < 18 ? k : 0)];   // second row tile: subbands reversed
           if (k >= 18) afr[h][kk] = 0.0f;
         }
       PD_UNROLL for (int h = 0; h < 2; h++)
-        PD_UNROLL for (int nt = 0; nt < 3; nt++) acc[h][nt] = mfma16(afr[h][0], bfr[nt], (f32x4){0, 0, 0, 0});
+        PD_UNROLL for (int nt = 0; nt < 2; nt++) acc[h][nt] = mfma16(afr[h][0], bfr[nt], (f32x4){0, 0, 0, 0});
       PD_UNROLL for (int kk = 1; kk < 5; kk++)
         PD_UNROLL for (int h = 0; h < 2; h++)
-          PD_UNROLL for (int nt = 0; nt < 3; nt++) acc[h][nt] = mfma16(afr[h][kk], bfr[kk * 3 + nt], acc[h][nt]);
-      f32x4 accl[3];
-      PD_UNROLL for (int nt = 0; nt < 3; nt++) accl[nt] = acc[0][nt];
+          PD_UNROLL for (int nt = 0; nt < 2; nt++) acc[h][nt] = mfma16(afr[h][kk], bfr[kk * 2 + nt], acc[h][nt]);
+      f32x4 accl[2];
+      PD_UNROLL for (int nt = 0; nt < 2; nt++) accl[nt] = acc[0][nt];
       if (shrt && mixrows) {             // wave-uniform: rows sb 0, 1 of the first tile take the long transform
-        PD_UNROLL for (int nt = 0; nt < 3; nt++) accl[nt] = mfma16(afr[0][0], R.bi[nt], (f32x4){0, 0, 0, 0});
+        PD_UNROLL for (int nt = 0; nt < 2; nt++) accl[nt] = mfma16(afr[0][0], R.bi[nt], (f32x4){0, 0, 0, 0});
         PD_UNROLL for (int kk = 1; kk < 5; kk++)
-          PD_UNROLL for (int nt = 0; nt < 3; nt++) accl[nt] = mfma16(afr[0][kk], R.bi[kk * 3 + nt], accl[nt]);
+          PD_UNROLL for (int nt = 0; nt < 2; nt++) accl[nt] = mfma16(afr[0][kk], R.bi[kk * 2 + nt], accl[nt]);
       }
-      // window factors of this lane's columns: t = j, p = 18 + j, and t = 16 + j / p = 34 + (j - 2)
-      const int zc = (j < 2) ? 16 + j : ((j < 4) ? 32 + j : 0);
+      // window factors of this lane's columns: t = j and p = 18 + j
       const float* wb = L.win[bt];
       const float* w0 = L.win[0];
-      const float wb1 = wb[j], wb2 = wb[18 + j], wbz = wb[zc];
-      const float w01 = w0[j], w02 = w0[18 + j], w0z = w0[zc];
+      const float wb1 = wb[j], wb2 = wb[18 + j];
+      const float w01 = w0[j], w02 = w0[18 + j];
       float outa[8];
       PD_UNROLL for (int h = 0; h < 2; h++)
         PD_UNROLL for (int r = 0; r < 4; r++) {
           const bool lowrow = mixrows && h == 0 && kq == 0 && r < 2;      // subbands 0, 1 (first tile, rows 0, 1)
-          float y1 = acc[h][0][r], y2 = acc[h][1][r], z = acc[h][2][r];
-          if (h == 0 && lowrow) { y1 = accl[0][r]; y2 = accl[1][r]; z = accl[2][r]; }
+          float y1 = acc[h][0][r], y2 = acc[h][1][r];
+          if (h == 0 && lowrow) { y1 = accl[0][r]; y2 = accl[1][r]; }
           const bool win_folded = shrt && !lowrow;                        // short transform: window is in the matrix
-          const float f1 = lowrow ? w01 : wb1, f2 = lowrow ? w02 : wb2, fz = lowrow ? w0z : wbz;
-          if (!win_folded) { y1 = y1 * f1; y2 = y2 * f2; z = z * fz; }
+          const float f1 = lowrow ? w01 : wb1, f2 = lowrow ? w02 : wb2;
+          if (!win_folded) { y1 = y1 * f1; y2 = y2 * f2; }
           const int oi = ch * 8 + h * 4 + r;
           float o = y1 + R.ovl[oi];                                       // P:1775
           R.ovl[oi] = y2;                                                 // P:1776
-          const float znext = __shfl(z, lane + 2);                        // p = 34 + j sits two columns to the right
-          float o2 = z + R.ovl[16 + oi];
-          R.ovl[16 + oi] = znext;
           const int sb = h ? 31 - (4 * kq + r) : 4 * kq + r;              // subband of this row (tile 1 is reversed)
-          if ((sb & 1) && (j & 1)) { o = -o; o2 = -o2; }                  // P:1738-1746: odd subband, odd sample
+          if ((sb & 1) && (j & 1)) o = -o;                                // P:1738-1746: odd subband, odd sample
           outa[h * 4 + r] = o;
-          out2[ch][h * 4 + r] = o2;
-          if (DUMP) {
-            dump3[ch * 4 * 576 + 18 * sb + j] = o;
-            if (j < 2) dump3[ch * 4 * 576 + 18 * sb + 16 + j] = o2;
-          }
+          if (DUMP) dump3[ch * 4 * 576 + 18 * sb + j] = o;
           if (ch == 0 && h == 0 && r == 0 && kq == 0 && j < 3) L.peek[j] = o;   // H5 source: (ch 0, sb 0, t 0..2)
         }
       // matrixing of time slots t = j (rows) of this channel: butterflies, then even / odd 16 x 16 products
@@ -661,15 +695,13 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, const GlobalTables& T, flo
       }
     }
   }
-  // the four left-over time slots (ch 0: t = 16, 17; ch 1: t = 16, 17) as one more row tile
+  // ---- the four left-over time slots (rows: ch 0 t 16, ch 0 t 17, ch 1 t 16, ch 1 t 17) as one more row tile
+  PD_WAVE_SYNC();                          // lo[] was written by other lanes
   {
     f32x4 me = (f32x4){0, 0, 0, 0}, mo = (f32x4){0, 0, 0, 0};
     PD_UNROLL for (int r = 0; r < 4; r++) {
-      const float a0 = out2[0][r] + out2[0][4 + r], b0 = out2[0][r] - out2[0][4 + r];
-      const float a1 = out2[1][r] + out2[1][4 + r], b1 = out2[1][r] - out2[1][4 + r];
-      const float a1s = __shfl(a1, lane - 2), b1s = __shfl(b1, lane - 2);   // rows 2, 3 <- channel 1's columns 0, 1
-      const float a = (j < 2) ? a0 : ((j < 4) ? a1s : 0.0f);
-      const float b = (j < 2) ? b0 : ((j < 4) ? b1s : 0.0f);
+      const float a = (j < 4) ? L.lo[0][j & 3][4 * kq + r] : 0.0f;
+      const float b = (j < 4) ? L.lo[1][j & 3][4 * kq + r] : 0.0f;
       me = mfma16(a, R.bm[r], me);
       mo = mfma16(b, R.bm[4 + r], mo);
     }
@@ -872,7 +904,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       ph_antialias(lane, L, cb);
     )
     PD_TICK(3)
-    PD_PHASE(ph_mfma<DUMP>(lane, L, R, T, dmp + 2 * 576, dmp + 3 * 576))
+    PD_PHASE(ph_mfma<DUMP>(lane, L, R, cb, T, dmp + 2 * 576, dmp + 3 * 576))
     PD_TICK(4)
     PD_TICK(5)
 #else

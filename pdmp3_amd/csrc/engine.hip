@@ -49,7 +49,7 @@ struct pdmp3_hip_ctx {
   float* d_pow43;
   uint16_t* d_linetab;
   float* d_win;
-  float* d_frag;            // frag_long [15][64] | frag_short [15][64] | frag_mat [8][64]
+  float* d_frag;            // frag_long [10][64] | frag_short [10][64] | frag_mat [8][64]
   float* d_state_tmp;
 };
 
@@ -91,10 +91,10 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
   HIP_TRY(hipMemcpy(c->d_pow43, H.pow43.data(), H.pow43.size() * sizeof(float), hipMemcpyHostToDevice), "upload pow43");
   HIP_TRY(hipMemcpy(c->d_linetab, H.linetab.data(), H.linetab.size() * sizeof(uint16_t), hipMemcpyHostToDevice), "upload linetab");
   HIP_TRY(hipMemcpy(c->d_win, H.win.data(), H.win.size() * sizeof(float), hipMemcpyHostToDevice), "upload win");
-  HIP_TRY(hipMalloc(&c->d_frag, (15 + 15 + 8) * 64 * sizeof(float)), "hipMalloc frag");
-  HIP_TRY(hipMemcpy(c->d_frag, H.frag_long.data(), 15 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_long");
-  HIP_TRY(hipMemcpy(c->d_frag + 15 * 64, H.frag_short.data(), 15 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_short");
-  HIP_TRY(hipMemcpy(c->d_frag + 30 * 64, H.frag_mat.data(), 8 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_mat");
+  HIP_TRY(hipMalloc(&c->d_frag, (10 + 10 + 8) * 64 * sizeof(float)), "hipMalloc frag");
+  HIP_TRY(hipMemcpy(c->d_frag, H.frag_long.data(), 10 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_long");
+  HIP_TRY(hipMemcpy(c->d_frag + 10 * 64, H.frag_short.data(), 10 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_short");
+  HIP_TRY(hipMemcpy(c->d_frag + 20 * 64, H.frag_mat.data(), 8 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_mat");
   HIP_TRY(hipDeviceSynchronize(), "sync after uploads");
   *out = c;
   return PDMP3_HIP_OK;
@@ -146,7 +146,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.n_frames = n_frames;
   a.chunk_frames = chunk_frames;
   a.prof = d_prof;
-  GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 15 * 64, c->d_frag + 30 * 64};
+  GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64};
   if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
   else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T);
   else hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), 0, s, a, T);

@@ -101,30 +101,31 @@ inline void build_host_tables(HostTables& H) {
 
   // ---- MFMA B-operand fragments (decode_core.h: ph_mfma).  Lane l = (j = l & 15, kq = l >> 4)
   // holds B[k = 4 kk + kq][column map(nt, j)].
-  auto col_of = [](int nt, int j) -> int {          // IMDCT output index p of tile column j; -1 = unused
-    if (nt == 0) return j;
-    if (nt == 1) return 18 + j;
-    if (j < 2) return 16 + j;
-    if (j < 4) return 32 + j;                       // 34, 35 sit two columns right of 16, 17
-    return -1;
-  };
+  auto col_of = [](int nt, int j) -> int { return nt == 0 ? j : 18 + j; };   // IMDCT output index p of tile column j
   // short transform as one 18 x 36 matrix, window folded in: out[6 w + p + 6] += in[w + 3 m] cos_N12[m][p] win[2][p]
   float bs[18][36];
   memset(bs, 0, sizeof bs);
   for (int w = 0; w < 3; w++)
     for (int m = 0; m < 6; m++)
       for (int p = 0; p < 12; p++) bs[w + 3 * m][6 * w + p + 6] = kCosN12[m * 12 + p] * kImdctWin[2 * 36 + p];
-  H.frag_long.assign(15 * 64, 0.0f);
-  H.frag_short.assign(15 * 64, 0.0f);
+  H.frag_long.assign(10 * 64, 0.0f);
+  H.frag_short.assign(10 * 64, 0.0f);
   for (int kk = 0; kk < 5; kk++)
-    for (int nt = 0; nt < 3; nt++)
+    for (int nt = 0; nt < 2; nt++)
       for (int l = 0; l < 64; l++) {
         const int j = l & 15, k = 4 * kk + (l >> 4), p = col_of(nt, j);
-        if (k < 18 && p >= 0) {
-          H.frag_long[(kk * 3 + nt) * 64 + l] = kCosN36[k * 36 + p];
-          H.frag_short[(kk * 3 + nt) * 64 + l] = bs[k][p];
+        if (k < 18) {
+          H.frag_long[(kk * 2 + nt) * 64 + l] = kCosN36[k * 36 + p];
+          H.frag_short[(kk * 2 + nt) * 64 + l] = bs[k][p];
         }
       }
+  // the four remaining IMDCT columns, computed on the VALU with scalar operands
+  static const int xcol[4] = {16, 17, 34, 35};
+  for (int q = 0; q < 4; q++)
+    for (int m = 0; m < 18; m++) {
+      cb.c36x[q][m] = kCosN36[m * 36 + xcol[q]];
+      cb.s36x[q][m] = bs[m][xcol[q]];
+    }
   // matrixing: C[n] = sum_sb s[sb] cos((2 sb + 1) n pi / 64), n = 0..31, taken from the reference's own matrix
   // N[i][sb] = (float)cos((float)((16 + i) (2 sb + 1)) * (pi / 64)) (pdmp3.c:1992):  C[n] = v[n - 16] (n >= 16),
   // C[n] = -v[48 - n] (n < 16); folded into the even / odd halves

@@ -152,3 +152,33 @@ def test_gpu_large_synthetic_properties(engine):
     torch.cuda.synchronize()
     assert torch.equal(pcm[:128], pcm3)
     assert int(pcm.abs().max()) > 1000
+
+
+def test_gpu_c5_shards(engine, oracle):
+    """BASELINE configs[4] (C5) at reduced scale on one GPU: the 1M-frame synthetic stream is cut into 8
+    frame-range shards (pdmp3_amd.sharding), each generated on device from its counter-based generator and
+    decoded from a 2-frame halo; parity against the oracle on every frame within +-2 of a shard boundary and
+    on a prefix of each shard (the oracle warms up on 8 frames before the window it checks).
+    PDMP3_FULL_C5=1 uses the full 125 000 frames per shard."""
+    import torch
+    from pdmp3_amd.sharding import shard_with_halo, frame_range
+    seed = 0x5EED0000C5
+    per = 125000 if os.environ.get("PDMP3_FULL_C5") else 20000
+    world, total = 8, 8 * per
+    for rank in range(world):
+        first, count, halo = shard_with_halo(total, rank, world)
+        lo, hi = frame_range(total, rank, world)
+        spectra, side, pcm = engine.alloc_frames(count)
+        engine.generate(seed, first, count, spectra, side)
+        engine.decode(spectra, side, pcm)
+        torch.cuda.synchronize()
+        got = pcm[halo:].cpu().numpy()                      # frames lo .. hi-1
+        assert got.shape[0] == hi - lo == per
+        for a, b in ((lo, lo + 48), (hi - 4, hi)):          # shard start (incl. prefix) and shard end
+            w0 = max(0, a - 8)
+            sp, sd = oracle.generate(seed, w0, b - w0)
+            if w0 > 0:
+                sd["frame"][0] |= 0x40                      # oracle starts cold; its first 8 frames are discarded
+            want = oracle.decode(sp, sd)[a - w0:]
+            assert_pcm_close(got[a - lo:b - lo], want, 1, "shard %d frames %d..%d" % (rank, a, b))
+        del spectra, side, pcm
