@@ -125,14 +125,11 @@ struct GlobalTables {
 };
 
 // LDS per wave (~12.3 KB).  Buffers whose lifetimes do not overlap share storage:
-//   spec (ph_commit .. ph_requant)          | pcm  (ph_window .. ph_store)
 //   xr   (ph_requant .. ph_fetch)           | hyb  (ph_imdct .. ph_window)
 // hyb rows are [slot t][33]: the DCT lane that owns slot t transforms its row in place.
 struct WaveLds {
-  union {
-    alignas(16) int16_t spec[2][576];
-    alignas(16) int16_t pcm[1152];
-  };
+  alignas(16) int16_t spec[2][576];     // committed one granule ahead (before the previous granule's PCM stores)
+  alignas(16) int16_t pcm[1152];
   alignas(16) uint8_t side[2][128];
   float scale[2][64];
   union {
@@ -792,10 +789,9 @@ PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R) {
 }
 
 // PCM: granule = 576 sample-frames = 1152*nch bytes
-PD_FN void ph_store(int lane, WaveLds& L, int16_t* pcm_g, bool emit) {
-  const GranuleInfo g = granule_info(L);
+PD_FN void ph_store(int lane, WaveLds& L, int nch, int16_t* pcm_g, bool emit) {
   if (emit) {
-    const int n16 = (576 * 2 * g.nch) / 16;   // 144 or 72 chunks of 16 B
+    const int n16 = (576 * 2 * nch) / 16;   // 144 or 72 chunks of 16 B
     const Chunk16* src = reinterpret_cast<const Chunk16*>(L.pcm);
     Chunk16* dst = reinterpret_cast<Chunk16*>(pcm_g);
     for (int c = lane; c < n16; c += 64) dst[c] = src[c];
@@ -873,13 +869,13 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     lane_init(lane, L, R, cb, T);
     if (from_stream_start && a.state_in) state_load(lane, R, a.state_in);
   )
+  PD_PHASE(ph_commit(lane, L, R))
   unsigned long long acc[kProfSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = PD_CLOCK();
 #define PD_TICK(k) if (PROF) { const unsigned long long tn_ = PD_CLOCK(); acc[k] += tn_ - tprev; tprev = tn_; }
   for (int g = g_start; g < g_end; ++g) {
     const int f = g >> 1, gr = g & 1;
     PD_LAUNDER(cb);
-    PD_PHASE(ph_commit(lane, L, R))
     {
       int sf = L.side[0][7] & PDMP3_FR_SFREQ_MASK;
       if (sf > 2) sf = 2;
@@ -921,10 +917,13 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
 #endif
     PD_PHASE(ph_window(lane, L, R))
     PD_TICK(6)
-    PD_PHASE(
-      const int nch = ((L.side[0][7] & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
-      ph_store(lane, L, a.pcm + (size_t)f * 2304 + gr * 576 * nch, g >= g_begin);
-    )
+    // the next granule is committed to LDS BEFORE this granule's PCM stores are issued: its prefetch
+    // loads are older than those stores, so waiting for them never waits for a store
+    const int nch_g = ((L.side[0][7] & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
+    if (g + 1 < g_end) {
+      PD_PHASE(ph_commit(lane, L, R))
+    }
+    PD_PHASE(ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, g >= g_begin))
     PD_TICK(7)
   }
 #undef PD_TICK
