@@ -101,12 +101,20 @@ def main():
                              % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # PDMP3_BENCH_BACKEND=gloo + several ranks on one GPU is only for exercising this code path on a
+    # single-GPU box; the real multi-GPU run is one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("PDMP3_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
-    eng = pdmp3_amd.Engine(local_rank)
+    eng = pdmp3_amd.Engine(dev_index)
     n = args.frames
     halo = 2 if rank > 0 else 0
     first = rank * n - halo
@@ -140,11 +148,11 @@ def main():
     kern_ms = ev0.elapsed_time(ev1) / args.steps
 
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # the path's one exchange: final PCM gather to rank 0 (RCCL over xGMI), outside the timed region
-        mine = pcm[halo:].contiguous().view(torch.uint8)   # RCCL has no int16: gather the PCM as bytes
+        mine = pcm[halo:].contiguous().view(torch.uint8).to(coll_dev)   # RCCL has no int16: gather the PCM as bytes
         bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
         torch.cuda.synchronize()
         dist.barrier()
