@@ -1,0 +1,65 @@
+/*
+ * pdmp3_bulk.h -- whole-stream decoding on top of include/pdmp3.h
+ * (pdmp3_amd/libpdmp3.so).
+ *
+ * NOT part of the reference's API: the reference decodes one frame per
+ * pdmp3_read() iteration on one core.  This is the throughput form of the same
+ * contract for callers that hold a whole file in memory (first
+ * "next" row: the host Huffman stage that feeds the transforms).  The OUTPUT
+ * is defined by the reference: byte for byte what its CLI driver pdmp3()
+ * (pdmp3.c:2540-2589: 4096-byte feeds, 16 KiB reads, raw int16 sink) writes
+ * for the same bytes, including the dropped tail and the stop at
+ * the first frame error.
+ *
+ * Inside: the reference's read loop runs sequentially but only as far as the
+ * bit reservoir (everything that depends on the previous frame); scalefactor +
+ * Huffman decoding of each frame, a pure function of its reservoir snapshot,
+ * runs on a pool of host threads straight into pinned staging memory; windows
+ * of frames go through pdmp3_hip_stream_submit() (include/pdmp3_hip.h) three
+ * deep, so upload, transforms, download and host decoding overlap.
+ */
+#ifndef PDMP3_BULK_H
+#define PDMP3_BULK_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "pdmp3_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bulk pdmp3_amd_bulk;
+
+/* threads <= 0: one worker per online CPU (at most 64).  window_frames <= 0:
+ * 2048 frames per GPU batch.  Returns NULL when there is no transform engine
+ * (no CPU fallback). */
+pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
+void pdmp3_amd_bulk_delete(pdmp3_amd_bulk* b);
+int pdmp3_amd_bulk_threads(const pdmp3_amd_bulk* b);
+
+/* PCM bytes (return value) and frames pdmp3() would produce for this stream;
+ * header / side-info / reservoir pass only, no Huffman, no GPU.  Use it to
+ * size the output of pdmp3_amd_bulk_decode. */
+long long pdmp3_amd_scan_buffer(const unsigned char* mp3, size_t n, long long* frames);
+
+/* Decode one whole stream with a fresh decoder state.  Returns the PCM byte
+ * count pdmp3() writes for it; pcm[0 .. min(return, pcm_cap)) holds them
+ * (interleaved int16; bytes of `pcm` past the return value are unspecified).
+ * -1 on an engine failure.  rate / channels (may be NULL): format of the last
+ * header seen, as pdmp3_getformat reports it. */
+long long pdmp3_amd_bulk_decode(pdmp3_amd_bulk* b, const unsigned char* mp3, size_t n,
+                                unsigned char* pcm, size_t pcm_cap, long* rate, int* channels);
+
+/* Host stages only, for tests on machines without a GPU: a decoder made by
+ * pdmp3_amd_bulk_new_parse_only() writes the gc records the engine would be
+ * given into caller memory (cap_frames frames of 2304 int16 / 4 records).
+ * Returns the frame count, -1 if they do not fit. */
+pdmp3_amd_bulk* pdmp3_amd_bulk_new_parse_only(int threads, int window_frames);
+long long pdmp3_amd_bulk_parse(pdmp3_amd_bulk* b, const unsigned char* mp3, size_t n,
+                               int16_t* spectra, pdmp3_gc_side* side, size_t cap_frames, long long* pcm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -175,6 +175,24 @@ const int16_t* pdmp3_hip_stream_pcm(pdmp3_hip_stream* hs);
 /* decode frames [0, n_frames) of the staging buffers; synchronous */
 int pdmp3_hip_stream_decode(pdmp3_hip_stream* hs, int n_frames);
 
+/* Pipelined form for bulk decoding of one long stream (the C3 / C4 corpora of
+ * SURVEY 8d): `n_slots` (1..4) independent staging slots of `max_frames` frames.
+ * While the host fills slot w+1, slot w is uploading / running / downloading.
+ * Batches are decoded in SUBMIT order, each from the synthesis state the
+ * previous one left (the same carry Decode_L3's static buffers give the
+ * reference, pdmp3.c:1777, 2126), whatever slot they sit in.  The accessors
+ * above and pdmp3_hip_stream_decode are slot 0. */
+int pdmp3_hip_stream_create_slots(pdmp3_hip_ctx* ctx, int max_frames, int n_slots, pdmp3_hip_stream** out);
+int pdmp3_hip_stream_slots(const pdmp3_hip_stream* hs);
+int pdmp3_hip_stream_capacity(const pdmp3_hip_stream* hs);
+int16_t* pdmp3_hip_stream_slot_spectra(pdmp3_hip_stream* hs, int slot);
+pdmp3_gc_side* pdmp3_hip_stream_slot_side(pdmp3_hip_stream* hs, int slot);
+const int16_t* pdmp3_hip_stream_slot_pcm(pdmp3_hip_stream* hs, int slot);
+/* enqueue H2D + transforms + D2H of the slot's first n_frames frames; returns at once */
+int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_frames);
+/* block until the slot's PCM is in its pinned buffer (no-op if nothing is in flight) */
+int pdmp3_hip_stream_wait(pdmp3_hip_stream* hs, int slot);
+
 /* Host-side twin of the generator (fills host buffers); used to build
  * identical inputs for the CPU baseline without a device round trip. */
 int pdmp3_host_generate_frames(uint64_t seed, int64_t first_frame, int n_frames,

@@ -13,6 +13,8 @@ PDMP3_OK, PDMP3_ERR, PDMP3_NEED_MORE, PDMP3_NEW_FORMAT, PDMP3_NO_SPACE = 0, -1, 
 PDMP3_ENC_SIGNED_16 = 0xD0
 _LIB = None
 
+BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads", "pdmp3_amd_scan_buffer",
+                "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse"]
 API_EXPORTS = ["pdmp3_new", "pdmp3_delete", "pdmp3_open_feed", "pdmp3_feed", "pdmp3_read",
                "pdmp3_decode", "pdmp3_getformat", "pdmp3"]
 
@@ -43,6 +45,19 @@ def load_library():
     lib.pdmp3_amd_set_tap.argtypes = [vp, vp, vp, C.c_int]
     lib.pdmp3_amd_tap_count.argtypes = [vp]
     lib.pdmp3_amd_parse_available.argtypes = [vp]
+    # include/pdmp3_bulk.h
+    lib.pdmp3_amd_bulk_new.restype = vp
+    lib.pdmp3_amd_bulk_new.argtypes = [C.c_int, C.c_int]
+    lib.pdmp3_amd_bulk_new_parse_only.restype = vp
+    lib.pdmp3_amd_bulk_new_parse_only.argtypes = [C.c_int, C.c_int]
+    lib.pdmp3_amd_bulk_delete.argtypes = [vp]
+    lib.pdmp3_amd_bulk_threads.argtypes = [vp]
+    lib.pdmp3_amd_scan_buffer.restype = C.c_longlong
+    lib.pdmp3_amd_scan_buffer.argtypes = [vp, C.c_size_t, C.POINTER(C.c_longlong)]
+    lib.pdmp3_amd_bulk_decode.restype = C.c_longlong
+    lib.pdmp3_amd_bulk_decode.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_int)]
+    lib.pdmp3_amd_bulk_parse.restype = C.c_longlong
+    lib.pdmp3_amd_bulk_parse.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_longlong)]
     _LIB = lib
     return lib
 
@@ -146,3 +161,66 @@ def parse_like_cli(mp3: bytes, cap_frames):
     sp, sd = dec.tap()
     dec.close()
     return sp.copy(), sd.copy()
+
+
+def _as_u8(data):
+    a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    return a if a.size else np.zeros(1, dtype=np.uint8)
+
+
+def scan_buffer(mp3):
+    """(pcm_bytes, frames) the CLI driver would produce for this stream (include/pdmp3_bulk.h)."""
+    lib = load_library()
+    a = _as_u8(mp3)
+    frames = C.c_longlong(0)
+    total = lib.pdmp3_amd_scan_buffer(a.ctypes.data_as(C.c_void_p), len(mp3), C.byref(frames))
+    return total, frames.value
+
+
+class BulkDecoder:
+    """include/pdmp3_bulk.h: whole-stream decode, host Huffman on a thread pool + pipelined GPU batches.
+    parse_only=True: host stages only (records out), for machines without a GPU."""
+
+    def __init__(self, threads=0, window_frames=0, parse_only=False):
+        self.lib = load_library()
+        self.parse_only = parse_only
+        new = self.lib.pdmp3_amd_bulk_new_parse_only if parse_only else self.lib.pdmp3_amd_bulk_new
+        self.h = new(threads, window_frames)
+        if not self.h:
+            raise RuntimeError("pdmp3_amd_bulk_new failed (no MI355X transform engine; there is no CPU fallback)")
+        self.threads = self.lib.pdmp3_amd_bulk_threads(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.pdmp3_amd_bulk_delete(self.h)
+            self.h = None
+
+    def decode_into(self, mp3, out: np.ndarray):
+        a = _as_u8(mp3)
+        rate, ch = C.c_long(0), C.c_int(0)
+        total = self.lib.pdmp3_amd_bulk_decode(self.h, a.ctypes.data_as(C.c_void_p), len(mp3),
+                                               out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(rate), C.byref(ch))
+        if total < 0:
+            raise RuntimeError("pdmp3_amd_bulk_decode: engine failure")
+        return total, rate.value, ch.value
+
+    def decode(self, mp3):
+        """-> interleaved int16 PCM (numpy), exactly the CLI driver's output for these bytes."""
+        total, _ = scan_buffer(mp3)
+        out = np.empty(max(total, 2) // 2, dtype=np.int16)
+        got, rate, ch = self.decode_into(mp3, out)
+        assert got == total, (got, total)
+        return out[:total // 2]
+
+    def parse(self, mp3):
+        _, frames = scan_buffer(mp3)
+        cap = frames + 1                           # frames of a failed last read are parsed too
+        sp = np.zeros((cap, 2, 2, 576), dtype=np.int16)
+        sd = np.zeros((cap, 2, 2), dtype=SIDE_DTYPE)
+        a = _as_u8(mp3)
+        pcm_bytes = C.c_longlong(0)
+        n = self.lib.pdmp3_amd_bulk_parse(self.h, a.ctypes.data_as(C.c_void_p), len(mp3), sp.ctypes.data_as(C.c_void_p),
+                                          sd.ctypes.data_as(C.c_void_p), cap, C.byref(pcm_bytes))
+        if n < 0:
+            raise RuntimeError("pdmp3_amd_bulk_parse failed")
+        return sp[:n], sd[:n], pcm_bytes.value

@@ -238,6 +238,27 @@ PD_FN void state_load(int lane, LaneRegs& R, const float* st) {
   }
 }
 
+// channel 1's part of the carried state only: its overlap tails (ovl[8..15] in every lane, ovl[16..17] in the
+// (ch 1, sb) lanes) and its polyphase history; what a run of mono frames leaves untouched (P:1777, P:2126 are
+// indexed by channel)
+PD_FN void state_load_ch1(int lane, LaneRegs& R, const float* st) {
+#if PD_MFMA
+  for (int m = 8; m < 16; m++) R.ovl[m] = st[m * 64 + lane];
+#endif
+  if (lane >= 32) {
+#if PD_MFMA
+    R.ovl[16] = st[16 * 64 + lane];
+    R.ovl[17] = st[17 * 64 + lane];
+#else   // host test build: the lane (ch, sb) owns all 18 tails of its subband
+    for (int m = 0; m < kOvlRegs; m++) R.ovl[m] = st[m * 64 + lane];
+#endif
+    for (int s = 0; s < kHistSlots; s++) {
+      R.he[s] = st[(kOvlRegs + s) * 64 + lane];
+      R.ho[s] = st[(kOvlRegs + kHistSlots + s) * 64 + lane];
+    }
+  }
+}
+
 PD_FN void state_store(int lane, const LaneRegs& R, float* st) {
   for (int m = 0; m < kOvlRegs; m++) st[m * 64 + lane] = R.ovl[m];
   for (int s = 0; s < kHistSlots; s++) {
@@ -798,6 +819,30 @@ PD_FN void ph_store(int lane, WaveLds& L, int nch, int16_t* pcm_g, bool emit) {
   }
 }
 
+// Highest frame in [f_lo, f_hi) that has two channels or carries the RESET flag, or -1.  Wave-uniform.
+PD_FN int last_stereo_or_reset(const pdmp3_gc_side* side, int f_lo, int f_hi) {
+#if defined(__HIPCC__)
+  const int lane = threadIdx.x;
+  for (int base = f_hi - 64;; base -= 64) {
+    const int f = base + lane;
+    bool hit = false;
+    if (f >= f_lo && f < f_hi) {
+      const uint8_t b = reinterpret_cast<const uint8_t*>(side + (size_t)f * 4)[7];
+      hit = ((b & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 || (b & PDMP3_FR_RESET);
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m) return base + 63 - __builtin_clzll(m);
+    if (base <= f_lo) return -1;
+  }
+#else
+  for (int f = f_hi - 1; f >= f_lo; --f) {
+    const uint8_t b = reinterpret_cast<const uint8_t*>(side + (size_t)f * 4)[7];
+    if (((b & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 || (b & PDMP3_FR_RESET)) return f;
+  }
+  return -1;
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // One chunk = one wavefront.  PD_PHASE runs its body for every lane and then
 // synchronises: on the device `lane` is threadIdx.x and the barrier is a
@@ -860,20 +905,53 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     g_start = g_begin - (shrt ? kHaloGranulesH5 : kHaloGranules);
     if (g_start < 0) g_start = 0;
   }
-  const bool from_stream_start = (g_start == 0);     // exact state: the caller's (or zero), no halo needed
   const bool last = (f1 == a.n_frames);
+  // Channel 1 across mono frames.  The halo re-derives a channel's state from the last two granules in which
+  // the channel was decoded; mono frames leave channel 1's overlap and polyphase history as the last stereo
+  // frame left them (the reference's store[ch] / v_vec[ch], P:1777, P:2126), however long ago that was.  So
+  // when the frame before the chunk is mono and channel 1 matters here (a stereo frame in the chunk, or this
+  // chunk writes state_out), first run a PRE-halo at the last stereo frame before it: its two granules plus
+  // the one in front (H5, as for the ordinary halo).  Channel 0 comes out of that wrong and is then
+  // re-derived by the ordinary halo, which does not touch channel 1.  No stereo frame back to the start of
+  // the batch: channel 1 is the caller's state_in (or zero); a RESET frame: zero.
+  int pre_end = 0, npre = 0;
+  bool ch1_from_state = false;
+  if (g_start > 0) {
+    const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f0 - 1) * 4)[7];
+    const bool prev_mono = ((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 && !(fb & PDMP3_FR_RESET);
+    if (prev_mono && (last || last_stereo_or_reset(a.side, f0, f1) >= 0)) {
+      const int fs = last_stereo_or_reset(a.side, 0, f0 - 1);
+      if (fs < 0) ch1_from_state = true;
+      else {
+        const uint8_t sb = reinterpret_cast<const uint8_t*>(a.side + (size_t)fs * 4)[7];
+        if (((sb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3) {     // (a mono RESET frame: zero, nothing to do)
+          pre_end = 2 * fs + 2;
+          npre = (fs > 0 && !(sb & PDMP3_FR_RESET)) ? 3 : 2;
+          if (pre_end >= g_start) { g_start = pre_end - npre; npre = 0; pre_end = 0; }   // touches the ordinary halo: one run
+        }
+      }
+    }
+  }
+  const int g_first = npre ? pre_end - npre : g_start;
+  const bool from_stream_start = (g_first == 0);     // exact state: the caller's (or zero), no halo needed
   int cur_sfreq = -1;
 
   PD_PHASE(
-    ph_prefetch(lane, R, a.spectra + (size_t)g_start * 1152, a.side + (size_t)g_start * 2);
+    ph_prefetch(lane, R, a.spectra + (size_t)g_first * 1152, a.side + (size_t)g_first * 2);
     lane_init(lane, L, R, cb, T);
-    if (from_stream_start && a.state_in) state_load(lane, R, a.state_in);
+    if (a.state_in) {
+      if (from_stream_start) state_load(lane, R, a.state_in);
+      else if (ch1_from_state) state_load_ch1(lane, R, a.state_in);
+    }
   )
   PD_PHASE(ph_commit(lane, L, R))
   unsigned long long acc[kProfSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = PD_CLOCK();
 #define PD_TICK(k) if (PROF) { const unsigned long long tn_ = PD_CLOCK(); acc[k] += tn_ - tprev; tprev = tn_; }
-  for (int g = g_start; g < g_end; ++g) {
+  // k < 0: the pre-halo granules pre_end + k; k >= 0: granule g_start + k (ordinary halo, then the chunk)
+  for (int k = -npre; g_start + k < g_end; ++k) {
+    const int g = k < 0 ? pre_end + k : g_start + k;
+    const int g_next = k + 1 < 0 ? pre_end + k + 1 : g_start + k + 1;
     const int f = g >> 1, gr = g & 1;
     PD_LAUNDER(cb);
     {
@@ -896,7 +974,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
 #if PD_MFMA
     PD_PHASE(
       // the next granule's HBM reads fly during this granule's transforms
-      if (g + 1 < g_end) ph_prefetch(lane, R, a.spectra + (size_t)(g + 1) * 1152, a.side + (size_t)(g + 1) * 2);
+      if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
       ph_antialias(lane, L, cb);
     )
     PD_TICK(3)
@@ -906,7 +984,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
 #else
     PD_PHASE(
       // the next granule's HBM reads fly during this granule's transforms
-      if (g + 1 < g_end) ph_prefetch(lane, R, a.spectra + (size_t)(g + 1) * 1152, a.side + (size_t)(g + 1) * 2);
+      if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
       ph_fetch<DUMP>(lane, L, R, cb, dmp + 2 * 576);
     )
     PD_TICK(3)
@@ -920,7 +998,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     // the next granule is committed to LDS BEFORE this granule's PCM stores are issued: its prefetch
     // loads are older than those stores, so waiting for them never waits for a store
     const int nch_g = ((L.side[0][7] & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
-    if (g + 1 < g_end) {
+    if (g_next < g_end) {
       PD_PHASE(ph_commit(lane, L, R))
     }
     PD_PHASE(ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, g >= g_begin))
@@ -931,7 +1009,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     PD_PHASE(
       if (lane == 0) {
         for (int k = 0; k < 8; k++) a.prof[(size_t)chunk * kProfSlots + k] = acc[k];
-        a.prof[(size_t)chunk * kProfSlots + 8] = (unsigned long long)(g_end - g_start);
+        a.prof[(size_t)chunk * kProfSlots + 8] = (unsigned long long)(g_end - g_start + npre);
         a.prof[(size_t)chunk * kProfSlots + 9] = PD_CLOCK();
       }
     )

@@ -170,74 +170,142 @@ extern "C" int pdmp3_hip_decode_frames_stages(pdmp3_hip_ctx* ctx, const int16_t*
 // ---------------------------------------------------------------------------
 // host-buffer streaming helper (pinned staging, hipMemcpyAsync both ways)
 // ---------------------------------------------------------------------------
-struct pdmp3_hip_stream {
-  pdmp3_hip_ctx* ctx;
-  int max_frames;
+// One pdmp3_hip_stream = one decoder's carried state + up to kMaxSlots staging slots.  Each slot has its own
+// HIP stream (H2D -> k_decode -> D2H), so slot w+1's upload overlaps slot w's kernel and download over the
+// two PCIe directions; the kernels themselves are chained in submit order through `ev_state` because each one
+// starts from the synthesis state its predecessor left (and they share ctx->d_state_tmp).
+constexpr int kMaxSlots = 4;
+struct StreamSlot {
   hipStream_t stream;
+  hipEvent_t done;
   int16_t* h_spectra; pdmp3_gc_side* h_side; int16_t* h_pcm;     // pinned
   int16_t* d_spectra; pdmp3_gc_side* d_side; int16_t* d_pcm;
+  int busy;
+};
+struct pdmp3_hip_stream {
+  pdmp3_hip_ctx* ctx;
+  int max_frames, n_slots;
+  StreamSlot s[kMaxSlots];
+  hipEvent_t ev_state;       // recorded after the latest kernel + state copy
+  int have_state_ev;
   float* d_state;
 };
 
 extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
   if (!hs) return;
   (void)hipSetDevice(hs->ctx->device);
-  if (hs->stream) (void)hipStreamDestroy(hs->stream);
-  (void)hipHostFree(hs->h_spectra); (void)hipHostFree(hs->h_side); (void)hipHostFree(hs->h_pcm);
-  (void)hipFree(hs->d_spectra); (void)hipFree(hs->d_side); (void)hipFree(hs->d_pcm); (void)hipFree(hs->d_state);
+  for (int i = 0; i < hs->n_slots; ++i) {
+    StreamSlot& t = hs->s[i];
+    if (t.stream) { (void)hipStreamSynchronize(t.stream); (void)hipStreamDestroy(t.stream); }
+    if (t.done) (void)hipEventDestroy(t.done);
+    (void)hipHostFree(t.h_spectra); (void)hipHostFree(t.h_side); (void)hipHostFree(t.h_pcm);
+    (void)hipFree(t.d_spectra); (void)hipFree(t.d_side); (void)hipFree(t.d_pcm);
+  }
+  if (hs->ev_state) (void)hipEventDestroy(hs->ev_state);
+  (void)hipFree(hs->d_state);
   free(hs);
 }
 
-extern "C" int pdmp3_hip_stream_create(pdmp3_hip_ctx* ctx, int max_frames, pdmp3_hip_stream** out) {
-  if (!ctx || !out || max_frames < 1) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_create: bad argument", hipSuccess);
+extern "C" int pdmp3_hip_stream_create_slots(pdmp3_hip_ctx* ctx, int max_frames, int n_slots, pdmp3_hip_stream** out) {
+  if (!ctx || !out || max_frames < 1 || n_slots < 1 || n_slots > kMaxSlots)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_create: bad argument", hipSuccess);
   *out = nullptr;
   HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
   pdmp3_hip_stream* hs = (pdmp3_hip_stream*)calloc(1, sizeof *hs);
   if (!hs) return fail(PDMP3_HIP_ENOMEM, "calloc", hipSuccess);
   hs->ctx = ctx;
   hs->max_frames = max_frames;
+  hs->n_slots = n_slots;
   const size_t n = (size_t)max_frames;
 #define HS_TRY(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { pdmp3_hip_stream_destroy(hs); return fail(PDMP3_HIP_EDEVICE, what, e_); } } while (0)
-  HS_TRY(hipStreamCreateWithFlags(&hs->stream, hipStreamNonBlocking), "hipStreamCreate");
-  HS_TRY(hipHostMalloc((void**)&hs->h_spectra, n * PDMP3_FRAME_SPECTRA_BYTES, hipHostMallocDefault), "hipHostMalloc spectra");
-  HS_TRY(hipHostMalloc((void**)&hs->h_side, n * PDMP3_FRAME_SIDE_BYTES, hipHostMallocDefault), "hipHostMalloc side");
-  HS_TRY(hipHostMalloc((void**)&hs->h_pcm, n * PDMP3_FRAME_PCM_BYTES, hipHostMallocDefault), "hipHostMalloc pcm");
-  HS_TRY(hipMalloc((void**)&hs->d_spectra, n * PDMP3_FRAME_SPECTRA_BYTES), "hipMalloc spectra");
-  HS_TRY(hipMalloc((void**)&hs->d_side, n * PDMP3_FRAME_SIDE_BYTES), "hipMalloc side");
-  HS_TRY(hipMalloc((void**)&hs->d_pcm, n * PDMP3_FRAME_PCM_BYTES), "hipMalloc pcm");
+  for (int i = 0; i < n_slots; ++i) {
+    StreamSlot& t = hs->s[i];
+    HS_TRY(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking), "hipStreamCreate");
+    HS_TRY(hipEventCreateWithFlags(&t.done, hipEventDisableTiming), "hipEventCreate");
+    HS_TRY(hipHostMalloc((void**)&t.h_spectra, n * PDMP3_FRAME_SPECTRA_BYTES, hipHostMallocDefault), "hipHostMalloc spectra");
+    HS_TRY(hipHostMalloc((void**)&t.h_side, n * PDMP3_FRAME_SIDE_BYTES, hipHostMallocDefault), "hipHostMalloc side");
+    HS_TRY(hipHostMalloc((void**)&t.h_pcm, n * PDMP3_FRAME_PCM_BYTES, hipHostMallocDefault), "hipHostMalloc pcm");
+    HS_TRY(hipMalloc((void**)&t.d_spectra, n * PDMP3_FRAME_SPECTRA_BYTES), "hipMalloc spectra");
+    HS_TRY(hipMalloc((void**)&t.d_side, n * PDMP3_FRAME_SIDE_BYTES), "hipMalloc side");
+    HS_TRY(hipMalloc((void**)&t.d_pcm, n * PDMP3_FRAME_PCM_BYTES), "hipMalloc pcm");
+  }
+  HS_TRY(hipEventCreateWithFlags(&hs->ev_state, hipEventDisableTiming), "hipEventCreate");
   HS_TRY(hipMalloc((void**)&hs->d_state, pdmp3_hip_state_bytes()), "hipMalloc state");
-  HS_TRY(hipMemsetAsync(hs->d_state, 0, pdmp3_hip_state_bytes(), hs->stream), "memset state");
-  HS_TRY(hipStreamSynchronize(hs->stream), "sync");
+  HS_TRY(hipMemsetAsync(hs->d_state, 0, pdmp3_hip_state_bytes(), hs->s[0].stream), "memset state");
+  HS_TRY(hipStreamSynchronize(hs->s[0].stream), "sync");
 #undef HS_TRY
   *out = hs;
+  return PDMP3_HIP_OK;
+}
+
+extern "C" int pdmp3_hip_stream_create(pdmp3_hip_ctx* ctx, int max_frames, pdmp3_hip_stream** out) {
+  return pdmp3_hip_stream_create_slots(ctx, max_frames, 1, out);
+}
+
+static int drain_slots(pdmp3_hip_stream* hs) {
+  for (int i = 0; i < hs->n_slots; ++i) {
+    HIP_TRY(hipStreamSynchronize(hs->s[i].stream), "stream sync");
+    hs->s[i].busy = 0;
+  }
   return PDMP3_HIP_OK;
 }
 
 extern "C" int pdmp3_hip_stream_reset(pdmp3_hip_stream* hs) {
   if (!hs) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_reset: NULL", hipSuccess);
   HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
-  HIP_TRY(hipMemsetAsync(hs->d_state, 0, pdmp3_hip_state_bytes(), hs->stream), "memset state");
-  HIP_TRY(hipStreamSynchronize(hs->stream), "sync");
+  int rc = drain_slots(hs);
+  if (rc != PDMP3_HIP_OK) return rc;
+  hs->have_state_ev = 0;
+  HIP_TRY(hipMemsetAsync(hs->d_state, 0, pdmp3_hip_state_bytes(), hs->s[0].stream), "memset state");
+  HIP_TRY(hipStreamSynchronize(hs->s[0].stream), "sync");
   return PDMP3_HIP_OK;
 }
 
-extern "C" int16_t* pdmp3_hip_stream_spectra(pdmp3_hip_stream* hs) { return hs ? hs->h_spectra : nullptr; }
-extern "C" pdmp3_gc_side* pdmp3_hip_stream_side(pdmp3_hip_stream* hs) { return hs ? hs->h_side : nullptr; }
-extern "C" const int16_t* pdmp3_hip_stream_pcm(pdmp3_hip_stream* hs) { return hs ? hs->h_pcm : nullptr; }
+#define SLOT_OK(hs, i) ((hs) && (i) >= 0 && (i) < (hs)->n_slots)
+extern "C" int pdmp3_hip_stream_slots(const pdmp3_hip_stream* hs) { return hs ? hs->n_slots : 0; }
+extern "C" int pdmp3_hip_stream_capacity(const pdmp3_hip_stream* hs) { return hs ? hs->max_frames : 0; }
+extern "C" int16_t* pdmp3_hip_stream_slot_spectra(pdmp3_hip_stream* hs, int slot) { return SLOT_OK(hs, slot) ? hs->s[slot].h_spectra : nullptr; }
+extern "C" pdmp3_gc_side* pdmp3_hip_stream_slot_side(pdmp3_hip_stream* hs, int slot) { return SLOT_OK(hs, slot) ? hs->s[slot].h_side : nullptr; }
+extern "C" const int16_t* pdmp3_hip_stream_slot_pcm(pdmp3_hip_stream* hs, int slot) { return SLOT_OK(hs, slot) ? hs->s[slot].h_pcm : nullptr; }
+extern "C" int16_t* pdmp3_hip_stream_spectra(pdmp3_hip_stream* hs) { return pdmp3_hip_stream_slot_spectra(hs, 0); }
+extern "C" pdmp3_gc_side* pdmp3_hip_stream_side(pdmp3_hip_stream* hs) { return pdmp3_hip_stream_slot_side(hs, 0); }
+extern "C" const int16_t* pdmp3_hip_stream_pcm(pdmp3_hip_stream* hs) { return pdmp3_hip_stream_slot_pcm(hs, 0); }
 
-extern "C" int pdmp3_hip_stream_decode(pdmp3_hip_stream* hs, int n_frames) {
-  if (!hs || n_frames < 0 || n_frames > hs->max_frames)
-    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_decode: bad argument", hipSuccess);
+extern "C" int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_frames) {
+  if (!SLOT_OK(hs, slot) || n_frames < 0 || n_frames > hs->max_frames)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit: bad argument", hipSuccess);
+  StreamSlot& t = hs->s[slot];
+  if (t.busy) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit: slot still in flight (wait for it first)", hipSuccess);
   if (n_frames == 0) return PDMP3_HIP_OK;
   HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
   const size_t n = (size_t)n_frames;
-  HIP_TRY(hipMemcpyAsync(hs->d_spectra, hs->h_spectra, n * PDMP3_FRAME_SPECTRA_BYTES, hipMemcpyHostToDevice, hs->stream), "H2D spectra");
-  HIP_TRY(hipMemcpyAsync(hs->d_side, hs->h_side, n * PDMP3_FRAME_SIDE_BYTES, hipMemcpyHostToDevice, hs->stream), "H2D side");
-  int rc = launch_decode(hs->ctx, hs->d_spectra, hs->d_side, n_frames, hs->d_state, hs->d_pcm, nullptr, 0, hs->stream);
+  HIP_TRY(hipMemcpyAsync(t.d_spectra, t.h_spectra, n * PDMP3_FRAME_SPECTRA_BYTES, hipMemcpyHostToDevice, t.stream), "H2D spectra");
+  HIP_TRY(hipMemcpyAsync(t.d_side, t.h_side, n * PDMP3_FRAME_SIDE_BYTES, hipMemcpyHostToDevice, t.stream), "H2D side");
+  if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
+  int rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream);
   if (rc != PDMP3_HIP_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(hs->h_pcm, hs->d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDeviceToHost, hs->stream), "D2H pcm");
-  HIP_TRY(hipStreamSynchronize(hs->stream), "stream sync");
+  HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
+  hs->have_state_ev = 1;
+  HIP_TRY(hipMemcpyAsync(t.h_pcm, t.d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDeviceToHost, t.stream), "D2H pcm");
+  HIP_TRY(hipEventRecord(t.done, t.stream), "record done event");
+  t.busy = 1;
   return PDMP3_HIP_OK;
+}
+
+extern "C" int pdmp3_hip_stream_wait(pdmp3_hip_stream* hs, int slot) {
+  if (!SLOT_OK(hs, slot)) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_wait: bad argument", hipSuccess);
+  StreamSlot& t = hs->s[slot];
+  if (!t.busy) return PDMP3_HIP_OK;
+  HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
+  HIP_TRY(hipEventSynchronize(t.done), "event sync");
+  t.busy = 0;
+  return PDMP3_HIP_OK;
+}
+
+extern "C" int pdmp3_hip_stream_decode(pdmp3_hip_stream* hs, int n_frames) {
+  int rc = pdmp3_hip_stream_submit(hs, 0, n_frames);
+  if (rc != PDMP3_HIP_OK) return rc;
+  return pdmp3_hip_stream_wait(hs, 0);
 }
 
 extern "C" int pdmp3_hip_generate_frames(pdmp3_hip_ctx* ctx, uint64_t seed, int64_t first_frame, int n_frames,

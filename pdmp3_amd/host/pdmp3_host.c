@@ -100,6 +100,18 @@ typedef struct {
   unsigned region0_count[2][2], region1_count[2][2], preflag[2][2], scalefac_scale[2][2], count1table_select[2][2];
 } side_info;
 
+/* what one frame's main data yields; merged into the handle's persistent state in frame order */
+typedef struct {
+  int16_t* is;                       /* [gr][ch][576] destination: the engine's staging spectra of this frame */
+  uint16_t count1[2][2];
+  uint8_t count1_set[2][2];          /* 0 when part2_3_length == 0: count1 keeps its old value (H6) */
+  uint8_t sf_l[2][2][21];
+  uint32_t sf_l_set[2][2];           /* bit sfb: scalefac_l[gr][ch][sfb] was read from the stream */
+  uint8_t sf_l_copy[2];              /* [ch] bit b: granule 1 takes band group b from granule 0 (scfsi) */
+  uint8_t sf_s[2][2][12][3];
+  uint16_t sf_s_set[2][2];           /* bit sfb: scalefac_s[gr][ch][sfb][0..2] were read */
+} main_out;
+
 struct pdmp3_handle {
   /* input ring, P:126-128 */
   size_t processed;
@@ -115,10 +127,9 @@ struct pdmp3_handle {
   uint8_t scalefac_l[2][2][21];
   uint8_t scalefac_s[2][2][12][3];
   uint16_t count1[2][2];
-  int16_t is[2][2][576];
   uint8_t main_vec[2048 + 16];     /* bit reservoir, P:137 */
   unsigned main_top;
-  unsigned bitpos;                 /* read position in main_vec, in bits */
+  main_out scratch_out;            /* this frame's decoded main data (inline path) */
   unsigned side_vec[36 + 8];
   unsigned side_ptr, side_idx;
   int new_header;                  /* P:147 */
@@ -341,50 +352,121 @@ static int fill_reservoir(pdmp3_handle* id, unsigned size, unsigned begin) {
     dst = id->main_vec + id->main_top;
     id->main_top += size;
   }
-  for (unsigned i = 0; i < size; i++) {
-    if ((size_t)(dst - id->main_vec) + i >= sizeof id->main_vec) break;
-    unsigned v = ring_byte(id);
-    if (v == BYTE_EOF) break;                  /* short read ignored (H18) */
-    dst[i] = (uint8_t)v;
-  }
-  id->bitpos = 0;
+  /* as many of `size` bytes as the ring holds and main_vec has room for; a short read is ignored (H18) */
+  const size_t off = (size_t)(dst - id->main_vec);
+  unsigned n = off >= sizeof id->main_vec ? 0 : (unsigned)(sizeof id->main_vec - off);
+  if (n > size) n = size;
+  if (n > ring_filled(id)) n = ring_filled(id);
+  unsigned first = INBUF_SIZE - id->istart;
+  if (first > n) first = n;
+  memcpy(dst, id->in + id->istart, first);
+  memcpy(dst + first, id->in, n - first);
+  id->istart = (id->istart + n) % INBUF_SIZE;
+  id->processed += n;
   return ok ? PDMP3_OK : PDMP3_NEED_MORE;
 }
 
-static inline uint32_t peek32(const pdmp3_handle* id) {   /* next 25+ valid bits, MSB first */
-  const unsigned byte = id->bitpos >> 3;
-  const uint8_t* p = id->main_vec + (byte < sizeof id->main_vec - 5 ? byte : sizeof id->main_vec - 5);
+/* ------------------------------------------------------------------------ */
+/* main data of ONE frame: scalefactors + Huffman, as a pure function of the */
+/* reservoir bytes, the header and the side info.  This is the part of the   */
+/* host stage that is independent from frame to frame: pdmp3_read runs it    */
+/* inline, the bulk entry point fans it out over host threads.               */
+/* ------------------------------------------------------------------------ */
+#define RESERVOIR_BYTES (2048 + 16)
+
+typedef struct {
+  const uint8_t* buf;       /* RESERVOIR_BYTES readable */
+  unsigned bitpos;
+} bitreader;
+
+static inline uint32_t peek32(const bitreader* b) {   /* next 25+ valid bits, MSB first */
+  const unsigned byte = b->bitpos >> 3;
+  const uint8_t* p = b->buf + (byte < RESERVOIR_BYTES - 5 ? byte : RESERVOIR_BYTES - 5);
   uint64_t w = ((uint64_t)p[0] << 32) | ((uint64_t)p[1] << 24) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 8) | p[4];
-  return (uint32_t)(w >> (8 - (id->bitpos & 7)));
+  return (uint32_t)(w >> (8 - (b->bitpos & 7)));
 }
-static inline unsigned get_bits(pdmp3_handle* id, unsigned n) {
+static inline unsigned get_bits(bitreader* b, unsigned n) {
   if (!n) return 0;
-  unsigned v = peek32(id) >> (32 - n);
-  id->bitpos += n;
+  unsigned v = peek32(b) >> (32 - n);
+  b->bitpos += n;
   return v;
 }
 
 /* one code word of `book`: returns the leaf value (x<<4 | y) */
-static inline unsigned huff_symbol(pdmp3_handle* id, int book) {
+static inline unsigned huff_symbol(bitreader* b, int book) {
   const huff_lut* L = &g_lut[book];
-  const uint32_t w = peek32(id);
+  const uint32_t w = peek32(b);
   unsigned e = L->first[w >> (32 - HL_BITS)];
   if (e & 0x8000) {
     const unsigned rest = (w << HL_BITS) >> (32 - L->sub_bits);
     const unsigned e2 = L->sub[((size_t)(e & 0x7fff) << L->sub_bits) + rest];
-    id->bitpos += HL_BITS + (e2 >> 8);
+    b->bitpos += HL_BITS + (e2 >> 8);
     return e2 & 0xff;
   }
-  id->bitpos += e >> 8;
+  b->bitpos += e >> 8;
   return e & 0xff;
 }
 
+/* one big_values pair, field by field (only used within 8 bytes of the end of the reservoir buffer) */
+static void pair_slow(bitreader* b, int book, unsigned linbits, int* px, int* py) {
+  const unsigned leaf = huff_symbol(b, book);
+  int x = leaf >> 4, y = leaf & 15;
+  if (linbits && x == 15) x += (int)get_bits(b, linbits);
+  if (x > 0 && get_bits(b, 1)) x = -x;
+  if (linbits && y == 15) y += (int)get_bits(b, linbits);
+  if (y > 0 && get_bits(b, 1)) y = -y;
+  *px = x; *py = y;
+}
+
+#define FAST_LIMIT ((RESERVOIR_BYTES - 8) * 8u)    /* bit positions from which one 8-byte load is in bounds */
+static inline uint64_t peek64(const bitreader* b) {           /* >= 57 valid bits, MSB first */
+  uint64_t w;
+  memcpy(&w, b->buf + (b->bitpos >> 3), 8);
+  return __builtin_bswap64(w) << (b->bitpos & 7);
+}
+
+/* pairs [pos, end) of one region.  A pair is at most 19 + 2 * (13 + 1) = 47 bits: one window per pair. */
+static unsigned decode_pairs(bitreader* b, unsigned tn, unsigned pos, unsigned end, int16_t* is) {
+  const int book = kHuffBookOfTable[tn];
+  if (book < 0) {                                  /* table 0 (and the unused 4, 14): no bits, zeros */
+    for (; pos < end; pos += 2) {
+      if (pos < 576) is[pos] = 0;
+      if (pos + 1 < 576) is[pos + 1] = 0;
+    }
+    return pos;
+  }
+  const huff_lut* L = &g_lut[book];
+  const unsigned linbits = kHuffLinbits[tn];
+  for (; pos < end; pos += 2) {
+    int x, y;
+    if (__builtin_expect(b->bitpos <= FAST_LIMIT, 1)) {
+      const uint64_t w = peek64(b);
+      unsigned e = L->first[w >> (64 - HL_BITS)], used;
+      if (e & 0x8000) {
+        const unsigned rest = (unsigned)((w << HL_BITS) >> (64 - L->sub_bits));
+        e = L->sub[((size_t)(e & 0x7fff) << L->sub_bits) + rest];
+        used = HL_BITS + (e >> 8);
+      } else used = e >> 8;
+      x = (e >> 4) & 15; y = e & 15;
+      if (linbits && x == 15) { x += (int)((w << used) >> (64 - linbits)); used += linbits; }
+      if (x) { if ((w << used) >> 63) x = -x; used++; }
+      if (linbits && y == 15) { y += (int)((w << used) >> (64 - linbits)); used += linbits; }
+      if (y) { if ((w << used) >> 63) y = -y; used++; }
+      b->bitpos += used;
+    } else pair_slow(b, book, linbits, &x, &y);
+    if (pos < 576) is[pos] = (int16_t)x;           /* big_values > 288 is not checked by the reference (H8) */
+    if (pos + 1 < 576) is[pos + 1] = (int16_t)y;
+  }
+  return pos;
+}
+
 /* P:2051-2115 */
-static void read_huffman(pdmp3_handle* id, unsigned part2_start, unsigned gr, unsigned ch) {
-  const side_info* S = &id->si;
-  int16_t* is = id->is[gr][ch];
+static void decode_huffman(bitreader* b, const frame_header* H, const side_info* S, unsigned part2_start,
+                           unsigned gr, unsigned ch, main_out* out) {
+  int16_t* is = out->is + (gr * 2 + ch) * 576;
   if (S->part2_3_length[gr][ch] == 0) {           /* all zero; count1 keeps its old value (H6) */
     memset(is, 0, 576 * sizeof *is);
+    out->count1_set[gr][ch] = 0;
     return;
   }
   const unsigned end = part2_start + S->part2_3_length[gr][ch] - 1;   /* last bit of this part */
@@ -392,116 +474,162 @@ static void read_huffman(pdmp3_handle* id, unsigned part2_start, unsigned gr, un
   if (S->win_switch[gr][ch] && S->block_type[gr][ch] == 2) { r1 = 36; r2 = 576; }
   else {
     /* l[23] s[14] are contiguous in the reference: indices 23, 24 read s[0], s[1] (H7) */
-    const uint16_t* l = id->hdr.sfreq == 0 ? kSfbLong0 : id->hdr.sfreq == 1 ? kSfbLong1 : kSfbLong2;
-    const uint16_t* s = id->hdr.sfreq == 0 ? kSfbShort0 : id->hdr.sfreq == 1 ? kSfbShort1 : kSfbShort2;
+    const uint16_t* l = H->sfreq == 0 ? kSfbLong0 : H->sfreq == 1 ? kSfbLong1 : kSfbLong2;
+    const uint16_t* s = H->sfreq == 0 ? kSfbShort0 : H->sfreq == 1 ? kSfbShort1 : kSfbShort2;
     const unsigned i1 = S->region0_count[gr][ch] + 1, i2 = S->region0_count[gr][ch] + S->region1_count[gr][ch] + 2;
     r1 = i1 < 23 ? l[i1] : s[i1 - 23];
     r2 = i2 < 23 ? l[i2] : s[i2 - 23];
   }
+  /* the pair at (even) pos takes table 0 while pos < r1, table 1 while pos < r2, else table 2 */
   const unsigned nbig = S->big_values[gr][ch] * 2;
-  unsigned pos = 0;
-  for (; pos < nbig; pos += 2) {
-    const unsigned tn = pos < r1 ? S->table_select[gr][ch][0] : pos < r2 ? S->table_select[gr][ch][1] : S->table_select[gr][ch][2];
-    int x = 0, y = 0;
-    const int book = kHuffBookOfTable[tn];
-    if (book >= 0) {
-      const unsigned leaf = huff_symbol(id, book), linbits = kHuffLinbits[tn];
-      x = leaf >> 4; y = leaf & 15;
-      if (linbits && x == 15) x += (int)get_bits(id, linbits);
-      if (x > 0 && get_bits(id, 1)) x = -x;
-      if (linbits && y == 15) y += (int)get_bits(id, linbits);
-      if (y > 0 && get_bits(id, 1)) y = -y;
-    }
-    if (pos < 576) is[pos] = (int16_t)x;           /* big_values > 288 is not checked by the reference (H8) */
-    if (pos + 1 < 576) is[pos + 1] = (int16_t)y;
-  }
-  /* count1 region: table 32, or the reference's mis-pointed table 33 (H1) */
+  unsigned e0 = (r1 + 1) & ~1u, e1 = (r2 + 1) & ~1u;
+  if (e0 > nbig) e0 = nbig;
+  if (e1 > nbig) e1 = nbig;
+  if (e1 < e0) e1 = e0;
+  unsigned pos = decode_pairs(b, S->table_select[gr][ch][0], 0, e0, is);
+  pos = decode_pairs(b, S->table_select[gr][ch][1], pos, e1, is);
+  pos = decode_pairs(b, S->table_select[gr][ch][2], pos, nbig, is);
+  /* count1 region: table 32, or the reference's mis-pointed table 33 (H1).  The loop runs while a whole quad
+   * fits below 576, so the reference's mid-quad bound check can never fire. */
   const int qbook = kHuffBookOfTable[32 + S->count1table_select[gr][ch]];
-  pos = nbig;
-  while (pos <= 572 && id->bitpos <= end) {
-    const unsigned leaf = huff_symbol(id, qbook);
-    int q[4] = {(int)(leaf >> 3) & 1, (int)(leaf >> 2) & 1, (int)(leaf >> 1) & 1, (int)leaf & 1};   /* v w x y */
-    for (int k = 0; k < 4; k++) if (q[k] && get_bits(id, 1)) q[k] = -1;
-    int stop = 0;
-    for (int k = 0; k < 4; k++) {
-      is[pos] = (int16_t)q[k];
-      if (k < 3) { pos++; if (pos >= 576) { stop = 1; break; } }
+  const huff_lut* Q = &g_lut[qbook];
+  while (pos <= 572 && b->bitpos <= end) {
+    unsigned leaf;
+    int q[4];
+    if (__builtin_expect(b->bitpos <= FAST_LIMIT && Q->sub_bits == 0, 1)) {
+      const uint64_t w = peek64(b);
+      const unsigned e = Q->first[w >> (64 - HL_BITS)];
+      unsigned used = e >> 8;
+      leaf = e & 0xff;
+      for (int k = 0; k < 4; k++) {                /* v w x y */
+        q[k] = (int)(leaf >> (3 - k)) & 1;
+        if (q[k]) { if ((w << used) >> 63) q[k] = -1; used++; }
+      }
+      b->bitpos += used;
+    } else {
+      leaf = huff_symbol(b, qbook);
+      for (int k = 0; k < 4; k++) {
+        q[k] = (int)(leaf >> (3 - k)) & 1;
+        if (q[k] && get_bits(b, 1)) q[k] = -1;
+      }
     }
-    if (stop) break;
-    pos++;
+    is[pos] = (int16_t)q[0]; is[pos + 1] = (int16_t)q[1]; is[pos + 2] = (int16_t)q[2]; is[pos + 3] = (int16_t)q[3];
+    pos += 4;
   }
-  if (id->bitpos > end + 1) pos -= 4;              /* overshoot: drop the last quad */
+  if (b->bitpos > end + 1) pos -= 4;               /* overshoot: drop the last quad */
   if (pos > 576) pos = 576;                        /* (unsigned wrap of the reference on pos < 4: corrupt input) */
-  id->count1[gr][ch] = (uint16_t)pos;
-  for (; pos < 576; pos++) is[pos] = 0;
-  id->bitpos = end + 1;
+  out->count1[gr][ch] = (uint16_t)pos;
+  out->count1_set[gr][ch] = 1;
+  if (pos < 576) memset(is + pos, 0, (576 - pos) * sizeof *is);
+  b->bitpos = end + 1;
 }
 
-/* P:1346-1442 */
-static int read_main_data(pdmp3_handle* id) {
+/* P:1376-1437: scalefactors, then Huffman, for every granule / channel of the frame */
+static void decode_main(const uint8_t* reservoir, const frame_header* H, const side_info* S, main_out* out) {
+  const unsigned nch = H->mode == 3 ? 1 : 2;
+  bitreader b = {reservoir, 0};
+  memset(out->sf_l_set, 0, sizeof out->sf_l_set);
+  memset(out->sf_s_set, 0, sizeof out->sf_s_set);
+  out->sf_l_copy[0] = out->sf_l_copy[1] = 0;
+  for (unsigned gr = 0; gr < 2; gr++)
+    for (unsigned ch = 0; ch < nch; ch++) {
+      const unsigned part2_start = b.bitpos;
+      const unsigned slen1 = kSlen[S->scalefac_compress[gr][ch] * 2], slen2 = kSlen[S->scalefac_compress[gr][ch] * 2 + 1];
+      if (S->win_switch[gr][ch] && S->block_type[gr][ch] == 2) {
+        unsigned first_short = 0;
+        if (S->mixed[gr][ch]) {
+          for (unsigned sfb = 0; sfb < 8; sfb++) out->sf_l[gr][ch][sfb] = (uint8_t)get_bits(&b, slen1);
+          out->sf_l_set[gr][ch] |= 0xffu;
+          first_short = 3;
+        }
+        for (unsigned sfb = first_short; sfb < 12; sfb++) {
+          for (unsigned w = 0; w < 3; w++) out->sf_s[gr][ch][sfb][w] = (uint8_t)get_bits(&b, sfb < 6 ? slen1 : slen2);
+          out->sf_s_set[gr][ch] |= (uint16_t)(1u << sfb);
+        }
+      } else {
+        static const uint8_t lo[5] = {0, 6, 11, 16, 21};
+        for (unsigned g4 = 0; g4 < 4; g4++) {
+          const unsigned nb = g4 < 2 ? slen1 : slen2;
+          if (gr == 1 && S->scfsi[ch][g4]) {       /* reuse granule 0's factors (whatever they are by then) */
+            out->sf_l_copy[ch] |= (uint8_t)(1u << g4);
+          } else {
+            for (unsigned sfb = lo[g4]; sfb < lo[g4 + 1]; sfb++) {
+              out->sf_l[gr][ch][sfb] = (uint8_t)get_bits(&b, nb);
+              out->sf_l_set[gr][ch] |= 1u << sfb;
+            }
+          }
+        }
+      }
+      decode_huffman(&b, H, S, part2_start, gr, ch, out);
+    }
+}
+
+/* merge one frame's main data into the state that survives frames (scalefactors, count1, is) */
+static void apply_main(pdmp3_handle* id, const frame_header* H, const main_out* out) {
+  static const uint8_t lo[5] = {0, 6, 11, 16, 21};
+  const unsigned nch = H->mode == 3 ? 1 : 2;
+  for (unsigned gr = 0; gr < 2; gr++)
+    for (unsigned ch = 0; ch < nch; ch++) {
+      for (unsigned sfb = 0; sfb < 21; sfb++)
+        if (out->sf_l_set[gr][ch] >> sfb & 1) id->scalefac_l[gr][ch][sfb] = out->sf_l[gr][ch][sfb];
+      if (gr == 1)
+        for (unsigned g4 = 0; g4 < 4; g4++)
+          if (out->sf_l_copy[ch] >> g4 & 1)
+            for (unsigned sfb = lo[g4]; sfb < lo[g4 + 1]; sfb++) id->scalefac_l[1][ch][sfb] = id->scalefac_l[0][ch][sfb];
+      for (unsigned sfb = 0; sfb < 12; sfb++)
+        if (out->sf_s_set[gr][ch] >> sfb & 1) memcpy(id->scalefac_s[gr][ch][sfb], out->sf_s[gr][ch][sfb], 3);
+      if (out->count1_set[gr][ch]) id->count1[gr][ch] = out->count1[gr][ch];
+    }
+}
+
+/* P:1346-1374: sizes + bit reservoir; the frame's bytes leave the ring here */
+static int stage_main_data(pdmp3_handle* id) {
   const unsigned nch = id->hdr.mode == 3 ? 1 : 2;
   const unsigned fb = frame_bytes(&id->hdr);
   if (fb > 2000) return PDMP3_ERR;
   unsigned size = fb - (nch == 1 ? 17 : 32) - 4;
   if (id->hdr.protection == 0) size -= 2;
-  const int res = fill_reservoir(id, size, id->si.main_data_begin);
-  if (res != PDMP3_OK) return res;
-  const side_info* S = &id->si;
-  for (unsigned gr = 0; gr < 2; gr++)
-    for (unsigned ch = 0; ch < nch; ch++) {
-      const unsigned part2_start = id->bitpos;
-      const unsigned slen1 = kSlen[S->scalefac_compress[gr][ch] * 2], slen2 = kSlen[S->scalefac_compress[gr][ch] * 2 + 1];
-      if (S->win_switch[gr][ch] && S->block_type[gr][ch] == 2) {
-        unsigned first_short = 0;
-        if (S->mixed[gr][ch]) {
-          for (unsigned sfb = 0; sfb < 8; sfb++) id->scalefac_l[gr][ch][sfb] = (uint8_t)get_bits(id, slen1);
-          first_short = 3;
-        }
-        for (unsigned sfb = first_short; sfb < 12; sfb++)
-          for (unsigned w = 0; w < 3; w++) id->scalefac_s[gr][ch][sfb][w] = (uint8_t)get_bits(id, sfb < 6 ? slen1 : slen2);
-      } else {
-        static const uint8_t lo[5] = {0, 6, 11, 16, 21};
-        for (unsigned b = 0; b < 4; b++) {
-          const unsigned nb = b < 2 ? slen1 : slen2;
-          if (gr == 1 && S->scfsi[ch][b]) {        /* reuse granule 0's factors */
-            for (unsigned sfb = lo[b]; sfb < lo[b + 1]; sfb++) id->scalefac_l[1][ch][sfb] = id->scalefac_l[0][ch][sfb];
-          } else {
-            for (unsigned sfb = lo[b]; sfb < lo[b + 1]; sfb++) id->scalefac_l[gr][ch][sfb] = (uint8_t)get_bits(id, nb);
-          }
-        }
-      }
-      read_huffman(id, part2_start, gr, ch);
-    }
-  return PDMP3_OK;
+  return fill_reservoir(id, size, id->si.main_data_begin);
 }
 
-/* P:1217-1244 */
-static int read_frame(pdmp3_handle* id) {
+/* P:1217-1244.  With `defer` the main data is left undecoded in the reservoir (the bulk path snapshots
+ * it and decodes on another thread); everything that touches the input ring has happened either way. */
+static int read_frame_staged(pdmp3_handle* id) {
   if (search_header(id) != PDMP3_OK) return PDMP3_ERR;
   if (id->hdr.protection == 0) {                   /* CRC is skipped, never checked (P:1206-1210) */
     if (ring_byte(id) != BYTE_EOF) (void)ring_byte(id);
   }
   if (id->hdr.layer != 3) return PDMP3_ERR;
   if (frame_bytes(&id->hdr) <= 2000) read_side_info(id);
-  return read_main_data(id);
+  return stage_main_data(id);
+}
+
+/* one whole frame, inline: `spectra` (2304 int16) receives is[gr][ch][576] of this frame */
+static int read_frame(pdmp3_handle* id, int16_t* spectra) {
+  const int res = read_frame_staged(id);
+  if (res != PDMP3_OK) return res;
+  main_out* out = &id->scratch_out;
+  out->is = spectra;
+  decode_main(id->main_vec, &id->hdr, &id->si, out);
+  apply_main(id, &id->hdr, out);
+  return PDMP3_OK;
 }
 
 /* ------------------------------------------------------------------------ */
 /* parsed frame -> 4 gc records (the engine boundary)                        */
 /* ------------------------------------------------------------------------ */
-static void emit_records(pdmp3_handle* id, int16_t* spectra, pdmp3_gc_side* sd) {
-  const unsigned nch = id->hdr.mode == 3 ? 1 : 2;
-  const side_info* S = &id->si;
+/* `spectra` already holds is[gr][ch] of the channels the frame has (decode_main wrote them there) */
+static void emit_records(pdmp3_handle* id, const frame_header* H, const side_info* S, int reset,
+                         int16_t* spectra, pdmp3_gc_side* sd) {
+  const unsigned nch = H->mode == 3 ? 1 : 2;
   memset(sd, 0, 4 * sizeof *sd);
-  const uint8_t fr = (uint8_t)((id->hdr.sfreq & 3) | (id->hdr.mode << PDMP3_FR_MODE_SHIFT) |
-                               (id->hdr.mode_ext << PDMP3_FR_MODEEXT_SHIFT) | (id->need_reset ? PDMP3_FR_RESET : 0));
-  id->need_reset = 0;
+  const uint8_t fr = (uint8_t)((H->sfreq & 3) | (H->mode << PDMP3_FR_MODE_SHIFT) |
+                               (H->mode_ext << PDMP3_FR_MODEEXT_SHIFT) | (reset ? PDMP3_FR_RESET : 0));
   for (unsigned g = 0; g < 4; g++) {
     const unsigned gr = g >> 1, ch = g & 1;
     pdmp3_gc_side* r = &sd[g];
     r->frame = fr;
     if (ch >= nch) { memset(spectra + g * 576, 0, 576 * sizeof(int16_t)); continue; }
-    memcpy(spectra + g * 576, id->is[gr][ch], 576 * sizeof(int16_t));
     r->count1 = id->count1[gr][ch];
     r->global_gain = (uint8_t)S->global_gain[gr][ch];
     r->flags = (uint8_t)((S->scalefac_scale[gr][ch] ? PDMP3_GC_SCALEFAC_SCALE : 0) |
@@ -539,7 +667,7 @@ static size_t drain_frame(pdmp3_handle* id, unsigned char* out, size_t buflen) {
   const unsigned bps = 2 * nch;
   size_t n = buflen / bps;
   if (n > 1152u - id->ostart) n = 1152u - id->ostart;
-  memcpy(out, (const unsigned char*)id->last_pcm + (size_t)id->ostart * bps, n * bps);
+  if (out) memcpy(out, (const unsigned char*)id->last_pcm + (size_t)id->ostart * bps, n * bps);
   id->ostart += (unsigned)n;
   if (id->ostart == 1152) id->ostart = 0;
   return n * bps;
@@ -548,13 +676,18 @@ static size_t drain_frame(pdmp3_handle* id, unsigned char* out, size_t buflen) {
 /* ------------------------------------------------------------------------ */
 /* pdmp3_read (P:2431-2481), batched                                         */
 /* ------------------------------------------------------------------------ */
-int pdmp3_read(pdmp3_handle* id, unsigned char* outmemory, size_t outsize, size_t* done) {
-  if (!(id && outmemory && outsize && done)) return PDMP3_ERR;
+struct bulk;
+static int bulk_push(struct bulk* b);             /* snapshot the frame read_frame_staged just staged */
+
+/* With `sink` the call only does what touches the input ring and the output cursor: main data decoding,
+ * the transforms and the PCM copy are the sink's business (bulk path below), byte counts are the same. */
+static int read_impl(pdmp3_handle* id, unsigned char* outmemory, size_t outsize, size_t* done, struct bulk* sink) {
   *done = 0;
   int res = PDMP3_ERR;
   if (id->ostart) {                               /* rest of the frame a previous call could not fit */
     const size_t n = drain_frame(id, outmemory, outsize);
-    *done = n; outmemory += n; outsize -= n;
+    *done = n; outsize -= n;
+    if (outmemory) outmemory += n;
     res = PDMP3_OK;
   }
   while (outsize) {
@@ -571,13 +704,19 @@ int pdmp3_read(pdmp3_handle* id, unsigned char* outmemory, size_t outsize, size_
       if (ring_filled(id) < 1152) { res = PDMP3_NEED_MORE; stop = 1; break; }
       const size_t pos = id->processed;
       const unsigned mark = id->istart;
-      res = read_frame(id);
+      int16_t* sp = spectra ? spectra + (size_t)nb * 2304 : scratch_sp;
+      res = sink ? read_frame_staged(id) : read_frame(id, sp);
       if (res != PDMP3_OK && res != PDMP3_NEW_FORMAT) {   /* failed: rewind to the frame start (P:2459-2462) */
         id->processed = pos; id->istart = mark;
         stop = 1;
         break;
       }
-      emit_records(id, spectra ? spectra + (size_t)nb * 2304 : scratch_sp, side ? side + (size_t)nb * 4 : scratch_sd);
+      if (sink) {
+        if (bulk_push(sink) != PDMP3_OK) return PDMP3_ERR;
+      } else {
+        emit_records(id, &id->hdr, &id->si, id->need_reset, sp, side ? side + (size_t)nb * 4 : scratch_sd);
+        id->need_reset = 0;
+      }
       nchs[nb] = id->hdr.mode == 3 ? 1 : 2;
       const size_t fbytes = 2304u * nchs[nb];
       budget -= budget < fbytes ? budget : fbytes;
@@ -585,23 +724,27 @@ int pdmp3_read(pdmp3_handle* id, unsigned char* outmemory, size_t outsize, size_
     }
     /* 2. transforms on the GPU, one batch */
     if (nb) {
-      if (!id->hs) return PDMP3_ERR;              /* parse-only handle: cannot decode */
-      if (pdmp3_hip_stream_decode(id->hs, nb) != PDMP3_HIP_OK) {
-        fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
-        return PDMP3_ERR;
+      const int16_t* pcm = NULL;
+      if (!sink) {
+        if (!id->hs) return PDMP3_ERR;            /* parse-only handle: cannot decode */
+        if (pdmp3_hip_stream_decode(id->hs, nb) != PDMP3_HIP_OK) {
+          fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
+          return PDMP3_ERR;
+        }
+        pcm = pdmp3_hip_stream_pcm(id->hs);
       }
-      const int16_t* pcm = pdmp3_hip_stream_pcm(id->hs);
       for (int k = 0; k < nb; k++) {
         const size_t fbytes = 2304u * nchs[k];
         if (outsize >= fbytes && k < nb - 1) {    /* whole frame fits: copy straight through */
-          memcpy(outmemory, pcm + (size_t)k * 2304, fbytes);
-          outmemory += fbytes; outsize -= fbytes; *done += fbytes;
+          if (pcm) { memcpy(outmemory, pcm + (size_t)k * 2304, fbytes); outmemory += fbytes; }
+          outsize -= fbytes; *done += fbytes;
         } else {                                  /* last frame of the batch: may be partial */
-          memcpy(id->last_pcm, pcm + (size_t)k * 2304, fbytes);
+          if (pcm) memcpy(id->last_pcm, pcm + (size_t)k * 2304, fbytes);
           id->last_nch = nchs[k];
           id->ostart = 0;
-          const size_t n = drain_frame(id, outmemory, outsize);
-          outmemory += n; outsize -= n; *done += n;
+          const size_t n = drain_frame(id, pcm ? outmemory : NULL, outsize);
+          if (pcm) outmemory += n;
+          outsize -= n; *done += n;
         }
       }
     }
@@ -609,6 +752,11 @@ int pdmp3_read(pdmp3_handle* id, unsigned char* outmemory, size_t outsize, size_
   }
   if (id->new_header == 1 && res == PDMP3_OK) res = PDMP3_NEW_FORMAT;
   return res;
+}
+
+int pdmp3_read(pdmp3_handle* id, unsigned char* outmemory, size_t outsize, size_t* done) {
+  if (!(id && outmemory && outsize && done)) return PDMP3_ERR;
+  return read_impl(id, outmemory, outsize, done, NULL);
 }
 
 /* parse-only variant of the read loop for host-logic tests: parses every frame
@@ -620,9 +768,10 @@ int pdmp3_amd_parse_available(pdmp3_handle* id) {
   while (ring_filled(id) >= 1152) {
     const size_t pos = id->processed;
     const unsigned mark = id->istart;
-    res = read_frame(id);
+    res = read_frame(id, sp);
     if (res != PDMP3_OK && res != PDMP3_NEW_FORMAT) { id->processed = pos; id->istart = mark; return res; }
-    emit_records(id, sp, sd);
+    emit_records(id, &id->hdr, &id->si, id->need_reset, sp, sd);
+    id->need_reset = 0;
   }
   return PDMP3_NEED_MORE;
 }
@@ -656,6 +805,348 @@ int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) 
   *channels = id->hdr.mode == 3 ? 1 : 2;
   id->new_header = -1;
   return PDMP3_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Bulk decode of one whole in-memory stream (first "next" row:   */
+/* the host Huffman stage in front of the transforms).  Not a reference      */
+/* entry point; its OUTPUT is defined by one: byte for byte what pdmp3()     */
+/* (P:2540-2589) writes for the same file.                                   */
+/*                                                                          */
+/*   A  sequential   the reference's read loop at the CLI's cadence (4096 B  */
+/*                   feeds, 16 KiB reads): ring, header sync, side info, bit */
+/*                   reservoir -- everything whose result depends on the     */
+/*                   previous frame.  Each frame leaves a job: header, side  */
+/*                   info and a snapshot of the reservoir.                   */
+/*   B  parallel     decode_main() per job on the worker threads, spectra    */
+/*                   written straight into the engine's pinned staging slot. */
+/*   C  sequential   apply_main() + emit_records() in frame order: the       */
+/*                   scalefactor / count1 state that survives frames.        */
+/*   D  GPU, async   pdmp3_hip_stream_submit(); the PCM of window w-2 is     */
+/*                   copied out while w-1 is on the GPU and w is in B.       */
+/* ------------------------------------------------------------------------ */
+#define BULK_SLOTS 3
+#define BULK_GRAB 8                   /* frames a worker takes per trip to the counter */
+
+typedef struct {
+  frame_header hdr;
+  side_info si;
+  uint8_t reset;
+  uint8_t res[RESERVOIR_BYTES];
+} frame_job;
+
+typedef struct {
+  frame_job* jobs;
+  main_out* outs;
+  int n;
+  int16_t* spectra;                   /* destination of this window's records */
+  pdmp3_gc_side* side;
+  int slot;
+} bulk_window;
+
+typedef struct {                      /* a window that is on the GPU */
+  int n, active;
+  size_t pcm_off;
+  uint8_t* nch;
+} bulk_flight;
+
+struct bulk {
+  pdmp3_handle* id;
+  int cap;                            /* frames per window */
+  int count_only;                     /* scan: stage A alone */
+  bulk_window win[2];
+  int cur;                            /* window stage A is filling */
+  bulk_window* in_b;                  /* window the workers hold, or NULL */
+  long long windows;                  /* windows handed to the workers so far */
+  long long frames;
+  /* workers */
+  pthread_t* th;
+  int nth;
+  pthread_mutex_t mu;
+  pthread_cond_t cv_work, cv_done;
+  bulk_window* work;
+  long long gen;
+  int next, active, quit;
+  /* sinks: the engine (hs) or caller memory (parse only, host tests) */
+  pdmp3_hip_stream* hs;
+  bulk_flight flight[BULK_SLOTS];
+  int16_t* rec_spectra; pdmp3_gc_side* rec_side; size_t rec_cap;
+  unsigned char* pcm; size_t pcm_cap;
+  size_t pcm_emitted;                 /* PCM bytes of all frames handed to stage C so far */
+  int failed;
+};
+
+static void* bulk_worker(void* arg) {
+  struct bulk* b = (struct bulk*)arg;
+  long long seen = 0;
+  for (;;) {
+    pthread_mutex_lock(&b->mu);
+    while (b->gen == seen && !b->quit) pthread_cond_wait(&b->cv_work, &b->mu);
+    if (b->quit) { pthread_mutex_unlock(&b->mu); return NULL; }
+    seen = b->gen;
+    bulk_window* w = b->work;
+    pthread_mutex_unlock(&b->mu);
+    for (;;) {
+      const int i0 = __atomic_fetch_add(&b->next, BULK_GRAB, __ATOMIC_RELAXED);
+      if (i0 >= w->n) break;
+      const int i1 = i0 + BULK_GRAB < w->n ? i0 + BULK_GRAB : w->n;
+      for (int i = i0; i < i1; i++) {
+        main_out* o = &w->outs[i];
+        o->is = w->spectra + (size_t)i * 2304;
+        decode_main(w->jobs[i].res, &w->jobs[i].hdr, &w->jobs[i].si, o);
+      }
+    }
+    pthread_mutex_lock(&b->mu);
+    if (--b->active == 0) pthread_cond_signal(&b->cv_done);
+    pthread_mutex_unlock(&b->mu);
+  }
+}
+
+static void bulk_start_b(struct bulk* b, bulk_window* w) {
+  pthread_mutex_lock(&b->mu);
+  b->work = w; b->next = 0; b->active = b->nth; b->gen++;
+  pthread_cond_broadcast(&b->cv_work);
+  pthread_mutex_unlock(&b->mu);
+  b->in_b = w;
+}
+static void bulk_wait_b(struct bulk* b) {
+  pthread_mutex_lock(&b->mu);
+  while (b->active) pthread_cond_wait(&b->cv_done, &b->mu);
+  pthread_mutex_unlock(&b->mu);
+}
+
+/* PCM of a finished slot -> caller memory */
+static int bulk_collect(struct bulk* b, int slot) {
+  bulk_flight* f = &b->flight[slot];
+  if (!f->active) return PDMP3_OK;
+  if (pdmp3_hip_stream_wait(b->hs, slot) != PDMP3_HIP_OK) return PDMP3_ERR;
+  f->active = 0;
+  const unsigned char* src = (const unsigned char*)pdmp3_hip_stream_slot_pcm(b->hs, slot);
+  size_t off = f->pcm_off;
+  int all_stereo = 1;
+  for (int i = 0; i < f->n; i++) if (f->nch[i] != 2) { all_stereo = 0; break; }
+  if (all_stereo) {
+    size_t n = (size_t)f->n * 4608;
+    if (off < b->pcm_cap) memcpy(b->pcm + off, src, n < b->pcm_cap - off ? n : b->pcm_cap - off);
+    return PDMP3_OK;
+  }
+  for (int i = 0; i < f->n; i++) {
+    const size_t fb = 2304u * f->nch[i];
+    if (off < b->pcm_cap) memcpy(b->pcm + off, src + (size_t)i * 4608, fb < b->pcm_cap - off ? fb : b->pcm_cap - off);
+    off += fb;
+  }
+  return PDMP3_OK;
+}
+
+/* stage C + D of the window the workers have just finished */
+static int bulk_finish_b(struct bulk* b) {
+  bulk_window* w = b->in_b;
+  if (!w) return PDMP3_OK;
+  bulk_wait_b(b);
+  b->in_b = NULL;
+  pdmp3_handle* id = b->id;
+  bulk_flight* f = b->hs ? &b->flight[w->slot] : NULL;
+  if (f) { f->pcm_off = b->pcm_emitted; f->n = w->n; }
+  for (int i = 0; i < w->n; i++) {
+    const frame_job* j = &w->jobs[i];
+    apply_main(id, &j->hdr, &w->outs[i]);
+    emit_records(id, &j->hdr, &j->si, j->reset, w->spectra + (size_t)i * 2304, w->side + (size_t)i * 4);
+    const unsigned nch = j->hdr.mode == 3 ? 1 : 2;
+    if (f) f->nch[i] = (uint8_t)nch;
+    b->pcm_emitted += 2304u * nch;
+  }
+  if (f) {
+    if (pdmp3_hip_stream_submit(b->hs, w->slot, w->n) != PDMP3_HIP_OK) {
+      fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
+      return PDMP3_ERR;
+    }
+    f->active = 1;
+  }
+  return PDMP3_OK;
+}
+
+/* the window stage A has filled goes to the workers; the one before it to the GPU; the one before that home */
+static int bulk_rotate(struct bulk* b) {
+  bulk_window* w = &b->win[b->cur];
+  if (bulk_finish_b(b) != PDMP3_OK) return PDMP3_ERR;
+  if (w->n) {
+    if (b->hs) {
+      w->slot = (int)(b->windows % BULK_SLOTS);
+      if (bulk_collect(b, w->slot) != PDMP3_OK) return PDMP3_ERR;      /* normally already home */
+      w->spectra = pdmp3_hip_stream_slot_spectra(b->hs, w->slot);
+      w->side = pdmp3_hip_stream_slot_side(b->hs, w->slot);
+    } else {
+      const size_t first = (size_t)b->frames - (size_t)w->n;
+      if (first + (size_t)w->n > b->rec_cap) return PDMP3_ERR;
+      w->spectra = b->rec_spectra + first * 2304;
+      w->side = b->rec_side + first * 4;
+    }
+    bulk_start_b(b, w);
+    b->windows++;
+    b->cur ^= 1;
+    b->win[b->cur].n = 0;
+  }
+  /* windows-1 is with the workers, windows-2 on the GPU: bring windows-3 home, its slot is the next to be filled */
+  if (b->hs && b->windows >= 3) {
+    if (bulk_collect(b, (int)((b->windows - 3) % BULK_SLOTS)) != PDMP3_OK) return PDMP3_ERR;
+  }
+  return PDMP3_OK;
+}
+
+static int bulk_push(struct bulk* b) {
+  pdmp3_handle* id = b->id;
+  b->frames++;
+  if (b->count_only) { id->need_reset = 0; return PDMP3_OK; }
+  bulk_window* w = &b->win[b->cur];
+  frame_job* j = &w->jobs[w->n++];
+  j->hdr = id->hdr;
+  j->si = id->si;
+  j->reset = (uint8_t)id->need_reset;
+  id->need_reset = 0;
+  memcpy(j->res, id->main_vec, RESERVOIR_BYTES);
+  if (w->n == b->cap && bulk_rotate(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
+  return PDMP3_OK;
+}
+
+/* stage A: the CLI's loop (P:2566-2583) over a memory buffer.  Returns the PCM bytes pdmp3() would write. */
+static long long bulk_drive(struct bulk* b, const unsigned char* mp3, size_t n) {
+  pdmp3_handle* id = b->id;
+  pdmp3_open_feed(id);
+  size_t fed = 0, done, total = 0;
+  int res;
+  while ((res = read_impl(id, NULL, INBUF_SIZE, &done, b)) != PDMP3_ERR) {
+    total += done;
+    if (res == PDMP3_NEED_MORE) {
+      size_t take = n - fed < 4096 ? n - fed : 4096;
+      if (!take) break;
+      (void)pdmp3_feed(id, mp3 + fed, take);
+      fed += take;
+    }
+  }
+  return (long long)total;
+}
+
+void pdmp3_amd_bulk_delete(struct bulk* b) {
+  if (!b) return;
+  if (b->th) {
+    pthread_mutex_lock(&b->mu);
+    b->quit = 1;
+    pthread_cond_broadcast(&b->cv_work);
+    pthread_mutex_unlock(&b->mu);
+    for (int i = 0; i < b->nth; i++) pthread_join(b->th[i], NULL);
+    free(b->th);
+    pthread_mutex_destroy(&b->mu); pthread_cond_destroy(&b->cv_work); pthread_cond_destroy(&b->cv_done);
+  }
+  for (int i = 0; i < 2; i++) { free(b->win[i].jobs); free(b->win[i].outs); }
+  for (int i = 0; i < BULK_SLOTS; i++) free(b->flight[i].nch);
+  if (b->hs) pdmp3_hip_stream_destroy(b->hs);
+  free(b->id);
+  free(b);
+}
+
+/* threads <= 0: one per online CPU (at most 64); window_frames <= 0: 2048.  with_engine = 0 gives a
+ * parse-only decoder (host tests on machines without a GPU). */
+static struct bulk* bulk_new(int threads, int window_frames, int with_engine) {
+  pthread_once(&g_lut_once, build_luts);
+  if (threads <= 0) {
+    long c = sysconf(_SC_NPROCESSORS_ONLN);
+    threads = c < 1 ? 1 : c > 64 ? 64 : (int)c;
+  }
+  if (window_frames <= 0) window_frames = 2048;
+  struct bulk* b = (struct bulk*)calloc(1, sizeof *b);
+  if (!b) return NULL;
+  b->cap = window_frames;
+  b->id = (pdmp3_handle*)calloc(1, sizeof *b->id);
+  if (!b->id) { free(b); return NULL; }
+  b->id->host_only = 1;
+  for (int i = 0; i < 2; i++) {
+    b->win[i].jobs = (frame_job*)malloc((size_t)b->cap * sizeof(frame_job));
+    b->win[i].outs = (main_out*)malloc((size_t)b->cap * sizeof(main_out));
+    if (!b->win[i].jobs || !b->win[i].outs) { pdmp3_amd_bulk_delete(b); return NULL; }
+  }
+  if (with_engine) {
+    pdmp3_hip_ctx* ctx = shared_ctx();
+    if (!ctx || pdmp3_hip_stream_create_slots(ctx, b->cap, BULK_SLOTS, &b->hs) != PDMP3_HIP_OK) {
+      fprintf(stderr, "pdmp3: no MI355X transform engine: %s\n", pdmp3_hip_last_error());
+      b->hs = NULL;
+      pdmp3_amd_bulk_delete(b);
+      return NULL;
+    }
+    for (int i = 0; i < BULK_SLOTS; i++) {
+      b->flight[i].nch = (uint8_t*)malloc((size_t)b->cap);
+      if (!b->flight[i].nch) { pdmp3_amd_bulk_delete(b); return NULL; }
+    }
+  }
+  pthread_mutex_init(&b->mu, NULL); pthread_cond_init(&b->cv_work, NULL); pthread_cond_init(&b->cv_done, NULL);
+  b->th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+  if (!b->th) { pdmp3_amd_bulk_delete(b); return NULL; }
+  for (b->nth = 0; b->nth < threads; b->nth++)
+    if (pthread_create(&b->th[b->nth], NULL, bulk_worker, b) != 0) break;
+  if (b->nth == 0) { pdmp3_amd_bulk_delete(b); return NULL; }
+  return b;
+}
+
+struct bulk* pdmp3_amd_bulk_new(int threads, int window_frames) { return bulk_new(threads, window_frames, 1); }
+struct bulk* pdmp3_amd_bulk_new_parse_only(int threads, int window_frames) { return bulk_new(threads, window_frames, 0); }
+int pdmp3_amd_bulk_threads(const struct bulk* b) { return b ? b->nth : 0; }
+
+static void bulk_begin(struct bulk* b) {
+  pdmp3_handle* id = b->id;
+  /* a fresh handle per stream: pdmp3() makes one per run, and parse state left by an earlier stream would
+   * show -- callers who want that carry use the streaming API */
+  memset(id, 0, sizeof *id);
+  id->host_only = 1;
+  b->cur = 0; b->win[0].n = b->win[1].n = 0; b->in_b = NULL;
+  b->windows = 0; b->frames = 0; b->pcm_emitted = 0; b->count_only = 0; b->failed = 0;
+  for (int i = 0; i < BULK_SLOTS; i++) b->flight[i].active = 0;
+}
+
+/* frames and PCM bytes pdmp3() would produce for this stream: stage A alone */
+long long pdmp3_amd_scan_buffer(const unsigned char* mp3, size_t n, long long* frames) {
+  pthread_once(&g_lut_once, build_luts);
+  struct bulk b;
+  memset(&b, 0, sizeof b);
+  b.id = (pdmp3_handle*)calloc(1, sizeof *b.id);
+  if (!b.id) return -1;
+  b.id->host_only = 1;
+  b.count_only = 1;
+  const long long total = bulk_drive(&b, mp3 ? mp3 : (const unsigned char*)"", mp3 ? n : 0);
+  if (frames) *frames = b.frames;
+  free(b.id);
+  return total;
+}
+
+/* Decode a whole stream.  Returns the PCM byte count pdmp3() writes for it (the first min(that, pcm_cap)
+ * bytes are in `pcm`), or -1 on an engine failure.  rate / channels: format of the last header seen. */
+long long pdmp3_amd_bulk_decode(struct bulk* b, const unsigned char* mp3, size_t n, unsigned char* pcm, size_t pcm_cap,
+                                long* rate, int* channels) {
+  if (!b || !b->hs || (!mp3 && n) || (!pcm && pcm_cap)) return -1;
+  bulk_begin(b);
+  if (pdmp3_hip_stream_reset(b->hs) != PDMP3_HIP_OK) return -1;
+  b->pcm = pcm; b->pcm_cap = pcm_cap;
+  const long long total = bulk_drive(b, mp3, n);
+  int ok = !b->failed && bulk_rotate(b) == PDMP3_OK;   /* the partly filled last window */
+  ok = ok && bulk_finish_b(b) == PDMP3_OK;
+  for (int i = 0; i < BULK_SLOTS; i++) ok = bulk_collect(b, i) == PDMP3_OK && ok;
+  if (b->in_b) { bulk_wait_b(b); b->in_b = NULL; }
+  if (rate) *rate = (long)kSampleRates[b->id->hdr.sfreq];
+  if (channels) *channels = b->id->hdr.mode == 3 ? 1 : 2;
+  return ok ? total : -1;
+}
+
+/* Host stages A-C only: the records the engine would be given, into caller memory (cap_frames frames).
+ * Returns the frame count, or -1 when they do not fit. */
+long long pdmp3_amd_bulk_parse(struct bulk* b, const unsigned char* mp3, size_t n, int16_t* spectra, pdmp3_gc_side* side,
+                               size_t cap_frames, long long* pcm_bytes) {
+  if (!b || b->hs || (!mp3 && n)) return -1;
+  bulk_begin(b);
+  b->rec_spectra = spectra; b->rec_side = side; b->rec_cap = cap_frames;
+  const long long total = bulk_drive(b, mp3, n);
+  int ok = !b->failed && bulk_rotate(b) == PDMP3_OK;
+  ok = ok && bulk_finish_b(b) == PDMP3_OK;
+  if (b->in_b) { bulk_wait_b(b); b->in_b = NULL; }
+  if (pcm_bytes) *pcm_bytes = total;
+  return ok ? b->frames : -1;
 }
 
 /* ------------------------------------------------------------------------ */

@@ -9,6 +9,7 @@
 #include "../../pdmp3_amd/csrc/gen_core.h"
 
 #include <memory>
+#include <vector>
 
 using namespace pdmp3;
 
@@ -20,17 +21,16 @@ extern "C" int emul_decode_frames(const int16_t* spectra, const pdmp3_gc_side* s
   GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data()};
   if (chunk_frames <= 0) chunk_frames = n_frames;
   if (stages) chunk_frames = n_frames;
-  DecodeArgs a{spectra, side, pcm, state, state, stages, n_frames, chunk_frames, nullptr};
+  // like engine.hip: the kernel writes the new state to scratch (any chunk may read the old one), then it is copied
+  std::vector<float> state_next(kStateFloats);
+  DecodeArgs a{spectra, side, pcm, state, state ? state_next.data() : nullptr, stages, n_frames, chunk_frames, nullptr};
   const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
   auto L = std::make_unique<WaveLds>();
-  // the final state is written by the last chunk; the first reads it: run the
-  // first chunk before the last one overwrites it (same order as on the device
-  // where chunk 0 reads `state` in its prologue -- see engine.hip for the
-  // double-buffered state there).
   for (int c = 0; c < nchunks; ++c) {
     if (stages) run_chunk<true>(a, T, &H.cb, c, *L);
     else run_chunk<false>(a, T, &H.cb, c, *L);
   }
+  if (state) std::copy(state_next.begin(), state_next.end(), state);
   return 0;
 }
 

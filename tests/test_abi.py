@@ -26,6 +26,17 @@ def test_hip_library_exports():
     assert lib.pdmp3_hip_state_bytes() > 0
 
 
+def test_api_library_exports():
+    """libpdmp3.so: every function include/pdmp3.h (the reference's API) and include/pdmp3_bulk.h declare"""
+    from pdmp3_amd import api
+    lib = api.load_library()
+    names = [n for h in ("pdmp3.h", "pdmp3_bulk.h") for n in _declared(h) if not n.startswith("pdmp3_hip_")]
+    names.append("pdmp3")                          # the CLI driver itself (pdmp3.c:2540)
+    assert set(api.API_EXPORTS) <= set(names) and set(api.BULK_EXPORTS) <= set(names)
+    for n in names:
+        assert hasattr(lib, n), "include/ declares %s but libpdmp3.so lacks it" % n
+
+
 def test_side_record_layout():
     from pdmp3_amd.hip import SIDE_DTYPE
     assert SIDE_DTYPE.itemsize == 128

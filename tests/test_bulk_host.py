@@ -1,0 +1,82 @@
+"""Bulk pipeline, host stages (include/pdmp3_bulk.h; pdmp3_host.c stages A-C):
+the threaded scalefactor/Huffman fan-out with the sequential state merge must
+give the same gc records as the oracle's front end driven like the CLI, for any
+thread count and window size; the scan pass must give the CLI's byte count.
+No GPU involved."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_host_stage import STREAMS, _records_equal
+from tools.packer import packer
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _streams():
+    out = {k: packer.generate(**v) for k, v in STREAMS.items()}
+    out["clip"] = open(os.path.join(GOLD, "clip_invalid_keypress.mp3"), "rb").read()
+    rs = np.random.RandomState(5)
+    body = packer.generate(n_frames=40, seed=21, bitrate_index=9)
+    junk = bytes(rs.randint(0, 255, size=700).astype(np.uint8).tolist()).replace(b"\xff", b"\x00")
+    out["junk_resync"] = junk + body[:9000] + junk[:333] + body[9000:-517]
+    out["long_tag"] = bytes(2000) + body
+    # format changes mid-stream: stale parse state crosses the boundary
+    out["stereo_then_mono_then_stereo"] = (packer.generate(n_frames=30, seed=31, bitrate_index=9) +
+                                           packer.generate(n_frames=30, seed=32, mode=3, bitrate_index=7) +
+                                           packer.generate(n_frames=30, seed=33, mode=1, mode_ext=2, bitrate_index=11,
+                                                           block_pct=(10, 10, 70, 10)))
+    out["empty"] = b""
+    out["tiny"] = body[:600]
+    return out
+
+
+@pytest.fixture(scope="module")
+def streams():
+    return _streams()
+
+
+@pytest.mark.parametrize("threads,window", [(1, 2048), (4, 7), (8, 1), (3, 64)])
+def test_bulk_records_match_oracle(oracle, streams, threads, window):
+    from pdmp3_amd import api
+    b = api.BulkDecoder(threads=threads, window_frames=window, parse_only=True)
+    assert b.threads == threads
+    try:
+        for name, mp3 in streams.items():
+            pcm_o, sp_o, sd_o = oracle.decode_buffer_like_cli(mp3, tap_frames=500)
+            sp, sd, pcm_bytes = b.parse(mp3)
+            # frames parsed in a read call that then failed are in the records but not in the PCM
+            assert sp.shape[0] >= sp_o.shape[0], name
+            n = sp_o.shape[0]
+            assert _records_equal((sp[:n], sd[:n]), (sp_o, sd_o)), name
+            assert pcm_bytes == len(pcm_o), name
+            assert api.scan_buffer(mp3) == (pcm_bytes, sp.shape[0]), name
+    finally:
+        b.close()
+
+
+def test_bulk_decoder_is_reusable_and_fresh(oracle, streams):
+    """each stream starts from a fresh decoder: order of streams does not matter"""
+    from pdmp3_amd import api
+    b = api.BulkDecoder(threads=2, window_frames=16, parse_only=True)
+    try:
+        first = {k: b.parse(v) for k, v in streams.items()}
+        for k in reversed(list(streams)):
+            sp, sd, nbytes = b.parse(streams[k])
+            assert _records_equal((sp, sd), first[k][:2]) and nbytes == first[k][2], k
+    finally:
+        b.close()
+
+
+def test_bulk_long_stream_many_windows(oracle):
+    from pdmp3_amd import api
+    mp3 = packer.generate(n_frames=1500, seed=77, vbr=True, block_pct=(40, 10, 40, 10))
+    pcm_o, sp_o, sd_o = oracle.decode_buffer_like_cli(mp3, tap_frames=1600)
+    b = api.BulkDecoder(threads=8, window_frames=100, parse_only=True)
+    try:
+        sp, sd, nbytes = b.parse(mp3)
+    finally:
+        b.close()
+    n = sp_o.shape[0]
+    assert n >= 1495 and _records_equal((sp[:n], sd[:n]), (sp_o, sd_o)) and nbytes == len(pcm_o)

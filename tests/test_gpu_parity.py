@@ -182,3 +182,19 @@ def test_gpu_c5_shards(engine, oracle):
             want = oracle.decode(sp, sd)[a - w0:]
             assert_pcm_close(got[a - lo:b - lo], want, 1, "shard %d frames %d..%d" % (rank, a, b))
         del spectra, side, pcm
+
+
+@pytest.mark.parametrize("chunk", [0, 1, 2, 3, 7])
+def test_gpu_channel1_state_survives_mono_runs(engine, oracle, chunk):
+    """stereo / mono / stereo: channel 1's overlap and polyphase history are what the last stereo frame left
+    (P:1777, P:2126 are per channel), for any chunking, and across batches through the carried state"""
+    from test_pipeline_emul import _mode_switch_records
+    sp, sd = _mode_switch_records()
+    want = oracle.decode(sp, sd)
+    whole = gpu_decode(engine, sp, sd, chunk=sp.shape[0])
+    assert_pcm_close(whole, want, 1, "one chunk")
+    assert np.array_equal(gpu_decode(engine, sp, sd, chunk=chunk), whole)
+    st = engine.new_state()
+    cuts = [0, 9, 14, 20, 22, 29, sp.shape[0]]
+    parts = [gpu_decode(engine, sp[a:b], sd[a:b], chunk=chunk, state=st) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(parts), whole)

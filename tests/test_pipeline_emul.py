@@ -57,3 +57,36 @@ def test_emul_generator(oracle, emul):
     sd2 = np.zeros_like(sd)
     emul.emul_generate_frames(C.c_uint64(C2_SEED), C.c_int64(3), 9, _p(sp2), _p(sd2))
     assert np.array_equal(sp, sp2) and np.array_equal(sd.view(np.uint8), sd2.view(np.uint8))
+
+
+def _mode_switch_records():
+    """stereo / mono / stereo runs, incl. single stereo frames between mono runs (records from the host parser)"""
+    from pdmp3_amd import api
+    from tools.packer import packer
+    parts = [dict(n_frames=9, seed=31, bitrate_index=9), dict(n_frames=11, seed=32, mode=3, bitrate_index=7),
+             dict(n_frames=2, seed=33, mode=1, mode_ext=2, bitrate_index=11, block_pct=(10, 10, 70, 10)),
+             dict(n_frames=7, seed=34, mode=3, bitrate_index=7),
+             dict(n_frames=12, seed=35, mode=1, mode_ext=2, bitrate_index=11, block_pct=(10, 10, 70, 10))]
+    mp3 = b"".join(packer.generate(**p) for p in parts)
+    return api.parse_like_cli(mp3, 64)
+
+
+@pytest.mark.parametrize("chunk", [1, 2, 3, 4, 7, 16])
+def test_emul_channel1_state_survives_mono_runs(oracle, emul, chunk):
+    """mono frames leave channel 1's overlap / polyphase history alone (P:1777, P:2126 are per channel): a chunk
+    that starts after a mono run must find channel 1 as the last stereo frame left it"""
+    sp, sd = _mode_switch_records()
+    assert sp.shape[0] >= 38
+    want = oracle.decode(sp, sd)
+    assert_pcm_close(emul_decode(emul, sp, sd, chunk), want, 1, "chunk %d" % chunk)
+    assert np.array_equal(emul_decode(emul, sp, sd, chunk), emul_decode(emul, sp, sd, 0))
+
+
+def test_emul_channel1_state_across_batches(oracle, emul):
+    """the carried state keeps channel 1 through an all-mono batch decoded in several chunks"""
+    sp, sd = _mode_switch_records()
+    whole = emul_decode(emul, sp, sd, 0)
+    st = np.zeros(emul.emul_state_floats(), np.float32)
+    cuts = [0, 9, 14, 20, 22, 29, sp.shape[0]]          # 9..20 mono (two batches), 22..29 mono
+    out = [emul_decode(emul, sp[a:b], sd[a:b], 2, st) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(out), whole)

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Throughput of the bulk pipeline (include/pdmp3_bulk.h) on a long synthetic
+stream (44.1 kHz joint stereo 320 kbps).  Host stages alone
+(--parse-only, runs anywhere) or end to end on the GPU box.
+
+  python tools/bulk_bench.py --frames 137813 --threads 1,8,32,64
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=20000)
+    ap.add_argument("--threads", default="1,4,8")
+    ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--parse-only", action="store_true")
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    from tools.packer import packer
+    from pdmp3_amd import api
+    t0 = time.perf_counter()
+    mp3 = packer.generate(n_frames=args.frames, seed=0xC3, sfreq=0, mode=1, mode_ext=2, bitrate_index=14)
+    a = np.frombuffer(mp3, dtype=np.uint8)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    total, frames = api.scan_buffer(a)
+    t_scan = time.perf_counter() - t0
+    rt = 44100.0 / 1152.0
+    out = {"frames": frames, "mp3_bytes": len(mp3), "pcm_bytes": total, "packer_s": round(t_gen, 2),
+           "scan_ms": round(t_scan * 1e3, 2), "scan_frames_per_s": round(frames / t_scan, 1), "host_cpus": os.cpu_count(),
+           "runs": []}
+    pcm = np.empty(total // 2, dtype=np.int16)
+    for th in [int(x) for x in args.threads.split(",")]:
+        b = api.BulkDecoder(threads=th, window_frames=args.window, parse_only=args.parse_only)
+        best = None
+        for _ in range(args.reps):
+            t0 = time.perf_counter()
+            if args.parse_only:
+                b.parse(a)
+            else:
+                got, _, _ = b.decode_into(a, pcm)
+                assert got == total
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        b.close()
+        out["runs"].append({"threads": th, "seconds": round(best, 4), "frames_per_s": round(frames / best, 1),
+                            "x_realtime": round(frames / best / rt, 1), "mode": "parse" if args.parse_only else "decode"})
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
