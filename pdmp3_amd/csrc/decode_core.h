@@ -600,7 +600,8 @@ PD_FN void ph_antialias(int lane, WaveLds& L, BankPtr cb) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
 
 template <bool DUMP>
-PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTables& T, float* dump2, float* dump3) {
+PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTables& T, float* dump2, float* dump3,
+                   bool do_matrix) {   // do_matrix (wave-uniform) = false: a halo granule whose polyphase input nobody reads
   const GranuleInfo g = granule_info(L);
   const int j = lane & 15, kq = lane >> 4;
   if (DUMP) {   // stage 2 = lines after alias reduction
@@ -639,10 +640,12 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTa
     if (sb & 1) o17 = -o17;                                               // P:1738-1746
     if (DUMP) { if (act) { dump3[cl * 4 * 576 + 18 * sb + 16] = o16; dump3[cl * 4 * 576 + 18 * sb + 17] = o17; } }
     // matrixing fold: x[k] +- x[31 - k]; subband 31 - sb of the same channel is lane ^ 31
-    const float p16 = __shfl_xor(o16, 31), p17 = __shfl_xor(o17, 31);
-    if (sb < 16) {
-      L.lo[0][2 * cl + 0][sb] = o16 + p16; L.lo[1][2 * cl + 0][sb] = o16 - p16;
-      L.lo[0][2 * cl + 1][sb] = o17 + p17; L.lo[1][2 * cl + 1][sb] = o17 - p17;
+    if (do_matrix) {
+      const float p16 = __shfl_xor(o16, 31), p17 = __shfl_xor(o17, 31);
+      if (sb < 16) {
+        L.lo[0][2 * cl + 0][sb] = o16 + p16; L.lo[1][2 * cl + 0][sb] = o16 - p16;
+        L.lo[0][2 * cl + 1][sb] = o17 + p17; L.lo[1][2 * cl + 1][sb] = o17 - p17;
+      }
     }
   }
   // ---- channel 1 first: its matrixing output overwrites xr[1][18..] and nothing of xr[0];
@@ -701,21 +704,23 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTa
           if (ch == 0 && h == 0 && r == 0 && kq == 0 && j < 3) L.peek[j] = o;   // H5 source: (ch 0, sb 0, t 0..2)
         }
       // matrixing of time slots t = j (rows) of this channel: butterflies, then even / odd 16 x 16 products
-      f32x4 me = (f32x4){0, 0, 0, 0}, mo = (f32x4){0, 0, 0, 0};
-      PD_UNROLL for (int r = 0; r < 4; r++) {
-        const float a = outa[r] + outa[4 + r], b = outa[r] - outa[4 + r];   // x[k] +- x[31 - k], k = 4 kq + r
-        me = mfma16(a, R.bm[r], me);
-        mo = mfma16(b, R.bm[4 + r], mo);
-      }
-      PD_UNROLL for (int r = 0; r < 4; r++) {      // D rows = time slot 4 kq + r, cols: C[2 j] and C[2 j + 1]
-        L.hyb[ch][4 * kq + r][2 * j] = me[r];
-        L.hyb[ch][4 * kq + r][2 * j + 1] = mo[r];
+      if (do_matrix) {
+        f32x4 me = (f32x4){0, 0, 0, 0}, mo = (f32x4){0, 0, 0, 0};
+        PD_UNROLL for (int r = 0; r < 4; r++) {
+          const float a = outa[r] + outa[4 + r], b = outa[r] - outa[4 + r];   // x[k] +- x[31 - k], k = 4 kq + r
+          me = mfma16(a, R.bm[r], me);
+          mo = mfma16(b, R.bm[4 + r], mo);
+        }
+        PD_UNROLL for (int r = 0; r < 4; r++) {      // D rows = time slot 4 kq + r, cols: C[2 j] and C[2 j + 1]
+          L.hyb[ch][4 * kq + r][2 * j] = me[r];
+          L.hyb[ch][4 * kq + r][2 * j + 1] = mo[r];
+        }
       }
     }
   }
   // ---- the four left-over time slots (rows: ch 0 t 16, ch 0 t 17, ch 1 t 16, ch 1 t 17) as one more row tile
   PD_WAVE_SYNC();                          // lo[] was written by other lanes
-  {
+  if (do_matrix) {
     f32x4 me = (f32x4){0, 0, 0, 0}, mo = (f32x4){0, 0, 0, 0};
     PD_UNROLL for (int r = 0; r < 4; r++) {
       const float a = (j < 4) ? L.lo[0][j & 3][4 * kq + r] : 0.0f;
@@ -784,10 +789,18 @@ PD_FN int pcm_from_sum(float sum) {
   return s;
 }
 
-PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R) {
+// full = false (wave-uniform): the last halo granule -- only its slots 3..17 are wanted, as the next granule's history
+PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full) {
   const GranuleInfo g = granule_info(L);
   const int ch = lane >> 5, i = lane & 31;
   if (ch >= g.nch) return;
+  if (!full) {
+    PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
+      R.he[s] = L.hyb[ch][3 + s][R.idx_e];
+      R.ho[s] = L.hyb[ch][3 + s][R.idx_o];
+    }
+    return;
+  }
   // E[s], O[s]: the lane's two coefficients of slot s; s = 0..14 history, 15..32 this granule
   float E[kHistSlots + 18], O[kHistSlots + 18];
   PD_UNROLL for (int s = 0; s < kHistSlots; s++) { E[s] = R.he[s]; O[s] = R.ho[s]; }
@@ -915,6 +928,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   // re-derived by the ordinary halo, which does not touch channel 1.  No stereo frame back to the start of
   // the batch: channel 1 is the caller's state_in (or zero); a RESET frame: zero.
   int pre_end = 0, npre = 0;
+  int g_keep = -1;           // merged pre-halo: the last granule that decodes channel 1 (its history must be kept)
   bool ch1_from_state = false;
   if (g_start > 0) {
     const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f0 - 1) * 4)[7];
@@ -927,7 +941,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
         if (((sb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3) {     // (a mono RESET frame: zero, nothing to do)
           pre_end = 2 * fs + 2;
           npre = (fs > 0 && !(sb & PDMP3_FR_RESET)) ? 3 : 2;
-          if (pre_end >= g_start) { g_start = pre_end - npre; npre = 0; pre_end = 0; }   // touches the ordinary halo: one run
+          if (pre_end >= g_start) { g_start = pre_end - npre; g_keep = pre_end - 1; npre = 0; pre_end = 0; }   // touches the ordinary halo: one run
         }
       }
     }
@@ -953,6 +967,11 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     const int g = k < 0 ? pre_end + k : g_start + k;
     const int g_next = k + 1 < 0 ? pre_end + k + 1 : g_start + k + 1;
     const int f = g >> 1, gr = g & 1;
+    // Halo granules are decoded only for what they leave behind: the IMDCT tails (every one of them) and the
+    // polyphase history, which is slots 3..17 of the LAST granule before a stretch that is emitted -- or, for the
+    // pre-halo, before channel 1 goes quiet.  Their own PCM, and the matrixing of the earlier ones, is never read.
+    const bool emit = (k >= 0) && (g >= g_begin);
+    const bool feeds_next = (k == -1) || (k >= 0 && (g == g_begin - 1 || g == g_keep));
     PD_LAUNDER(cb);
     {
       int sf = L.side[0][7] & PDMP3_FR_SFREQ_MASK;
@@ -978,7 +997,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       ph_antialias(lane, L, cb);
     )
     PD_TICK(3)
-    PD_PHASE(ph_mfma<DUMP>(lane, L, R, cb, T, dmp + 2 * 576, dmp + 3 * 576))
+    PD_PHASE(ph_mfma<DUMP>(lane, L, R, cb, T, dmp + 2 * 576, dmp + 3 * 576, emit || feeds_next))
     PD_TICK(4)
     PD_TICK(5)
 #else
@@ -990,10 +1009,14 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     PD_TICK(3)
     PD_PHASE(ph_imdct<DUMP>(lane, L, R, cb, dmp + 3 * 576))
     PD_TICK(4)
-    PD_PHASE(ph_dct32(lane, L))
+    if (emit || feeds_next) {
+      PD_PHASE(ph_dct32(lane, L))
+    }
     PD_TICK(5)
 #endif
-    PD_PHASE(ph_window(lane, L, R))
+    if (emit || feeds_next) {
+      PD_PHASE(ph_window(lane, L, R, emit))
+    }
     PD_TICK(6)
     // the next granule is committed to LDS BEFORE this granule's PCM stores are issued: its prefetch
     // loads are older than those stores, so waiting for them never waits for a store
@@ -1001,7 +1024,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     if (g_next < g_end) {
       PD_PHASE(ph_commit(lane, L, R))
     }
-    PD_PHASE(ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, g >= g_begin))
+    PD_PHASE(ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, emit))
     PD_TICK(7)
   }
 #undef PD_TICK

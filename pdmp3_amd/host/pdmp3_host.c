@@ -827,6 +827,7 @@ int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) 
 /* ------------------------------------------------------------------------ */
 #define BULK_SLOTS 3
 #define BULK_GRAB 8                   /* frames a worker takes per trip to the counter */
+#define BULK_COPY_PIECE ((size_t)256 << 10)
 
 typedef struct {
   frame_header hdr;
@@ -845,7 +846,7 @@ typedef struct {
 } bulk_window;
 
 typedef struct {                      /* a window that is on the GPU */
-  int n, active;
+  int n, active, all_stereo;
   size_t pcm_off;
   uint8_t* nch;
 } bulk_flight;
@@ -865,6 +866,7 @@ struct bulk {
   pthread_mutex_t mu;
   pthread_cond_t cv_work, cv_done;
   bulk_window* work;
+  const unsigned char* copy_src; unsigned char* copy_dst; size_t copy_bytes, copy_next;
   long long gen;
   int next, active, quit;
   /* sinks: the engine (hs) or caller memory (parse only, host tests) */
@@ -873,7 +875,7 @@ struct bulk {
   int16_t* rec_spectra; pdmp3_gc_side* rec_side; size_t rec_cap;
   unsigned char* pcm; size_t pcm_cap;
   size_t pcm_emitted;                 /* PCM bytes of all frames handed to stage C so far */
-  int failed;
+  int failed, busy;
 };
 
 static void* bulk_worker(void* arg) {
@@ -885,8 +887,11 @@ static void* bulk_worker(void* arg) {
     if (b->quit) { pthread_mutex_unlock(&b->mu); return NULL; }
     seen = b->gen;
     bulk_window* w = b->work;
+    const unsigned char* csrc = b->copy_src;
+    unsigned char* cdst = b->copy_dst;
+    const size_t cbytes = b->copy_bytes;
     pthread_mutex_unlock(&b->mu);
-    for (;;) {
+    while (w) {
       const int i0 = __atomic_fetch_add(&b->next, BULK_GRAB, __ATOMIC_RELAXED);
       if (i0 >= w->n) break;
       const int i1 = i0 + BULK_GRAB < w->n ? i0 + BULK_GRAB : w->n;
@@ -896,38 +901,52 @@ static void* bulk_worker(void* arg) {
         decode_main(w->jobs[i].res, &w->jobs[i].hdr, &w->jobs[i].si, o);
       }
     }
+    for (;;) {                                     /* PCM of an older window: pinned slot -> caller memory */
+      const size_t c0 = __atomic_fetch_add(&b->copy_next, BULK_COPY_PIECE, __ATOMIC_RELAXED);
+      if (c0 >= cbytes) break;
+      memcpy(cdst + c0, csrc + c0, cbytes - c0 < BULK_COPY_PIECE ? cbytes - c0 : BULK_COPY_PIECE);
+    }
     pthread_mutex_lock(&b->mu);
     if (--b->active == 0) pthread_cond_signal(&b->cv_done);
     pthread_mutex_unlock(&b->mu);
   }
 }
 
-static void bulk_start_b(struct bulk* b, bulk_window* w) {
+/* hand the workers a window to decode (or NULL) and a byte range to copy (or none) */
+static void bulk_start_b(struct bulk* b, bulk_window* w, const unsigned char* src, unsigned char* dst, size_t nbytes) {
   pthread_mutex_lock(&b->mu);
-  b->work = w; b->next = 0; b->active = b->nth; b->gen++;
+  b->work = w; b->next = 0;
+  b->copy_src = src; b->copy_dst = dst; b->copy_bytes = nbytes; b->copy_next = 0;
+  b->active = b->nth; b->gen++;
   pthread_cond_broadcast(&b->cv_work);
   pthread_mutex_unlock(&b->mu);
   b->in_b = w;
+  b->busy = 1;
 }
 static void bulk_wait_b(struct bulk* b) {
+  if (!b->busy) return;
   pthread_mutex_lock(&b->mu);
   while (b->active) pthread_cond_wait(&b->cv_done, &b->mu);
   pthread_mutex_unlock(&b->mu);
+  b->busy = 0;
 }
 
-/* PCM of a finished slot -> caller memory */
-static int bulk_collect(struct bulk* b, int slot) {
+/* PCM of a finished slot -> caller memory.  An all-stereo window is one contiguous block: with `job` it is
+ * left to the workers (returned through src/dst/nbytes), otherwise copied here. */
+static int bulk_collect(struct bulk* b, int slot, const unsigned char** jsrc, unsigned char** jdst, size_t* jbytes) {
   bulk_flight* f = &b->flight[slot];
+  if (jbytes) *jbytes = 0;
   if (!f->active) return PDMP3_OK;
   if (pdmp3_hip_stream_wait(b->hs, slot) != PDMP3_HIP_OK) return PDMP3_ERR;
   f->active = 0;
   const unsigned char* src = (const unsigned char*)pdmp3_hip_stream_slot_pcm(b->hs, slot);
   size_t off = f->pcm_off;
-  int all_stereo = 1;
-  for (int i = 0; i < f->n; i++) if (f->nch[i] != 2) { all_stereo = 0; break; }
-  if (all_stereo) {
+  if (f->all_stereo) {
     size_t n = (size_t)f->n * 4608;
-    if (off < b->pcm_cap) memcpy(b->pcm + off, src, n < b->pcm_cap - off ? n : b->pcm_cap - off);
+    if (off >= b->pcm_cap) return PDMP3_OK;
+    if (n > b->pcm_cap - off) n = b->pcm_cap - off;
+    if (jbytes) { *jsrc = src; *jdst = b->pcm + off; *jbytes = n; }
+    else memcpy(b->pcm + off, src, n);
     return PDMP3_OK;
   }
   for (int i = 0; i < f->n; i++) {
@@ -941,18 +960,18 @@ static int bulk_collect(struct bulk* b, int slot) {
 /* stage C + D of the window the workers have just finished */
 static int bulk_finish_b(struct bulk* b) {
   bulk_window* w = b->in_b;
-  if (!w) return PDMP3_OK;
   bulk_wait_b(b);
+  if (!w) return PDMP3_OK;
   b->in_b = NULL;
   pdmp3_handle* id = b->id;
   bulk_flight* f = b->hs ? &b->flight[w->slot] : NULL;
-  if (f) { f->pcm_off = b->pcm_emitted; f->n = w->n; }
+  if (f) { f->pcm_off = b->pcm_emitted; f->n = w->n; f->all_stereo = 1; }
   for (int i = 0; i < w->n; i++) {
     const frame_job* j = &w->jobs[i];
     apply_main(id, &j->hdr, &w->outs[i]);
     emit_records(id, &j->hdr, &j->si, j->reset, w->spectra + (size_t)i * 2304, w->side + (size_t)i * 4);
     const unsigned nch = j->hdr.mode == 3 ? 1 : 2;
-    if (f) f->nch[i] = (uint8_t)nch;
+    if (f) { f->nch[i] = (uint8_t)nch; if (nch != 2) f->all_stereo = 0; }
     b->pcm_emitted += 2304u * nch;
   }
   if (f) {
@@ -965,31 +984,30 @@ static int bulk_finish_b(struct bulk* b) {
   return PDMP3_OK;
 }
 
-/* the window stage A has filled goes to the workers; the one before it to the GPU; the one before that home */
+/* The window stage A has filled (k) goes to the workers, together with the PCM copy of window k-3, whose slot it
+ * takes over; before that, window k-1 leaves the workers for stage C and the GPU. */
 static int bulk_rotate(struct bulk* b) {
   bulk_window* w = &b->win[b->cur];
   if (bulk_finish_b(b) != PDMP3_OK) return PDMP3_ERR;
-  if (w->n) {
-    if (b->hs) {
-      w->slot = (int)(b->windows % BULK_SLOTS);
-      if (bulk_collect(b, w->slot) != PDMP3_OK) return PDMP3_ERR;      /* normally already home */
-      w->spectra = pdmp3_hip_stream_slot_spectra(b->hs, w->slot);
-      w->side = pdmp3_hip_stream_slot_side(b->hs, w->slot);
-    } else {
-      const size_t first = (size_t)b->frames - (size_t)w->n;
-      if (first + (size_t)w->n > b->rec_cap) return PDMP3_ERR;
-      w->spectra = b->rec_spectra + first * 2304;
-      w->side = b->rec_side + first * 4;
-    }
-    bulk_start_b(b, w);
-    b->windows++;
-    b->cur ^= 1;
-    b->win[b->cur].n = 0;
+  if (!w->n) return PDMP3_OK;
+  const unsigned char* src = NULL;
+  unsigned char* dst = NULL;
+  size_t nbytes = 0;
+  if (b->hs) {
+    w->slot = (int)(b->windows % BULK_SLOTS);
+    if (bulk_collect(b, w->slot, &src, &dst, &nbytes) != PDMP3_OK) return PDMP3_ERR;   /* window k-3 */
+    w->spectra = pdmp3_hip_stream_slot_spectra(b->hs, w->slot);
+    w->side = pdmp3_hip_stream_slot_side(b->hs, w->slot);
+  } else {
+    const size_t first = (size_t)b->frames - (size_t)w->n;
+    if (first + (size_t)w->n > b->rec_cap) return PDMP3_ERR;
+    w->spectra = b->rec_spectra + first * 2304;
+    w->side = b->rec_side + first * 4;
   }
-  /* windows-1 is with the workers, windows-2 on the GPU: bring windows-3 home, its slot is the next to be filled */
-  if (b->hs && b->windows >= 3) {
-    if (bulk_collect(b, (int)((b->windows - 3) % BULK_SLOTS)) != PDMP3_OK) return PDMP3_ERR;
-  }
+  bulk_start_b(b, w, src, dst, nbytes);
+  b->windows++;
+  b->cur ^= 1;
+  b->win[b->cur].n = 0;
   return PDMP3_OK;
 }
 
@@ -1097,7 +1115,7 @@ static void bulk_begin(struct bulk* b) {
   memset(id, 0, sizeof *id);
   id->host_only = 1;
   b->cur = 0; b->win[0].n = b->win[1].n = 0; b->in_b = NULL;
-  b->windows = 0; b->frames = 0; b->pcm_emitted = 0; b->count_only = 0; b->failed = 0;
+  b->windows = 0; b->frames = 0; b->pcm_emitted = 0; b->count_only = 0; b->failed = 0; b->busy = 0;
   for (int i = 0; i < BULK_SLOTS; i++) b->flight[i].active = 0;
 }
 
@@ -1127,8 +1145,14 @@ long long pdmp3_amd_bulk_decode(struct bulk* b, const unsigned char* mp3, size_t
   const long long total = bulk_drive(b, mp3, n);
   int ok = !b->failed && bulk_rotate(b) == PDMP3_OK;   /* the partly filled last window */
   ok = ok && bulk_finish_b(b) == PDMP3_OK;
-  for (int i = 0; i < BULK_SLOTS; i++) ok = bulk_collect(b, i) == PDMP3_OK && ok;
-  if (b->in_b) { bulk_wait_b(b); b->in_b = NULL; }
+  for (int i = 0; i < BULK_SLOTS && ok; i++) {         /* what is still on the GPU: the pool copies it out */
+    const unsigned char* src; unsigned char* dst; size_t nbytes;
+    ok = bulk_collect(b, i, &src, &dst, &nbytes) == PDMP3_OK;
+    if (ok && nbytes) { bulk_start_b(b, NULL, src, dst, nbytes); bulk_wait_b(b); }
+  }
+  bulk_wait_b(b);
+  b->in_b = NULL;
+  if (!ok) for (int i = 0; i < BULK_SLOTS; i++) { (void)pdmp3_hip_stream_wait(b->hs, i); b->flight[i].active = 0; }
   if (rate) *rate = (long)kSampleRates[b->id->hdr.sfreq];
   if (channels) *channels = b->id->hdr.mode == 3 ? 1 : 2;
   return ok ? total : -1;
@@ -1144,7 +1168,8 @@ long long pdmp3_amd_bulk_parse(struct bulk* b, const unsigned char* mp3, size_t 
   const long long total = bulk_drive(b, mp3, n);
   int ok = !b->failed && bulk_rotate(b) == PDMP3_OK;
   ok = ok && bulk_finish_b(b) == PDMP3_OK;
-  if (b->in_b) { bulk_wait_b(b); b->in_b = NULL; }
+  bulk_wait_b(b);
+  b->in_b = NULL;
   if (pcm_bytes) *pcm_bytes = total;
   return ok ? b->frames : -1;
 }

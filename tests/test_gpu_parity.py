@@ -195,6 +195,7 @@ def test_gpu_channel1_state_survives_mono_runs(engine, oracle, chunk):
     assert_pcm_close(whole, want, 1, "one chunk")
     assert np.array_equal(gpu_decode(engine, sp, sd, chunk=chunk), whole)
     st = engine.new_state()
-    cuts = [0, 9, 14, 20, 22, 29, sp.shape[0]]
-    parts = [gpu_decode(engine, sp[a:b], sd[a:b], chunk=chunk, state=st) for a, b in zip(cuts[:-1], cuts[1:])]
-    assert np.array_equal(np.concatenate(parts), whole)
+    for cuts in ([0, 9, 14, 20, 22, 29, sp.shape[0]], [0, 7, 11, 19, 24, 31, sp.shape[0]], [0, 8, 10, 21, 23, 30, sp.shape[0]]):
+        st.zero_()
+        parts = [gpu_decode(engine, sp[a:b], sd[a:b], chunk=chunk, state=st) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts), whole), cuts

@@ -90,3 +90,9 @@ def test_emul_channel1_state_across_batches(oracle, emul):
     cuts = [0, 9, 14, 20, 22, 29, sp.shape[0]]          # 9..20 mono (two batches), 22..29 mono
     out = [emul_decode(emul, sp[a:b], sd[a:b], 2, st) for a, b in zip(cuts[:-1], cuts[1:])]
     assert np.array_equal(np.concatenate(out), whole)
+    # batches that end in mono right after stereo frames (pre-halo touching the ordinary halo), every chunk size
+    for chunk in (1, 2, 3):
+        for cuts in ([0, 7, 11, 19, 24, 31, sp.shape[0]], [0, 8, 10, 21, 23, 30, sp.shape[0]]):
+            st[:] = 0
+            out = [emul_decode(emul, sp[a:b], sd[a:b], chunk, st) for a, b in zip(cuts[:-1], cuts[1:])]
+            assert np.array_equal(np.concatenate(out), whole), (chunk, cuts)
