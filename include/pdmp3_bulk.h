@@ -35,6 +35,11 @@ typedef struct bulk pdmp3_amd_bulk;
  * 2048 frames per GPU batch.  Returns NULL when there is no transform engine
  * (no CPU fallback). */
 pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
+/* host_huffman = 0 (what pdmp3_amd_bulk_new gives unless PDMP3_BULK_HOST_HUFFMAN=1 is set): the host only runs
+ * the sequential scan and ships side info + reservoir snapshots; scalefactors, Huffman and the frame-to-frame
+ * merge run on the device (pdmp3_hip_stream_submit_bits) and the pool just copies PCM out.  host_huffman = 1:
+ * they run on the pool and the engine is given decoded records (pdmp3_hip_stream_submit). */
+pdmp3_amd_bulk* pdmp3_amd_bulk_new_ex(int threads, int window_frames, int host_huffman);
 void pdmp3_amd_bulk_delete(pdmp3_amd_bulk* b);
 int pdmp3_amd_bulk_threads(const pdmp3_amd_bulk* b);
 
@@ -58,6 +63,12 @@ long long pdmp3_amd_bulk_decode(pdmp3_amd_bulk* b, const unsigned char* mp3, siz
 pdmp3_amd_bulk* pdmp3_amd_bulk_new_parse_only(int threads, int window_frames);
 long long pdmp3_amd_bulk_parse(pdmp3_amd_bulk* b, const unsigned char* mp3, size_t n,
                                int16_t* spectra, pdmp3_gc_side* side, size_t cap_frames, long long* pcm_bytes);
+
+/* The scan alone, in the device-Huffman form: per frame the pdmp3_frame_bits and PDMP3_RESERVOIR_BYTES of
+ * reservoir that the engine would be given (host tests). */
+pdmp3_amd_bulk* pdmp3_amd_bulk_new_parse_bits(void);
+long long pdmp3_amd_bulk_parse_bits(pdmp3_amd_bulk* b, const unsigned char* mp3, size_t n, pdmp3_frame_bits* bits,
+                                    uint8_t* reservoir, size_t cap_frames, long long* pcm_bytes);
 
 #ifdef __cplusplus
 }

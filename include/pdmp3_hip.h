@@ -190,6 +190,49 @@ pdmp3_gc_side* pdmp3_hip_stream_slot_side(pdmp3_hip_stream* hs, int slot);
 const int16_t* pdmp3_hip_stream_slot_pcm(pdmp3_hip_stream* hs, int slot);
 /* enqueue H2D + transforms + D2H of the slot's first n_frames frames; returns at once */
 int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_frames);
+
+/* ------------------------------------------------------------------------
+ * Bitstream-level input: scalefactor + Huffman decoding on the
+ * device.  The host keeps only the strictly sequential part of Read_Frame
+ * (pdmp3.c:1217-1244: header sync, side info P:1129-1200, bit reservoir
+ * P:1096-1122) and hands over, per frame, the side info and a snapshot of the
+ * reservoir buffer g_main_data_vec (P:137) as Get_Main_Data left it.  One lane
+ * per granule-channel then does what Read_Main_L3 (P:1376-1437), Read_Huffman
+ * (P:2051-2115) and Huffman_Decode (P:1593-1643) do, a second small kernel
+ * carries scalefactors / count1 from frame to frame exactly as the reference's
+ * never-cleared g_main_data / g_side_info do, and the transform
+ * kernel runs on the records in place: decoded spectra never cross PCIe
+ * (2144 B per frame up instead of 5120).
+ * ---------------------------------------------------------------------- */
+#define PDMP3_RESERVOIR_BYTES 2064          /* 2048 + 16: one row per frame              */
+
+typedef struct pdmp3_gc_bits {              /* side info of one granule-channel, P:74-93 */
+  uint16_t part2_3_length;                  /* P:75 */
+  uint16_t big_values;                      /* P:76 */
+  uint8_t  global_gain;                     /* P:77 */
+  uint8_t  scalefac_compress;               /* P:78 */
+  uint8_t  flags;                           /* PDMP3_GC_* exactly as in pdmp3_gc_side    */
+  uint8_t  table_select[3];                 /* P:84 */
+  uint8_t  subblock_gain[3];                /* P:85 */
+  uint8_t  region0_count, region1_count;    /* P:86-87 (the implicit 8 / 7 and 20 - r0 of
+                                               P:1177-1180 already filled in)            */
+  uint8_t  count1table_select;              /* P:90 */
+} pdmp3_gc_bits;                            /* 16 bytes */
+
+typedef struct pdmp3_frame_bits {
+  uint8_t  frame;                           /* PDMP3_FR_* */
+  uint8_t  scfsi[2];                        /* [ch]: bit b = band group b reuses granule 0, P:73 */
+  uint8_t  reserved[13];
+  pdmp3_gc_bits gc[4];                      /* [gr][ch] */
+} pdmp3_frame_bits;                         /* 80 bytes */
+
+/* pinned staging of a slot: n frames of side info and n reservoir rows */
+pdmp3_frame_bits* pdmp3_hip_stream_slot_bits(pdmp3_hip_stream* hs, int slot);
+uint8_t* pdmp3_hip_stream_slot_reservoir(pdmp3_hip_stream* hs, int slot);
+/* like pdmp3_hip_stream_submit, from bits: H2D, unpack, merge, transforms, D2H of the PCM */
+int pdmp3_hip_stream_submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames);
+/* test hook: the gc records the device built for the slot's last submit_bits (after pdmp3_hip_stream_wait) */
+int pdmp3_hip_stream_fetch_records(pdmp3_hip_stream* hs, int slot, int n_frames, int16_t* spectra, pdmp3_gc_side* side);
 /* block until the slot's PCM is in its pinned buffer (no-op if nothing is in flight) */
 int pdmp3_hip_stream_wait(pdmp3_hip_stream* hs, int slot);
 

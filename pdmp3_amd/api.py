@@ -13,8 +13,16 @@ PDMP3_OK, PDMP3_ERR, PDMP3_NEED_MORE, PDMP3_NEW_FORMAT, PDMP3_NO_SPACE = 0, -1, 
 PDMP3_ENC_SIGNED_16 = 0xD0
 _LIB = None
 
-BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads", "pdmp3_amd_scan_buffer",
-                "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse"]
+BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads",
+                "pdmp3_amd_scan_buffer", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
+                "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits"]
+
+# include/pdmp3_hip.h: pdmp3_gc_bits / pdmp3_frame_bits
+GC_BITS_DTYPE = np.dtype([("part2_3_length", "<u2"), ("big_values", "<u2"), ("global_gain", "u1"), ("scalefac_compress", "u1"),
+                          ("flags", "u1"), ("table_select", "u1", (3,)), ("subblock_gain", "u1", (3,)),
+                          ("region0_count", "u1"), ("region1_count", "u1"), ("count1table_select", "u1")])
+FRAME_BITS_DTYPE = np.dtype([("frame", "u1"), ("scfsi", "u1", (2,)), ("reserved", "u1", (13,)), ("gc", GC_BITS_DTYPE, (4,))])
+RESERVOIR_BYTES = 2064
 API_EXPORTS = ["pdmp3_new", "pdmp3_delete", "pdmp3_open_feed", "pdmp3_feed", "pdmp3_read",
                "pdmp3_decode", "pdmp3_getformat", "pdmp3"]
 
@@ -56,6 +64,12 @@ def load_library():
     lib.pdmp3_amd_scan_buffer.argtypes = [vp, C.c_size_t, C.POINTER(C.c_longlong)]
     lib.pdmp3_amd_bulk_decode.restype = C.c_longlong
     lib.pdmp3_amd_bulk_decode.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_int)]
+    lib.pdmp3_amd_bulk_new_ex.restype = vp
+    lib.pdmp3_amd_bulk_new_ex.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.pdmp3_amd_bulk_new_parse_bits.restype = vp
+    lib.pdmp3_amd_bulk_new_parse_bits.argtypes = []
+    lib.pdmp3_amd_bulk_parse_bits.restype = C.c_longlong
+    lib.pdmp3_amd_bulk_parse_bits.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_longlong)]
     lib.pdmp3_amd_bulk_parse.restype = C.c_longlong
     lib.pdmp3_amd_bulk_parse.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_longlong)]
     _LIB = lib
@@ -181,11 +195,15 @@ class BulkDecoder:
     """include/pdmp3_bulk.h: whole-stream decode, host Huffman on a thread pool + pipelined GPU batches.
     parse_only=True: host stages only (records out), for machines without a GPU."""
 
-    def __init__(self, threads=0, window_frames=0, parse_only=False):
+    def __init__(self, threads=0, window_frames=0, parse_only=False, host_huffman=False):
+        """host_huffman=False: scalefactors + Huffman run on the device (pdmp3_hip_stream_submit_bits), the pool only
+        copies PCM out; True: they run on the pool's threads (the engine gets decoded records)."""
         self.lib = load_library()
         self.parse_only = parse_only
-        new = self.lib.pdmp3_amd_bulk_new_parse_only if parse_only else self.lib.pdmp3_amd_bulk_new
-        self.h = new(threads, window_frames)
+        if parse_only:
+            self.h = self.lib.pdmp3_amd_bulk_new_parse_only(threads, window_frames)
+        else:
+            self.h = self.lib.pdmp3_amd_bulk_new_ex(threads, window_frames, 1 if host_huffman else 0)
         if not self.h:
             raise RuntimeError("pdmp3_amd_bulk_new failed (no MI355X transform engine; there is no CPU fallback)")
         self.threads = self.lib.pdmp3_amd_bulk_threads(self.h)
@@ -224,3 +242,23 @@ class BulkDecoder:
         if n < 0:
             raise RuntimeError("pdmp3_amd_bulk_parse failed")
         return sp[:n], sd[:n], pcm_bytes.value
+
+
+def parse_bits(mp3):
+    """Stage A of the bulk pipeline alone: per frame the side info (pdmp3_frame_bits) and the reservoir snapshot
+    that pdmp3_hip_stream_submit_bits is given.  No GPU."""
+    lib = load_library()
+    _, frames = scan_buffer(mp3)
+    cap = frames + 1
+    bits = np.zeros(cap, dtype=FRAME_BITS_DTYPE)
+    res = np.zeros((cap, RESERVOIR_BYTES), dtype=np.uint8)
+    assert FRAME_BITS_DTYPE.itemsize == 80
+    a = _as_u8(mp3)
+    h = lib.pdmp3_amd_bulk_new_parse_bits()
+    pcm_bytes = C.c_longlong(0)
+    n = lib.pdmp3_amd_bulk_parse_bits(h, a.ctypes.data_as(C.c_void_p), len(mp3), bits.ctypes.data_as(C.c_void_p),
+                                      res.ctypes.data_as(C.c_void_p), cap, C.byref(pcm_bytes))
+    lib.pdmp3_amd_bulk_delete(h)
+    if n < 0:
+        raise RuntimeError("pdmp3_amd_bulk_parse_bits failed")
+    return bits[:n], res[:n], pcm_bytes.value

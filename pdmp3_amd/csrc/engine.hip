@@ -9,6 +9,7 @@
 // 3-granule halo (decode_core.h).
 #include <hip/hip_runtime.h>
 
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,6 +17,7 @@
 #include "decode_core.h"
 #include "gen_core.h"
 #include "host_tables.h"
+#include "unpack_core.h"
 
 using namespace pdmp3;
 
@@ -44,8 +46,66 @@ __global__ __launch_bounds__(64) void k_generate(uint64_t seed, int64_t first, i
          spectra + gc * 576, side + gc);
 }
 
+// ---------------------------------------------------------------------------
+// main-data decoding on the device (unpack_core.h)
+// ---------------------------------------------------------------------------
+constexpr int kUnpackThreads = 256;   // 64 frames per workgroup pass; the 34 KB table blob lives in LDS
+
+__global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* tabs, const pdmp3_frame_bits* bits,
+                                                            const uint8_t* res, int n_frames, int16_t* spectra,
+                                                            pdmp3_gc_side* side, GcRaw* raw) {
+  __shared__ UnpackTables U;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(tabs);
+    uint4* dst = reinterpret_cast<uint4*>(&U);
+    const int n16 = (int)((offsetof(UnpackTables, lut) + (size_t)tabs->n_lut * 4 + 15) / 16);
+    for (int i = threadIdx.x; i < n16; i += kUnpackThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int total = n_frames * 4;
+  for (int idx = blockIdx.x * kUnpackThreads + threadIdx.x; idx < total; idx += gridDim.x * kUnpackThreads) {
+    const int f = idx >> 2, g = idx & 3;
+    unpack_gc(U, U.lut, res + (size_t)f * PDMP3_RESERVOIR_BYTES, bits[f], g, spectra + (size_t)idx * 576, side + idx, raw + idx);
+  }
+}
+
+// inclusive "last lane that has a value" scan over the wave; lanes without any take `carry`
+__device__ __forceinline__ unsigned scan_last(bool has, unsigned val, unsigned carry, int lane) {
+  int h = has ? 1 : 0;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int hu = __shfl_up(h, d);
+    const unsigned vu = __shfl_up(val, d);
+    if (lane >= d && !h) { h = hu; val = vu; }
+  }
+  return h ? val : carry;
+}
+
+// one wave per surviving value (unpack_core.h merge_slot), 64 frames per step
+__global__ __launch_bounds__(64) void k_merge(const GcRaw* raw, const pdmp3_frame_bits* bits, int n_frames,
+                                               const uint16_t* state_in, uint16_t* state_out, pdmp3_gc_side* side) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int tw = merge_twin(t);
+  unsigned carry = state_in[t], carry0 = tw >= 0 ? state_in[tw] : 0;
+  for (int base = 0; base < n_frames; base += 64) {
+    const int f = base + lane;
+    const bool valid = f < n_frames;
+    MergeIn m{false, false, false, 0, 0};
+    if (valid) m = merge_load(t, raw + (size_t)f * 4);
+    unsigned v0 = 0;
+    if (tw >= 0) {                                   // wave-uniform
+      v0 = scan_last(m.set0, m.val0, carry0, lane);
+      carry0 = __shfl(v0, 63);
+    }
+    const unsigned v = scan_last(m.set || m.copy, m.copy ? v0 : m.val, carry, lane);
+    carry = __shfl(v, 63);
+    if (valid) merge_store(t, bits[f], side + (size_t)f * 4, v);
+  }
+  if (lane == 0) state_out[t] = (uint16_t)carry;
+}
+
 struct pdmp3_hip_ctx {
   int device;
+  UnpackTables* d_unpack;
   float* d_pow43;
   uint16_t* d_linetab;
   float* d_win;
@@ -95,6 +155,15 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
   HIP_TRY(hipMemcpy(c->d_frag, H.frag_long.data(), 10 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_long");
   HIP_TRY(hipMemcpy(c->d_frag + 10 * 64, H.frag_short.data(), 10 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_short");
   HIP_TRY(hipMemcpy(c->d_frag + 20 * 64, H.frag_mat.data(), 8 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_mat");
+  {
+    UnpackTables* U = new UnpackTables;
+    const bool ok = build_unpack_tables(*U);
+    hipError_t e = ok ? hipMalloc((void**)&c->d_unpack, sizeof(UnpackTables)) : hipSuccess;
+    if (ok && e == hipSuccess) e = hipMemcpy(c->d_unpack, U, sizeof(UnpackTables), hipMemcpyHostToDevice);
+    delete U;
+    if (!ok) return fail(PDMP3_HIP_EDEVICE, "Huffman lookup tables exceed kHuffLutMax", hipSuccess);
+    if (e != hipSuccess) return fail(PDMP3_HIP_EDEVICE, "upload unpack tables", e);
+  }
   HIP_TRY(hipDeviceSynchronize(), "sync after uploads");
   *out = c;
   return PDMP3_HIP_OK;
@@ -108,6 +177,7 @@ extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   (void)hipFree(c->d_win);
   (void)hipFree(c->d_frag);
   (void)hipFree(c->d_state_tmp);
+  (void)hipFree(c->d_unpack);
   free(c);
 }
 
@@ -180,6 +250,9 @@ struct StreamSlot {
   hipEvent_t done;
   int16_t* h_spectra; pdmp3_gc_side* h_side; int16_t* h_pcm;     // pinned
   int16_t* d_spectra; pdmp3_gc_side* d_side; int16_t* d_pcm;
+  // bitstream-level input (allocated on first use)
+  pdmp3_frame_bits* h_bits; uint8_t* h_res;                       // pinned
+  pdmp3_frame_bits* d_bits; uint8_t* d_res; GcRaw* d_raw;
   int busy;
 };
 struct pdmp3_hip_stream {
@@ -189,6 +262,9 @@ struct pdmp3_hip_stream {
   hipEvent_t ev_state;       // recorded after the latest kernel + state copy
   int have_state_ev;
   float* d_state;
+  uint16_t* d_sfstate;       // [2][256]: scalefactors / count1 carried from frame to frame (unpack_core.h), double-buffered
+  int sf_cur;
+  int have_bits;
 };
 
 extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
@@ -200,7 +276,10 @@ extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
     if (t.done) (void)hipEventDestroy(t.done);
     (void)hipHostFree(t.h_spectra); (void)hipHostFree(t.h_side); (void)hipHostFree(t.h_pcm);
     (void)hipFree(t.d_spectra); (void)hipFree(t.d_side); (void)hipFree(t.d_pcm);
+    (void)hipHostFree(t.h_bits); (void)hipHostFree(t.h_res);
+    (void)hipFree(t.d_bits); (void)hipFree(t.d_res); (void)hipFree(t.d_raw);
   }
+  (void)hipFree(hs->d_sfstate);
   if (hs->ev_state) (void)hipEventDestroy(hs->ev_state);
   (void)hipFree(hs->d_state);
   free(hs);
@@ -257,6 +336,7 @@ extern "C" int pdmp3_hip_stream_reset(pdmp3_hip_stream* hs) {
   if (rc != PDMP3_HIP_OK) return rc;
   hs->have_state_ev = 0;
   HIP_TRY(hipMemsetAsync(hs->d_state, 0, pdmp3_hip_state_bytes(), hs->s[0].stream), "memset state");
+  if (hs->d_sfstate) HIP_TRY(hipMemsetAsync(hs->d_sfstate, 0, 2 * 256 * sizeof(uint16_t), hs->s[0].stream), "memset sfstate");
   HIP_TRY(hipStreamSynchronize(hs->s[0].stream), "sync");
   return PDMP3_HIP_OK;
 }
@@ -299,6 +379,80 @@ extern "C" int pdmp3_hip_stream_wait(pdmp3_hip_stream* hs, int slot) {
   HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
   HIP_TRY(hipEventSynchronize(t.done), "event sync");
   t.busy = 0;
+  return PDMP3_HIP_OK;
+}
+
+// ---- bitstream-level input ------------------------------------------------
+static int ensure_bits(pdmp3_hip_stream* hs) {
+  if (hs->have_bits) return PDMP3_HIP_OK;
+  HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
+  const size_t n = (size_t)hs->max_frames;
+  for (int i = 0; i < hs->n_slots; ++i) {
+    StreamSlot& t = hs->s[i];
+    HIP_TRY(hipHostMalloc((void**)&t.h_bits, n * sizeof(pdmp3_frame_bits), hipHostMallocDefault), "hipHostMalloc bits");
+    HIP_TRY(hipHostMalloc((void**)&t.h_res, n * PDMP3_RESERVOIR_BYTES + 16, hipHostMallocDefault), "hipHostMalloc reservoir");
+    HIP_TRY(hipMalloc((void**)&t.d_bits, n * sizeof(pdmp3_frame_bits)), "hipMalloc bits");
+    HIP_TRY(hipMalloc((void**)&t.d_res, n * PDMP3_RESERVOIR_BYTES + 16), "hipMalloc reservoir");
+    HIP_TRY(hipMalloc((void**)&t.d_raw, n * 4 * sizeof(GcRaw)), "hipMalloc raw");
+  }
+  HIP_TRY(hipMalloc((void**)&hs->d_sfstate, 2 * 256 * sizeof(uint16_t)), "hipMalloc sfstate");
+  HIP_TRY(hipMemset(hs->d_sfstate, 0, 2 * 256 * sizeof(uint16_t)), "memset sfstate");
+  hs->have_bits = 1;
+  return PDMP3_HIP_OK;
+}
+
+extern "C" pdmp3_frame_bits* pdmp3_hip_stream_slot_bits(pdmp3_hip_stream* hs, int slot) {
+  if (!SLOT_OK(hs, slot) || ensure_bits(hs) != PDMP3_HIP_OK) return nullptr;
+  return hs->s[slot].h_bits;
+}
+extern "C" uint8_t* pdmp3_hip_stream_slot_reservoir(pdmp3_hip_stream* hs, int slot) {
+  if (!SLOT_OK(hs, slot) || ensure_bits(hs) != PDMP3_HIP_OK) return nullptr;
+  return hs->s[slot].h_res;
+}
+
+extern "C" int pdmp3_hip_stream_submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames) {
+  if (!SLOT_OK(hs, slot) || n_frames < 0 || n_frames > hs->max_frames)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_bits: bad argument", hipSuccess);
+  StreamSlot& t = hs->s[slot];
+  if (t.busy) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_bits: slot still in flight (wait for it first)", hipSuccess);
+  if (n_frames == 0) return PDMP3_HIP_OK;
+  int rc = ensure_bits(hs);
+  if (rc != PDMP3_HIP_OK) return rc;
+  HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
+  const size_t n = (size_t)n_frames;
+  HIP_TRY(hipMemcpyAsync(t.d_bits, t.h_bits, n * sizeof(pdmp3_frame_bits), hipMemcpyHostToDevice, t.stream), "H2D bits");
+  HIP_TRY(hipMemcpyAsync(t.d_res, t.h_res, n * PDMP3_RESERVOIR_BYTES, hipMemcpyHostToDevice, t.stream), "H2D reservoir");
+  HIP_TRY(hipMemsetAsync(t.d_spectra, 0, n * PDMP3_FRAME_SPECTRA_BYTES, t.stream), "zero spectra");
+  {
+    int blocks = (n_frames * 4 + kUnpackThreads - 1) / kUnpackThreads;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(kUnpackThreads), 0, t.stream, hs->ctx->d_unpack, t.d_bits, t.d_res,
+                       n_frames, t.d_spectra, t.d_side, t.d_raw);
+    HIP_TRY(hipGetLastError(), "launch k_unpack");
+  }
+  // everything from here on continues the previous batch (scalefactor / count1 carry, synthesis state)
+  if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
+  hipLaunchKernelGGL(k_merge, dim3(kMergeSlots), dim3(64), 0, t.stream, t.d_raw, t.d_bits, n_frames,
+                     hs->d_sfstate + 256 * hs->sf_cur, hs->d_sfstate + 256 * (hs->sf_cur ^ 1), t.d_side);
+  HIP_TRY(hipGetLastError(), "launch k_merge");
+  hs->sf_cur ^= 1;
+  rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream);
+  if (rc != PDMP3_HIP_OK) return rc;
+  HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
+  hs->have_state_ev = 1;
+  HIP_TRY(hipMemcpyAsync(t.h_pcm, t.d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDeviceToHost, t.stream), "D2H pcm");
+  HIP_TRY(hipEventRecord(t.done, t.stream), "record done event");
+  t.busy = 1;
+  return PDMP3_HIP_OK;
+}
+
+extern "C" int pdmp3_hip_stream_fetch_records(pdmp3_hip_stream* hs, int slot, int n_frames, int16_t* spectra, pdmp3_gc_side* side) {
+  if (!SLOT_OK(hs, slot) || n_frames < 0 || n_frames > hs->max_frames || !spectra || !side)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_fetch_records: bad argument", hipSuccess);
+  HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
+  HIP_TRY(hipStreamSynchronize(hs->s[slot].stream), "stream sync");
+  HIP_TRY(hipMemcpy(spectra, hs->s[slot].d_spectra, (size_t)n_frames * PDMP3_FRAME_SPECTRA_BYTES, hipMemcpyDeviceToHost), "D2H spectra");
+  HIP_TRY(hipMemcpy(side, hs->s[slot].d_side, (size_t)n_frames * PDMP3_FRAME_SIDE_BYTES, hipMemcpyDeviceToHost), "D2H side");
   return PDMP3_HIP_OK;
 }
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "decode_core.h"
+#include "unpack_core.h"
 #include "tables_data.h"
 
 namespace pdmp3 {
@@ -141,5 +142,59 @@ inline void build_host_tables(HostTables& H) {
         H.frag_mat[(eo * 4 + r) * 64 + l] = n >= 16 ? nref : -nref;
       }
 }
+
+// Code books (tables_data.h: kHuffBooks, derived from the reference's tree arrays P:160-520) -> the two-level
+// lookup of unpack_core.h: 8-bit first level, and under every prefix that longer codes share a second level just
+// wide enough for the longest of them.  Returns false if the blob does not fit.
+inline bool build_unpack_tables(UnpackTables& U) {
+  memset(&U, 0, sizeof U);
+  for (int t = 0; t < 34; t++) { U.book_of_table[t] = (int8_t)kHuffBookOfTable[t]; U.linbits[t] = (uint8_t)kHuffLinbits[t]; }
+  for (int i = 0; i < 32; i++) U.slen[i] = kSlen[i];
+  for (int sf = 0; sf < 3; sf++) {
+    for (int i = 0; i < 23; i++) U.sfb_l[sf][i] = sfb_long_of(sf)[i];
+    U.sfb_l[sf][23] = sfb_short_of(sf)[0];
+    for (int i = 0; i < 14; i++) U.sfb_s[sf][i] = sfb_short_of(sf)[i];
+  }
+  constexpr int HL = kHuffFirstBits;
+  uint32_t n = 0;
+  for (int b = 0; b < PDMP3_NUM_HUFF_BOOKS; b++) {
+    const pdmp3_hcode* codes = kHuffBooks[b];
+    const int nc = kHuffBookSize[b];
+    if (n + (1u << HL) > (uint32_t)kHuffLutMax) return false;
+    U.book_base[b] = (uint16_t)n;
+    uint32_t* first = U.lut + n;
+    n += 1u << HL;
+    int deepest[1 << HL];
+    for (int p = 0; p < (1 << HL); p++) deepest[p] = 0;
+    for (int i = 0; i < nc; i++)
+      if (codes[i].len > HL) {
+        const uint32_t p = codes[i].code >> (codes[i].len - HL);
+        if (codes[i].len - HL > deepest[p]) deepest[p] = codes[i].len - HL;
+      }
+    for (int p = 0; p < (1 << HL); p++)
+      if (deepest[p]) {
+        if (n + (1u << deepest[p]) > (uint32_t)kHuffLutMax) return false;
+        first[p] = 0x80000000u | ((uint32_t)deepest[p] << 24) | n;
+        n += 1u << deepest[p];
+      }
+    for (int i = 0; i < nc; i++) {
+      const int len = codes[i].len;
+      const uint32_t val = codes[i].err ? 0 : codes[i].val;
+      if (len <= HL) {
+        const uint32_t base = codes[i].code << (HL - len);
+        for (uint32_t k = 0; k < (1u << (HL - len)); k++) first[base + k] = ((uint32_t)len << 8) | val;
+      } else {
+        const uint32_t p = codes[i].code >> (len - HL);
+        const int sb = deepest[p], extra = len - HL;
+        uint32_t* sub = U.lut + (first[p] & 0xffffffu);
+        const uint32_t base = (codes[i].code & ((1u << extra) - 1)) << (sb - extra);
+        for (uint32_t k = 0; k < (1u << (sb - extra)); k++) sub[base + k] = ((uint32_t)extra << 8) | val;
+      }
+    }
+  }
+  U.n_lut = n;
+  return true;
+}
+
 
 }  // namespace pdmp3

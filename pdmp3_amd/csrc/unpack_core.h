@@ -1,0 +1,367 @@
+// unpack_core.h -- main-data decoding on the device: scalefactors
+// + Huffman of one granule-channel per LANE, then the frame-to-frame merge of
+// the scalefactor / count1 state that the reference never clears.
+//
+// Replaces, for whole windows of frames at once, what the host stage does per
+// frame (pdmp3_host.c decode_main / apply_main / emit_records, themselves
+// restatements of pdmp3.c:1376-1437 Read_Main_L3, P:2051-2115 Read_Huffman,
+// P:1593-1643 Huffman_Decode).  The input is what is left after the strictly
+// sequential part of the bitstream (ring, header sync, side info, bit
+// reservoir): per frame a pdmp3_frame_bits and a snapshot of the reservoir
+// buffer.  The output is exactly the gc records of include/pdmp3_hip.h, which
+// the transform kernel then consumes in place -- decoded spectra never cross
+// PCIe.
+//
+//   unpack_gc    lane = (frame, gr, ch).  The start bit of a granule-channel
+//                inside the reservoir follows from the side info alone
+//                (part2_3_length of the ones before it, P:2110), so the four
+//                of a frame decode independently.  Two-level code-book lookup
+//                from LDS (8-bit first level, per-prefix second level), one
+//                unaligned 8-byte load per pair / quad.  Writes int16 spectra
+//                [0, count1) (the buffer is zeroed beforehand), the fields of
+//                the side record that come straight from the side info, and a
+//                GcRaw: the scalefactors it read and which ones (masks).
+//   merge_slot   thread = one of the 232 values that survive frames
+//                (scalefac_l[2][2][21], scalefac_s[2][2][12][3], count1[2][2];
+//                SURVEY H4-H6): walks the window's frames in order, keeps
+//                "the last value written", and stores it into the records --
+//                including the one-past-the-end reads of the reference
+//                (scalefac_l[21], scalefac_s[12][*]), which land on the first
+//                element of the next block.
+//
+// Same file for hipcc (kernels in engine.hip) and g++ (tests/host_emul: CPU
+// test of the logic against the host stage; not a product path).
+#pragma once
+
+#include "decode_core.h"
+
+namespace pdmp3 {
+
+constexpr int kHuffFirstBits = 8;
+constexpr int kHuffLutMax = 8448;                 // entries; the 18 books need 8290 (host_tables.h checks)
+constexpr unsigned kResBytes = PDMP3_RESERVOIR_BYTES;
+constexpr unsigned kFastLimit = (kResBytes - 8) * 8u;   // bit positions from which an 8-byte load stays inside the row
+
+// One contiguous blob; every workgroup copies it into LDS.
+// lut entry: leaf  = len << 8 | (x << 4 | y)            (len = bits of this level)
+//            link  = 0x80000000 | sub_bits << 24 | offset of the second-level table (entries from lut[0])
+struct UnpackTables {
+  uint16_t book_base[20];        // first-level table of book b starts at lut[book_base[b]]
+  int8_t book_of_table[36];      // ISO table number (0..33) -> book, -1: no code words (tables 0, 4, 14)
+  uint8_t linbits[36];
+  uint8_t slen[32];              // [scalefac_compress][2], P:1378-1381
+  uint16_t sfb_l[3][24];         // g_sf_band_indices[].l, P:879-892; [23] = s[0] (the arrays are contiguous, H7)
+  uint16_t sfb_s[3][16];
+  uint32_t n_lut, pad[3];
+  uint32_t lut[kHuffLutMax];
+};
+
+// what one granule-channel's main data yields (cf. main_out in pdmp3_host.c)
+struct alignas(16) GcRaw {
+  uint16_t count1;
+  uint8_t count1_set;            // 0 when part2_3_length == 0: count1 keeps its old value (H6)
+  uint8_t sf_l_copy;             // granule 1: bit b = band group b is taken from granule 0 (scfsi)
+  uint32_t sf_l_set;             // bit sfb: scalefac_l[sfb] was read from the stream
+  uint16_t sf_s_set;             // bit sfb: scalefac_s[sfb][0..2] were read
+  uint16_t pad0;
+  uint8_t sf_l[24];
+  uint8_t sf_s[36];
+  uint8_t pad1[8];
+};
+static_assert(sizeof(GcRaw) == 80, "GcRaw layout");
+
+constexpr int kMergeSlots = 84 + 144 + 4;          // scalefac_l, scalefac_s, count1
+
+// ---------------------------------------------------------------------------
+// bit reader over one reservoir row (same windows as pdmp3_host.c peek32 / peek64)
+// ---------------------------------------------------------------------------
+struct BitPos {
+  const uint8_t* buf;
+  unsigned pos;
+};
+
+PD_HD uint32_t peek32(const BitPos& b) {            // next 25+ valid bits, MSB first; clamped at the row's end
+  const unsigned byte = b.pos >> 3;
+  const uint8_t* p = b.buf + (byte < kResBytes - 5 ? byte : kResBytes - 5);
+  const uint64_t w = ((uint64_t)p[0] << 32) | ((uint64_t)p[1] << 24) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 8) | p[4];
+  return (uint32_t)(w >> (8 - (b.pos & 7)));
+}
+PD_HD unsigned get_bits(BitPos& b, unsigned n) {
+  if (!n) return 0;
+  const unsigned v = peek32(b) >> (32 - n);
+  b.pos += n;
+  return v;
+}
+PD_HD uint64_t peek64(const BitPos& b) {            // >= 57 valid bits; caller guarantees pos <= kFastLimit
+  uint64_t w;
+  __builtin_memcpy(&w, b.buf + (b.pos >> 3), 8);
+  return __builtin_bswap64(w) << (b.pos & 7);
+}
+
+// one code word from a 64-bit window: returns leaf value, adds its length to `used`
+PD_HD unsigned lut_symbol(const uint32_t* lut, unsigned base, uint64_t w, unsigned& used) {
+  uint32_t e = lut[base + (unsigned)(w >> (64 - kHuffFirstBits))];
+  unsigned len = 0;
+  if (e & 0x80000000u) {
+    const unsigned sb = (e >> 24) & 0x1f;
+    e = lut[(e & 0xffffffu) + (unsigned)((w << kHuffFirstBits) >> (64 - sb))];
+    len = kHuffFirstBits;
+  }
+  used += len + (e >> 8);
+  return e & 0xff;
+}
+PD_HD unsigned lut_symbol_slow(const uint32_t* lut, unsigned base, BitPos& b) {
+  const uint64_t w = (uint64_t)peek32(b) << 32;
+  unsigned used = 0;
+  const unsigned leaf = lut_symbol(lut, base, w, used);     // codes are <= 19 bits: inside peek32's 25
+  b.pos += used;
+  return leaf;
+}
+
+// bits of part 2 (scalefactors) of one granule-channel, from the side info alone (P:1376-1437)
+PD_HD unsigned part2_bits(const UnpackTables& U, const pdmp3_frame_bits& F, int gr, int ch) {
+  const pdmp3_gc_bits& s = F.gc[gr * 2 + ch];
+  const unsigned slen1 = U.slen[s.scalefac_compress * 2], slen2 = U.slen[s.scalefac_compress * 2 + 1];
+  const bool shrt = (s.flags & PDMP3_GC_WIN_SWITCH) && ((s.flags & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
+  if (shrt) return (s.flags & PDMP3_GC_MIXED) ? 8 * slen1 + 9 * slen1 + 18 * slen2 : 18 * slen1 + 18 * slen2;
+  unsigned n = 0;
+  for (int g4 = 0; g4 < 4; g4++)
+    if (!(gr == 1 && (F.scfsi[ch] >> g4 & 1))) n += (g4 == 0 ? 6u : 5u) * (g4 < 2 ? slen1 : slen2);
+  return n;
+}
+
+// pairs [pos, end) of one region (cf. decode_pairs in pdmp3_host.c)
+PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& b, unsigned tn, unsigned pos, unsigned end,
+                            int16_t* is) {
+  const int book = U.book_of_table[tn];
+  if (pos >= end) return pos;
+  if (book < 0) return pos + ((end - pos + 1) & ~1u);   // no code words: zeros (already there), no bits
+  const unsigned base = U.book_base[book], linbits = U.linbits[tn];
+  for (; pos < end; pos += 2) {
+    int x, y;
+    if (b.pos <= kFastLimit) {
+      const uint64_t w = peek64(b);
+      unsigned used = 0;
+      const unsigned leaf = lut_symbol(lut, base, w, used);
+      x = leaf >> 4; y = leaf & 15;
+      if (linbits && x == 15) { x += (int)((w << used) >> (64 - linbits)); used += linbits; }
+      if (x) { if ((w << used) >> 63) x = -x; used++; }
+      if (linbits && y == 15) { y += (int)((w << used) >> (64 - linbits)); used += linbits; }
+      if (y) { if ((w << used) >> 63) y = -y; used++; }
+      b.pos += used;
+    } else {
+      const unsigned leaf = lut_symbol_slow(lut, base, b);
+      x = leaf >> 4; y = leaf & 15;
+      if (linbits && x == 15) x += (int)get_bits(b, linbits);
+      if (x > 0 && get_bits(b, 1)) x = -x;
+      if (linbits && y == 15) y += (int)get_bits(b, linbits);
+      if (y > 0 && get_bits(b, 1)) y = -y;
+    }
+    if (pos + 1 < 576) {                           // one 4-byte store (lines are 2-byte, pos is even)
+      const uint32_t v = (uint32_t)(uint16_t)(int16_t)x | ((uint32_t)(uint16_t)(int16_t)y << 16);
+      __builtin_memcpy(is + pos, &v, 4);
+    } else if (pos < 576) is[pos] = (int16_t)x;    // big_values > 288 is not checked by the reference (H8)
+  }
+  return pos;
+}
+
+// `spectra_gc` (576 int16) must be zero on entry.  `rec` and `raw` are fully written.
+PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* res, const pdmp3_frame_bits& F, int g,
+                     int16_t* spectra_gc, pdmp3_gc_side* rec, GcRaw* raw) {
+  const int gr = g >> 1, ch = g & 1;
+  const int nch = ((F.frame & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
+  const int sfreq = (F.frame & PDMP3_FR_SFREQ_MASK) > 2 ? 2 : (F.frame & PDMP3_FR_SFREQ_MASK);
+  {
+    uint32_t* r32 = reinterpret_cast<uint32_t*>(rec);
+    for (int i = 0; i < 32; i++) r32[i] = 0;
+    uint32_t* w32 = reinterpret_cast<uint32_t*>(raw);
+    for (int i = 0; i < 20; i++) w32[i] = 0;
+  }
+  rec->frame = F.frame;
+  if (ch >= nch) return;
+  const pdmp3_gc_bits& s = F.gc[g];
+  rec->global_gain = s.global_gain;
+  rec->flags = s.flags;
+  rec->subblock_gain[0] = s.subblock_gain[0]; rec->subblock_gain[1] = s.subblock_gain[1]; rec->subblock_gain[2] = s.subblock_gain[2];
+  if (g == 3) rec->scalefac_s[12][0] = rec->scalefac_s[12][1] = rec->scalefac_s[12][2] = PDMP3_SF_PEEK;
+
+  // where this granule-channel starts: every one before it ends at start + part2_3_length -- or, when that is
+  // zero, right after its scalefactors (P:2062: Read_Huffman returns before touching the position)
+  BitPos b{res, 0};
+  for (int q = 0; q < g; q++) {
+    if ((q & 1) >= nch) continue;
+    const unsigned p23 = F.gc[q].part2_3_length;
+    b.pos += p23 ? p23 : part2_bits(U, F, q >> 1, q & 1);
+  }
+  const unsigned part2_start = b.pos;
+
+  // ---- scalefactors (P:1383-1430)
+  const unsigned slen1 = U.slen[s.scalefac_compress * 2], slen2 = U.slen[s.scalefac_compress * 2 + 1];
+  const bool wsf = (s.flags & PDMP3_GC_WIN_SWITCH) != 0;
+  const unsigned bt = (s.flags & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT;
+  if (wsf && bt == 2) {
+    unsigned first_short = 0;
+    if (s.flags & PDMP3_GC_MIXED) {
+      for (unsigned sfb = 0; sfb < 8; sfb++) raw->sf_l[sfb] = (uint8_t)get_bits(b, slen1);
+      raw->sf_l_set = 0xffu;
+      first_short = 3;
+    }
+    unsigned set = 0;
+    for (unsigned sfb = first_short; sfb < 12; sfb++) {
+      for (unsigned w = 0; w < 3; w++) raw->sf_s[sfb * 3 + w] = (uint8_t)get_bits(b, sfb < 6 ? slen1 : slen2);
+      set |= 1u << sfb;
+    }
+    raw->sf_s_set = (uint16_t)set;
+  } else {
+    unsigned set = 0, copy = 0;
+    for (unsigned g4 = 0; g4 < 4; g4++) {
+      const unsigned lo = g4 ? 1 + 5 * g4 : 0, hi = 6 + 5 * g4, nb = g4 < 2 ? slen1 : slen2;
+      if (gr == 1 && (F.scfsi[ch] >> g4 & 1)) copy |= 1u << g4;
+      else for (unsigned sfb = lo; sfb < hi; sfb++) { raw->sf_l[sfb] = (uint8_t)get_bits(b, nb); set |= 1u << sfb; }
+    }
+    raw->sf_l_set = set;
+    raw->sf_l_copy = (uint8_t)copy;
+  }
+
+  // ---- Huffman (P:2051-2115)
+  if (s.part2_3_length == 0) return;               // spectra stay zero; count1 keeps its old value (H6)
+  const unsigned end = part2_start + s.part2_3_length - 1;
+  unsigned r1, r2;
+  if (wsf && bt == 2) { r1 = 36; r2 = 576; }
+  else {
+    const unsigned i1 = s.region0_count + 1u, i2 = s.region0_count + s.region1_count + 2u;
+    r1 = i1 < 23 ? U.sfb_l[sfreq][i1] : U.sfb_s[sfreq][i1 - 23];      // H7
+    r2 = i2 < 23 ? U.sfb_l[sfreq][i2] : U.sfb_s[sfreq][i2 - 23];
+  }
+  const unsigned nbig = s.big_values * 2u;
+  unsigned e0 = (r1 + 1) & ~1u, e1 = (r2 + 1) & ~1u;
+  if (e0 > nbig) e0 = nbig;
+  if (e1 > nbig) e1 = nbig;
+  if (e1 < e0) e1 = e0;
+  unsigned pos = unpack_pairs(U, lut, b, s.table_select[0], 0, e0, spectra_gc);
+  pos = unpack_pairs(U, lut, b, s.table_select[1], pos, e1, spectra_gc);
+  pos = unpack_pairs(U, lut, b, s.table_select[2], pos, nbig, spectra_gc);
+  // count1 region: table 32 or the reference's mis-pointed table 33 (H1); both books are <= 8 bits deep
+  const unsigned qbase = U.book_base[U.book_of_table[32 + s.count1table_select]];
+  while (pos <= 572 && b.pos <= end) {
+    int q[4];
+    if (b.pos <= kFastLimit) {
+      const uint64_t w = peek64(b);
+      unsigned used = 0;
+      const unsigned leaf = lut_symbol(lut, qbase, w, used);
+      for (int k = 0; k < 4; k++) {                // v w x y
+        q[k] = (int)(leaf >> (3 - k)) & 1;
+        if (q[k]) { if ((w << used) >> 63) q[k] = -1; used++; }
+      }
+      b.pos += used;
+    } else {
+      const unsigned leaf = lut_symbol_slow(lut, qbase, b);
+      for (int k = 0; k < 4; k++) {
+        q[k] = (int)(leaf >> (3 - k)) & 1;
+        if (q[k] && get_bits(b, 1)) q[k] = -1;
+      }
+    }
+    const uint32_t v0 = (uint32_t)(uint16_t)(int16_t)q[0] | ((uint32_t)(uint16_t)(int16_t)q[1] << 16);
+    const uint32_t v1 = (uint32_t)(uint16_t)(int16_t)q[2] | ((uint32_t)(uint16_t)(int16_t)q[3] << 16);
+    __builtin_memcpy(spectra_gc + pos, &v0, 4);
+    __builtin_memcpy(spectra_gc + pos + 2, &v1, 4);
+    pos += 4;
+  }
+  // Overshoot: the reference takes the last four lines back (P:2106-2108) -- the last quad, or, when no quad
+  // was read, the last two PAIRS -- and zero-fills from there.  (pos < 4 wraps like the reference's unsigned:
+  // count1 becomes 576 and nothing is zeroed.)
+  if (b.pos > end + 1) {
+    pos -= 4;
+    for (unsigned i = pos; i < 576 && i < pos + 4; i++) spectra_gc[i] = 0;
+  }
+  if (pos > 576) pos = 576;
+  raw->count1 = (uint16_t)pos;
+  raw->count1_set = 1;
+}
+
+// ---------------------------------------------------------------------------
+// frame-to-frame merge: slot t of the 232 surviving values
+//   t <  84          scalefac_l[g][sfb]      g = t / 21
+//   t < 228          scalefac_s[g][sfb][w]   g = (t - 84) / 36
+//   t < 232          count1[g]
+// state[kMergeSlots] (uint16) carries the values from one window to the next.
+// ---------------------------------------------------------------------------
+PD_HD bool gc_active(const pdmp3_frame_bits& F, int g) {
+  return (g & 1) == 0 || ((F.frame & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
+}
+
+// state index of the granule-0 twin that a granule-1 scalefac_l slot may copy from (scfsi), else -1
+PD_HD int merge_twin(int t) {
+  if (t >= 42 && t < 84) return t - 42;            // (gr 1, ch, sfb) -> (gr 0, ch, sfb)
+  return -1;
+}
+
+// what frame f does to slot t: `set` = the stream carried a new value `val`; for granule-1 scalefac_l slots also
+// the same for the twin (set0 / val0) and `copy` = this frame takes the twin's value instead
+struct MergeIn {
+  bool set, set0, copy;
+  unsigned val, val0;
+};
+
+PD_HD MergeIn merge_load(int t, const GcRaw* raw_f /* raw + f * 4 */) {
+  MergeIn m{false, false, false, 0, 0};
+  if (t < 84) {
+    const int g = t / 21, sfb = t - 21 * g;
+    const GcRaw& r = raw_f[g];
+    m.set = (r.sf_l_set >> sfb & 1) != 0;
+    m.val = r.sf_l[sfb];
+    if (g >= 2) {
+      const int grp = sfb < 6 ? 0 : sfb < 11 ? 1 : sfb < 16 ? 2 : 3;
+      const GcRaw& r0 = raw_f[g & 1];
+      m.set0 = (r0.sf_l_set >> sfb & 1) != 0;
+      m.val0 = r0.sf_l[sfb];
+      m.copy = (r.sf_l_copy >> grp & 1) != 0;
+    }
+  } else if (t < 228) {
+    const int u = t - 84, g = u / 36, k = u - 36 * g;
+    const GcRaw& r = raw_f[g];
+    m.set = (r.sf_s_set >> (k / 3) & 1) != 0;
+    m.val = r.sf_s[k];
+  } else {
+    const GcRaw& r = raw_f[t - 228];
+    m.set = r.count1_set != 0;
+    m.val = r.count1;
+  }
+  return m;
+}
+
+// slot t's value after frame f goes into the frame's records: its own field, and where the reference's
+// one-past-the-end reads land (the first element of the NEXT [gr][ch] block)
+PD_HD void merge_store(int t, const pdmp3_frame_bits& F, pdmp3_gc_side* R /* rec + f * 4 */, unsigned val) {
+  if (t < 84) {
+    const int g = t / 21, sfb = t - 21 * g;
+    if (gc_active(F, g)) R[g].scalefac_l[sfb] = (uint8_t)val;
+    if (sfb == 0 && g >= 1 && gc_active(F, g - 1)) R[g - 1].scalefac_l[21] = (uint8_t)val;
+  } else if (t < 228) {
+    const int u = t - 84, g = u / 36, k = u - 36 * g, sfb = k / 3, w = k - 3 * sfb;
+    if (gc_active(F, g)) R[g].scalefac_s[sfb][w] = (uint8_t)val;
+    if (sfb == 0 && g >= 1 && gc_active(F, g - 1)) R[g - 1].scalefac_s[12][w] = (uint8_t)val;
+    if (k == 0 && g == 0 && gc_active(F, 3)) R[3].scalefac_l[21] = (uint8_t)val;                 // last block: scalefac_s follows
+  } else {
+    const int g = t - 228;
+    if (gc_active(F, g)) R[g].count1 = (uint16_t)val;
+  }
+}
+
+// sequential form (host test build; the device kernel k_merge does the same with wave scans over 64 frames)
+// state_in must not alias state_out: granule-1 slots also read their twin's incoming value
+PD_HD void merge_slot(int t, const GcRaw* raw, const pdmp3_frame_bits* F, int n, const uint16_t* state_in, uint16_t* state,
+                      pdmp3_gc_side* rec) {
+  const int tw = merge_twin(t);
+  unsigned val = state_in[t], val0 = tw >= 0 ? state_in[tw] : 0;
+  for (int f = 0; f < n; f++) {
+    const MergeIn m = merge_load(t, raw + (size_t)f * 4);
+    if (m.set0) val0 = m.val0;
+    if (m.set) val = m.val;
+    if (m.copy) val = val0;
+    merge_store(t, F[f], rec + (size_t)f * 4, val);
+  }
+  state[t] = (uint16_t)val;
+}
+
+}  // namespace pdmp3

@@ -855,6 +855,10 @@ struct bulk {
   pdmp3_handle* id;
   int cap;                            /* frames per window */
   int count_only;                     /* scan: stage A alone */
+  int bits_mode;                      /* main data goes to the device undecoded (pdmp3_hip_stream_submit_bits) */
+  pdmp3_frame_bits* bits_dst; uint8_t* res_dst;   /* where stage A writes the current window (bits mode) */
+  int bits_n, bits_slot, bits_open;
+  pdmp3_frame_bits* rec_bits; uint8_t* rec_res;   /* parse-only bits mode: caller memory */
   bulk_window win[2];
   int cur;                            /* window stage A is filling */
   bulk_window* in_b;                  /* window the workers hold, or NULL */
@@ -1011,10 +1015,100 @@ static int bulk_rotate(struct bulk* b) {
   return PDMP3_OK;
 }
 
+/* ---- bits mode: stage A writes side info + reservoir snapshot straight into the engine's pinned slot; scale-
+ * factors, Huffman and the frame-to-frame merge run on the device (include/pdmp3_hip.h, submit_bits) ---- */
+static void fill_frame_bits(const pdmp3_handle* id, pdmp3_frame_bits* fb) {
+  const frame_header* H = &id->hdr;
+  const side_info* S = &id->si;
+  const unsigned nch = H->mode == 3 ? 1 : 2;
+  memset(fb, 0, sizeof *fb);
+  fb->frame = (uint8_t)((H->sfreq & 3) | (H->mode << PDMP3_FR_MODE_SHIFT) | (H->mode_ext << PDMP3_FR_MODEEXT_SHIFT) |
+                        (id->need_reset ? PDMP3_FR_RESET : 0));
+  for (unsigned ch = 0; ch < nch; ch++)
+    for (unsigned g4 = 0; g4 < 4; g4++) if (S->scfsi[ch][g4]) fb->scfsi[ch] |= (uint8_t)(1u << g4);
+  for (unsigned gr = 0; gr < 2; gr++)
+    for (unsigned ch = 0; ch < nch; ch++) {
+      pdmp3_gc_bits* g = &fb->gc[gr * 2 + ch];
+      g->part2_3_length = (uint16_t)S->part2_3_length[gr][ch];
+      g->big_values = (uint16_t)S->big_values[gr][ch];
+      g->global_gain = (uint8_t)S->global_gain[gr][ch];
+      g->scalefac_compress = (uint8_t)S->scalefac_compress[gr][ch];
+      g->flags = (uint8_t)((S->scalefac_scale[gr][ch] ? PDMP3_GC_SCALEFAC_SCALE : 0) |
+                           (S->preflag[gr][ch] ? PDMP3_GC_PREFLAG : 0) |
+                           (S->win_switch[gr][ch] ? PDMP3_GC_WIN_SWITCH : 0) |
+                           ((S->block_type[gr][ch] & 3) << PDMP3_GC_BLOCK_TYPE_SHIFT) |
+                           ((S->win_switch[gr][ch] && S->mixed[gr][ch]) ? PDMP3_GC_MIXED : 0));
+      for (unsigned k = 0; k < 3; k++) {
+        g->table_select[k] = (uint8_t)S->table_select[gr][ch][k];
+        g->subblock_gain[k] = (uint8_t)S->subblock_gain[gr][ch][k];
+      }
+      g->region0_count = (uint8_t)S->region0_count[gr][ch];
+      g->region1_count = (uint8_t)S->region1_count[gr][ch];
+      g->count1table_select = (uint8_t)S->count1table_select[gr][ch];
+    }
+}
+
+/* make the slot of window `windows` writable: its previous occupant (window - 3) must be off the GPU; its PCM
+ * goes home on the worker pool while stage A fills the slot's input side */
+static int bits_open_window(struct bulk* b) {
+  b->bits_n = 0;
+  b->bits_open = 1;
+  if (!b->hs) {                                   /* parse only: one "window" = the caller's arrays */
+    b->bits_dst = b->rec_bits;
+    b->res_dst = b->rec_res;
+    return PDMP3_OK;
+  }
+  b->bits_slot = (int)(b->windows % BULK_SLOTS);
+  const unsigned char* src; unsigned char* dst; size_t nbytes;
+  if (bulk_collect(b, b->bits_slot, &src, &dst, &nbytes) != PDMP3_OK) return PDMP3_ERR;
+  if (nbytes) bulk_start_b(b, NULL, src, dst, nbytes);
+  b->bits_dst = pdmp3_hip_stream_slot_bits(b->hs, b->bits_slot);
+  b->res_dst = pdmp3_hip_stream_slot_reservoir(b->hs, b->bits_slot);
+  return b->bits_dst && b->res_dst ? PDMP3_OK : PDMP3_ERR;
+}
+
+static int bits_close_window(struct bulk* b) {
+  if (!b->bits_open) return PDMP3_OK;
+  b->bits_open = 0;
+  if (!b->bits_n) return PDMP3_OK;
+  if (b->hs) {
+    bulk_wait_b(b);                               /* the slot's old PCM has been copied out */
+    bulk_flight* f = &b->flight[b->bits_slot];
+    f->n = b->bits_n;
+    f->pcm_off = b->pcm_emitted;
+    f->all_stereo = 1;
+    for (int i = 0; i < f->n; i++) {
+      if (f->nch[i] != 2) f->all_stereo = 0;
+      b->pcm_emitted += 2304u * f->nch[i];
+    }
+    if (pdmp3_hip_stream_submit_bits(b->hs, b->bits_slot, b->bits_n) != PDMP3_HIP_OK) {
+      fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
+      return PDMP3_ERR;
+    }
+    f->active = 1;
+  }
+  b->windows++;
+  return PDMP3_OK;
+}
+
+static int bits_push(struct bulk* b) {
+  pdmp3_handle* id = b->id;
+  if (!b->bits_open && bits_open_window(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
+  if (!b->hs && (size_t)b->frames > b->rec_cap) { b->failed = 1; return PDMP3_ERR; }
+  const int i = b->bits_n++;
+  fill_frame_bits(id, &b->bits_dst[i]);
+  id->need_reset = 0;
+  memcpy(b->res_dst + (size_t)i * RESERVOIR_BYTES, id->main_vec, RESERVOIR_BYTES);
+  if (b->hs) b->flight[b->bits_slot].nch[i] = (uint8_t)(id->hdr.mode == 3 ? 1 : 2);
+  if (b->hs && b->bits_n == b->cap && bits_close_window(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
+  return PDMP3_OK;
+}
+
 static int bulk_push(struct bulk* b) {
   pdmp3_handle* id = b->id;
   b->frames++;
   if (b->count_only) { id->need_reset = 0; return PDMP3_OK; }
+  if (b->bits_mode) return bits_push(b);
   bulk_window* w = &b->win[b->cur];
   frame_job* j = &w->jobs[w->n++];
   j->hdr = id->hdr;
@@ -1064,7 +1158,7 @@ void pdmp3_amd_bulk_delete(struct bulk* b) {
 
 /* threads <= 0: one per online CPU (at most 64); window_frames <= 0: 2048.  with_engine = 0 gives a
  * parse-only decoder (host tests on machines without a GPU). */
-static struct bulk* bulk_new(int threads, int window_frames, int with_engine) {
+static struct bulk* bulk_new(int threads, int window_frames, int with_engine, int bits_mode) {
   pthread_once(&g_lut_once, build_luts);
   if (threads <= 0) {
     long c = sysconf(_SC_NPROCESSORS_ONLN);
@@ -1074,10 +1168,11 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine) {
   struct bulk* b = (struct bulk*)calloc(1, sizeof *b);
   if (!b) return NULL;
   b->cap = window_frames;
+  b->bits_mode = bits_mode;
   b->id = (pdmp3_handle*)calloc(1, sizeof *b->id);
   if (!b->id) { free(b); return NULL; }
   b->id->host_only = 1;
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < 2 && !bits_mode; i++) {
     b->win[i].jobs = (frame_job*)malloc((size_t)b->cap * sizeof(frame_job));
     b->win[i].outs = (main_out*)malloc((size_t)b->cap * sizeof(main_out));
     if (!b->win[i].jobs || !b->win[i].outs) { pdmp3_amd_bulk_delete(b); return NULL; }
@@ -1104,8 +1199,16 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine) {
   return b;
 }
 
-struct bulk* pdmp3_amd_bulk_new(int threads, int window_frames) { return bulk_new(threads, window_frames, 1); }
-struct bulk* pdmp3_amd_bulk_new_parse_only(int threads, int window_frames) { return bulk_new(threads, window_frames, 0); }
+/* default: Huffman decoding on the device; PDMP3_BULK_HOST_HUFFMAN=1 (or _new_ex) keeps it on the host pool */
+struct bulk* pdmp3_amd_bulk_new_ex(int threads, int window_frames, int host_huffman) {
+  return bulk_new(threads, window_frames, 1, !host_huffman);
+}
+struct bulk* pdmp3_amd_bulk_new(int threads, int window_frames) {
+  const char* e = getenv("PDMP3_BULK_HOST_HUFFMAN");
+  return bulk_new(threads, window_frames, 1, !(e && *e && *e != '0'));
+}
+struct bulk* pdmp3_amd_bulk_new_parse_only(int threads, int window_frames) { return bulk_new(threads, window_frames, 0, 0); }
+struct bulk* pdmp3_amd_bulk_new_parse_bits(void) { return bulk_new(1, 1, 0, 1); }
 int pdmp3_amd_bulk_threads(const struct bulk* b) { return b ? b->nth : 0; }
 
 static void bulk_begin(struct bulk* b) {
@@ -1116,6 +1219,7 @@ static void bulk_begin(struct bulk* b) {
   id->host_only = 1;
   b->cur = 0; b->win[0].n = b->win[1].n = 0; b->in_b = NULL;
   b->windows = 0; b->frames = 0; b->pcm_emitted = 0; b->count_only = 0; b->failed = 0; b->busy = 0;
+  b->bits_open = 0; b->bits_n = 0;
   for (int i = 0; i < BULK_SLOTS; i++) b->flight[i].active = 0;
 }
 
@@ -1143,8 +1247,13 @@ long long pdmp3_amd_bulk_decode(struct bulk* b, const unsigned char* mp3, size_t
   if (pdmp3_hip_stream_reset(b->hs) != PDMP3_HIP_OK) return -1;
   b->pcm = pcm; b->pcm_cap = pcm_cap;
   const long long total = bulk_drive(b, mp3, n);
-  int ok = !b->failed && bulk_rotate(b) == PDMP3_OK;   /* the partly filled last window */
-  ok = ok && bulk_finish_b(b) == PDMP3_OK;
+  int ok = !b->failed;
+  if (b->bits_mode) ok = ok && bits_close_window(b) == PDMP3_OK;
+  else {
+    ok = ok && bulk_rotate(b) == PDMP3_OK;               /* the partly filled last window */
+    ok = ok && bulk_finish_b(b) == PDMP3_OK;
+  }
+  bulk_wait_b(b);
   for (int i = 0; i < BULK_SLOTS && ok; i++) {         /* what is still on the GPU: the pool copies it out */
     const unsigned char* src; unsigned char* dst; size_t nbytes;
     ok = bulk_collect(b, i, &src, &dst, &nbytes) == PDMP3_OK;
@@ -1162,7 +1271,7 @@ long long pdmp3_amd_bulk_decode(struct bulk* b, const unsigned char* mp3, size_t
  * Returns the frame count, or -1 when they do not fit. */
 long long pdmp3_amd_bulk_parse(struct bulk* b, const unsigned char* mp3, size_t n, int16_t* spectra, pdmp3_gc_side* side,
                                size_t cap_frames, long long* pcm_bytes) {
-  if (!b || b->hs || (!mp3 && n)) return -1;
+  if (!b || b->hs || b->bits_mode || (!mp3 && n)) return -1;
   bulk_begin(b);
   b->rec_spectra = spectra; b->rec_side = side; b->rec_cap = cap_frames;
   const long long total = bulk_drive(b, mp3, n);
@@ -1172,6 +1281,17 @@ long long pdmp3_amd_bulk_parse(struct bulk* b, const unsigned char* mp3, size_t 
   b->in_b = NULL;
   if (pcm_bytes) *pcm_bytes = total;
   return ok ? b->frames : -1;
+}
+
+/* Stage A only, bits mode, into caller memory: what pdmp3_hip_stream_submit_bits would be given (host tests) */
+long long pdmp3_amd_bulk_parse_bits(struct bulk* b, const unsigned char* mp3, size_t n, pdmp3_frame_bits* bits, uint8_t* res,
+                                    size_t cap_frames, long long* pcm_bytes) {
+  if (!b || b->hs || !b->bits_mode || (!mp3 && n)) return -1;
+  bulk_begin(b);
+  b->rec_bits = bits; b->rec_res = res; b->rec_cap = cap_frames;
+  const long long total = bulk_drive(b, mp3, n);
+  if (pcm_bytes) *pcm_bytes = total;
+  return b->failed ? -1 : b->frames;
 }
 
 /* ------------------------------------------------------------------------ */

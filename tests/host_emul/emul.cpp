@@ -52,3 +52,22 @@ extern "C" void emul_tables(float* pow43, float* t1, float* t2) {
   memcpy(t1, H.t1.data(), kT1Size * 4);
   memcpy(t2, H.t2.data(), kT2Size * 4);
 }
+
+// ---- unpack_core.h on the host: every granule-channel, then every merge slot --------------------------------
+#include "../../pdmp3_amd/csrc/unpack_core.h"
+extern "C" int emul_unpack_frames(const pdmp3_frame_bits* bits, const uint8_t* res, int n_frames, uint16_t* state /*[256]*/,
+                                  int16_t* spectra, pdmp3_gc_side* side) {
+  static UnpackTables* U = nullptr;
+  if (!U) { U = new UnpackTables; if (!build_unpack_tables(*U)) return -1; }
+  std::vector<GcRaw> raw((size_t)n_frames * 4);
+  memset(spectra, 0, (size_t)n_frames * 2304 * sizeof(int16_t));
+  for (int f = 0; f < n_frames; ++f)
+    for (int g = 0; g < 4; ++g)
+      unpack_gc(*U, U->lut, res + (size_t)f * PDMP3_RESERVOIR_BYTES, bits[f], g, spectra + ((size_t)f * 4 + g) * 576,
+                side + (size_t)f * 4 + g, &raw[(size_t)f * 4 + g]);
+  uint16_t st_in[256];
+  memcpy(st_in, state, sizeof st_in);
+  for (int t = 0; t < kMergeSlots; ++t) merge_slot(t, raw.data(), bits, n_frames, st_in, state, side);
+  return (int)U->n_lut;
+}
+

@@ -21,10 +21,12 @@ def streams():
     return _streams()
 
 
+@pytest.mark.parametrize("host_huffman", [False, True])
 @pytest.mark.parametrize("threads,window", [(4, 2048), (3, 5), (8, 32)])
-def test_bulk_decode_matches_oracle_and_streaming_api(oracle, streams, threads, window):
+def test_bulk_decode_matches_oracle_and_streaming_api(oracle, streams, threads, window, host_huffman):
+    """host_huffman=False: scalefactors + Huffman + state merge on the device (submit_bits); True: on the host pool"""
     from pdmp3_amd import api
-    b = api.BulkDecoder(threads=threads, window_frames=window)
+    b = api.BulkDecoder(threads=threads, window_frames=window, host_huffman=host_huffman)
     try:
         for name, mp3 in streams.items():
             want = np.frombuffer(oracle.decode_buffer_like_cli(mp3), dtype=np.int16)
@@ -44,14 +46,18 @@ def test_bulk_long_vbr_stream(oracle):
     mp3 = packer.generate(n_frames=6000, seed=78, vbr=True, block_pct=(40, 10, 40, 10))
     want = np.frombuffer(oracle.decode_buffer_like_cli(mp3), dtype=np.int16)
     b = api.BulkDecoder(threads=8, window_frames=500)
+    bh = api.BulkDecoder(threads=8, window_frames=300, host_huffman=True)
     try:
         got = b.decode(mp3)
         again = b.decode(mp3)
+        via_host_huffman = bh.decode(mp3)
     finally:
         b.close()
+        bh.close()
     assert got.shape == want.shape and got.size >= 5990 * 2304
     assert_pcm_close(got, want, 1, "vbr6000")
     assert np.array_equal(got, again)                   # a reused decoder starts fresh
+    assert np.array_equal(got, via_host_huffman)        # device Huffman == host Huffman, bit for bit
 
 
 def test_bulk_output_smaller_than_stream():
@@ -109,3 +115,47 @@ def test_slots_decode_in_submit_order(engine):
     finally:
         lib.pdmp3_hip_stream_destroy(hs)
     assert np.array_equal(got.reshape(want.shape), want)
+
+
+def test_device_unpack_builds_the_host_stage_records(engine, streams):
+    """pdmp3_hip_stream_submit_bits: the gc records the device builds from side info + reservoir snapshots are the
+    host stage's, byte for byte (which test_host_stage.py pins to the oracle / reference), across window cuts"""
+    import ctypes as C
+    from pdmp3_amd import api, hip
+    lib = hip.load_library()
+    vp = C.c_void_p
+    lib.pdmp3_hip_stream_create_slots.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    for f in ("pdmp3_hip_stream_slot_bits", "pdmp3_hip_stream_slot_reservoir"):
+        getattr(lib, f).restype = vp
+        getattr(lib, f).argtypes = [vp, C.c_int]
+    lib.pdmp3_hip_stream_submit_bits.argtypes = [vp, C.c_int, C.c_int]
+    lib.pdmp3_hip_stream_wait.argtypes = [vp, C.c_int]
+    lib.pdmp3_hip_stream_reset.argtypes = [vp]
+    lib.pdmp3_hip_stream_fetch_records.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    lib.pdmp3_hip_stream_destroy.argtypes = [vp]
+    per = 37
+    hs = vp()
+    assert lib.pdmp3_hip_stream_create_slots(engine.h, per, 2, C.byref(hs)) == 0
+    host = api.BulkDecoder(threads=2, window_frames=64, parse_only=True)
+    try:
+        for name, mp3 in streams.items():
+            sp_h, sd_h, _ = host.parse(mp3)
+            bits, res, _ = api.parse_bits(mp3)
+            n = bits.shape[0]
+            assert n == sp_h.shape[0], name
+            assert lib.pdmp3_hip_stream_reset(hs) == 0
+            sp = np.zeros_like(sp_h)
+            sd = np.zeros_like(sd_h)
+            for w, a in enumerate(range(0, n, per)):
+                k = min(per, n - a)
+                slot = w % 2
+                C.memmove(lib.pdmp3_hip_stream_slot_bits(hs, slot), bits[a:].ctypes.data, k * 80)
+                C.memmove(lib.pdmp3_hip_stream_slot_reservoir(hs, slot), res[a:].ctypes.data, k * 2064)
+                assert lib.pdmp3_hip_stream_submit_bits(hs, slot, k) == 0
+                assert lib.pdmp3_hip_stream_wait(hs, slot) == 0
+                assert lib.pdmp3_hip_stream_fetch_records(hs, slot, k, sp[a:].ctypes.data, sd[a:].ctypes.data) == 0
+            assert np.array_equal(sp, sp_h), name
+            assert np.array_equal(sd.view(np.uint8), sd_h.view(np.uint8)), name
+    finally:
+        host.close()
+        lib.pdmp3_hip_stream_destroy(hs)

@@ -1,0 +1,71 @@
+"""Device-side main-data decoding (pdmp3_amd/csrc/unpack_core.h: scalefactors + Huffman per granule-channel,
+frame-to-frame merge) compiled for the host (tests/host_emul) against the product's host stage, which is itself
+pinned bit-for-bit to the oracle / reference (test_host_stage.py, test_bulk_host.py): from the same side info and
+reservoir snapshots both must build IDENTICAL gc records, for any split of the stream into windows.  No GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_bulk_host import _streams
+from test_host_stage import _records_equal
+from tools.packer import packer
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def emul_unpack(emul, bits, res, cuts=None):
+    from pdmp3_amd.hip import SIDE_DTYPE
+    n = bits.shape[0]
+    sp = np.zeros((n, 2, 2, 576), np.int16)
+    sd = np.zeros((n, 2, 2), SIDE_DTYPE)
+    state = np.zeros(256, np.uint16)
+    cuts = [0, n] if cuts is None else cuts
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            rc = emul.emul_unpack_frames(_p(bits[a:b]), _p(res[a:b]), b - a, _p(state), _p(sp[a:b]), _p(sd[a:b]))
+            assert 0 < rc <= 8448
+    return sp, sd
+
+
+@pytest.fixture(scope="module")
+def streams():
+    s = _streams()
+    # corrupt main data: part2_3_length / big_values that overrun the reservoir (slow-path windows, H8, count1 wrap)
+    rs = np.random.RandomState(9)
+    body = bytearray(packer.generate(n_frames=60, seed=41, bitrate_index=11, block_pct=(40, 10, 40, 10)))
+    for k in rs.randint(200, len(body) - 200, size=120):
+        body[k] ^= 1 << int(rs.randint(0, 8))
+    s["bit_flips"] = bytes(body)
+    return s
+
+
+def test_unpack_matches_host_stage(emul, streams):
+    from pdmp3_amd import api
+    b = api.BulkDecoder(threads=2, window_frames=64, parse_only=True)
+    try:
+        for name, mp3 in streams.items():
+            sp_h, sd_h, nbytes = b.parse(mp3)
+            bits, res, nbytes2 = api.parse_bits(mp3)
+            assert bits.shape[0] == sp_h.shape[0] and nbytes == nbytes2, name
+            if not bits.shape[0]:
+                continue
+            got = emul_unpack(emul, bits, res)
+            assert np.array_equal(got[0], sp_h), name
+            assert np.array_equal(got[1].view(np.uint8), sd_h.view(np.uint8)), name
+            n = bits.shape[0]
+            for cuts in ([0, 1, n], [0, n // 3, n // 2, n - 1, n], list(range(0, n, 7)) + [n]):
+                assert _records_equal(emul_unpack(emul, bits, res, cuts), got), (name, cuts)
+    finally:
+        b.close()
+
+
+def test_unpack_table_blob_fits_lds(emul):
+    bits = np.zeros(1, dtype=np.dtype([("b", "u1", (80,))]))
+    res = np.zeros((1, 2064), np.uint8)
+    from pdmp3_amd.hip import SIDE_DTYPE
+    n_lut = emul.emul_unpack_frames(_p(bits), _p(res), 1, _p(np.zeros(256, np.uint16)), _p(np.zeros(2304, np.int16)),
+                                    _p(np.zeros(4, SIDE_DTYPE)))
+    assert 8000 < n_lut <= 8448           # 8-bit first level + per-prefix second levels of the 18 books

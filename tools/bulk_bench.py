@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--parse-only", action="store_true")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--host-huffman", action="store_true", help="scalefactors + Huffman on the host pool instead of the device")
     args = ap.parse_args()
     from tools.packer import packer
     from pdmp3_amd import api
@@ -38,7 +39,7 @@ def main():
            "runs": []}
     pcm = np.empty(total // 2, dtype=np.int16)
     for th in [int(x) for x in args.threads.split(",")]:
-        b = api.BulkDecoder(threads=th, window_frames=args.window, parse_only=args.parse_only)
+        b = api.BulkDecoder(threads=th, window_frames=args.window, parse_only=args.parse_only, host_huffman=args.host_huffman)
         best = None
         for _ in range(args.reps):
             t0 = time.perf_counter()
@@ -51,7 +52,7 @@ def main():
             best = dt if best is None else min(best, dt)
         b.close()
         out["runs"].append({"threads": th, "seconds": round(best, 4), "frames_per_s": round(frames / best, 1),
-                            "x_realtime": round(frames / best / rt, 1), "mode": "parse" if args.parse_only else "decode"})
+                            "x_realtime": round(frames / best / rt, 1), "mode": "parse" if args.parse_only else ("decode, host Huffman" if args.host_huffman else "decode, device Huffman")})
     print(json.dumps(out))
 
 
