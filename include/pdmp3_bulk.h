@@ -31,6 +31,15 @@ extern "C" {
 
 typedef struct bulk pdmp3_amd_bulk;
 
+/* Returned by the scan / decode / parse entry points when the stream drives the reference into replaying its
+ * 16 KiB input ring: pdmp3_feed leaves the write index AT the end of the ring when a feed ends exactly there
+ * (pdmp3.c:2410-2417), and a frame that then ends exactly there too -- only 1152-byte frames can: 32 kHz at
+ * 256 kbps, the limit of SURVEY H10 -- wraps the read index past it (pdmp3.c:1464-1474), after which the ring
+ * looks full of its own stale bytes.  The reference's CLI then writes the same audio again, usually forever
+ * (libpdmp3.so's pdmp3_read / pdmp3() keep that behaviour, as a drop-in must).  There is no finite reference
+ * output to reproduce, so the whole-stream entry points stop and say so. */
+#define PDMP3_BULK_REPLAY (-2)
+
 /* threads <= 0: one worker per online CPU (at most 64).  window_frames <= 0:
  * 2048 frames per GPU batch.  Returns NULL when there is no transform engine
  * (no CPU fallback). */

@@ -182,12 +182,18 @@ def _as_u8(data):
     return a if a.size else np.zeros(1, dtype=np.uint8)
 
 
+class RingReplay(RuntimeError):
+    """PDMP3_BULK_REPLAY: the reference would replay its input ring on this stream (include/pdmp3_bulk.h)"""
+
+
 def scan_buffer(mp3):
     """(pcm_bytes, frames) the CLI driver would produce for this stream (include/pdmp3_bulk.h)."""
     lib = load_library()
     a = _as_u8(mp3)
     frames = C.c_longlong(0)
     total = lib.pdmp3_amd_scan_buffer(a.ctypes.data_as(C.c_void_p), len(mp3), C.byref(frames))
+    if total == -2:
+        raise RingReplay("the reference replays its input ring on this stream (no finite output)")
     return total, frames.value
 
 
@@ -218,6 +224,8 @@ class BulkDecoder:
         rate, ch = C.c_long(0), C.c_int(0)
         total = self.lib.pdmp3_amd_bulk_decode(self.h, a.ctypes.data_as(C.c_void_p), len(mp3),
                                                out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(rate), C.byref(ch))
+        if total == -2:
+            raise RingReplay("the reference replays its input ring on this stream (no finite output)")
         if total < 0:
             raise RuntimeError("pdmp3_amd_bulk_decode: engine failure")
         return total, rate.value, ch.value

@@ -835,7 +835,7 @@ PD_FN void ph_store(int lane, WaveLds& L, int nch, int16_t* pcm_g, bool emit) {
 // Highest frame in [f_lo, f_hi) that has two channels or carries the RESET flag, or -1.  Wave-uniform.
 PD_FN int last_stereo_or_reset(const pdmp3_gc_side* side, int f_lo, int f_hi) {
 #if defined(__HIPCC__)
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   for (int base = f_hi - 64;; base -= 64) {
     const int f = base + lane;
     bool hit = false;
@@ -874,7 +874,7 @@ struct DecodeArgs {
   unsigned long long* prof;      // PROF builds: [n_chunks][kProfSlots] shader-clock ticks per phase
 };
 
-constexpr int kProfSlots = 10;
+constexpr int kProfSlots = 12;
 
 #if defined(__HIPCC__)
 #define PD_NLANES 1
@@ -885,7 +885,7 @@ constexpr int kProfSlots = 10;
 // the compiler from moving memory operations across the phase boundary.
 #define PD_PHASE(...)                                   \
   {                                                     \
-    const int lane = threadIdx.x;                       \
+    const int lane = threadIdx.x & 63;                  \
     LaneRegs& R = Rs[0];                                \
     (void)R; (void)lane;                                \
     __VA_ARGS__;                                        \
@@ -906,6 +906,7 @@ constexpr int kProfSlots = 10;
 template <bool DUMP, bool PROF = false>
 PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveLds& L) {
   LaneRegs Rs[PD_NLANES];
+  const unsigned long long t_wave_start = PROF ? PD_CLOCK() : 0ull;
   const int f0 = chunk * a.chunk_frames;
   int f1 = f0 + a.chunk_frames;
   if (f1 > a.n_frames) f1 = a.n_frames;
@@ -959,8 +960,9 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     }
   )
   PD_PHASE(ph_commit(lane, L, R))
-  unsigned long long acc[kProfSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long acc[kProfSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = PD_CLOCK();
+  acc[11] = tprev;                 // end of the per-wave setup
 #define PD_TICK(k) if (PROF) { const unsigned long long tn_ = PD_CLOCK(); acc[k] += tn_ - tprev; tprev = tn_; }
   // k < 0: the pre-halo granules pre_end + k; k >= 0: granule g_start + k (ordinary halo, then the chunk)
   for (int k = -npre; g_start + k < g_end; ++k) {
@@ -1034,6 +1036,8 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
         for (int k = 0; k < 8; k++) a.prof[(size_t)chunk * kProfSlots + k] = acc[k];
         a.prof[(size_t)chunk * kProfSlots + 8] = (unsigned long long)(g_end - g_start + npre);
         a.prof[(size_t)chunk * kProfSlots + 9] = PD_CLOCK();
+        a.prof[(size_t)chunk * kProfSlots + 10] = t_wave_start;
+        a.prof[(size_t)chunk * kProfSlots + 11] = acc[11];
       }
     )
   }

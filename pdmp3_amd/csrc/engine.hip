@@ -27,10 +27,19 @@ using namespace pdmp3;
 
 __constant__ ConstBank c_bank;
 
+// A workgroup is PDMP3_WAVES_PER_WG independent wavefronts (one chunk each, no barrier between them): fewer,
+// larger workgroups only make the dispatch ramp of a launch shorter.
+#ifndef PDMP3_WAVES_PER_WG
+#define PDMP3_WAVES_PER_WG 1
+#endif
+constexpr int kWavesPerWg = PDMP3_WAVES_PER_WG;
+
 template <bool DUMP>
-__global__ __launch_bounds__(64, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a, GlobalTables T) {
-  __shared__ WaveLds L;
-  run_chunk<DUMP>(a, T, (BankPtr)&c_bank, (int)blockIdx.x, L);
+__global__ __launch_bounds__(64 * kWavesPerWg, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a, GlobalTables T, int n_chunks) {
+  __shared__ WaveLds L[kWavesPerWg];
+  const int w = threadIdx.x >> 6;
+  const int chunk = (int)blockIdx.x * kWavesPerWg + w;
+  if (chunk < n_chunks) run_chunk<DUMP>(a, T, (BankPtr)&c_bank, chunk, L[w]);
 }
 
 // same kernel with shader-clock stamps after every phase (tools/phase_profile.py)
@@ -110,7 +119,6 @@ struct pdmp3_hip_ctx {
   uint16_t* d_linetab;
   float* d_win;
   float* d_frag;            // frag_long [10][64] | frag_short [10][64] | frag_mat [8][64]
-  float* d_state_tmp;
 };
 
 static thread_local char g_err[256] = "";
@@ -147,7 +155,6 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
   HIP_TRY(hipMalloc(&c->d_pow43, H.pow43.size() * sizeof(float)), "hipMalloc pow43");
   HIP_TRY(hipMalloc(&c->d_linetab, H.linetab.size() * sizeof(uint16_t)), "hipMalloc linetab");
   HIP_TRY(hipMalloc(&c->d_win, H.win.size() * sizeof(float)), "hipMalloc win");
-  HIP_TRY(hipMalloc(&c->d_state_tmp, pdmp3_hip_state_bytes()), "hipMalloc state");
   HIP_TRY(hipMemcpy(c->d_pow43, H.pow43.data(), H.pow43.size() * sizeof(float), hipMemcpyHostToDevice), "upload pow43");
   HIP_TRY(hipMemcpy(c->d_linetab, H.linetab.data(), H.linetab.size() * sizeof(uint16_t), hipMemcpyHostToDevice), "upload linetab");
   HIP_TRY(hipMemcpy(c->d_win, H.win.data(), H.win.size() * sizeof(float), hipMemcpyHostToDevice), "upload win");
@@ -176,7 +183,6 @@ extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   (void)hipFree(c->d_linetab);
   (void)hipFree(c->d_win);
   (void)hipFree(c->d_frag);
-  (void)hipFree(c->d_state_tmp);
   (void)hipFree(c->d_unpack);
   free(c);
 }
@@ -192,9 +198,12 @@ static int auto_chunk(int n_frames) {
   return L;
 }
 
+// d_state_tmp: where the kernel leaves the new state before it is copied over d_state (chunk 0 and the channel-1
+// pre-halo read the OLD state while the last chunk writes the new one).  Streams own one; a bare
+// pdmp3_hip_decode_frames call takes a stream-ordered allocation so that calls on different HIP streams never share it.
 static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3_gc_side* d_side, int n_frames,
                          void* d_state, int16_t* d_pcm, float* d_stages, int chunk_frames, void* stream,
-                         unsigned long long* d_prof = nullptr) {
+                         unsigned long long* d_prof = nullptr, float* d_state_tmp = nullptr) {
   if (!c || n_frames < 0) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: bad argument", hipSuccess);
   if (n_frames == 0) return PDMP3_HIP_OK;
   if (!d_spectra || !d_side || !d_pcm)
@@ -211,18 +220,24 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.side = d_side;
   a.pcm = d_pcm;
   a.state_in = (const float*)d_state;
-  a.state_out = d_state ? c->d_state_tmp : nullptr;
+  bool own_tmp = false;
+  if (d_state && !d_state_tmp) {
+    HIP_TRY(hipMallocAsync((void**)&d_state_tmp, pdmp3_hip_state_bytes(), s), "hipMallocAsync state");
+    own_tmp = true;
+  }
+  a.state_out = d_state ? d_state_tmp : nullptr;
   a.stages = d_stages;
   a.n_frames = n_frames;
   a.chunk_frames = chunk_frames;
   a.prof = d_prof;
   GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64};
   if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
-  else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T);
-  else hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), 0, s, a, T);
+  else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3((nchunks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, s, a, T, nchunks);
+  else hipLaunchKernelGGL(k_decode<false>, dim3((nchunks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, s, a, T, nchunks);
   HIP_TRY(hipGetLastError(), "launch k_decode");
   if (d_state)
-    HIP_TRY(hipMemcpyAsync(d_state, c->d_state_tmp, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, s), "state copy");
+    HIP_TRY(hipMemcpyAsync(d_state, d_state_tmp, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, s), "state copy");
+  if (own_tmp) HIP_TRY(hipFreeAsync(d_state_tmp, s), "hipFreeAsync state");
   return PDMP3_HIP_OK;
 }
 
@@ -243,7 +258,7 @@ extern "C" int pdmp3_hip_decode_frames_stages(pdmp3_hip_ctx* ctx, const int16_t*
 // One pdmp3_hip_stream = one decoder's carried state + up to kMaxSlots staging slots.  Each slot has its own
 // HIP stream (H2D -> k_decode -> D2H), so slot w+1's upload overlaps slot w's kernel and download over the
 // two PCIe directions; the kernels themselves are chained in submit order through `ev_state` because each one
-// starts from the synthesis state its predecessor left (and they share ctx->d_state_tmp).
+// starts from the synthesis state its predecessor left (and they share the stream's d_state_tmp).
 constexpr int kMaxSlots = 4;
 struct StreamSlot {
   hipStream_t stream;
@@ -262,6 +277,7 @@ struct pdmp3_hip_stream {
   hipEvent_t ev_state;       // recorded after the latest kernel + state copy
   int have_state_ev;
   float* d_state;
+  float* d_state_tmp;
   uint16_t* d_sfstate;       // [2][256]: scalefactors / count1 carried from frame to frame (unpack_core.h), double-buffered
   int sf_cur;
   int have_bits;
@@ -282,6 +298,7 @@ extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
   (void)hipFree(hs->d_sfstate);
   if (hs->ev_state) (void)hipEventDestroy(hs->ev_state);
   (void)hipFree(hs->d_state);
+  (void)hipFree(hs->d_state_tmp);
   free(hs);
 }
 
@@ -310,6 +327,7 @@ extern "C" int pdmp3_hip_stream_create_slots(pdmp3_hip_ctx* ctx, int max_frames,
   }
   HS_TRY(hipEventCreateWithFlags(&hs->ev_state, hipEventDisableTiming), "hipEventCreate");
   HS_TRY(hipMalloc((void**)&hs->d_state, pdmp3_hip_state_bytes()), "hipMalloc state");
+  HS_TRY(hipMalloc((void**)&hs->d_state_tmp, pdmp3_hip_state_bytes()), "hipMalloc state");
   HS_TRY(hipMemsetAsync(hs->d_state, 0, pdmp3_hip_state_bytes(), hs->s[0].stream), "memset state");
   HS_TRY(hipStreamSynchronize(hs->s[0].stream), "sync");
 #undef HS_TRY
@@ -362,7 +380,7 @@ extern "C" int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_fra
   HIP_TRY(hipMemcpyAsync(t.d_spectra, t.h_spectra, n * PDMP3_FRAME_SPECTRA_BYTES, hipMemcpyHostToDevice, t.stream), "H2D spectra");
   HIP_TRY(hipMemcpyAsync(t.d_side, t.h_side, n * PDMP3_FRAME_SIDE_BYTES, hipMemcpyHostToDevice, t.stream), "H2D side");
   if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
-  int rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream);
+  int rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp);
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
   hs->have_state_ev = 1;
@@ -436,7 +454,7 @@ extern "C" int pdmp3_hip_stream_submit_bits(pdmp3_hip_stream* hs, int slot, int 
                      hs->d_sfstate + 256 * hs->sf_cur, hs->d_sfstate + 256 * (hs->sf_cur ^ 1), t.d_side);
   HIP_TRY(hipGetLastError(), "launch k_merge");
   hs->sf_cur ^= 1;
-  rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream);
+  rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp);
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
   hs->have_state_ev = 1;

@@ -826,6 +826,7 @@ int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) 
 /*                   copied out while w-1 is on the GPU and w is in B.       */
 /* ------------------------------------------------------------------------ */
 #define BULK_SLOTS 3
+#define PDMP3_BULK_REPLAY (-2)         /* see bulk_drive */
 #define BULK_GRAB 8                   /* frames a worker takes per trip to the counter */
 #define BULK_COPY_PIECE ((size_t)256 << 10)
 
@@ -1128,6 +1129,13 @@ static long long bulk_drive(struct bulk* b, const unsigned char* mp3, size_t n) 
   int res;
   while ((res = read_impl(id, NULL, INBUF_SIZE, &done, b)) != PDMP3_ERR) {
     total += done;
+    /* More bytes consumed than were ever fed: the ring is being replayed.  pdmp3_feed parks iend AT INBUF_SIZE
+     * when a feed ends exactly at the end of the ring (P:2410-2417); a frame that then ends exactly there (only
+     * 1152-byte frames can: 32 kHz / 256 kbps, the H10 limit) wraps the read index to 0 != iend and the ring
+     * looks full of its own stale contents (P:1464-1474).  The reference -- and pdmp3_read / pdmp3(), which keep
+     * its behaviour -- then emit the last 16 KiB again, often forever.  There is no finite reference output to
+     * match, so the whole-stream entry points stop here. */
+    if (id->processed > fed) { b->failed = 2; return PDMP3_BULK_REPLAY; }
     if (res == PDMP3_NEED_MORE) {
       size_t take = n - fed < 4096 ? n - fed : 4096;
       if (!take) break;
@@ -1235,7 +1243,7 @@ long long pdmp3_amd_scan_buffer(const unsigned char* mp3, size_t n, long long* f
   const long long total = bulk_drive(&b, mp3 ? mp3 : (const unsigned char*)"", mp3 ? n : 0);
   if (frames) *frames = b.frames;
   free(b.id);
-  return total;
+  return total;                                   /* PDMP3_BULK_REPLAY (-2) passes through */
 }
 
 /* Decode a whole stream.  Returns the PCM byte count pdmp3() writes for it (the first min(that, pcm_cap)
@@ -1264,6 +1272,7 @@ long long pdmp3_amd_bulk_decode(struct bulk* b, const unsigned char* mp3, size_t
   if (!ok) for (int i = 0; i < BULK_SLOTS; i++) { (void)pdmp3_hip_stream_wait(b->hs, i); b->flight[i].active = 0; }
   if (rate) *rate = (long)kSampleRates[b->id->hdr.sfreq];
   if (channels) *channels = b->id->hdr.mode == 3 ? 1 : 2;
+  if (total == PDMP3_BULK_REPLAY) return PDMP3_BULK_REPLAY;
   return ok ? total : -1;
 }
 
@@ -1280,6 +1289,7 @@ long long pdmp3_amd_bulk_parse(struct bulk* b, const unsigned char* mp3, size_t 
   bulk_wait_b(b);
   b->in_b = NULL;
   if (pcm_bytes) *pcm_bytes = total;
+  if (total == PDMP3_BULK_REPLAY) return PDMP3_BULK_REPLAY;
   return ok ? b->frames : -1;
 }
 
@@ -1291,6 +1301,7 @@ long long pdmp3_amd_bulk_parse_bits(struct bulk* b, const unsigned char* mp3, si
   b->rec_bits = bits; b->rec_res = res; b->rec_cap = cap_frames;
   const long long total = bulk_drive(b, mp3, n);
   if (pcm_bytes) *pcm_bytes = total;
+  if (total == PDMP3_BULK_REPLAY) return PDMP3_BULK_REPLAY;
   return b->failed ? -1 : b->frames;
 }
 

@@ -80,3 +80,25 @@ def test_bulk_long_stream_many_windows(oracle):
         b.close()
     n = sp_o.shape[0]
     assert n >= 1495 and _records_equal((sp[:n], sd[:n]), (sp_o, sd_o)) and nbytes == len(pcm_o)
+
+
+def test_ring_replay_is_reported_not_looped():
+    """32 kHz / 256 kbps frames are exactly 1152 bytes (the H10 limit); when one of them ends exactly at the end of
+    the 16 KiB ring right after a feed that ended there too, the reference replays the ring (its CLI never
+    terminates on this file: `timeout 20 oracle/_ref/pdmp3_ref_cli` keeps writing).  The whole-stream entry points
+    report it instead of spinning."""
+    from pdmp3_amd import api
+    mp3 = packer.generate(n_frames=4147, seed=435, sfreq=2, mode=0, mode_ext=0, vbr=True, vbr_lo=4, vbr_hi=13, bitrate_index=12,
+                          block_pct=(40, 20, 20, 20), mixed_pct=50)
+    with pytest.raises(api.RingReplay):
+        api.scan_buffer(mp3)
+    b = api.BulkDecoder(threads=2, window_frames=64, parse_only=True)
+    try:
+        with pytest.raises(api.RingReplay):
+            b.parse(mp3)
+        # same stream capped below the H10 limit: fine
+        ok = packer.generate(n_frames=300, seed=435, sfreq=2, mode=0, mode_ext=0, vbr=True, vbr_lo=4, vbr_hi=12, bitrate_index=12,
+                             block_pct=(40, 20, 20, 20), mixed_pct=50)
+        assert b.parse(ok)[0].shape[0] >= 297
+    finally:
+        b.close()

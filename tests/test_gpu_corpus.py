@@ -78,6 +78,58 @@ def test_c4_mixed_corpus(oracle):
     assert worst <= 1
 
 
+def _c4_files(n_base=40, n_mod=50, hi_32k=13):
+    """hi_32k: top bitrate index at 32 kHz.  13 = 256 kbps = 1152-byte frames, the H10 limit -- long streams of
+    those drive the reference into replaying its input ring (include/pdmp3_bulk.h PDMP3_BULK_REPLAY), so the
+    full-size corpus stops at 12."""
+    files, seed = [], 400
+    for mode, mext in ((3, 0), (0, 0), (1, 2)):
+        for sfreq in (0, 1, 2):
+            for vbr in (False, True):
+                for blocks in ((100, 0, 0, 0), (40, 20, 20, 20), (20, 10, 60, 10)):
+                    seed += 1
+                    hi = hi_32k if sfreq == 2 else 14
+                    files.append(packer.generate(n_frames=n_base + seed % n_mod, seed=seed, sfreq=sfreq, mode=mode, mode_ext=mext,
+                                                 vbr=vbr, vbr_lo=4, vbr_hi=hi, bitrate_index=min(12, hi), block_pct=blocks,
+                                                 mixed_pct=50 if blocks[2] else 0))
+    return files
+
+
+def test_c4_bulk_decoders_in_parallel(oracle):
+    """the C4 corpus through the bulk decoder (device Huffman), several decoders live at once on their own host
+    threads and HIP streams: nothing is shared between them but read-only tables.
+    PDMP3_FULL_C4=1: the full-size corpus of SURVEY 8d (>= 64 files x >= 4096 frames; slow on the CPU side: oracle)."""
+    import threading
+    from pdmp3_amd import api
+    full = bool(os.environ.get("PDMP3_FULL_C4"))
+    files = _c4_files(4096, 64, 12) + _c4_files(4096, 64, 12)[:10] if full else _c4_files()
+    assert len(files) >= (64 if full else 54)
+    want = [np.frombuffer(oracle.decode_buffer_like_cli(f), dtype=np.int16) for f in files]
+    got = [None] * len(files)
+    jobs = 6
+
+    def work(j):
+        b = api.BulkDecoder(threads=2, window_frames=512 if full else 16)
+        try:
+            for i in range(j, len(files), jobs):
+                got[i] = b.decode(files[i])
+        finally:
+            b.close()
+    t0 = time.time()
+    ts = [threading.Thread(target=work, args=(j,)) for j in range(jobs)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.time() - t0
+    frames = 0
+    for i in range(len(files)):
+        assert got[i] is not None and got[i].shape == want[i].shape, i
+        assert_pcm_close(got[i], want[i], 1, "file %d" % i)
+        frames += got[i].size // 1152 // (1 if i < 18 else 2)
+    print("C4 bulk: %d files, %d frames, %d decoders in parallel: %.3f s = %.0f frames/s" % (len(files), frames, jobs, dt, frames / dt))
+
+
 def test_cli_writes_raw(oracle, tmp_path):
     mp3 = packer.generate(n_frames=200, seed=0xC1, sfreq=0, mode=1, mode_ext=2, bitrate_index=9)
     path = tmp_path / "c1_128k.mp3"

@@ -15,6 +15,43 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
+def c4(args, api):
+    """files dealt largest-first to JOBS decoders (pdmp3_amd.sharding.assign_files), each on its own host thread
+    with its own HIP streams; decoders and output buffers exist before the clock starts"""
+    import threading
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from test_gpu_corpus import _c4_files
+    from pdmp3_amd.sharding import assign_files
+    files = _c4_files(4096, 64, 12)
+    files = [np.frombuffer(f, dtype=np.uint8) for f in files + files[:10]]
+    sizes = [api.scan_buffer(f) for f in files]
+    outs = [np.zeros(max(b, 2) // 2, dtype=np.int16) for b, _ in sizes]
+    plan = assign_files([len(f) for f in files], args.c4)
+    decs = [api.BulkDecoder(threads=2, window_frames=args.window, host_huffman=args.host_huffman) for _ in range(args.c4)]
+
+    def work(j):
+        for i in plan[j]:
+            got, _, _ = decs[j].decode_into(files[i], outs[i])
+            assert got == sizes[i][0]
+    best = None
+    for _ in range(args.reps + 1):                      # first pass = warm-up
+        ts = [threading.Thread(target=work, args=(j,)) for j in range(args.c4)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    for d in decs:
+        d.close()
+    frames = sum(fr for _, fr in sizes)
+    print(json.dumps({"workload": "C4: %d files, %d frames, mono/stereo/joint x 32/44.1/48 kHz x CBR/VBR x block mixes" % (len(files), frames),
+                      "decoders": args.c4, "seconds": round(best, 4), "frames_per_s": round(frames / best, 1),
+                      "mp3_bytes": int(sum(len(f) for f in files)), "pcm_bytes": int(sum(b for b, _ in sizes)),
+                      "mode": "host Huffman" if args.host_huffman else "device Huffman", "host_cpus": os.cpu_count()}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=20000)
@@ -22,10 +59,14 @@ def main():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--parse-only", action="store_true")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--c4", type=int, default=0, metavar="JOBS",
+                    help="SURVEY 8d C4 instead: the mixed corpus (64 files x >= 4096 frames), JOBS decoders in parallel")
     ap.add_argument("--host-huffman", action="store_true", help="scalefactors + Huffman on the host pool instead of the device")
     args = ap.parse_args()
     from tools.packer import packer
     from pdmp3_amd import api
+    if args.c4:
+        return c4(args, api)
     t0 = time.perf_counter()
     mp3 = packer.generate(n_frames=args.frames, seed=0xC3, sfreq=0, mode=1, mode_ext=2, bitrate_index=14)
     a = np.frombuffer(mp3, dtype=np.uint8)

@@ -15,7 +15,7 @@ lib.pdmp3_hip_debug_profile_phases.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_v
 sp, sd, pcm = eng.alloc_frames(n)
 eng.generate(0x5EED0000C5, 0, n, sp, sd)
 nchunks = (n + chunk - 1) // chunk
-prof = torch.zeros((nchunks, 10), dtype=torch.int64, device=eng.tdev)
+prof = torch.zeros((nchunks, 12), dtype=torch.int64, device=eng.tdev)
 for _ in range(2):
     rc = lib.pdmp3_hip_debug_profile_phases(eng.h, sp.data_ptr(), sd.data_ptr(), n, pcm.data_ptr(), chunk, prof.data_ptr(), None)
     assert rc == 0, lib.pdmp3_hip_last_error()
@@ -29,9 +29,16 @@ p = prof.cpu().numpy().astype(np.float64)
 gran = p[:, 8].sum()
 names = ["load", "scales", "requant", "fetch+aa", "imdct", "dct32", "window", "store"]
 tot = p[:, :8].sum()
-print("n_frames %d chunk %d chunks %d kernel %.3f ms  (s_memtime ticks; 100 MHz constant clock on gfx9)" % (n, chunk, nchunks, a.elapsed_time(b)))
+print("n_frames %d chunk %d chunks %d kernel %.3f ms  (s_memtime ticks)" % (n, chunk, nchunks, a.elapsed_time(b)))
 for k, nm in enumerate(names):
     print("  %-9s %10.1f ticks/granule  %5.1f %%" % (nm, p[:, k].sum() / gran, 100 * p[:, k].sum() / tot))
 print("  total     %10.1f ticks/granule-wave" % (tot / gran))
-span = p[:, 9].max() - (p[:, 9] - p[:, :8].sum(axis=1)).min()
-print("  span of the launch in ticks: %.0f" % span)
+t0 = p[:, 10].min()
+def st(x):
+    return "min %.0f  median %.0f  p90 %.0f  max %.0f" % (x.min(), np.median(x), np.percentile(x, 90), x.max())
+print("  timeline in ticks from the first wave's start (span of the launch %.0f):" % (p[:, 9].max() - t0))
+print("    wave start   " + st(p[:, 10] - t0))
+print("    setup        " + st(p[:, 11] - p[:, 10]))
+print("    granule loop " + st(p[:, :8].sum(axis=1)))
+print("    wave end     " + st(p[:, 9] - t0))
+print("    granules per wave " + st(p[:, 8]))
