@@ -35,7 +35,7 @@ FP32_PEAK_TFLOPS = 157.3              # MI355X fp32 vector = fp32 matrix peak (t
 RT_FRAMES_PER_S = 44100.0 / 1152.0
 
 
-def cpu_baseline(sample_frames, target_seconds):
+def cpu_baseline(sample_frames, target_seconds, all_cores_seconds=0.0):
     """The reference CPU path on this box's host cores (rank 0, N = 1 only).
     kind "reference": the real pdmp3.c Decode_L3 from oracle/_ref (prebuilt in
     the build container); falls back to the oracle port when _ref is absent."""
@@ -50,13 +50,50 @@ def cpu_baseline(sample_frames, target_seconds):
     reps = max(1, int(target_seconds / max(t1, 1e-6)))
     t = dec.time_decode(sp, sd, reps)
     fps = sample_frames * reps / t
-    return {
+    out = {
         "value": round(fps, 1), "unit": "frames/s", "cores": 1, "kind": kind,
         "sample": "%d passes of Decode_L3 over the same %d C2 frames (%.1f s, 1 thread; "
                   "the reference is single-threaded with process-global state)" % (reps, sample_frames, t),
         "x_realtime": round(fps / RT_FRAMES_PER_S, 1),
         "host_cpus": os.cpu_count(),
     }
+    # all host cores.  The reference keeps its synthesis state in function statics, so "all cores"
+    # = one forked process per CPU, each decoding the same sample (what a per-file farm of the reference would do).
+    if all_cores_seconds > 0 and (os.cpu_count() or 1) > 1:
+        import multiprocessing as mp
+        procs = min(os.cpu_count(), 256)
+        reps_all = max(1, int(all_cores_seconds / max(t1, 1e-6)))
+        global _MP_JOB
+        _MP_JOB = (dec, sp, sd, reps_all)
+        try:
+            ctx = mp.get_context("fork")
+            with ctx.Pool(procs) as pool:
+                pool.map(_mp_warm, range(procs))                 # every worker up and paged in
+                w0 = time.perf_counter()
+                pool.map(_mp_run, range(procs), chunksize=1)
+                wall = time.perf_counter() - w0
+            agg = procs * sample_frames * reps_all / wall
+            out["all_cores"] = {"value": round(agg, 1), "unit": "frames/s", "cores": procs, "kind": kind,
+                                "sample": "%d processes x %d passes over the same %d frames (%.1f s wall)" %
+                                          (procs, reps_all, sample_frames, wall),
+                                "x_realtime": round(agg / RT_FRAMES_PER_S, 1)}
+        except Exception as e:                                   # a reported extra, never fatal
+            out["all_cores"] = {"error": repr(e)}
+    return out
+
+
+_MP_JOB = None
+
+
+def _mp_warm(_):
+    dec, sp, sd, _reps = _MP_JOB
+    dec.time_decode(sp[:64], sd[:64], 1)
+    return 0
+
+
+def _mp_run(_):
+    dec, sp, sd, reps = _MP_JOB
+    return dec.time_decode(sp, sd, reps)
 
 
 def measured_traffic(frames, n_halo):
@@ -86,16 +123,22 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="frames per workgroup chunk (0 = engine default)")
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-all-seconds", type=float, default=6.0, help="all-host-cores leg of the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--big", type=int, default=131072, help="frames of the extra large-batch roofline probe (0 = skip)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    # the CPU legs run first: they fork workers, which must happen before this process touches the GPU
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu:
+        cpu = cpu_baseline(FRAMES_PER_GPU, args.cpu_seconds, args.cpu_all_seconds)
 
     import torch
     import torch.distributed as dist
     import pdmp3_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
@@ -238,8 +281,8 @@ def main():
         }
         del sp2, sd2, pcm2
 
-    if world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(FRAMES_PER_GPU, args.cpu_seconds)
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
