@@ -35,6 +35,25 @@ FP32_PEAK_TFLOPS = 157.3              # MI355X fp32 vector = fp32 matrix peak (t
 RT_FRAMES_PER_S = 44100.0 / 1152.0
 
 
+def effective_cpus():
+    """CPUs this process can actually keep busy: affinity mask capped by the cgroup CPU quota (the GPU boxes show
+    256 CPUs but run the job under a quota of a few)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(sample_frames, target_seconds, all_cores_seconds=0.0):
     """The reference CPU path on this box's host cores (rank 0, N = 1 only).
     kind "reference": the real pdmp3.c Decode_L3 from oracle/_ref (prebuilt in
@@ -59,9 +78,10 @@ def cpu_baseline(sample_frames, target_seconds, all_cores_seconds=0.0):
     }
     # all host cores.  The reference keeps its synthesis state in function statics, so "all cores"
     # = one forked process per CPU, each decoding the same sample (what a per-file farm of the reference would do).
-    if all_cores_seconds > 0 and (os.cpu_count() or 1) > 1:
+    out["effective_cpus"] = effective_cpus()
+    if all_cores_seconds > 0 and out["effective_cpus"] > 1:
         import multiprocessing as mp
-        procs = min(os.cpu_count(), 256)
+        procs = min(out["effective_cpus"], 256)
         reps_all = max(1, int(all_cores_seconds / max(t1, 1e-6)))
         global _MP_JOB
         _MP_JOB = (dec, sp, sd, reps_all)

@@ -14,6 +14,15 @@ pmc write WRITE_SIZE
 pmc sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
 pmc sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 pmc sq3 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32
+# the whole-stream pipeline (device Huffman): kernel durations per 2048-frame window
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bulk_stats -o bulk -- python3 tools/bulk_bench.py --frames 40000 --threads 2 --reps 2 > $OUT/bulk_under_rocprof.json 2> $OUT/bulk_stats.log; echo "bulk stats rc=$?"
+cat $OUT/bulk_stats/bulk_kernel_stats.csv | cut -c1-160
+# un-profiled lines
+timeout 600 python3 bench.py 2> /dev/null > $OUT/bench.json; echo "bench rc=$?"; cat $OUT/bench.json
+timeout 600 python3 tools/bulk_bench.py --frames 137813 --threads 2 2> /dev/null | tail -1 > $OUT/bulk_decode.json; cat $OUT/bulk_decode.json
+timeout 600 python3 tools/bulk_bench.py --frames 137813 --threads 1,8,16,32 --host-huffman 2> /dev/null | tail -1 > $OUT/bulk_decode_host_huffman.json; cat $OUT/bulk_decode_host_huffman.json
+timeout 600 python3 tools/bulk_bench.py --c4 4 2> /dev/null | tail -1 > $OUT/bulk_c4.json; cat $OUT/bulk_c4.json
+timeout 300 python3 tools/phase_profile.py 131072 32 > $OUT/phase_profile.txt 2>&1; timeout 300 python3 tools/phase_profile.py 2048 1 >> $OUT/phase_profile.txt 2>&1
 # the same for a C5-shard-sized launch
 pmcb() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 tools/pmc_target.py 131072 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
 pmcb big_fetch FETCH_SIZE

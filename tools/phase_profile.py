@@ -33,12 +33,10 @@ print("n_frames %d chunk %d chunks %d kernel %.3f ms  (s_memtime ticks)" % (n, c
 for k, nm in enumerate(names):
     print("  %-9s %10.1f ticks/granule  %5.1f %%" % (nm, p[:, k].sum() / gran, 100 * p[:, k].sum() / tot))
 print("  total     %10.1f ticks/granule-wave" % (tot / gran))
-t0 = p[:, 10].min()
 def st(x):
     return "min %.0f  median %.0f  p90 %.0f  max %.0f" % (x.min(), np.median(x), np.percentile(x, 90), x.max())
-print("  timeline in ticks from the first wave's start (span of the launch %.0f):" % (p[:, 9].max() - t0))
-print("    wave start   " + st(p[:, 10] - t0))
-print("    setup        " + st(p[:, 11] - p[:, 10]))
+# (s_memtime counters of different XCDs are not synchronised: only per-wave differences mean anything)
+print("  per wave, in ticks:")
+print("    setup (tables -> LDS/registers, first prefetch) " + st(p[:, 11] - p[:, 10]))
 print("    granule loop " + st(p[:, :8].sum(axis=1)))
-print("    wave end     " + st(p[:, 9] - t0))
 print("    granules per wave " + st(p[:, 8]))
