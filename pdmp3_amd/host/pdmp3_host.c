@@ -470,6 +470,11 @@ static void decode_huffman(bitreader* b, const frame_header* H, const side_info*
     return;
   }
   const unsigned end = part2_start + S->part2_3_length[gr][ch] - 1;   /* last bit of this part */
+  /* Every line is defined: the ones neither a pair nor a quad writes are zero.  (They are the rzero region, which
+   * the reference zeroes too -- except when its line counter wraps below zero on a corrupt part2_3_length, P:2106:
+   * then it requantises the FLOATS the previous frame's synthesis left in is[], which no int16 record can carry.
+   * Host and device Huffman both give zeros there.) */
+  memset(is, 0, 576 * sizeof *is);
   unsigned r1, r2;
   if (S->win_switch[gr][ch] && S->block_type[gr][ch] == 2) { r1 = 36; r2 = 576; }
   else {

@@ -69,3 +69,44 @@ def test_unpack_table_blob_fits_lds(emul):
     n_lut = emul.emul_unpack_frames(_p(bits), _p(res), 1, _p(np.zeros(256, np.uint16)), _p(np.zeros(2304, np.int16)),
                                     _p(np.zeros(4, SIDE_DTYPE)))
     assert 8000 < n_lut <= 8448           # 8-bit first level + per-prefix second levels of the 18 books
+
+
+@pytest.mark.parametrize("base", ["vbr_mixed", "mono_32k", "linbits_320k"])
+def test_unpack_fuzz_matches_host_stage(emul, base):
+    """random corruption (bit flips, byte splats, truncation): whatever the host stage builds from a broken stream --
+    region overruns (H7, H8), part2_3_length running off the reservoir, count1 wrapping below zero -- the device
+    logic builds the same records, with random window cuts.  (ASan/UBSan builds of both were fuzzed the same way.)"""
+    from pdmp3_amd import api
+    kw = {"vbr_mixed": dict(n_frames=90, seed=51, vbr=True, block_pct=(40, 10, 40, 10), mixed_pct=50),
+          "mono_32k": dict(n_frames=90, seed=52, sfreq=2, mode=3, bitrate_index=7),
+          "linbits_320k": dict(n_frames=70, seed=53, mode=1, mode_ext=2, bitrate_index=14, big_pct=200, gain=(100, 140))}[base]
+    orig = np.frombuffer(packer.generate(**kw), dtype=np.uint8)
+    rs = np.random.RandomState({"vbr_mixed": 7, "mono_32k": 8, "linbits_320k": 9}[base])
+    b = api.BulkDecoder(threads=2, window_frames=32, parse_only=True)
+    frames = 0
+    try:
+        for it in range(25):
+            m = orig.copy()
+            kind = it % 3
+            for p in rs.randint(0, len(m), size=1 + rs.randint(0, 6 if kind == 0 else 150)):
+                m[p] = rs.randint(0, 256) if kind == 2 else m[p] ^ (1 << rs.randint(0, 8))
+            if it % 5 == 4:
+                m = m[:rs.randint(1, len(m))]
+            m = np.ascontiguousarray(m)
+            try:
+                sp_h, sd_h, _ = b.parse(m)
+            except api.RingReplay:
+                continue
+            bits, res, _ = api.parse_bits(m)
+            n = bits.shape[0]
+            assert n == sp_h.shape[0]
+            if not n:
+                continue
+            cuts = sorted(set([0, n] + rs.randint(0, n, size=rs.randint(0, 5)).tolist()))
+            got = emul_unpack(emul, bits, res, cuts)
+            assert np.array_equal(got[0], sp_h), (base, it)
+            assert np.array_equal(got[1].view(np.uint8), sd_h.view(np.uint8)), (base, it)
+            frames += n
+    finally:
+        b.close()
+    assert frames > 500
