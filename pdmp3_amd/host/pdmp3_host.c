@@ -130,7 +130,7 @@ struct pdmp3_handle {
   uint8_t main_vec[2048 + 16];     /* bit reservoir, P:137 */
   unsigned main_top;
   main_out scratch_out;            /* this frame's decoded main data (inline path) */
-  unsigned side_vec[36 + 8];
+  uint8_t side_vec[64 + 8];        /* side info bytes, P:138 */
   unsigned side_ptr, side_idx;
   int new_header;                  /* P:147 */
   int need_reset;                  /* hsynth_init / synth_init, P:134-135 */
@@ -283,14 +283,13 @@ static int search_header(pdmp3_handle* id) {
 /* ------------------------------------------------------------------------ */
 /* side info (P:1129-1200)                                                   */
 /* ------------------------------------------------------------------------ */
-static unsigned side_bits(pdmp3_handle* id, unsigned n) {
-  const unsigned* p = &id->side_vec[id->side_ptr];
-  uint32_t w = (p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3];
-  w <<= id->side_idx;
-  w >>= (32 - n);
+static inline unsigned side_bits(pdmp3_handle* id, unsigned n) {   /* n <= 12 */
+  uint64_t w;
+  memcpy(&w, &id->side_vec[id->side_ptr & 63], 8);
+  w = __builtin_bswap64(w) << id->side_idx;
   id->side_ptr += (id->side_idx + n) >> 3;
   id->side_idx = (id->side_idx + n) & 7;
-  return w;
+  return (unsigned)(w >> (64 - n));
 }
 
 static unsigned frame_bytes(const frame_header* H) {   /* P:1135-1138 */
@@ -299,11 +298,15 @@ static unsigned frame_bytes(const frame_header* H) {   /* P:1135-1138 */
 
 static void read_side_info(pdmp3_handle* id) {
   const unsigned nch = id->hdr.mode == 3 ? 1 : 2, nbytes = nch == 1 ? 17 : 32;
-  unsigned got = 0;
-  for (; got < nbytes; got++) {
-    unsigned v = ring_byte(id);
-    if (v == BYTE_EOF) break;
-    id->side_vec[got] = v;
+  unsigned got = ring_filled(id);
+  if (got > nbytes) got = nbytes;
+  {
+    unsigned first = INBUF_SIZE - id->istart;
+    if (first > got) first = got;
+    memcpy(id->side_vec, id->in + id->istart, first);
+    memcpy(id->side_vec + first, id->in, got - first);
+    id->istart = (id->istart + got) % INBUF_SIZE;
+    id->processed += got;
   }
   if (got == nbytes) { id->side_ptr = 0; id->side_idx = 0; }   /* pointers move only on a full read (P:1576-1586) */
   side_info* S = &id->si;
