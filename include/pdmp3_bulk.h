@@ -49,6 +49,10 @@ pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
  * merge run on the device (pdmp3_hip_stream_submit_bits) and the pool just copies PCM out.  host_huffman = 1:
  * they run on the pool and the engine is given decoded records (pdmp3_hip_stream_submit). */
 pdmp3_amd_bulk* pdmp3_amd_bulk_new_ex(int threads, int window_frames, int host_huffman);
+/* the same on HIP device `device` (the others use $PDMP3_DEVICE, default 0).  Decoders are independent: a corpus of
+ * files is dealt over the GPUs of a node by giving each host thread its own decoder (whole files per GPU,
+ * largest first; pdmp3_amd/sharding.py assign_files) -- there is nothing to exchange between them. */
+pdmp3_amd_bulk* pdmp3_amd_bulk_new_on(int threads, int window_frames, int host_huffman, int device);
 void pdmp3_amd_bulk_delete(pdmp3_amd_bulk* b);
 int pdmp3_amd_bulk_threads(const pdmp3_amd_bulk* b);
 

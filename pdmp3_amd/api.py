@@ -13,7 +13,7 @@ PDMP3_OK, PDMP3_ERR, PDMP3_NEED_MORE, PDMP3_NEW_FORMAT, PDMP3_NO_SPACE = 0, -1, 
 PDMP3_ENC_SIGNED_16 = 0xD0
 _LIB = None
 
-BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads",
+BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads",
                 "pdmp3_amd_scan_buffer", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
                 "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits"]
 
@@ -66,6 +66,8 @@ def load_library():
     lib.pdmp3_amd_bulk_decode.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_int)]
     lib.pdmp3_amd_bulk_new_ex.restype = vp
     lib.pdmp3_amd_bulk_new_ex.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.pdmp3_amd_bulk_new_on.restype = vp
+    lib.pdmp3_amd_bulk_new_on.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.pdmp3_amd_bulk_new_parse_bits.restype = vp
     lib.pdmp3_amd_bulk_new_parse_bits.argtypes = []
     lib.pdmp3_amd_bulk_parse_bits.restype = C.c_longlong
@@ -201,13 +203,15 @@ class BulkDecoder:
     """include/pdmp3_bulk.h: whole-stream decode, host Huffman on a thread pool + pipelined GPU batches.
     parse_only=True: host stages only (records out), for machines without a GPU."""
 
-    def __init__(self, threads=0, window_frames=0, parse_only=False, host_huffman=False):
+    def __init__(self, threads=0, window_frames=0, parse_only=False, host_huffman=False, device=None):
         """host_huffman=False: scalefactors + Huffman run on the device (pdmp3_hip_stream_submit_bits), the pool only
         copies PCM out; True: they run on the pool's threads (the engine gets decoded records)."""
         self.lib = load_library()
         self.parse_only = parse_only
         if parse_only:
             self.h = self.lib.pdmp3_amd_bulk_new_parse_only(threads, window_frames)
+        elif device is not None:
+            self.h = self.lib.pdmp3_amd_bulk_new_on(threads, window_frames, 1 if host_huffman else 0, int(device))
         else:
             self.h = self.lib.pdmp3_amd_bulk_new_ex(threads, window_frames, 1 if host_huffman else 0)
         if not self.h:

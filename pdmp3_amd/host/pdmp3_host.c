@@ -142,19 +142,25 @@ struct pdmp3_handle {
 };
 
 static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
-static pdmp3_hip_ctx* g_ctx = NULL;
+#define MAX_DEVICES 16
+static pdmp3_hip_ctx* g_ctx[MAX_DEVICES];
 
-static pdmp3_hip_ctx* shared_ctx(void) {
+/* one engine (tables in HBM) per HIP device, shared by every handle / bulk decoder of the process on that device */
+static pdmp3_hip_ctx* shared_ctx_on(int dev) {
+  if (dev < 0 || dev >= MAX_DEVICES) return NULL;
   pthread_mutex_lock(&g_ctx_lock);
-  if (!g_ctx) {
-    int dev = 0;
-    const char* e = getenv("PDMP3_DEVICE");
-    if (e) dev = atoi(e);
-    if (pdmp3_hip_create(dev, &g_ctx) != PDMP3_HIP_OK) g_ctx = NULL;
-  }
+  if (!g_ctx[dev] && pdmp3_hip_create(dev, &g_ctx[dev]) != PDMP3_HIP_OK) g_ctx[dev] = NULL;
+  pdmp3_hip_ctx* c = g_ctx[dev];
   pthread_mutex_unlock(&g_ctx_lock);
-  return g_ctx;
+  return c;
 }
+
+static int default_device(void) {
+  const char* e = getenv("PDMP3_DEVICE");
+  return e ? atoi(e) : 0;
+}
+
+static pdmp3_hip_ctx* shared_ctx(void) { return shared_ctx_on(default_device()); }
 
 /* P:2351: pdmp3_new(decoder, error) -- `decoder` is ignored like in the reference */
 pdmp3_handle* pdmp3_new(const char* decoder, int* error) {
@@ -1174,7 +1180,7 @@ void pdmp3_amd_bulk_delete(struct bulk* b) {
 
 /* threads <= 0: one per online CPU (at most 64); window_frames <= 0: 2048.  with_engine = 0 gives a
  * parse-only decoder (host tests on machines without a GPU). */
-static struct bulk* bulk_new(int threads, int window_frames, int with_engine, int bits_mode) {
+static struct bulk* bulk_new(int threads, int window_frames, int with_engine, int bits_mode, int device) {
   pthread_once(&g_lut_once, build_luts);
   if (threads <= 0) {
     long c = sysconf(_SC_NPROCESSORS_ONLN);
@@ -1194,7 +1200,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
     if (!b->win[i].jobs || !b->win[i].outs) { pdmp3_amd_bulk_delete(b); return NULL; }
   }
   if (with_engine) {
-    pdmp3_hip_ctx* ctx = shared_ctx();
+    pdmp3_hip_ctx* ctx = shared_ctx_on(device);
     if (!ctx || pdmp3_hip_stream_create_slots(ctx, b->cap, BULK_SLOTS, &b->hs) != PDMP3_HIP_OK) {
       fprintf(stderr, "pdmp3: no MI355X transform engine: %s\n", pdmp3_hip_last_error());
       b->hs = NULL;
@@ -1216,15 +1222,18 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
 }
 
 /* default: Huffman decoding on the device; PDMP3_BULK_HOST_HUFFMAN=1 (or _new_ex) keeps it on the host pool */
+struct bulk* pdmp3_amd_bulk_new_on(int threads, int window_frames, int host_huffman, int device) {
+  return bulk_new(threads, window_frames, 1, !host_huffman, device);
+}
 struct bulk* pdmp3_amd_bulk_new_ex(int threads, int window_frames, int host_huffman) {
-  return bulk_new(threads, window_frames, 1, !host_huffman);
+  return bulk_new(threads, window_frames, 1, !host_huffman, default_device());
 }
 struct bulk* pdmp3_amd_bulk_new(int threads, int window_frames) {
   const char* e = getenv("PDMP3_BULK_HOST_HUFFMAN");
-  return bulk_new(threads, window_frames, 1, !(e && *e && *e != '0'));
+  return bulk_new(threads, window_frames, 1, !(e && *e && *e != '0'), default_device());
 }
-struct bulk* pdmp3_amd_bulk_new_parse_only(int threads, int window_frames) { return bulk_new(threads, window_frames, 0, 0); }
-struct bulk* pdmp3_amd_bulk_new_parse_bits(void) { return bulk_new(1, 1, 0, 1); }
+struct bulk* pdmp3_amd_bulk_new_parse_only(int threads, int window_frames) { return bulk_new(threads, window_frames, 0, 0, 0); }
+struct bulk* pdmp3_amd_bulk_new_parse_bits(void) { return bulk_new(1, 1, 0, 1, 0); }
 int pdmp3_amd_bulk_threads(const struct bulk* b) { return b ? b->nth : 0; }
 
 static void bulk_begin(struct bulk* b) {

@@ -27,7 +27,10 @@ def c4(args, api):
     sizes = [api.scan_buffer(f) for f in files]
     outs = [np.zeros(max(b, 2) // 2, dtype=np.int16) for b, _ in sizes]
     plan = assign_files([len(f) for f in files], args.c4)
-    decs = [api.BulkDecoder(threads=2, window_frames=args.window, host_huffman=args.host_huffman) for _ in range(args.c4)]
+    import torch
+    ngpu = max(1, min(args.gpus, torch.cuda.device_count()))
+    decs = [api.BulkDecoder(threads=2, window_frames=args.window, host_huffman=args.host_huffman, device=j % ngpu)
+            for j in range(args.c4)]
 
     def work(j):
         for i in plan[j]:
@@ -47,7 +50,7 @@ def c4(args, api):
         d.close()
     frames = sum(fr for _, fr in sizes)
     print(json.dumps({"workload": "C4: %d files, %d frames, mono/stereo/joint x 32/44.1/48 kHz x CBR/VBR x block mixes" % (len(files), frames),
-                      "decoders": args.c4, "seconds": round(best, 4), "frames_per_s": round(frames / best, 1),
+                      "decoders": args.c4, "gpus": ngpu, "seconds": round(best, 4), "frames_per_s": round(frames / best, 1),
                       "mp3_bytes": int(sum(len(f) for f in files)), "pcm_bytes": int(sum(b for b, _ in sizes)),
                       "mode": "host Huffman" if args.host_huffman else "device Huffman", "host_cpus": os.cpu_count()}))
 
@@ -61,6 +64,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--c4", type=int, default=0, metavar="JOBS",
                     help="SURVEY 8d C4 instead: the mixed corpus (64 files x >= 4096 frames), JOBS decoders in parallel")
+    ap.add_argument("--gpus", type=int, default=1, help="--c4: decoder j runs on GPU j %% GPUS")
     ap.add_argument("--host-huffman", action="store_true", help="scalefactors + Huffman on the host pool instead of the device")
     args = ap.parse_args()
     from tools.packer import packer
