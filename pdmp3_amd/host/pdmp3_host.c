@@ -895,6 +895,7 @@ struct bulk {
   unsigned char* pcm; size_t pcm_cap;
   size_t pcm_emitted;                 /* PCM bytes of all frames handed to stage C so far */
   int failed, busy;
+  int carry;                          /* keep parse state (host handle / device sfstate) from the previous stream */
 };
 
 static void* bulk_worker(void* arg) {
@@ -1185,6 +1186,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
   if (threads <= 0) {
     long c = sysconf(_SC_NPROCESSORS_ONLN);
     threads = c < 1 ? 1 : c > 64 ? 64 : (int)c;
+    if (bits_mode && threads > 4) threads = 4;   /* the pool only copies PCM out */
   }
   if (window_frames <= 0) window_frames = 2048;
   struct bulk* b = (struct bulk*)calloc(1, sizeof *b);
@@ -1238,10 +1240,12 @@ int pdmp3_amd_bulk_threads(const struct bulk* b) { return b ? b->nth : 0; }
 
 static void bulk_begin(struct bulk* b) {
   pdmp3_handle* id = b->id;
-  /* a fresh handle per stream: pdmp3() makes one per run, and parse state left by an earlier stream would
-   * show -- callers who want that carry use the streaming API */
-  memset(id, 0, sizeof *id);
-  id->host_only = 1;
+  /* a fresh handle per stream -- unless the caller is pdmp3(), which decodes all its files with ONE handle: parse
+   * state left by the previous file shows in the next one, so it is kept (b->carry) */
+  if (!b->carry) {
+    memset(id, 0, sizeof *id);
+    id->host_only = 1;
+  }
   b->cur = 0; b->win[0].n = b->win[1].n = 0; b->in_b = NULL;
   b->windows = 0; b->frames = 0; b->pcm_emitted = 0; b->count_only = 0; b->failed = 0; b->busy = 0;
   b->bits_open = 0; b->bits_n = 0;
@@ -1269,7 +1273,8 @@ long long pdmp3_amd_bulk_decode(struct bulk* b, const unsigned char* mp3, size_t
                                 long* rate, int* channels) {
   if (!b || !b->hs || (!mp3 && n) || (!pcm && pcm_cap)) return -1;
   bulk_begin(b);
-  if (pdmp3_hip_stream_reset(b->hs) != PDMP3_HIP_OK) return -1;
+  /* (with carry the synthesis state needs no reset either: the stream's first frame carries PDMP3_FR_RESET) */
+  if (!b->carry && pdmp3_hip_stream_reset(b->hs) != PDMP3_HIP_OK) return -1;
   b->pcm = pcm; b->pcm_cap = pcm_cap;
   const long long total = bulk_drive(b, mp3, n);
   int ok = !b->failed;
@@ -1343,28 +1348,75 @@ static void write_raw(const char* filename, const unsigned char* data, size_t nb
   }
 }
 
-void pdmp3(char* const* mp3s) {
+/* one file through the reference's own loop (P:2566-2583): stdin, and files the whole-stream path declines */
+static void cli_stream_file(pdmp3_handle* id, const char* filename, FILE* fp) {
   unsigned char out[INBUF_SIZE];
+  pdmp3_open_feed(id);
+  size_t done;
+  int res;
+  while ((res = pdmp3_read(id, out, INBUF_SIZE, &done)) != PDMP3_ERR) {
+    write_raw(filename, out, done);
+    if (res == PDMP3_NEED_MORE) {
+      unsigned char in[4096];
+      const size_t n = fread(in, 1, sizeof in, fp);
+      if (!n) break;
+      (void)pdmp3_feed(id, in, n);
+    }
+  }
+}
+
+/* Same contract as the reference's driver: every named file is decoded to interleaved int16 and appended to
+ * "<first name>.raw".  Regular files take the whole-stream path (include/pdmp3_bulk.h), whose output is by
+ * definition what the loop above produces -- parse state carried from file to file like the reference's single
+ * handle does; PDMP3_CLI_STREAMING=1 forces the loop. */
+void pdmp3(char* const* mp3s) {
   if (*mp3s && !strncmp("/dev/dsp", *mp3s, 8)) mp3s++;      /* OSS device argument accepted, playback not supported */
   pdmp3_handle* id = pdmp3_new(NULL, NULL);
   if (!id) { fputs("Cannot open stream API (no transform engine)\n", stderr); exit(0); }
+  const char* force = getenv("PDMP3_CLI_STREAMING");
+  const int streaming_only = force && *force && *force != '0';
+  struct bulk* b = NULL;
+  int bulk_used = 0, loop_used = 0;
   for (; *mp3s; mp3s++) {
     const char* filename = *mp3s;
     FILE* fp = strcmp(filename, "-") ? fopen(filename, "r") : stdin;
     if (!fp) { fputs("Cannot open file\n", stderr); exit(0); }
-    pdmp3_open_feed(id);
-    size_t done;
-    int res;
-    while ((res = pdmp3_read(id, out, INBUF_SIZE, &done)) != PDMP3_ERR) {
-      write_raw(filename, out, done);
-      if (res == PDMP3_NEED_MORE) {
-        unsigned char in[4096];
-        const size_t n = fread(in, 1, sizeof in, fp);
-        if (!n) break;
-        (void)pdmp3_feed(id, in, n);
+    unsigned char* data = NULL;
+    long size = -1;
+    /* the two paths keep their parse state in different handles: once one of them has decoded a file, later
+     * files stay on it */
+    if (fp != stdin && !streaming_only && !loop_used && fseek(fp, 0, SEEK_END) == 0 && (size = ftell(fp)) >= 0 &&
+        fseek(fp, 0, SEEK_SET) == 0) {
+      data = (unsigned char*)malloc((size_t)size + 1);
+      if (data && fread(data, 1, (size_t)size, fp) != (size_t)size) { free(data); data = NULL; }
+      if (!data) (void)fseek(fp, 0, SEEK_SET);
+    }
+    long long total = -1;
+    if (data) {
+      total = pdmp3_amd_scan_buffer(data, (size_t)size, NULL);
+      if (total == PDMP3_BULK_REPLAY && bulk_used) {            /* the reference would not terminate on this file */
+        fprintf(stderr, "pdmp3: %s: the reference decoder replays its input ring on this stream; skipped\n", filename);
+        total = 0;
       }
     }
+    if (data && total >= 0) {
+      if (!b) b = pdmp3_amd_bulk_new(0, 0);
+      unsigned char* pcm = (unsigned char*)malloc((size_t)total + 1);
+      if (!b || !pcm) { fputs("Cannot open stream API (no transform engine)\n", stderr); exit(0); }
+      b->carry = bulk_used;                       /* first file: fresh state, like the reference's new handle */
+      const long long got = pdmp3_amd_bulk_decode(b, data, (size_t)size, pcm, (size_t)total, NULL, NULL);
+      if (got != total) { fputs("pdmp3: engine failure\n", stderr); exit(-1); }
+      write_raw(filename, pcm, (size_t)total);
+      free(pcm);
+      bulk_used = 1;
+    } else {
+      if (data) (void)fseek(fp, 0, SEEK_SET);
+      cli_stream_file(id, filename, fp);
+      loop_used = 1;
+    }
+    free(data);
     if (fp != stdin) fclose(fp);
   }
+  if (b) pdmp3_amd_bulk_delete(b);
   pdmp3_delete(id);
 }

@@ -140,3 +140,32 @@ def test_cli_writes_raw(oracle, tmp_path):
     want = oracle.decode_buffer_like_cli(mp3)
     assert len(got) == len(want)
     assert_pcm_close(_as16(got), _as16(want), 1, "CLI")
+
+
+def test_cli_several_files_one_handle(oracle, tmp_path):
+    """pdmp3() decodes all its files with ONE handle into "<first name>.raw": parse state left by a file shows in
+    the next (SURVEY H4-H6, H20).  The whole-stream path the CLI takes for regular files carries it the same way;
+    PDMP3_CLI_STREAMING=1 (the reference's own feed/read loop) must give the identical bytes."""
+    from oracle.oracle import OracleStream
+    specs = [dict(n_frames=60, seed=0xD1, mode=1, mode_ext=2, bitrate_index=11, block_pct=(10, 10, 70, 10), mixed_pct=50),
+             dict(n_frames=45, seed=0xD2, sfreq=1, mode=3, bitrate_index=8, block_pct=(30, 20, 30, 20)),
+             dict(n_frames=70, seed=0xD3, sfreq=2, mode=0, mode_ext=0, vbr=True, vbr_lo=3, vbr_hi=12, block_pct=(20, 10, 60, 10))]
+    files = [packer.generate(**s) for s in specs]
+    paths = []
+    for i, f in enumerate(files):
+        p = tmp_path / ("f%d.mp3" % i)
+        p.write_bytes(f)
+        paths.append(str(p))
+    o = OracleStream(oracle)
+    want = b"".join(o.decode_like_cli(f) for f in files)
+    o.close()
+    cli = os.path.join(ROOT, "pdmp3_amd", "pdmp3_cli")
+    raw = tmp_path / "f0.mp3.raw"
+    subprocess.check_call([cli] + paths, timeout=120)
+    got = raw.read_bytes()
+    raw.unlink()
+    subprocess.check_call([cli] + paths, timeout=120, env=dict(os.environ, PDMP3_CLI_STREAMING="1"))
+    got_loop = raw.read_bytes()
+    assert len(got) == len(want) == len(got_loop)
+    assert got == got_loop
+    assert_pcm_close(_as16(got), _as16(want), 1, "3 files, one handle")
