@@ -40,7 +40,8 @@ typedef struct bulk pdmp3_amd_bulk;
  * output to reproduce, so the whole-stream entry points stop and say so. */
 #define PDMP3_BULK_REPLAY (-2)
 
-/* threads <= 0: one worker per online CPU (at most 64).  window_frames <= 0:
+/* threads <= 0: one worker per usable CPU (affinity and cgroup quota; at most 64; 4 with device Huffman, where the
+ * pool only copies PCM out).  window_frames <= 0:
  * 2048 frames per GPU batch.  Returns NULL when there is no transform engine
  * (no CPU fallback). */
 pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);

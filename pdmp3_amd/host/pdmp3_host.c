@@ -21,12 +21,14 @@
  * There is no CPU fallback for the transforms: without the engine library or
  * a HIP device pdmp3_new() fails.
  */
+#define _GNU_SOURCE
 #include "../../include/pdmp3.h"
 #include "../../include/pdmp3_hip.h"
 #include "../csrc/tables_data.h"
 
 #include <fcntl.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1179,13 +1181,33 @@ void pdmp3_amd_bulk_delete(struct bulk* b) {
   free(b);
 }
 
-/* threads <= 0: one per online CPU (at most 64); window_frames <= 0: 2048.  with_engine = 0 gives a
+/* CPUs this process can keep busy: the affinity mask, capped by the cgroup CPU quota (containers often show every
+ * CPU of the host but run under a quota of a few; threads beyond it only get throttled) */
+static int usable_cpus(void) {
+  long n = sysconf(_SC_NPROCESSORS_ONLN);
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < n) n = CPU_COUNT(&set);
+  FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (f) {
+    char q[32];
+    long long period = 0;
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") && period > 0) {
+      const long long quota = atoll(q);
+      const long c = (long)((quota + period / 2) / period);
+      if (c >= 1 && c < n) n = c;
+    }
+    fclose(f);
+  }
+  return n < 1 ? 1 : (int)n;
+}
+
+/* threads <= 0: one per usable CPU (at most 64); window_frames <= 0: 2048.  with_engine = 0 gives a
  * parse-only decoder (host tests on machines without a GPU). */
 static struct bulk* bulk_new(int threads, int window_frames, int with_engine, int bits_mode, int device) {
   pthread_once(&g_lut_once, build_luts);
   if (threads <= 0) {
-    long c = sysconf(_SC_NPROCESSORS_ONLN);
-    threads = c < 1 ? 1 : c > 64 ? 64 : (int)c;
+    const int c = usable_cpus();
+    threads = c > 64 ? 64 : c;
     if (bits_mode && threads > 4) threads = 4;   /* the pool only copies PCM out */
   }
   if (window_frames <= 0) window_frames = 2048;
