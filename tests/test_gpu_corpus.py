@@ -43,6 +43,17 @@ def test_c3_long_stream(oracle):
     print("C3: %d frames in %.2f s = %.0f frames/s = %.0fx real time (python ctypes loop included); "
           "max diff %d LSB in %.3f%% of samples" % (len(got) // 4608, dt, fps, fps / 38.28125, dmax, 100.0 * ndiff / (len(got) // 2)))
     assert fps / 38.28125 >= 50, "north_star: >= 50x real time"
+    # the same bytes through the whole-stream decoder (device Huffman, then host Huffman): identical PCM, bit for bit
+    for host_huffman in (False, True):
+        b = api.BulkDecoder(threads=4, host_huffman=host_huffman)
+        try:
+            t0 = time.time()
+            bulk = b.decode(mp3)
+            dt = time.time() - t0
+        finally:
+            b.close()
+        assert bulk.nbytes == len(got) and np.array_equal(bulk, _as16(got)), "bulk (host_huffman=%s) != streaming API" % host_huffman
+        print("C3 bulk (%s Huffman): %.3f s = %.0fx real time" % ("host" if host_huffman else "device", dt, (len(got) / 4608) / dt / 38.28125))
 
 
 def test_c4_mixed_corpus(oracle):
