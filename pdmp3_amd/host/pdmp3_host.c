@@ -842,6 +842,9 @@ int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) 
 /*                   copied out while w-1 is on the GPU and w is in B.       */
 /* ------------------------------------------------------------------------ */
 #define BULK_SLOTS 3
+#include <time.h>
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+static double g_t_submit, g_t_gpuwait, g_t_poolwait;   /* PDMP3_BULK_TRACE=1: where the scanning thread waits */
 #define PDMP3_BULK_REPLAY (-2)         /* see bulk_drive */
 #define BULK_GRAB 8                   /* frames a worker takes per trip to the counter */
 #define BULK_COPY_PIECE ((size_t)256 << 10)
@@ -898,6 +901,14 @@ struct bulk {
   size_t pcm_emitted;                 /* PCM bytes of all frames handed to stage C so far */
   int failed, busy;
   int carry;                          /* keep parse state (host handle / device sfstate) from the previous stream */
+  /* bits mode: the engine calls of a window (H2D, kernels, D2H: ~40 us of driver time) are issued by a thread
+   * of their own, in window order, so that the scanning thread does not stop for them */
+  pthread_t sub_th;
+  int sub_started, sub_quit, sub_rc;
+  pthread_mutex_t sub_mu;
+  pthread_cond_t sub_cv, sub_done_cv;
+  int sub_slot[8], sub_n[8];
+  long long sub_head, sub_tail;       /* jobs enqueued / completed */
 };
 
 static void* bulk_worker(void* arg) {
@@ -947,9 +958,11 @@ static void bulk_start_b(struct bulk* b, bulk_window* w, const unsigned char* sr
 }
 static void bulk_wait_b(struct bulk* b) {
   if (!b->busy) return;
+  const double t0 = now_s();
   pthread_mutex_lock(&b->mu);
   while (b->active) pthread_cond_wait(&b->cv_done, &b->mu);
   pthread_mutex_unlock(&b->mu);
+  g_t_poolwait += now_s() - t0;
   b->busy = 0;
 }
 
@@ -959,7 +972,10 @@ static int bulk_collect(struct bulk* b, int slot, const unsigned char** jsrc, un
   bulk_flight* f = &b->flight[slot];
   if (jbytes) *jbytes = 0;
   if (!f->active) return PDMP3_OK;
-  if (pdmp3_hip_stream_wait(b->hs, slot) != PDMP3_HIP_OK) return PDMP3_ERR;
+  const double t0 = now_s();
+  const int wrc = pdmp3_hip_stream_wait(b->hs, slot);
+  g_t_gpuwait += now_s() - t0;
+  if (wrc != PDMP3_HIP_OK) return PDMP3_ERR;
   f->active = 0;
   const unsigned char* src = (const unsigned char*)pdmp3_hip_stream_slot_pcm(b->hs, slot);
   size_t off = f->pcm_off;
@@ -1066,6 +1082,39 @@ static void fill_frame_bits(const pdmp3_handle* id, pdmp3_frame_bits* fb) {
     }
 }
 
+static void* bulk_submitter(void* arg) {
+  struct bulk* b = (struct bulk*)arg;
+  for (;;) {
+    pthread_mutex_lock(&b->sub_mu);
+    while (b->sub_tail == b->sub_head && !b->sub_quit) pthread_cond_wait(&b->sub_cv, &b->sub_mu);
+    if (b->sub_tail == b->sub_head) { pthread_mutex_unlock(&b->sub_mu); return NULL; }
+    const int slot = b->sub_slot[b->sub_tail & 7], n = b->sub_n[b->sub_tail & 7];
+    pthread_mutex_unlock(&b->sub_mu);
+    const int rc = pdmp3_hip_stream_submit_bits(b->hs, slot, n);
+    if (rc != PDMP3_HIP_OK) fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
+    pthread_mutex_lock(&b->sub_mu);
+    if (rc != PDMP3_HIP_OK) b->sub_rc = rc;
+    b->sub_tail++;
+    pthread_cond_broadcast(&b->sub_done_cv);
+    pthread_mutex_unlock(&b->sub_mu);
+  }
+}
+static void sub_enqueue(struct bulk* b, int slot, int n) {
+  pthread_mutex_lock(&b->sub_mu);
+  b->sub_slot[b->sub_head & 7] = slot; b->sub_n[b->sub_head & 7] = n;
+  b->sub_head++;
+  pthread_cond_signal(&b->sub_cv);
+  pthread_mutex_unlock(&b->sub_mu);
+}
+static int sub_drain(struct bulk* b) {            /* every enqueued window has been handed to the GPU */
+  if (!b->sub_started) return PDMP3_OK;
+  pthread_mutex_lock(&b->sub_mu);
+  while (b->sub_tail != b->sub_head) pthread_cond_wait(&b->sub_done_cv, &b->sub_mu);
+  const int rc = b->sub_rc;
+  pthread_mutex_unlock(&b->sub_mu);
+  return rc == PDMP3_HIP_OK ? PDMP3_OK : PDMP3_ERR;
+}
+
 /* make the slot of window `windows` writable: its previous occupant (window - 3) must be off the GPU; its PCM
  * goes home on the worker pool while stage A fills the slot's input side */
 static int bits_open_window(struct bulk* b) {
@@ -1078,6 +1127,7 @@ static int bits_open_window(struct bulk* b) {
   }
   b->bits_slot = (int)(b->windows % BULK_SLOTS);
   const unsigned char* src; unsigned char* dst; size_t nbytes;
+  if (b->flight[b->bits_slot].active && sub_drain(b) != PDMP3_OK) return PDMP3_ERR;   /* (long done: 3 windows ago) */
   if (bulk_collect(b, b->bits_slot, &src, &dst, &nbytes) != PDMP3_OK) return PDMP3_ERR;
   if (nbytes) bulk_start_b(b, NULL, src, dst, nbytes);
   b->bits_dst = pdmp3_hip_stream_slot_bits(b->hs, b->bits_slot);
@@ -1099,10 +1149,9 @@ static int bits_close_window(struct bulk* b) {
       if (f->nch[i] != 2) f->all_stereo = 0;
       b->pcm_emitted += 2304u * f->nch[i];
     }
-    if (pdmp3_hip_stream_submit_bits(b->hs, b->bits_slot, b->bits_n) != PDMP3_HIP_OK) {
-      fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
-      return PDMP3_ERR;
-    }
+    const double t0 = now_s();
+    sub_enqueue(b, b->bits_slot, b->bits_n);
+    g_t_submit += now_s() - t0;
     f->active = 1;
   }
   b->windows++;
@@ -1174,6 +1223,14 @@ void pdmp3_amd_bulk_delete(struct bulk* b) {
     free(b->th);
     pthread_mutex_destroy(&b->mu); pthread_cond_destroy(&b->cv_work); pthread_cond_destroy(&b->cv_done);
   }
+  if (b->sub_started) {
+    pthread_mutex_lock(&b->sub_mu);
+    b->sub_quit = 1;
+    pthread_cond_signal(&b->sub_cv);
+    pthread_mutex_unlock(&b->sub_mu);
+    pthread_join(b->sub_th, NULL);
+    pthread_mutex_destroy(&b->sub_mu); pthread_cond_destroy(&b->sub_cv); pthread_cond_destroy(&b->sub_done_cv);
+  }
   for (int i = 0; i < 2; i++) { free(b->win[i].jobs); free(b->win[i].outs); }
   for (int i = 0; i < BULK_SLOTS; i++) free(b->flight[i].nch);
   if (b->hs) pdmp3_hip_stream_destroy(b->hs);
@@ -1235,6 +1292,11 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
       b->flight[i].nch = (uint8_t*)malloc((size_t)b->cap);
       if (!b->flight[i].nch) { pdmp3_amd_bulk_delete(b); return NULL; }
     }
+    if (bits_mode) {
+      pthread_mutex_init(&b->sub_mu, NULL); pthread_cond_init(&b->sub_cv, NULL); pthread_cond_init(&b->sub_done_cv, NULL);
+      if (pthread_create(&b->sub_th, NULL, bulk_submitter, b) != 0) { pdmp3_amd_bulk_delete(b); return NULL; }
+      b->sub_started = 1;
+    }
   }
   pthread_mutex_init(&b->mu, NULL); pthread_cond_init(&b->cv_work, NULL); pthread_cond_init(&b->cv_done, NULL);
   b->th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
@@ -1270,7 +1332,7 @@ static void bulk_begin(struct bulk* b) {
   }
   b->cur = 0; b->win[0].n = b->win[1].n = 0; b->in_b = NULL;
   b->windows = 0; b->frames = 0; b->pcm_emitted = 0; b->count_only = 0; b->failed = 0; b->busy = 0;
-  b->bits_open = 0; b->bits_n = 0;
+  b->bits_open = 0; b->bits_n = 0; b->sub_rc = 0;
   for (int i = 0; i < BULK_SLOTS; i++) b->flight[i].active = 0;
 }
 
@@ -1300,8 +1362,10 @@ long long pdmp3_amd_bulk_decode(struct bulk* b, const unsigned char* mp3, size_t
   b->pcm = pcm; b->pcm_cap = pcm_cap;
   const long long total = bulk_drive(b, mp3, n);
   int ok = !b->failed;
-  if (b->bits_mode) ok = ok && bits_close_window(b) == PDMP3_OK;
-  else {
+  if (b->bits_mode) {
+    ok = ok && bits_close_window(b) == PDMP3_OK;
+    ok = sub_drain(b) == PDMP3_OK && ok;
+  } else {
     ok = ok && bulk_rotate(b) == PDMP3_OK;               /* the partly filled last window */
     ok = ok && bulk_finish_b(b) == PDMP3_OK;
   }
@@ -1316,6 +1380,10 @@ long long pdmp3_amd_bulk_decode(struct bulk* b, const unsigned char* mp3, size_t
   if (!ok) for (int i = 0; i < BULK_SLOTS; i++) { (void)pdmp3_hip_stream_wait(b->hs, i); b->flight[i].active = 0; }
   if (rate) *rate = (long)kSampleRates[b->id->hdr.sfreq];
   if (channels) *channels = b->id->hdr.mode == 3 ? 1 : 2;
+  if (getenv("PDMP3_BULK_TRACE")) {
+    fprintf(stderr, "bulk trace: submit %.2f ms, gpu wait %.2f ms, pool wait %.2f ms (cumulative)\n", g_t_submit * 1e3,
+            g_t_gpuwait * 1e3, g_t_poolwait * 1e3);
+  }
   if (total == PDMP3_BULK_REPLAY) return PDMP3_BULK_REPLAY;
   return ok ? total : -1;
 }
