@@ -58,23 +58,46 @@ __global__ __launch_bounds__(64) void k_generate(uint64_t seed, int64_t first, i
 // ---------------------------------------------------------------------------
 // main-data decoding on the device (unpack_core.h)
 // ---------------------------------------------------------------------------
-constexpr int kUnpackThreads = 256;   // 64 frames per workgroup pass; the 34 KB table blob lives in LDS
+constexpr int kUnpackThreads = 64;                      // one wave = 16 frames per pass
+constexpr int kUnpackRows = kUnpackThreads / 4;
+constexpr int kRowWords = PDMP3_RESERVOIR_BYTES / 16;   // 129 x 16 B
 
+// LDS: the 34 KB table blob, the 16 reservoir rows the wave works on (33 KB) and the 64 x 576 int16 lines it
+// produces (72 KB), moved in and out with coalesced 16-byte accesses; in between a lane touches global memory only
+// for its 80-byte side info and the two small records it writes.
 __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* tabs, const pdmp3_frame_bits* bits,
                                                             const uint8_t* res, int n_frames, int16_t* spectra,
                                                             pdmp3_gc_side* side, GcRaw* raw) {
   __shared__ UnpackTables U;
+  __shared__ uint4 rows[kUnpackRows * kRowWords + 1];
+  __shared__ uint4 lines[kUnpackThreads * 72];            // [lane][576 int16]
   {
     const uint4* src = reinterpret_cast<const uint4*>(tabs);
     uint4* dst = reinterpret_cast<uint4*>(&U);
     const int n16 = (int)((offsetof(UnpackTables, lut) + (size_t)tabs->n_lut * 4 + 15) / 16);
     for (int i = threadIdx.x; i < n16; i += kUnpackThreads) dst[i] = src[i];
   }
-  __syncthreads();
-  const int total = n_frames * 4;
-  for (int idx = blockIdx.x * kUnpackThreads + threadIdx.x; idx < total; idx += gridDim.x * kUnpackThreads) {
-    const int f = idx >> 2, g = idx & 3;
-    unpack_gc(U, U.lut, res + (size_t)f * PDMP3_RESERVOIR_BYTES, bits[f], g, spectra + (size_t)idx * 576, side + idx, raw + idx);
+  for (int f0 = blockIdx.x * kUnpackRows; f0 < n_frames; f0 += gridDim.x * kUnpackRows) {
+    const int nrows = n_frames - f0 < kUnpackRows ? n_frames - f0 : kUnpackRows;
+    __syncthreads();                                       // (previous pass done with `rows`; first pass: U complete)
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(res + (size_t)f0 * PDMP3_RESERVOIR_BYTES);
+      for (int i = threadIdx.x; i < nrows * kRowWords; i += kUnpackThreads) rows[i] = src[i];
+      for (int i = threadIdx.x; i < kUnpackThreads * 72; i += kUnpackThreads) lines[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const int fl = threadIdx.x >> 2, g = threadIdx.x & 3;
+    if (fl < nrows) {
+      const int f = f0 + fl;
+      const size_t idx = (size_t)f * 4 + g;
+      unpack_gc(U, U.lut, reinterpret_cast<const uint8_t*>(rows) + (size_t)fl * PDMP3_RESERVOIR_BYTES, bits[f], g,
+                reinterpret_cast<int16_t*>(lines) + (size_t)threadIdx.x * 576, side + idx, raw + idx);
+    }
+    __syncthreads();
+    {
+      uint4* dst = reinterpret_cast<uint4*>(spectra + (size_t)f0 * 4 * 576);
+      for (int i = threadIdx.x; i < nrows * 4 * 72; i += kUnpackThreads) dst[i] = lines[i];
+    }
   }
 }
 
@@ -440,10 +463,9 @@ extern "C" int pdmp3_hip_stream_submit_bits(pdmp3_hip_stream* hs, int slot, int 
   const size_t n = (size_t)n_frames;
   HIP_TRY(hipMemcpyAsync(t.d_bits, t.h_bits, n * sizeof(pdmp3_frame_bits), hipMemcpyHostToDevice, t.stream), "H2D bits");
   HIP_TRY(hipMemcpyAsync(t.d_res, t.h_res, n * PDMP3_RESERVOIR_BYTES, hipMemcpyHostToDevice, t.stream), "H2D reservoir");
-  HIP_TRY(hipMemsetAsync(t.d_spectra, 0, n * PDMP3_FRAME_SPECTRA_BYTES, t.stream), "zero spectra");
   {
-    int blocks = (n_frames * 4 + kUnpackThreads - 1) / kUnpackThreads;
-    if (blocks > 1024) blocks = 1024;
+    int blocks = (n_frames + kUnpackRows - 1) / kUnpackRows;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(kUnpackThreads), 0, t.stream, hs->ctx->d_unpack, t.d_bits, t.d_res,
                        n_frames, t.d_spectra, t.d_side, t.d_raw);
     HIP_TRY(hipGetLastError(), "launch k_unpack");

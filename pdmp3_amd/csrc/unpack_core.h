@@ -86,16 +86,24 @@ PD_HD uint32_t peek32(const BitPos& b) {            // next 25+ valid bits, MSB 
   const uint64_t w = ((uint64_t)p[0] << 32) | ((uint64_t)p[1] << 24) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 8) | p[4];
   return (uint32_t)(w >> (8 - (b.pos & 7)));
 }
-PD_HD unsigned get_bits(BitPos& b, unsigned n) {
+PD_HD uint64_t peek64(const BitPos& b);
+PD_HD unsigned get_bits(BitPos& b, unsigned n) {    // n <= 16
   if (!n) return 0;
-  const unsigned v = peek32(b) >> (32 - n);
+  const unsigned v = b.pos <= kFastLimit ? (unsigned)(peek64(b) >> (64 - n)) : peek32(b) >> (32 - n);
   b.pos += n;
   return v;
 }
-PD_HD uint64_t peek64(const BitPos& b) {            // >= 57 valid bits; caller guarantees pos <= kFastLimit
-  uint64_t w;
-  __builtin_memcpy(&w, b.buf + (b.pos >> 3), 8);
-  return __builtin_bswap64(w) << (b.pos & 7);
+// 64 valid bits from bit `pos` on, out of three ALIGNED 32-bit words (the row sits in LDS in the kernel: aligned
+// ds_read_b32s, no dependence on global-memory latency -- with the row in HBM every symbol waited ~500 cycles for
+// its load, behind the acknowledgement of the scattered stores before it: 365 us per 2048-frame window).
+// Caller guarantees pos <= kFastLimit; the third word may lie up to 4 bytes past the row, none of its bits that
+// reach the result do.
+PD_HD uint64_t peek64(const BitPos& b) {
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(b.buf) + (b.pos >> 5);
+  const uint32_t d0 = __builtin_bswap32(p[0]), d1 = __builtin_bswap32(p[1]), d2 = __builtin_bswap32(p[2]);
+  const unsigned s = b.pos & 31;
+  const uint64_t two = ((uint64_t)d0 << 32) | d1;
+  return s ? (two << s) | (uint64_t)(d2 >> (32 - s)) : two;
 }
 
 // one code word from a 64-bit window: returns leaf value, adds its length to `used`
@@ -130,19 +138,30 @@ PD_HD unsigned part2_bits(const UnpackTables& U, const pdmp3_frame_bits& F, int 
   return n;
 }
 
-// pairs [pos, end) of one region (cf. decode_pairs in pdmp3_host.c)
-PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& b, unsigned tn, unsigned pos, unsigned end,
-                            int16_t* is) {
-  const int book = U.book_of_table[tn];
-  if (pos >= end) return pos;
-  if (book < 0) return pos + ((end - pos + 1) & ~1u);   // no code words: zeros (already there), no bits
-  const unsigned base = U.book_base[book], linbits = U.linbits[tn];
-  for (; pos < end; pos += 2) {
+// The big_values pairs [0, nbig) of one granule-channel (cf. decode_pairs in pdmp3_host.c), ONE loop over the three
+// regions: the lanes of a wave sit in different regions with different tables, and three loops in a row would cost
+// the sum of the longest region of each kind instead of the longest granule-channel.  A region whose table has no
+// code words (0, 4, 14) reads no bits and leaves its (pre-zeroed) lines alone.
+PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& b, const pdmp3_gc_bits& s, unsigned e0,
+                            unsigned e1, unsigned nbig, int16_t* is) {
+  int base_r[3];
+  unsigned lin_r[3];
+  for (int r = 0; r < 3; r++) {
+    const unsigned tn = s.table_select[r];
+    const int book = U.book_of_table[tn];
+    base_r[r] = book < 0 ? -1 : (int)U.book_base[book];
+    lin_r[r] = U.linbits[tn];
+  }
+  unsigned pos = 0;
+  for (; pos < nbig; pos += 2) {
+    const int base = pos < e0 ? base_r[0] : pos < e1 ? base_r[1] : base_r[2];
+    const unsigned linbits = pos < e0 ? lin_r[0] : pos < e1 ? lin_r[1] : lin_r[2];
+    if (base < 0) continue;
     int x, y;
     if (b.pos <= kFastLimit) {
       const uint64_t w = peek64(b);
       unsigned used = 0;
-      const unsigned leaf = lut_symbol(lut, base, w, used);
+      const unsigned leaf = lut_symbol(lut, (unsigned)base, w, used);
       x = leaf >> 4; y = leaf & 15;
       if (linbits && x == 15) { x += (int)((w << used) >> (64 - linbits)); used += linbits; }
       if (x) { if ((w << used) >> 63) x = -x; used++; }
@@ -150,7 +169,7 @@ PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& 
       if (y) { if ((w << used) >> 63) y = -y; used++; }
       b.pos += used;
     } else {
-      const unsigned leaf = lut_symbol_slow(lut, base, b);
+      const unsigned leaf = lut_symbol_slow(lut, (unsigned)base, b);
       x = leaf >> 4; y = leaf & 15;
       if (linbits && x == 15) x += (int)get_bits(b, linbits);
       if (x > 0 && get_bits(b, 1)) x = -x;
@@ -238,9 +257,7 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
   if (e0 > nbig) e0 = nbig;
   if (e1 > nbig) e1 = nbig;
   if (e1 < e0) e1 = e0;
-  unsigned pos = unpack_pairs(U, lut, b, s.table_select[0], 0, e0, spectra_gc);
-  pos = unpack_pairs(U, lut, b, s.table_select[1], pos, e1, spectra_gc);
-  pos = unpack_pairs(U, lut, b, s.table_select[2], pos, nbig, spectra_gc);
+  unsigned pos = unpack_pairs(U, lut, b, s, e0, e1, nbig, spectra_gc);
   // count1 region: table 32 or the reference's mis-pointed table 33 (H1); both books are <= 8 bits deep
   const unsigned qbase = U.book_base[U.book_of_table[32 + s.count1table_select]];
   while (pos <= 572 && b.pos <= end) {

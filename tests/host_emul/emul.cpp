@@ -60,6 +60,9 @@ extern "C" int emul_unpack_frames(const pdmp3_frame_bits* bits, const uint8_t* r
   static UnpackTables* U = nullptr;
   if (!U) { U = new UnpackTables; if (!build_unpack_tables(*U)) return -1; }
   std::vector<GcRaw> raw((size_t)n_frames * 4);
+  std::vector<uint32_t> padded(((size_t)n_frames * PDMP3_RESERVOIR_BYTES + 16) / 4, 0);   // peek64 may touch 4 bytes past the last row
+  memcpy(padded.data(), res, (size_t)n_frames * PDMP3_RESERVOIR_BYTES);
+  res = reinterpret_cast<const uint8_t*>(padded.data());
   memset(spectra, 0, (size_t)n_frames * 2304 * sizeof(int16_t));
   for (int f = 0; f < n_frames; ++f)
     for (int g = 0; g < 4; ++g)
