@@ -16,11 +16,12 @@
 //                inside the reservoir follows from the side info alone
 //                (part2_3_length of the ones before it, P:2110), so the four
 //                of a frame decode independently.  Two-level code-book lookup
-//                from LDS (8-bit first level, per-prefix second level), one
-//                unaligned 8-byte load per pair / quad.  Writes int16 spectra
-//                [0, count1) (the buffer is zeroed beforehand), the fields of
-//                the side record that come straight from the side info, and a
-//                GcRaw: the scalefactors it read and which ones (masks).
+//                (8-bit first level, per-prefix second level); the kernel keeps
+//                the books, the reservoir rows and the output lines of its 16
+//                frames in LDS, so the symbol loop never waits for HBM.  Writes
+//                int16 lines [0, count1) (the buffer is zero on entry), the
+//                fields of the side record that come straight from the side
+//                info, and a GcRaw: the scalefactors it read and which ones.
 //   merge_slot   thread = one of the 232 values that survive frames
 //                (scalefac_l[2][2][21], scalefac_s[2][2][12][3], count1[2][2];
 //                SURVEY H4-H6): walks the window's frames in order, keeps
