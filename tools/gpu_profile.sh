@@ -6,9 +6,9 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu --big 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats.log; echo "stats rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu --no-e2e --big 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats.log; echo "stats rc=$?"
 cat $OUT/stats/bench_kernel_stats.csv
-pmc() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 bench.py --steps 20 --warmup 2 --no-cpu --big 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
+pmc() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 bench.py --steps 20 --warmup 2 --no-cpu --no-e2e --big 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
