@@ -338,7 +338,8 @@ PD_FN void ph_scales(int lane, WaveLds& L) {
 // REORDERED lines l, l + 64, ..., l + 512 of both channels (consecutive lanes
 // touch consecutive LDS words: no bank conflicts on the int16 / u16 tables).
 // ---------------------------------------------------------------------------
-template <bool DUMP>
+// NI = 9: the whole granule.  NI = 1: only the reordered lines 0..63 (the peek-only halo granule, see run_chunk).
+template <bool DUMP, int NI = 9>
 PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, float* dump0, float* dump1) {
   const GranuleInfo g = granule_info(L);
   const bool joint = (g.nch == 2) && (g.mode == 1) && (g.mode_ext != 0);
@@ -346,44 +347,44 @@ PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, f
   const bool is = joint && (g.mode_ext & 1);
   const int cmin = (g.count1_0 > g.count1_1) ? g.count1_1 : g.count1_0;   // P:1920 (H2)
   const int kind0 = g.kind(0), kind1 = g.kind(1);
-  float x0[9], x1[9];
+  float x0[NI], x1[NI];
 #define PD_LINE(i) (lane + 64 * (i))
   {
-    unsigned e0[9], e1[9];
-    PD_UNROLL for (int i = 0; i < 9; i++) e0[i] = L.ltab[kind0][PD_LINE(i)];
-    PD_UNROLL for (int i = 0; i < 9; i++) e1[i] = L.ltab[kind1][PD_LINE(i)];
-    int v0[9], v1[9];
-    float s0[9], s1[9];
-    PD_UNROLL for (int i = 0; i < 9; i++) { v0[i] = L.spec[0][e0[i] & 1023]; s0[i] = L.scale[0][e0[i] >> 10]; }
-    PD_UNROLL for (int i = 0; i < 9; i++) { v1[i] = L.spec[1][e1[i] & 1023]; s1[i] = L.scale[1][e1[i] >> 10]; }
+    unsigned e0[NI], e1[NI];
+    PD_UNROLL for (int i = 0; i < NI; i++) e0[i] = L.ltab[kind0][PD_LINE(i)];
+    PD_UNROLL for (int i = 0; i < NI; i++) e1[i] = L.ltab[kind1][PD_LINE(i)];
+    int v0[NI], v1[NI];
+    float s0[NI], s1[NI];
+    PD_UNROLL for (int i = 0; i < NI; i++) { v0[i] = L.spec[0][e0[i] & 1023]; s0[i] = L.scale[0][e0[i] >> 10]; }
+    PD_UNROLL for (int i = 0; i < NI; i++) { v1[i] = L.spec[1][e1[i] & 1023]; s1[i] = L.scale[1][e1[i] >> 10]; }
     // |is|^(4/3): LDS copy for magnitudes < 128; for the rare larger ones every lane issues an
     // unconditional gather from the full table (index 0 when not needed, i.e. one shared line), all
     // 18 in flight together with the LDS lookups -- no per-value branch, one wait.
-    int a0[9], a1[9];
-    float pg0[9], pg1[9], ps0[9], ps1[9];
-    PD_UNROLL for (int i = 0; i < 9; i++) { a0[i] = v0[i] < 0 ? -v0[i] : v0[i]; a1[i] = v1[i] < 0 ? -v1[i] : v1[i]; }
-    PD_UNROLL for (int i = 0; i < 9; i++) {
+    int a0[NI], a1[NI];
+    float pg0[NI], pg1[NI], ps0[NI], ps1[NI];
+    PD_UNROLL for (int i = 0; i < NI; i++) { a0[i] = v0[i] < 0 ? -v0[i] : v0[i]; a1[i] = v1[i] < 0 ? -v1[i] : v1[i]; }
+    PD_UNROLL for (int i = 0; i < NI; i++) {
       pg0[i] = T.pow43[a0[i] >= kPow43Small ? (a0[i] > 8206 ? 8206 : a0[i]) : 0];
       pg1[i] = T.pow43[a1[i] >= kPow43Small ? (a1[i] > 8206 ? 8206 : a1[i]) : 0];
     }
-    PD_UNROLL for (int i = 0; i < 9; i++) { ps0[i] = L.pow43s[a0[i] & (kPow43Small - 1)]; ps1[i] = L.pow43s[a1[i] & (kPow43Small - 1)]; }
-    PD_UNROLL for (int i = 0; i < 9; i++) {
+    PD_UNROLL for (int i = 0; i < NI; i++) { ps0[i] = L.pow43s[a0[i] & (kPow43Small - 1)]; ps1[i] = L.pow43s[a1[i] & (kPow43Small - 1)]; }
+    PD_UNROLL for (int i = 0; i < NI; i++) {
       const float p = a0[i] >= kPow43Small ? pg0[i] : ps0[i];
       x0[i] = s0[i] * (v0[i] < 0 ? -p : p);                 // (t1*t2)*t3, P:2132
     }
-    PD_UNROLL for (int i = 0; i < 9; i++) {
+    PD_UNROLL for (int i = 0; i < NI; i++) {
       const float p = a1[i] >= kPow43Small ? pg1[i] : ps1[i];
       x1[i] = (g.nch == 2) ? s1[i] * (v1[i] < 0 ? -p : p) : 0.0f;
     }
   }
   if (DUMP) {
-    PD_UNROLL for (int i = 0; i < 9; i++) {
+    PD_UNROLL for (int i = 0; i < NI; i++) {
       dump0[PD_LINE(i)] = x0[i];
       if (g.nch == 2) dump0[4 * 576 + PD_LINE(i)] = x1[i];
     }
   }
   if (ms) {   // P:1921-1928
-    PD_UNROLL for (int i = 0; i < 9; i++) {
+    PD_UNROLL for (int i = 0; i < NI; i++) {
       const float sum = x0[i] + x1[i], dif = x0[i] - x1[i];
       const float l = (float)((double)sum * 0.70710678118654752440);
       const float r = (float)((double)dif * 0.70710678118654752440);
@@ -395,10 +396,10 @@ PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, f
   if (is) {   // P:1932-1971; block shape taken from channel 0.  Rare (no common encoder emits it).
     const uint8_t* sd0 = L.side[0];
     const int c1 = g.count1_1;
-    PD_NOUNROLL for (int i = 0; i < 9; i++) {
+    PD_NOUNROLL for (int i = 0; i < NI; i++) {
       const int d = PD_LINE(i);
       float a0 = 0.0f, a1 = 0.0f;
-      PD_UNROLL for (int k = 0; k < 9; k++) if (k == i) { a0 = x0[k]; a1 = x1[k]; }
+      PD_UNROLL for (int k = 0; k < NI; k++) if (k == i) { a0 = x0[k]; a1 = x1[k]; }
       bool do_long = false, do_short = false;
       int sfb = 0, win = 0;
       if (kind0 == 0) {
@@ -433,15 +434,15 @@ PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, f
           a0 = vv; a1 = vv;
         }
       }
-      PD_UNROLL for (int k = 0; k < 9; k++) if (k == i) { x0[k] = a0; x1[k] = a1; }
+      PD_UNROLL for (int k = 0; k < NI; k++) if (k == i) { x0[k] = a0; x1[k] = a1; }
     }
   }
-  PD_UNROLL for (int i = 0; i < 9; i++) {
+  PD_UNROLL for (int i = 0; i < NI; i++) {
     L.xr[0][PD_LINE(i)] = x0[i];
     if (g.nch == 2) L.xr[1][PD_LINE(i)] = x1[i];
   }
   if (DUMP) {
-    PD_UNROLL for (int i = 0; i < 9; i++) {
+    PD_UNROLL for (int i = 0; i < NI; i++) {
       dump1[PD_LINE(i)] = x0[i];
       if (g.nch == 2) dump1[4 * 576 + PD_LINE(i)] = x1[i];
     }
@@ -579,10 +580,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 PD_FN f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // alias reduction in place (P:1706-1732): lane (ch, sb) owns the boundary below subband sb
-PD_FN void ph_antialias(int lane, WaveLds& L, BankPtr cb) {
+PD_FN void ph_antialias(int lane, WaveLds& L, BankPtr cb, bool only_first = false) {   // only_first: boundary sb 0 | 1 alone
   const GranuleInfo g = granule_info(L);
   const int ch = lane >> 5, sb = lane & 31;
   if (ch >= g.nch || sb == 0) return;
+  if (only_first && sb != 1) return;
   const bool shrt = g.is_short(ch), mixed = g.is_mixed(ch);
   if (shrt && !(mixed && sb == 1)) return;
   float* x = L.xr[ch];
@@ -598,6 +600,23 @@ PD_FN void ph_antialias(int lane, WaveLds& L, BankPtr cb) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
   __builtin_amdgcn_wave_barrier();                          \
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
+
+// The peek-only halo granule (run_chunk): all that is wanted from it are the three IMDCT tail values p = 18, 19, 20 of
+// (channel 0, subband 0) -- the overlap that the next granule's hybrid output (ch 0, sb 0, t 0..2) adds, which is what the
+// H5 scalefactor peek of the granule after that reads.  Lanes 0..2 = j: an 18-term dot product against column 18 + j of
+// the same matrices the MFMA path uses (fragment layout: element (k, n) of column tile nt sits at [(k / 4) * 2 + nt][(k % 4) * 16 + n]),
+// windowed like the epilogue of ph_mfma, left in the lane's overlap register of (ch 0, h 0, r 0).
+PD_FN void ph_peek_tail(int lane, const WaveLds& L, LaneRegs& R, const GlobalTables& T) {
+  if (lane >= 3) return;
+  const GranuleInfo g = granule_info(L);
+  const bool shrt = g.is_short(0);
+  const bool lowrow = (g.flags(0) & PDMP3_GC_WIN_SWITCH) && g.is_mixed(0);     // subbands 0, 1 of a mixed block: long transform, window 0
+  const float* frag = (shrt && !lowrow) ? T.frag_short : T.frag_long;
+  float y = 0.0f;
+  PD_UNROLL for (int m = 0; m < 18; m++) y = PD_FMA(L.xr[0][m], frag[((m >> 2) * 2 + 1) * 64 + (m & 3) * 16 + lane], y);
+  if (!(shrt && !lowrow)) y = y * L.win[lowrow ? 0 : g.block_type(0)][18 + lane];
+  R.ovl[0] = y;
+}
 
 template <bool DUMP>
 PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTables& T, float* dump2, float* dump3,
@@ -912,11 +931,17 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   if (f1 > a.n_frames) f1 = a.n_frames;
   const int g_begin = 2 * f0, g_end = 2 * f1;
   int g_start = 0;
+  // the third halo granule is there for ONE thing, the H5 peek two granules later: it is decoded "peek-only"
+  // (26 lines, one subband, three IMDCT outputs; ph_peek_tail) unless it is also granule 0 of the batch, whose
+  // state is the caller's
+  int g_peek = -1;
+  (void)g_peek;              // (host test build: every halo granule is decoded in full)
   if (g_begin > 0) {
     // channel 1 of the granule just before the chunk: flags byte of its side record (wave-uniform)
     const uint8_t fl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(g_begin - 1) * 2 + 1)[3];
     const bool shrt = (fl & PDMP3_GC_WIN_SWITCH) && ((fl & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
     g_start = g_begin - (shrt ? kHaloGranulesH5 : kHaloGranules);
+    if (shrt && g_start > 0) g_peek = g_start;
     if (g_start < 0) g_start = 0;
   }
   const bool last = (f1 == a.n_frames);
@@ -942,6 +967,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
         if (((sb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3) {     // (a mono RESET frame: zero, nothing to do)
           pre_end = 2 * fs + 2;
           npre = (fs > 0 && !(sb & PDMP3_FR_RESET)) ? 3 : 2;
+          if (npre == 3 && pre_end - 3 > 0) g_peek = pre_end - 3;
           if (pre_end >= g_start) { g_start = pre_end - npre; g_keep = pre_end - 1; npre = 0; pre_end = 0; }   // touches the ordinary halo: one run
         }
       }
@@ -990,19 +1016,33 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     )
     PD_TICK(1)
     float* dmp = DUMP ? a.stages + ((size_t)f * 16 + gr * 8) * 576 : nullptr;
-    PD_PHASE(ph_requant<DUMP>(lane, L, cb, T, dmp, dmp + 576))
-    PD_TICK(2)
 #if PD_MFMA
-    PD_PHASE(
-      // the next granule's HBM reads fly during this granule's transforms
-      if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
-      ph_antialias(lane, L, cb);
-    )
-    PD_TICK(3)
-    PD_PHASE(ph_mfma<DUMP>(lane, L, R, cb, T, dmp + 2 * 576, dmp + 3 * 576, emit || feeds_next))
-    PD_TICK(4)
+    if (g == g_peek) {                     // wave-uniform: lines 0..63, boundary sb 0 | 1, three IMDCT outputs
+      PD_PHASE(ph_requant<false, 1>(lane, L, cb, T, nullptr, nullptr))
+      PD_TICK(2)
+      PD_PHASE(
+        if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
+        ph_antialias(lane, L, cb, true);
+      )
+      PD_TICK(3)
+      PD_PHASE(ph_peek_tail(lane, L, R, T))
+      PD_TICK(4)
+    } else {
+      PD_PHASE(ph_requant<DUMP>(lane, L, cb, T, dmp, dmp + 576))
+      PD_TICK(2)
+      PD_PHASE(
+        // the next granule's HBM reads fly during this granule's transforms
+        if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
+        ph_antialias(lane, L, cb);
+      )
+      PD_TICK(3)
+      PD_PHASE(ph_mfma<DUMP>(lane, L, R, cb, T, dmp + 2 * 576, dmp + 3 * 576, emit || feeds_next))
+      PD_TICK(4)
+    }
     PD_TICK(5)
 #else
+    PD_PHASE(ph_requant<DUMP>(lane, L, cb, T, dmp, dmp + 576))
+    PD_TICK(2)
     PD_PHASE(
       // the next granule's HBM reads fly during this granule's transforms
       if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
