@@ -975,10 +975,14 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   }
   const int g_first = npre ? pre_end - npre : g_start;
   const bool from_stream_start = (g_first == 0);     // exact state: the caller's (or zero), no halo needed
-  int cur_sfreq = -1;
+  // the line tables of the first granule's sampling rate are fetched together with its spectra (one memory round
+  // trip instead of two before the first granule can start)
+  int cur_sfreq = reinterpret_cast<const uint8_t*>(a.side + (size_t)g_first * 2)[7] & PDMP3_FR_SFREQ_MASK;
+  if (cur_sfreq > 2) cur_sfreq = 2;
 
   PD_PHASE(
     ph_prefetch(lane, R, a.spectra + (size_t)g_first * 1152, a.side + (size_t)g_first * 2);
+    load_linetab(lane, L, T, cur_sfreq);
     lane_init(lane, L, R, cb, T);
     if (a.state_in) {
       if (from_stream_start) state_load(lane, R, a.state_in);
