@@ -137,6 +137,7 @@ __global__ __launch_bounds__(64) void k_merge(const GcRaw* raw, const pdmp3_fram
 
 struct pdmp3_hip_ctx {
   int device;
+  int wave_slots;           // waves of k_decode the device holds at once (CUs x 4 SIMDs x 2)
   UnpackTables* d_unpack;
   float* d_pow43;
   uint16_t* d_linetab;
@@ -170,6 +171,11 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
   pdmp3_hip_ctx* c = (pdmp3_hip_ctx*)calloc(1, sizeof *c);
   if (!c) return fail(PDMP3_HIP_ENOMEM, "calloc", hipSuccess);
   c->device = device;
+  {
+    hipDeviceProp_t prop;
+    c->wave_slots = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                        ? prop.multiProcessorCount * 4 * PDMP3_WAVES_PER_EU : 2048;
+  }
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_bank), &H.cb, sizeof(ConstBank)), "upload const bank");
   if (!H.ldexp_forms_exact) {
     free(c);
@@ -210,15 +216,18 @@ extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   free(c);
 }
 
-static int auto_chunk(int n_frames) {
-  // One wave per chunk: aim for >= 1024 chunks (4 waves on each of the 256 CUs)
-  // before growing the chunk; measured on MI355X (profiles/): a 2048-frame batch
-  // is fastest at 2 frames per chunk despite the 3-granule halo, 10^5+ frames
-  // at 16-32.
-  int L = n_frames / 2048;
-  if (L < 1) L = 1;
-  if (L > 32) L = 32;
-  return L;
+// Frames per chunk (= per wave).  The kernel holds 2 waves per SIMD, so a launch runs in rounds of `slots` waves
+// (2048 on MI355X: 256 CUs x 4 SIMDs x 2); a partly filled last round costs as much as a full one (measured: 131072
+// frames at 48 frames per chunk = 1.33 rounds take 20 % longer than at 32 or 64).  So: the fewest rounds that keep a
+// chunk at <= 32 frames (halo overhead 2-3 granules per chunk), and the chunk size that spreads the frames evenly
+// over them.  Up to one round of frames: one frame per chunk (measured fastest for the 2048-frame batch).
+static int auto_chunk(int n_frames, int slots) {
+  if (slots < 64) slots = 2048;
+  if (n_frames <= slots) return 1;
+  const long long per_round_max = (long long)slots * 32;
+  const long long rounds = (n_frames + per_round_max - 1) / per_round_max;
+  const long long L = (n_frames + slots * rounds - 1) / (slots * rounds);
+  return (int)(L < 1 ? 1 : L);
 }
 
 // d_state_tmp: where the kernel leaves the new state before it is copied over d_state (chunk 0 and the channel-1
@@ -235,7 +244,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: buffers must be 16-byte aligned", hipSuccess);
   if (n_frames == 0) return PDMP3_HIP_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (chunk_frames <= 0) chunk_frames = auto_chunk(n_frames);
+  if (chunk_frames <= 0) chunk_frames = auto_chunk(n_frames, c->wave_slots);
   if (d_stages || chunk_frames > n_frames) chunk_frames = n_frames;
   const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
   DecodeArgs a;
