@@ -159,3 +159,20 @@ def test_device_unpack_builds_the_host_stage_records(engine, streams):
     finally:
         host.close()
         lib.pdmp3_hip_stream_destroy(hs)
+
+
+def test_bulk_decoder_on_named_device(oracle):
+    """pdmp3_amd_bulk_new_on: the decoder's engine context is per HIP device (device 0 here; a multi-GPU corpus run
+    gives each host thread a decoder on its own GPU, tools/bulk_bench.py --c4 N --gpus G)"""
+    from pdmp3_amd import api
+    mp3 = packer.generate(n_frames=80, seed=91, bitrate_index=11)
+    want = np.frombuffer(oracle.decode_buffer_like_cli(mp3), dtype=np.int16)
+    b = api.BulkDecoder(threads=2, window_frames=32, device=0)
+    try:
+        got = b.decode(mp3)
+    finally:
+        b.close()
+    assert got.shape == want.shape
+    assert_pcm_close(got, want, 1, "device 0")
+    with pytest.raises(RuntimeError):
+        api.BulkDecoder(threads=1, device=99)        # no such device: fails loudly, no fallback
