@@ -844,7 +844,6 @@ int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) 
 #define BULK_SLOTS 3
 #include <time.h>
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
-static double g_t_submit, g_t_gpuwait, g_t_poolwait;   /* PDMP3_BULK_TRACE=1: where the scanning thread waits */
 #define PDMP3_BULK_REPLAY (-2)         /* see bulk_drive */
 #define BULK_GRAB 8                   /* frames a worker takes per trip to the counter */
 #define BULK_COPY_PIECE ((size_t)256 << 10)
@@ -909,6 +908,7 @@ struct bulk {
   pthread_cond_t sub_cv, sub_done_cv;
   int sub_slot[8], sub_n[8];
   long long sub_head, sub_tail;       /* jobs enqueued / completed */
+  double t_submit, t_gpuwait, t_poolwait;   /* PDMP3_BULK_TRACE=1: where the scanning thread waits */
 };
 
 static void* bulk_worker(void* arg) {
@@ -962,7 +962,7 @@ static void bulk_wait_b(struct bulk* b) {
   pthread_mutex_lock(&b->mu);
   while (b->active) pthread_cond_wait(&b->cv_done, &b->mu);
   pthread_mutex_unlock(&b->mu);
-  g_t_poolwait += now_s() - t0;
+  b->t_poolwait += now_s() - t0;
   b->busy = 0;
 }
 
@@ -974,7 +974,7 @@ static int bulk_collect(struct bulk* b, int slot, const unsigned char** jsrc, un
   if (!f->active) return PDMP3_OK;
   const double t0 = now_s();
   const int wrc = pdmp3_hip_stream_wait(b->hs, slot);
-  g_t_gpuwait += now_s() - t0;
+  b->t_gpuwait += now_s() - t0;
   if (wrc != PDMP3_HIP_OK) return PDMP3_ERR;
   f->active = 0;
   const unsigned char* src = (const unsigned char*)pdmp3_hip_stream_slot_pcm(b->hs, slot);
@@ -1151,7 +1151,7 @@ static int bits_close_window(struct bulk* b) {
     }
     const double t0 = now_s();
     sub_enqueue(b, b->bits_slot, b->bits_n);
-    g_t_submit += now_s() - t0;
+    b->t_submit += now_s() - t0;
     f->active = 1;
   }
   b->windows++;
@@ -1381,8 +1381,8 @@ long long pdmp3_amd_bulk_decode(struct bulk* b, const unsigned char* mp3, size_t
   if (rate) *rate = (long)kSampleRates[b->id->hdr.sfreq];
   if (channels) *channels = b->id->hdr.mode == 3 ? 1 : 2;
   if (getenv("PDMP3_BULK_TRACE")) {
-    fprintf(stderr, "bulk trace: submit %.2f ms, gpu wait %.2f ms, pool wait %.2f ms (cumulative)\n", g_t_submit * 1e3,
-            g_t_gpuwait * 1e3, g_t_poolwait * 1e3);
+    fprintf(stderr, "bulk trace: submit %.2f ms, gpu wait %.2f ms, pool wait %.2f ms (cumulative)\n", b->t_submit * 1e3,
+            b->t_gpuwait * 1e3, b->t_poolwait * 1e3);
   }
   if (total == PDMP3_BULK_REPLAY) return PDMP3_BULK_REPLAY;
   return ok ? total : -1;
