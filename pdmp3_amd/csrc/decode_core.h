@@ -854,16 +854,23 @@ PD_FN void ph_store(int lane, WaveLds& L, int nch, int16_t* pcm_g, bool emit) {
 // Highest frame in [f_lo, f_hi) that has two channels or carries the RESET flag, or -1.  Wave-uniform.
 PD_FN int last_stereo_or_reset(const pdmp3_gc_side* side, int f_lo, int f_hi) {
 #if defined(__HIPCC__)
+  // 256 frames per step: four independent byte loads per lane in flight (a step costs one memory round trip; an
+  // all-mono batch makes its last chunk walk the whole batch, so the steps had better be few)
   const int lane = threadIdx.x & 63;
-  for (int base = f_hi - 64;; base -= 64) {
-    const int f = base + lane;
-    bool hit = false;
-    if (f >= f_lo && f < f_hi) {
-      const uint8_t b = reinterpret_cast<const uint8_t*>(side + (size_t)f * 4)[7];
-      hit = ((b & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 || (b & PDMP3_FR_RESET);
+  for (int base = f_hi - 256;; base -= 256) {
+    bool hit[4];
+    PD_UNROLL for (int q = 0; q < 4; q++) {
+      const int f = base + 64 * q + lane;
+      hit[q] = false;
+      if (f >= f_lo && f < f_hi) {
+        const uint8_t b = reinterpret_cast<const uint8_t*>(side + (size_t)f * 4)[7];
+        hit[q] = ((b & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 || (b & PDMP3_FR_RESET);
+      }
     }
-    const unsigned long long m = __ballot(hit);
-    if (m) return base + 63 - __builtin_clzll(m);
+    PD_UNROLL for (int q = 3; q >= 0; q--) {
+      const unsigned long long m = __ballot(hit[q]);
+      if (m) return base + 64 * q + 63 - __builtin_clzll(m);
+    }
     if (base <= f_lo) return -1;
   }
 #else
@@ -959,7 +966,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   if (g_start > 0) {
     const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f0 - 1) * 4)[7];
     const bool prev_mono = ((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 && !(fb & PDMP3_FR_RESET);
-    if (prev_mono && (last || last_stereo_or_reset(a.side, f0, f1) >= 0)) {
+    if (prev_mono && ((last && a.state_out) || last_stereo_or_reset(a.side, f0, f1) >= 0)) {
       const int fs = last_stereo_or_reset(a.side, 0, f0 - 1);
       if (fs < 0) ch1_from_state = true;
       else {
