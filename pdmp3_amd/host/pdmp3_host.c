@@ -865,7 +865,7 @@ typedef struct {
 } bulk_window;
 
 typedef struct {                      /* a window that is on the GPU */
-  int n, active, all_stereo;
+  int n, active, all_stereo;          /* all_stereo: 2 = every frame stereo, 1 = every frame mono, 0 = mixed */
   size_t pcm_off;
   uint8_t* nch;
 } bulk_flight;
@@ -889,7 +889,7 @@ struct bulk {
   pthread_mutex_t mu;
   pthread_cond_t cv_work, cv_done;
   bulk_window* work;
-  const unsigned char* copy_src; unsigned char* copy_dst; size_t copy_bytes, copy_next;
+  const unsigned char* copy_src; unsigned char* copy_dst; size_t copy_bytes, copy_next, copy_row;
   long long gen;
   int next, active, quit;
   /* sinks: the engine (hs) or caller memory (parse only, host tests) */
@@ -908,6 +908,7 @@ struct bulk {
   pthread_cond_t sub_cv, sub_done_cv;
   int sub_slot[8], sub_n[8];
   long long sub_head, sub_tail;       /* jobs enqueued / completed */
+  size_t next_copy_row;               /* row size of the copy job bulk_collect last handed out */
   double t_submit, t_gpuwait, t_poolwait;   /* PDMP3_BULK_TRACE=1: where the scanning thread waits */
 };
 
@@ -922,7 +923,7 @@ static void* bulk_worker(void* arg) {
     bulk_window* w = b->work;
     const unsigned char* csrc = b->copy_src;
     unsigned char* cdst = b->copy_dst;
-    const size_t cbytes = b->copy_bytes;
+    const size_t cbytes = b->copy_bytes, crow = b->copy_row;
     pthread_mutex_unlock(&b->mu);
     while (w) {
       const int i0 = __atomic_fetch_add(&b->next, BULK_GRAB, __ATOMIC_RELAXED);
@@ -937,7 +938,16 @@ static void* bulk_worker(void* arg) {
     for (;;) {                                     /* PCM of an older window: pinned slot -> caller memory */
       const size_t c0 = __atomic_fetch_add(&b->copy_next, BULK_COPY_PIECE, __ATOMIC_RELAXED);
       if (c0 >= cbytes) break;
-      memcpy(cdst + c0, csrc + c0, cbytes - c0 < BULK_COPY_PIECE ? cbytes - c0 : BULK_COPY_PIECE);
+      const size_t c1 = cbytes - c0 < BULK_COPY_PIECE ? cbytes : c0 + BULK_COPY_PIECE;
+      if (crow == 4608) memcpy(cdst + c0, csrc + c0, c1 - c0);
+      else {                                       /* mono: 2304-byte frames out of 4608-byte slots */
+        for (size_t off = c0; off < c1;) {
+          const size_t r = off / 2304, w = off % 2304;
+          const size_t n = 2304 - w < c1 - off ? 2304 - w : c1 - off;
+          memcpy(cdst + off, csrc + r * 4608 + w, n);
+          off += n;
+        }
+      }
     }
     pthread_mutex_lock(&b->mu);
     if (--b->active == 0) pthread_cond_signal(&b->cv_done);
@@ -949,7 +959,7 @@ static void* bulk_worker(void* arg) {
 static void bulk_start_b(struct bulk* b, bulk_window* w, const unsigned char* src, unsigned char* dst, size_t nbytes) {
   pthread_mutex_lock(&b->mu);
   b->work = w; b->next = 0;
-  b->copy_src = src; b->copy_dst = dst; b->copy_bytes = nbytes; b->copy_next = 0;
+  b->copy_src = src; b->copy_dst = dst; b->copy_bytes = nbytes; b->copy_next = 0; b->copy_row = b->next_copy_row;
   b->active = b->nth; b->gen++;
   pthread_cond_broadcast(&b->cv_work);
   pthread_mutex_unlock(&b->mu);
@@ -979,11 +989,12 @@ static int bulk_collect(struct bulk* b, int slot, const unsigned char** jsrc, un
   f->active = 0;
   const unsigned char* src = (const unsigned char*)pdmp3_hip_stream_slot_pcm(b->hs, slot);
   size_t off = f->pcm_off;
-  if (f->all_stereo) {
-    size_t n = (size_t)f->n * 4608;
+  if (f->all_stereo == 2 || (f->all_stereo == 1 && jbytes)) {
+    const size_t row = f->all_stereo == 2 ? 4608 : 2304;
+    size_t n = (size_t)f->n * row;
     if (off >= b->pcm_cap) return PDMP3_OK;
     if (n > b->pcm_cap - off) n = b->pcm_cap - off;
-    if (jbytes) { *jsrc = src; *jdst = b->pcm + off; *jbytes = n; }
+    if (jbytes) { *jsrc = src; *jdst = b->pcm + off; *jbytes = n; b->next_copy_row = row; }
     else memcpy(b->pcm + off, src, n);
     return PDMP3_OK;
   }
@@ -1003,13 +1014,13 @@ static int bulk_finish_b(struct bulk* b) {
   b->in_b = NULL;
   pdmp3_handle* id = b->id;
   bulk_flight* f = b->hs ? &b->flight[w->slot] : NULL;
-  if (f) { f->pcm_off = b->pcm_emitted; f->n = w->n; f->all_stereo = 1; }
+  if (f) { f->pcm_off = b->pcm_emitted; f->n = w->n; f->all_stereo = -1; }
   for (int i = 0; i < w->n; i++) {
     const frame_job* j = &w->jobs[i];
     apply_main(id, &j->hdr, &w->outs[i]);
     emit_records(id, &j->hdr, &j->si, j->reset, w->spectra + (size_t)i * 2304, w->side + (size_t)i * 4);
     const unsigned nch = j->hdr.mode == 3 ? 1 : 2;
-    if (f) { f->nch[i] = (uint8_t)nch; if (nch != 2) f->all_stereo = 0; }
+    if (f) { f->nch[i] = (uint8_t)nch; f->all_stereo = f->all_stereo < 0 ? (int)nch : (f->all_stereo == (int)nch ? f->all_stereo : 0); }
     b->pcm_emitted += 2304u * nch;
   }
   if (f) {
@@ -1144,9 +1155,9 @@ static int bits_close_window(struct bulk* b) {
     bulk_flight* f = &b->flight[b->bits_slot];
     f->n = b->bits_n;
     f->pcm_off = b->pcm_emitted;
-    f->all_stereo = 1;
+    f->all_stereo = f->nch[0];
     for (int i = 0; i < f->n; i++) {
-      if (f->nch[i] != 2) f->all_stereo = 0;
+      if (f->nch[i] != f->nch[0]) f->all_stereo = 0;
       b->pcm_emitted += 2304u * f->nch[i];
     }
     const double t0 = now_s();
