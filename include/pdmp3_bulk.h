@@ -70,6 +70,16 @@ long long pdmp3_amd_scan_buffer(const unsigned char* mp3, size_t n, long long* f
 long long pdmp3_amd_bulk_decode(pdmp3_amd_bulk* b, const unsigned char* mp3, size_t n,
                                 unsigned char* pcm, size_t pcm_cap, long* rate, int* channels);
 
+/* The same without waiting for the tail: returns as soon as the stream is scanned and its windows are queued on
+ * the device (`mp3` may be released then, `pcm` must stay); the PCM of every stream given so far is complete after
+ * pdmp3_amd_bulk_wait() returns 0.  The next stream's scan overlaps the previous one's GPU work and copy-out, so a
+ * corpus of medium-sized files runs at the long-stream rate instead of paying a pipeline fill and drain per file.
+ * Each stream starts from a fresh decoder state, exactly as with pdmp3_amd_bulk_decode (PDMP3_FR_RESET /
+ * PDMP3_FR_NEWSTREAM on its first frame; nothing is reset from the host).  Host-Huffman decoders simply wait. */
+long long pdmp3_amd_bulk_decode_async(pdmp3_amd_bulk* b, const unsigned char* mp3, size_t n,
+                                      unsigned char* pcm, size_t pcm_cap, long* rate, int* channels);
+int pdmp3_amd_bulk_wait(pdmp3_amd_bulk* b);
+
 /* Host stages only, for tests on machines without a GPU: a decoder made by
  * pdmp3_amd_bulk_new_parse_only() writes the gc records the engine would be
  * given into caller memory (cap_frames frames of 2304 int16 / 4 records).

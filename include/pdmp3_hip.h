@@ -219,8 +219,14 @@ typedef struct pdmp3_gc_bits {              /* side info of one granule-channel,
   uint8_t  count1table_select;              /* P:90 */
 } pdmp3_gc_bits;                            /* 16 bytes */
 
+/* pdmp3_frame_bits.frame only: the parse state that survives frames (scalefactors, count1: SURVEY H4-H6) is zero
+ * before this frame -- what a freshly allocated handle of the reference starts with.  Lets several independent
+ * streams follow each other through one pdmp3_hip_stream without a host-side reset in between (the synthesis
+ * state has PDMP3_FR_RESET for that).  Not copied into the gc records. */
+#define PDMP3_FR_NEWSTREAM       0x80u
+
 typedef struct pdmp3_frame_bits {
-  uint8_t  frame;                           /* PDMP3_FR_* */
+  uint8_t  frame;                           /* PDMP3_FR_* (+ PDMP3_FR_NEWSTREAM) */
   uint8_t  scfsi[2];                        /* [ch]: bit b = band group b reuses granule 0, P:73 */
   uint8_t  reserved[13];
   pdmp3_gc_bits gc[4];                      /* [gr][ch] */

@@ -14,7 +14,7 @@ PDMP3_ENC_SIGNED_16 = 0xD0
 _LIB = None
 
 BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads",
-                "pdmp3_amd_scan_buffer", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
+                "pdmp3_amd_scan_buffer", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_decode_async", "pdmp3_amd_bulk_wait", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
                 "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits"]
 
 # include/pdmp3_hip.h: pdmp3_gc_bits / pdmp3_frame_bits
@@ -72,6 +72,9 @@ def load_library():
     lib.pdmp3_amd_bulk_new_parse_bits.argtypes = []
     lib.pdmp3_amd_bulk_parse_bits.restype = C.c_longlong
     lib.pdmp3_amd_bulk_parse_bits.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_longlong)]
+    lib.pdmp3_amd_bulk_decode_async.restype = C.c_longlong
+    lib.pdmp3_amd_bulk_decode_async.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_int)]
+    lib.pdmp3_amd_bulk_wait.argtypes = [vp]
     lib.pdmp3_amd_bulk_parse.restype = C.c_longlong
     lib.pdmp3_amd_bulk_parse.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_longlong)]
     _LIB = lib
@@ -233,6 +236,35 @@ class BulkDecoder:
         if total < 0:
             raise RuntimeError("pdmp3_amd_bulk_decode: engine failure")
         return total, rate.value, ch.value
+
+    def decode_into_async(self, mp3, out: np.ndarray):
+        """queue one stream; `out` is complete after wait()"""
+        a = _as_u8(mp3)
+        rate, ch = C.c_long(0), C.c_int(0)
+        total = self.lib.pdmp3_amd_bulk_decode_async(self.h, a.ctypes.data_as(C.c_void_p), len(mp3),
+                                                     out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(rate), C.byref(ch))
+        if total == -2:
+            raise RingReplay("the reference replays its input ring on this stream (no finite output)")
+        if total < 0:
+            raise RuntimeError("pdmp3_amd_bulk_decode_async: engine failure")
+        return total, rate.value, ch.value
+
+    def wait(self):
+        if self.lib.pdmp3_amd_bulk_wait(self.h) != 0:
+            raise RuntimeError("pdmp3_amd_bulk_wait: engine failure")
+
+    def decode_many(self, mp3s):
+        """-> list of int16 PCM arrays, one per stream, each exactly the CLI driver's output for its bytes; the
+        streams go through the pipeline back to back (pdmp3_amd_bulk_decode_async)."""
+        outs = []
+        for m in mp3s:
+            total, _ = scan_buffer(m)
+            out = np.empty(max(total, 2) // 2, dtype=np.int16)
+            got, _, _ = self.decode_into_async(m, out)
+            assert got == total, (got, total)
+            outs.append(out[:total // 2])
+        self.wait()
+        return outs
 
     def decode(self, mp3):
         """-> interleaved int16 PCM (numpy), exactly the CLI driver's output for these bytes."""

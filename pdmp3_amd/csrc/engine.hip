@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void k_merge(const GcRaw* raw, const pdmp3_fram
     const int f = base + lane;
     const bool valid = f < n_frames;
     MergeIn m{false, false, false, 0, 0};
-    if (valid) m = merge_load(t, raw + (size_t)f * 4);
+    if (valid) m = merge_load(t, raw + (size_t)f * 4, (bits[f].frame & PDMP3_FR_NEWSTREAM) != 0);
     unsigned v0 = 0;
     if (tw >= 0) {                                   // wave-uniform
       v0 = scan_last(m.set0, m.val0, carry0, lane);

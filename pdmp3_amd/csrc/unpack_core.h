@@ -197,7 +197,7 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
     uint32_t* w32 = reinterpret_cast<uint32_t*>(raw);
     for (int i = 0; i < 20; i++) w32[i] = 0;
   }
-  rec->frame = F.frame;
+  rec->frame = F.frame & (uint8_t)~PDMP3_FR_NEWSTREAM;
   if (ch >= nch) return;
   const pdmp3_gc_bits& s = F.gc[g];
   rec->global_gain = s.global_gain;
@@ -321,29 +321,34 @@ struct MergeIn {
   unsigned val, val0;
 };
 
-PD_HD MergeIn merge_load(int t, const GcRaw* raw_f /* raw + f * 4 */) {
+PD_HD MergeIn merge_load(int t, const GcRaw* raw_f /* raw + f * 4 */, bool newstream = false) {
   MergeIn m{false, false, false, 0, 0};
+  if (newstream) { m.set = true; m.set0 = true; }   // PDMP3_FR_NEWSTREAM: the old value is gone -- 0 unless this frame writes one
   if (t < 84) {
     const int g = t / 21, sfb = t - 21 * g;
     const GcRaw& r = raw_f[g];
-    m.set = (r.sf_l_set >> sfb & 1) != 0;
-    m.val = r.sf_l[sfb];
+    const bool w = (r.sf_l_set >> sfb & 1) != 0;
+    m.val = w ? r.sf_l[sfb] : 0;
+    m.set = m.set || w;
     if (g >= 2) {
       const int grp = sfb < 6 ? 0 : sfb < 11 ? 1 : sfb < 16 ? 2 : 3;
       const GcRaw& r0 = raw_f[g & 1];
-      m.set0 = (r0.sf_l_set >> sfb & 1) != 0;
-      m.val0 = r0.sf_l[sfb];
+      const bool w0 = (r0.sf_l_set >> sfb & 1) != 0;
+      m.val0 = w0 ? r0.sf_l[sfb] : 0;
+      m.set0 = m.set0 || w0;
       m.copy = (r.sf_l_copy >> grp & 1) != 0;
     }
   } else if (t < 228) {
     const int u = t - 84, g = u / 36, k = u - 36 * g;
     const GcRaw& r = raw_f[g];
-    m.set = (r.sf_s_set >> (k / 3) & 1) != 0;
-    m.val = r.sf_s[k];
+    const bool w = (r.sf_s_set >> (k / 3) & 1) != 0;
+    m.val = w ? r.sf_s[k] : 0;
+    m.set = m.set || w;
   } else {
     const GcRaw& r = raw_f[t - 228];
-    m.set = r.count1_set != 0;
-    m.val = r.count1;
+    const bool w = r.count1_set != 0;
+    m.val = w ? r.count1 : 0;
+    m.set = m.set || w;
   }
   return m;
 }
@@ -373,7 +378,7 @@ PD_HD void merge_slot(int t, const GcRaw* raw, const pdmp3_frame_bits* F, int n,
   const int tw = merge_twin(t);
   unsigned val = state_in[t], val0 = tw >= 0 ? state_in[tw] : 0;
   for (int f = 0; f < n; f++) {
-    const MergeIn m = merge_load(t, raw + (size_t)f * 4);
+    const MergeIn m = merge_load(t, raw + (size_t)f * 4, (F[f].frame & PDMP3_FR_NEWSTREAM) != 0);
     if (m.set0) val0 = m.val0;
     if (m.set) val = m.val;
     if (m.copy) val = val0;

@@ -176,3 +176,26 @@ def test_bulk_decoder_on_named_device(oracle):
     assert_pcm_close(got, want, 1, "device 0")
     with pytest.raises(RuntimeError):
         api.BulkDecoder(threads=1, device=99)        # no such device: fails loudly, no fallback
+
+
+@pytest.mark.parametrize("window", [2048, 16])
+def test_streams_back_to_back_without_draining(oracle, streams, window):
+    """pdmp3_amd_bulk_decode_async: streams follow each other through the pipeline with no host-side reset between
+    them (PDMP3_FR_RESET / PDMP3_FR_NEWSTREAM on each first frame): every one must come out as if decoded alone --
+    also mono after stereo, different sampling rates, empty streams in between"""
+    from pdmp3_amd import api
+    names = list(streams)
+    order = names + names[::-1]
+    b = api.BulkDecoder(threads=3, window_frames=window)
+    alone = api.BulkDecoder(threads=2, window_frames=64)
+    try:
+        got = b.decode_many([streams[k] for k in order])
+        for k, g in zip(order, got):
+            want = np.frombuffer(oracle.decode_buffer_like_cli(streams[k]), dtype=np.int16)
+            assert g.shape == want.shape, k
+            if g.size:
+                assert_pcm_close(g, want, 1, k)
+            assert np.array_equal(g, alone.decode(streams[k])), k       # bit-identical to a decoder of its own
+    finally:
+        b.close()
+        alone.close()

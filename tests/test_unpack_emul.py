@@ -110,3 +110,22 @@ def test_unpack_fuzz_matches_host_stage(emul, base):
     finally:
         b.close()
     assert frames > 500
+
+
+def test_newstream_flag_restarts_the_parse_state(emul, streams):
+    """PDMP3_FR_NEWSTREAM on a stream's first frame: streams unpacked back to back in ONE pass, with whatever
+    scalefactor / count1 state the previous one left, come out as if each had been unpacked alone"""
+    from pdmp3_amd import api
+    names = ["short_heavy_dual", "mono_32k_96", "cbr128_js_441", "vbr_48k_stereo_crc_tab33", "stereo_then_mono_then_stereo"]
+    parts = [api.parse_bits(streams[k])[:2] for k in names]
+    for bits, _ in parts:
+        assert bits["frame"][0] & 0x80 and not (bits["frame"][1:] & 0x80).any()
+    alone = [emul_unpack(emul, b, r) for b, r in parts]
+    bits = np.concatenate([b for b, _ in parts])
+    res = np.concatenate([r for _, r in parts])
+    n = bits.shape[0]
+    for cuts in ([0, n], [0, 7, n // 2, n - 3, n]):
+        sp, sd = emul_unpack(emul, bits, res, cuts)
+        assert np.array_equal(sp, np.concatenate([a[0] for a in alone]))
+        assert np.array_equal(sd.view(np.uint8), np.concatenate([a[1] for a in alone]).view(np.uint8))
+    assert not (sd["frame"] & 0x80).any()              # the flag stays out of the gc records

@@ -15,6 +15,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # before HIP starts (torch brings it up): see pdmp3_host.c shared_ctx_on
+
+
 def c4(args, api):
     """files dealt largest-first to JOBS decoders (pdmp3_amd.sharding.assign_files), each on its own host thread
     with its own HIP streams; decoders and output buffers exist before the clock starts"""
@@ -33,9 +36,10 @@ def c4(args, api):
             for j in range(args.c4)]
 
     def work(j):
-        for i in plan[j]:
-            got, _, _ = decs[j].decode_into(files[i], outs[i])
+        for i in plan[j]:                                  # back to back, one wait at the end
+            got, _, _ = decs[j].decode_into_async(files[i], outs[i])
             assert got == sizes[i][0]
+        decs[j].wait()
     best = None
     for _ in range(args.reps + 1):                      # first pass = warm-up
         ts = [threading.Thread(target=work, args=(j,)) for j in range(args.c4)]
