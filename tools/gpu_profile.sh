@@ -21,7 +21,7 @@ cat $OUT/bulk_stats/bulk_kernel_stats.csv | cut -c1-160
 timeout 600 python3 bench.py 2> /dev/null > $OUT/bench.json; echo "bench rc=$?"; cat $OUT/bench.json
 timeout 600 python3 tools/bulk_bench.py --frames 137813 --threads 2 2> /dev/null | tail -1 > $OUT/bulk_decode.json; cat $OUT/bulk_decode.json
 timeout 600 python3 tools/bulk_bench.py --frames 137813 --threads 1,8,16,32 --host-huffman 2> /dev/null | tail -1 > $OUT/bulk_decode_host_huffman.json; cat $OUT/bulk_decode_host_huffman.json
-timeout 600 python3 tools/bulk_bench.py --c4 4 2> /dev/null | tail -1 > $OUT/bulk_c4.json; cat $OUT/bulk_c4.json
+for j in 1 4 6; do timeout 600 python3 tools/bulk_bench.py --c4 $j 2> /dev/null | tail -1; done > $OUT/bulk_c4.json; cat $OUT/bulk_c4.json
 timeout 300 python3 tools/phase_profile.py 131072 32 > $OUT/phase_profile.txt 2>&1; timeout 300 python3 tools/phase_profile.py 2048 1 >> $OUT/phase_profile.txt 2>&1
 # the same for a C5-shard-sized launch
 pmcb() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 tools/pmc_target.py 131072 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
