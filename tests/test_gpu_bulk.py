@@ -199,3 +199,39 @@ def test_streams_back_to_back_without_draining(oracle, streams, window):
     finally:
         b.close()
         alone.close()
+
+
+def test_corrupted_streams_device_equals_host_huffman():
+    """bit flips, byte splats, truncation: whatever a broken stream makes of the host stage, the device-Huffman path
+    (k_unpack / k_merge, rows and lines in LDS) produces the very same PCM -- 120 mutated streams back to back"""
+    from pdmp3_amd import api
+    rs = np.random.RandomState(21)
+    bases = [np.frombuffer(packer.generate(n_frames=90, seed=51, vbr=True, block_pct=(40, 10, 40, 10), mixed_pct=50), dtype=np.uint8),
+             np.frombuffer(packer.generate(n_frames=90, seed=52, sfreq=2, mode=3, bitrate_index=7), dtype=np.uint8),
+             np.frombuffer(packer.generate(n_frames=70, seed=53, mode=1, mode_ext=2, bitrate_index=14, big_pct=200, gain=(100, 140)), dtype=np.uint8)]
+    muts = []
+    for it in range(120):
+        m = bases[it % 3].copy()
+        kind = (it // 3) % 3
+        for p in rs.randint(0, len(m), size=1 + rs.randint(0, 6 if kind == 0 else 150)):
+            m[p] = rs.randint(0, 256) if kind == 2 else m[p] ^ (1 << rs.randint(0, 8))
+        if it % 7 == 6:
+            m = m[:rs.randint(1, len(m))]
+        m = np.ascontiguousarray(m)
+        try:
+            api.scan_buffer(m)
+        except api.RingReplay:
+            continue
+        muts.append(m)
+    dev = api.BulkDecoder(threads=2, window_frames=40)
+    host = api.BulkDecoder(threads=4, window_frames=24, host_huffman=True)
+    try:
+        got = dev.decode_many(muts)
+        frames = 0
+        for m, g in zip(muts, got):
+            assert np.array_equal(g, host.decode(m))
+            frames += g.size // 1152
+    finally:
+        dev.close()
+        host.close()
+    assert len(muts) > 100 and frames > 5000
