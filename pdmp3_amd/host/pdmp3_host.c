@@ -961,7 +961,9 @@ static void* bulk_worker(void* arg) {
 }
 
 /* hand the workers a window to decode (or NULL) and a byte range to copy (or none) */
+static void bulk_wait_b(struct bulk* b);
 static void bulk_start_b(struct bulk* b, bulk_window* w, const unsigned char* src, unsigned char* dst, size_t nbytes) {
+  bulk_wait_b(b);                                 /* one job at a time */
   pthread_mutex_lock(&b->mu);
   b->work = w; b->next = 0;
   b->copy_src = src; b->copy_dst = dst; b->copy_bytes = nbytes; b->copy_next = 0; b->copy_row = b->next_copy_row;

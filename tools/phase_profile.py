@@ -14,6 +14,9 @@ lib = eng.lib
 lib.pdmp3_hip_debug_profile_phases.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
 sp, sd, pcm = eng.alloc_frames(n)
 eng.generate(0x5EED0000C5, 0, n, sp, sd)
+if os.environ.get("PDMP3_PROFILE_MONO"):            # same records as mono frames: channel 1 idle
+    sd[:, :, 7] = (sd[:, :, 7] & 0xF3) | 0x0C
+    sd[:, 1, :7] = 0; sd[:, 3, :7] = 0; sd[:, 1, 8:] = 0; sd[:, 3, 8:] = 0
 nchunks = (n + chunk - 1) // chunk
 prof = torch.zeros((nchunks, 12), dtype=torch.int64, device=eng.tdev)
 for _ in range(2):
