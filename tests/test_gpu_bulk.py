@@ -235,3 +235,26 @@ def test_corrupted_streams_device_equals_host_huffman():
         dev.close()
         host.close()
     assert len(muts) > 100 and frames > 5000
+
+
+def test_decoder_survives_a_declined_stream(oracle):
+    """a stream the whole-stream path declines (PDMP3_BULK_REPLAY, detected after part of it was already queued)
+    leaves the decoder usable: the streams before and after it decode as if alone"""
+    from pdmp3_amd import api
+    good = packer.generate(n_frames=120, seed=61, bitrate_index=11, block_pct=(40, 10, 40, 10))
+    replay = packer.generate(n_frames=4147, seed=435, sfreq=2, mode=0, mode_ext=0, vbr=True, vbr_lo=4, vbr_hi=13, bitrate_index=12,
+                             block_pct=(40, 20, 20, 20), mixed_pct=50)
+    want = np.frombuffer(oracle.decode_buffer_like_cli(good), dtype=np.int16)
+    b = api.BulkDecoder(threads=2, window_frames=256)
+    try:
+        first = b.decode(good)
+        junk = np.zeros(4147 * 2304, dtype=np.int16)
+        with pytest.raises(api.RingReplay):
+            b.decode_into(replay, junk)
+        with pytest.raises(api.RingReplay):
+            b.decode_into_async(replay, junk)
+        again = b.decode_many([good, good])
+    finally:
+        b.close()
+    assert_pcm_close(first, want, 1, "before")
+    assert np.array_equal(again[0], first) and np.array_equal(again[1], first)
