@@ -101,15 +101,26 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
   }
 }
 
-// inclusive "last lane that has a value" scan over the wave; lanes without any take `carry`
+// inclusive "last lane that has a value" scan over the wave; lanes without any take `carry`.  (has, 16-bit value) in
+// one register, Hillis-Steele inside each row of 16 lanes with DPP row shifts, then the two row broadcasts of the
+// classic GCN wave scan -- 6 cross-lane moves at VALU rate.  (With __shfl_up = ds_bpermute the 24 dependent LDS round
+// trips of a step were most of k_merge's 43 us per window.)
 __device__ __forceinline__ unsigned scan_last(bool has, unsigned val, unsigned carry, int lane) {
-  int h = has ? 1 : 0;
-  for (int d = 1; d < 64; d <<= 1) {
-    const int hu = __shfl_up(h, d);
-    const unsigned vu = __shfl_up(val, d);
-    if (lane >= d && !h) { h = hu; val = vu; }
+  (void)lane;
+  unsigned r = (has ? 0x10000u : 0u) | (val & 0xffffu);
+#define PD_SCAN_STEP(ctrl, row_mask)                                                                     \
+  {                                                                                                      \
+    const unsigned s_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r, ctrl, row_mask, 0xf, false);    \
+    r = (r & 0x10000u) ? r : s_;                                                                         \
   }
-  return h ? val : carry;
+  PD_SCAN_STEP(0x111, 0xf)     // row_shr:1
+  PD_SCAN_STEP(0x112, 0xf)     // row_shr:2
+  PD_SCAN_STEP(0x114, 0xf)     // row_shr:4
+  PD_SCAN_STEP(0x118, 0xf)     // row_shr:8   -> prefix within each row
+  PD_SCAN_STEP(0x142, 0xa)     // row_bcast:15 into rows 1, 3
+  PD_SCAN_STEP(0x143, 0xc)     // row_bcast:31 into rows 2, 3
+#undef PD_SCAN_STEP
+  return (r & 0x10000u) ? (r & 0xffffu) : carry;
 }
 
 // one wave per surviving value (unpack_core.h merge_slot), 64 frames per step
@@ -118,19 +129,35 @@ __global__ __launch_bounds__(64) void k_merge(const GcRaw* raw, const pdmp3_fram
   const int t = blockIdx.x, lane = threadIdx.x;
   const int tw = merge_twin(t);
   unsigned carry = state_in[t], carry0 = tw >= 0 ? state_in[tw] : 0;
-  for (int base = 0; base < n_frames; base += 64) {
-    const int f = base + lane;
-    const bool valid = f < n_frames;
-    MergeIn m{false, false, false, 0, 0};
-    if (valid) m = merge_load(t, raw + (size_t)f * 4, (bits[f].frame & PDMP3_FR_NEWSTREAM) != 0);
-    unsigned v0 = 0;
-    if (tw >= 0) {                                   // wave-uniform
-      v0 = scan_last(m.set0, m.val0, carry0, lane);
-      carry0 = __shfl(v0, 63);
+  // 256 frames per trip: the loads of four 64-frame steps are issued together (one memory round trip), then the
+  // four scans run back to back on the carry chain
+  for (int base = 0; base < n_frames; base += 256) {
+    MergeIn m[4];
+    uint8_t fr[4];
+    PD_UNROLL for (int q = 0; q < 4; q++) {
+      const int f = base + 64 * q + lane;
+      m[q] = MergeIn{false, false, false, 0, 0};
+      fr[q] = 0;
+      if (f < n_frames) {
+        fr[q] = bits[f].frame;
+        m[q] = merge_load(t, raw + (size_t)f * 4, (fr[q] & PDMP3_FR_NEWSTREAM) != 0);
+      }
     }
-    const unsigned v = scan_last(m.set || m.copy, m.copy ? v0 : m.val, carry, lane);
-    carry = __shfl(v, 63);
-    if (valid) merge_store(t, bits[f], side + (size_t)f * 4, v);
+    PD_UNROLL for (int q = 0; q < 4; q++) {
+      const int f = base + 64 * q + lane;
+      unsigned v0 = 0;
+      if (tw >= 0) {                                 // wave-uniform
+        v0 = scan_last(m[q].set0, m[q].val0, carry0, lane);
+        carry0 = __shfl(v0, 63);
+      }
+      const unsigned v = scan_last(m[q].set || m[q].copy, m[q].copy ? v0 : m[q].val, carry, lane);
+      carry = __shfl(v, 63);
+      if (f < n_frames) {
+        pdmp3_frame_bits F;
+        F.frame = fr[q];
+        merge_store(t, F, side + (size_t)f * 4, v);
+      }
+    }
   }
   if (lane == 0) state_out[t] = (uint16_t)carry;
 }
