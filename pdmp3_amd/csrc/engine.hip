@@ -60,17 +60,24 @@ __global__ __launch_bounds__(64) void k_generate(uint64_t seed, int64_t first, i
 // ---------------------------------------------------------------------------
 constexpr int kUnpackThreads = 64;                      // one wave = 16 frames per pass
 constexpr int kUnpackRows = kUnpackThreads / 4;
-constexpr int kRowWords = PDMP3_RESERVOIR_BYTES / 16;   // 129 x 16 B
+constexpr int kRowBytes = PDMP3_RESERVOIR_BYTES;
+// LDS row stride in 32-bit words, chosen ODD: the 64 lanes read their rows at about the same offset at the same
+// time, and with the natural stride (516 words) that is 8 of the 32 banks for the whole wave
+constexpr int kRowStrideW = kRowBytes / 4 + 1;          // 517
+constexpr int kFrameBitsW = sizeof(pdmp3_frame_bits) / 4;   // 20
 
-// LDS: the 34 KB table blob, the 16 reservoir rows the wave works on (33 KB) and the 64 x 576 int16 lines it
-// produces (72 KB), moved in and out with coalesced 16-byte accesses; in between a lane touches global memory only
-// for its 80-byte side info and the two small records it writes.
+// LDS: the 34 KB table blob, the 16 reservoir rows the wave works on (33 KB) and their side info, brought in with
+// coalesced loads: 68 KB per workgroup, so two workgroups share a CU and four windows' k_unpack (128 workgroups
+// each) can be resident at once -- the kernel is a long dependent chain per lane with the SIMD to itself, what
+// counts is how many streams' windows overlap.  (Staging the output lines in LDS as well, 141 KB, changed nothing
+// for one window and halved that.)  The lines go straight to HBM: the wave zeroes its 16 frames' spectra with
+// coalesced stores first, then each lane stores its pairs / quads (same wave, same addresses: program order holds).
 __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* tabs, const pdmp3_frame_bits* bits,
                                                             const uint8_t* res, int n_frames, int16_t* spectra,
                                                             pdmp3_gc_side* side, GcRaw* raw) {
   __shared__ UnpackTables U;
-  __shared__ uint4 rows[kUnpackRows * kRowWords + 1];
-  __shared__ uint4 lines[kUnpackThreads * 72];            // [lane][576 int16]
+  __shared__ uint32_t rows[kUnpackRows * kRowStrideW + 4];
+  __shared__ uint32_t fbits[kUnpackRows * kFrameBitsW];
   {
     const uint4* src = reinterpret_cast<const uint4*>(tabs);
     uint4* dst = reinterpret_cast<uint4*>(&U);
@@ -79,24 +86,25 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
   }
   for (int f0 = blockIdx.x * kUnpackRows; f0 < n_frames; f0 += gridDim.x * kUnpackRows) {
     const int nrows = n_frames - f0 < kUnpackRows ? n_frames - f0 : kUnpackRows;
-    __syncthreads();                                       // (previous pass done with `rows`; first pass: U complete)
+    __syncthreads();                                       // (previous pass done with the buffers; first pass: U complete)
     {
-      const uint4* src = reinterpret_cast<const uint4*>(res + (size_t)f0 * PDMP3_RESERVOIR_BYTES);
-      for (int i = threadIdx.x; i < nrows * kRowWords; i += kUnpackThreads) rows[i] = src[i];
-      for (int i = threadIdx.x; i < kUnpackThreads * 72; i += kUnpackThreads) lines[i] = make_uint4(0, 0, 0, 0);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(res + (size_t)f0 * kRowBytes);
+      for (int i = threadIdx.x; i < nrows * (kRowBytes / 4); i += kUnpackThreads) {
+        const int r = i / (kRowBytes / 4), c = i - r * (kRowBytes / 4);
+        rows[r * kRowStrideW + c] = src[i];
+      }
+      const uint32_t* fsrc = reinterpret_cast<const uint32_t*>(bits + f0);
+      for (int i = threadIdx.x; i < nrows * kFrameBitsW; i += kUnpackThreads) fbits[i] = fsrc[i];
+      uint4* z = reinterpret_cast<uint4*>(spectra + (size_t)f0 * 4 * 576);
+      for (int i = threadIdx.x; i < nrows * 4 * 72; i += kUnpackThreads) z[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     const int fl = threadIdx.x >> 2, g = threadIdx.x & 3;
     if (fl < nrows) {
-      const int f = f0 + fl;
-      const size_t idx = (size_t)f * 4 + g;
-      unpack_gc(U, U.lut, reinterpret_cast<const uint8_t*>(rows) + (size_t)fl * PDMP3_RESERVOIR_BYTES, bits[f], g,
-                reinterpret_cast<int16_t*>(lines) + (size_t)threadIdx.x * 576, side + idx, raw + idx);
-    }
-    __syncthreads();
-    {
-      uint4* dst = reinterpret_cast<uint4*>(spectra + (size_t)f0 * 4 * 576);
-      for (int i = threadIdx.x; i < nrows * 4 * 72; i += kUnpackThreads) dst[i] = lines[i];
+      const size_t idx = (size_t)(f0 + fl) * 4 + g;
+      unpack_gc(U, U.lut, reinterpret_cast<const uint8_t*>(rows + fl * kRowStrideW),
+                *reinterpret_cast<const pdmp3_frame_bits*>(fbits + fl * kFrameBitsW), g, spectra + idx * 576, side + idx,
+                raw + idx);
     }
   }
 }

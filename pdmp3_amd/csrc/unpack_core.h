@@ -139,27 +139,31 @@ PD_HD unsigned part2_bits(const UnpackTables& U, const pdmp3_frame_bits& F, int 
   return n;
 }
 
-// The big_values pairs [0, nbig) of one granule-channel (cf. decode_pairs in pdmp3_host.c), ONE loop over the three
-// regions: the lanes of a wave sit in different regions with different tables, and three loops in a row would cost
-// the sum of the longest region of each kind instead of the longest granule-channel.  A region whose table has no
-// code words (0, 4, 14) reads no bits and leaves its (pre-zeroed) lines alone.
-PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& b, const pdmp3_gc_bits& s, unsigned e0,
-                            unsigned e1, unsigned nbig, int16_t* is) {
-  int base_r[3];
-  unsigned lin_r[3];
-  for (int r = 0; r < 3; r++) {
-    const unsigned tn = s.table_select[r];
-    const int book = U.book_of_table[tn];
-    base_r[r] = book < 0 ? -1 : (int)U.book_base[book];
-    lin_r[r] = U.linbits[tn];
-  }
-  unsigned pos = 0;
+#if defined(__HIPCC__)
+#define PD_COLD __device__ __noinline__
+#else
+#define PD_COLD static __attribute__((noinline))
+#endif
+
+// store the pair at (even) line pos; big_values > 288 is not checked by the reference (H8): lines >= 576 are dropped
+PD_HD void store_pair(int16_t* is, unsigned pos, int x, int y) {
+  if (pos + 1 < 576) {
+    const uint32_t v = (uint32_t)(uint16_t)(int16_t)x | ((uint32_t)(uint16_t)(int16_t)y << 16);
+    __builtin_memcpy(is + pos, &v, 4);
+  } else if (pos < 576) is[pos] = (int16_t)x;
+}
+
+// The rest of the pairs once the bit position has left the fast region (corrupt streams only): byte-wise windows,
+// clamped at the row's end.  Out of line: the hot loop below stays small.
+PD_COLD unsigned unpack_pairs_slow(const uint32_t* lut, BitPos& b, int base0, int base1, int base2, unsigned lin0,
+                                   unsigned lin1, unsigned lin2, unsigned e0, unsigned e1, unsigned nbig, unsigned pos,
+                                   int16_t* is) {
   for (; pos < nbig; pos += 2) {
-    const int base = pos < e0 ? base_r[0] : pos < e1 ? base_r[1] : base_r[2];
-    const unsigned linbits = pos < e0 ? lin_r[0] : pos < e1 ? lin_r[1] : lin_r[2];
+    const int base = pos < e0 ? base0 : pos < e1 ? base1 : base2;
+    const unsigned linbits = pos < e0 ? lin0 : pos < e1 ? lin1 : lin2;
     if (base < 0) continue;
     int x, y;
-    if (b.pos <= kFastLimit) {
+    if (b.pos <= kFastLimit) {                     // (a region without code words may have brought us back here)
       const uint64_t w = peek64(b);
       unsigned used = 0;
       const unsigned leaf = lut_symbol(lut, (unsigned)base, w, used);
@@ -177,11 +181,58 @@ PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& 
       if (linbits && y == 15) y += (int)get_bits(b, linbits);
       if (y > 0 && get_bits(b, 1)) y = -y;
     }
-    if (pos + 1 < 576) {                           // one 4-byte store (lines are 2-byte, pos is even)
-      const uint32_t v = (uint32_t)(uint16_t)(int16_t)x | ((uint32_t)(uint16_t)(int16_t)y << 16);
-      __builtin_memcpy(is + pos, &v, 4);
-    } else if (pos < 576) is[pos] = (int16_t)x;    // big_values > 288 is not checked by the reference (H8)
+    store_pair(is, pos, x, y);
   }
+  return pos;
+}
+
+// The big_values pairs [0, nbig) of one granule-channel (cf. decode_pairs in pdmp3_host.c), ONE loop over the three
+// regions: the lanes of a wave sit in different regions with different tables, and three loops in a row would cost
+// the sum of the longest region of each kind instead of the longest granule-channel.  A region whose table has no
+// code words (0, 4, 14) reads no bits and leaves its (pre-zeroed) lines alone.  The loop body is branch-free apart
+// from that: second-level lookup, linbits and sign bits are selects (64 lanes decode 64 different streams -- every
+// data-dependent branch is taken by some lane anyway, and its overhead by all).
+PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& b, const pdmp3_gc_bits& s, unsigned e0,
+                            unsigned e1, unsigned nbig, int16_t* is) {
+  int base_r[3];
+  unsigned lin_r[3];
+  for (int r = 0; r < 3; r++) {
+    const unsigned tn = s.table_select[r];
+    const int book = U.book_of_table[tn];
+    base_r[r] = book < 0 ? -1 : (int)U.book_base[book];
+    lin_r[r] = U.linbits[tn];
+  }
+  unsigned pos = 0;
+  for (; pos < nbig && b.pos <= kFastLimit; pos += 2) {
+    const int base = pos < e0 ? base_r[0] : pos < e1 ? base_r[1] : base_r[2];
+    const unsigned linbits = pos < e0 ? lin_r[0] : pos < e1 ? lin_r[1] : lin_r[2];
+    if (base < 0) continue;
+    const uint64_t w = peek64(b);
+    const unsigned i1 = (unsigned)base + (unsigned)(w >> (64 - kHuffFirstBits));
+    const uint32_t e1st = lut[i1];
+    const bool link = (e1st & 0x80000000u) != 0;
+    const unsigned sb = (e1st >> 24) & 0x1f;                                   // 1..11 when link
+    // (v >> 1) >> (63 - n) == v >> (64 - n) for n = 1..63 and 0 for n = 0: no shift by 64
+    uint32_t e = e1st;
+    if (link) e = lut[(e1st & 0xffffffu) + (unsigned)(((w << kHuffFirstBits) >> 1) >> (63 - sb))];   // only books deeper than 8 bits
+    unsigned used = (link ? (unsigned)kHuffFirstBits : 0u) + ((e >> 8) & 0xff);
+    int x = (int)((e >> 4) & 15), y = (int)(e & 15);
+    const unsigned lbx = (x == 15) ? linbits : 0;
+    x += (int)(((w << used) >> 1) >> (63 - lbx));
+    used += lbx;
+    const bool nx = x != 0 && ((w << used) >> 63) != 0;
+    used += x != 0;
+    x = nx ? -x : x;
+    const unsigned lby = (y == 15) ? linbits : 0;
+    y += (int)(((w << used) >> 1) >> (63 - lby));
+    used += lby;
+    const bool ny = y != 0 && ((w << used) >> 63) != 0;
+    used += y != 0;
+    y = ny ? -y : y;
+    b.pos += used;
+    store_pair(is, pos, x, y);
+  }
+  if (pos < nbig) pos = unpack_pairs_slow(lut, b, base_r[0], base_r[1], base_r[2], lin_r[0], lin_r[1], lin_r[2], e0, e1, nbig, pos, is);
   return pos;
 }
 
