@@ -107,6 +107,28 @@ PD_HD uint64_t peek64(const BitPos& b) {
   return s ? (two << s) | (uint64_t)(d2 >> (32 - s)) : two;
 }
 
+// Short fields in a row (scalefactors): one window serves as many of them as it has bits for, instead of one LDS round
+// trip each.  Same per-call decision as get_bits: past kFastLimit the byte-wise clamped window.
+struct FieldWin {
+  uint64_t w;
+  unsigned avail;
+};
+PD_HD unsigned get_field(BitPos& b, FieldWin& fw, unsigned n) {   // n <= 16
+  if (!n) return 0;
+  if (b.pos > kFastLimit) {
+    fw.avail = 0;
+    const unsigned v = peek32(b) >> (32 - n);
+    b.pos += n;
+    return v;
+  }
+  if (fw.avail < n) { fw.w = peek64(b); fw.avail = 64; }
+  const unsigned v = (unsigned)(fw.w >> (64 - n));
+  fw.w <<= n;
+  fw.avail -= n;
+  b.pos += n;
+  return v;
+}
+
 // one code word from a 64-bit window: returns leaf value, adds its length to `used`
 PD_HD unsigned lut_symbol(const uint32_t* lut, unsigned base, uint64_t w, unsigned& used) {
   uint32_t e = lut[base + (unsigned)(w >> (64 - kHuffFirstBits))];
@@ -236,6 +258,33 @@ PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& 
   return pos;
 }
 
+// the rest of the count1 quads once the bit position has left the fast region (corrupt streams only)
+PD_COLD unsigned unpack_quads_slow(const uint32_t* lut, BitPos& b, unsigned qbase, unsigned end, unsigned pos, int16_t* is) {
+  while (pos <= 572 && b.pos <= end) {
+    int q[4];
+    if (b.pos <= kFastLimit) {
+      const uint64_t w = peek64(b);
+      unsigned used = 0;
+      const unsigned leaf = lut_symbol(lut, qbase, w, used);
+      for (int k = 0; k < 4; k++) {
+        q[k] = (int)(leaf >> (3 - k)) & 1;
+        if (q[k]) { if ((w << used) >> 63) q[k] = -1; used++; }
+      }
+      b.pos += used;
+    } else {
+      const unsigned leaf = lut_symbol_slow(lut, qbase, b);
+      for (int k = 0; k < 4; k++) {
+        q[k] = (int)(leaf >> (3 - k)) & 1;
+        if (q[k] && get_bits(b, 1)) q[k] = -1;
+      }
+    }
+    store_pair(is, pos, q[0], q[1]);
+    store_pair(is, pos + 2, q[2], q[3]);
+    pos += 4;
+  }
+  return pos;
+}
+
 // `spectra_gc` (576 int16) must be zero on entry.  `rec` and `raw` are fully written.
 PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* res, const pdmp3_frame_bits& F, int g,
                      int16_t* spectra_gc, pdmp3_gc_side* rec, GcRaw* raw) {
@@ -270,16 +319,17 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
   const unsigned slen1 = U.slen[s.scalefac_compress * 2], slen2 = U.slen[s.scalefac_compress * 2 + 1];
   const bool wsf = (s.flags & PDMP3_GC_WIN_SWITCH) != 0;
   const unsigned bt = (s.flags & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT;
+  FieldWin fw{0, 0};
   if (wsf && bt == 2) {
     unsigned first_short = 0;
     if (s.flags & PDMP3_GC_MIXED) {
-      for (unsigned sfb = 0; sfb < 8; sfb++) raw->sf_l[sfb] = (uint8_t)get_bits(b, slen1);
+      for (unsigned sfb = 0; sfb < 8; sfb++) raw->sf_l[sfb] = (uint8_t)get_field(b, fw, slen1);
       raw->sf_l_set = 0xffu;
       first_short = 3;
     }
     unsigned set = 0;
     for (unsigned sfb = first_short; sfb < 12; sfb++) {
-      for (unsigned w = 0; w < 3; w++) raw->sf_s[sfb * 3 + w] = (uint8_t)get_bits(b, sfb < 6 ? slen1 : slen2);
+      for (unsigned w = 0; w < 3; w++) raw->sf_s[sfb * 3 + w] = (uint8_t)get_field(b, fw, sfb < 6 ? slen1 : slen2);
       set |= 1u << sfb;
     }
     raw->sf_s_set = (uint16_t)set;
@@ -288,7 +338,7 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
     for (unsigned g4 = 0; g4 < 4; g4++) {
       const unsigned lo = g4 ? 1 + 5 * g4 : 0, hi = 6 + 5 * g4, nb = g4 < 2 ? slen1 : slen2;
       if (gr == 1 && (F.scfsi[ch] >> g4 & 1)) copy |= 1u << g4;
-      else for (unsigned sfb = lo; sfb < hi; sfb++) { raw->sf_l[sfb] = (uint8_t)get_bits(b, nb); set |= 1u << sfb; }
+      else for (unsigned sfb = lo; sfb < hi; sfb++) { raw->sf_l[sfb] = (uint8_t)get_field(b, fw, nb); set |= 1u << sfb; }
     }
     raw->sf_l_set = set;
     raw->sf_l_copy = (uint8_t)copy;
@@ -312,30 +362,23 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
   unsigned pos = unpack_pairs(U, lut, b, s, e0, e1, nbig, spectra_gc);
   // count1 region: table 32 or the reference's mis-pointed table 33 (H1); both books are <= 8 bits deep
   const unsigned qbase = U.book_base[U.book_of_table[32 + s.count1table_select]];
-  while (pos <= 572 && b.pos <= end) {
+  while (pos <= 572 && b.pos <= end && b.pos <= kFastLimit) {     // both count1 books are <= 8 bits deep: one lookup
+    const uint64_t w = peek64(b);
+    const uint32_t e = lut[qbase + (unsigned)(w >> (64 - kHuffFirstBits))];
+    unsigned used = (e >> 8) & 0xff;
     int q[4];
-    if (b.pos <= kFastLimit) {
-      const uint64_t w = peek64(b);
-      unsigned used = 0;
-      const unsigned leaf = lut_symbol(lut, qbase, w, used);
-      for (int k = 0; k < 4; k++) {                // v w x y
-        q[k] = (int)(leaf >> (3 - k)) & 1;
-        if (q[k]) { if ((w << used) >> 63) q[k] = -1; used++; }
-      }
-      b.pos += used;
-    } else {
-      const unsigned leaf = lut_symbol_slow(lut, qbase, b);
-      for (int k = 0; k < 4; k++) {
-        q[k] = (int)(leaf >> (3 - k)) & 1;
-        if (q[k] && get_bits(b, 1)) q[k] = -1;
-      }
+    for (int k = 0; k < 4; k++) {                  // v w x y: a sign bit follows each nonzero one
+      const bool nz = ((e >> (3 - k)) & 1) != 0;
+      const bool neg = nz && ((w << used) >> 63) != 0;
+      used += nz;
+      q[k] = neg ? -1 : (int)nz;
     }
-    const uint32_t v0 = (uint32_t)(uint16_t)(int16_t)q[0] | ((uint32_t)(uint16_t)(int16_t)q[1] << 16);
-    const uint32_t v1 = (uint32_t)(uint16_t)(int16_t)q[2] | ((uint32_t)(uint16_t)(int16_t)q[3] << 16);
-    __builtin_memcpy(spectra_gc + pos, &v0, 4);
-    __builtin_memcpy(spectra_gc + pos + 2, &v1, 4);
+    b.pos += used;
+    store_pair(spectra_gc, pos, q[0], q[1]);
+    store_pair(spectra_gc, pos + 2, q[2], q[3]);
     pos += 4;
   }
+  if (pos <= 572 && b.pos <= end) pos = unpack_quads_slow(lut, b, qbase, end, pos, spectra_gc);
   // Overshoot: the reference takes the last four lines back (P:2106-2108) -- the last quad, or, when no quad
   // was read, the last two PAIRS -- and zero-fills from there.  (pos < 4 wraps like the reference's unsigned:
   // count1 becomes 576 and nothing is zeroed.)
