@@ -70,6 +70,12 @@ long long pdmp3_amd_scan_buffer(const unsigned char* mp3, size_t n, long long* f
 long long pdmp3_amd_bulk_decode(pdmp3_amd_bulk* b, const unsigned char* mp3, size_t n,
                                 unsigned char* pcm, size_t pcm_cap, long* rate, int* channels);
 
+/* Optional: PCM buffers in pinned host memory.  When the `pcm` given to the decode calls lies in such a buffer the
+ * GPU downloads every window straight into it (mono frames packed on the way) and the host never touches the
+ * samples; any other memory works too, through a staging buffer and a copy by the pool. */
+void* pdmp3_amd_pcm_alloc(size_t bytes);
+void pdmp3_amd_pcm_free(void* p);
+
 /* The same without waiting for the tail: returns as soon as the stream is scanned and its windows are queued on
  * the device (`mp3` may be released then, `pcm` must stay); the PCM of every stream given so far is complete after
  * pdmp3_amd_bulk_wait() returns 0.  The next stream's scan overlaps the previous one's GPU work and copy-out, so a

@@ -15,7 +15,7 @@ _LIB = None
 
 BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads",
                 "pdmp3_amd_scan_buffer", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_decode_async", "pdmp3_amd_bulk_wait", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
-                "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits"]
+                "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits", "pdmp3_amd_pcm_alloc", "pdmp3_amd_pcm_free"]
 
 # include/pdmp3_hip.h: pdmp3_gc_bits / pdmp3_frame_bits
 GC_BITS_DTYPE = np.dtype([("part2_3_length", "<u2"), ("big_values", "<u2"), ("global_gain", "u1"), ("scalefac_compress", "u1"),
@@ -75,6 +75,9 @@ def load_library():
     lib.pdmp3_amd_bulk_decode_async.restype = C.c_longlong
     lib.pdmp3_amd_bulk_decode_async.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_int)]
     lib.pdmp3_amd_bulk_wait.argtypes = [vp]
+    lib.pdmp3_amd_pcm_alloc.restype = vp
+    lib.pdmp3_amd_pcm_alloc.argtypes = [C.c_size_t]
+    lib.pdmp3_amd_pcm_free.argtypes = [vp]
     lib.pdmp3_amd_bulk_parse.restype = C.c_longlong
     lib.pdmp3_amd_bulk_parse.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_longlong)]
     _LIB = lib
@@ -306,3 +309,21 @@ def parse_bits(mp3):
     if n < 0:
         raise RuntimeError("pdmp3_amd_bulk_parse_bits failed")
     return bits[:n], res[:n], pcm_bytes.value
+
+
+class PinnedPCM:
+    """int16 numpy view of a pinned host buffer (pdmp3_amd_pcm_alloc): decode into it and the GPU writes it directly"""
+
+    def __init__(self, n_samples):
+        self.lib = load_library()
+        self.nbytes = max(2, int(n_samples) * 2)
+        self.ptr = self.lib.pdmp3_amd_pcm_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("pdmp3_amd_pcm_alloc(%d)" % self.nbytes)
+        self.array = np.ctypeslib.as_array((C.c_int16 * (self.nbytes // 2)).from_address(self.ptr))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.lib.pdmp3_amd_pcm_free(self.ptr)
+            self.ptr = None

@@ -436,7 +436,51 @@ extern "C" int16_t* pdmp3_hip_stream_spectra(pdmp3_hip_stream* hs) { return pdmp
 extern "C" pdmp3_gc_side* pdmp3_hip_stream_side(pdmp3_hip_stream* hs) { return pdmp3_hip_stream_slot_side(hs, 0); }
 extern "C" const int16_t* pdmp3_hip_stream_pcm(pdmp3_hip_stream* hs) { return pdmp3_hip_stream_slot_pcm(hs, 0); }
 
+// PCM of a batch back to the host: into the slot's pinned buffer, or -- when the caller hands over pinned memory of
+// its own (pdmp3_hip_host_alloc) -- straight to where it is wanted, `row` bytes per frame (4608; 2304 = mono frames
+// packed densely out of their 4608-byte slots).
+static int download_pcm(StreamSlot& t, size_t n, void* host_dst, int row) {
+  if (!host_dst) {
+    HIP_TRY(hipMemcpyAsync(t.h_pcm, t.d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDeviceToHost, t.stream), "D2H pcm");
+  } else if (row == PDMP3_FRAME_PCM_BYTES) {
+    HIP_TRY(hipMemcpyAsync(host_dst, t.d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDeviceToHost, t.stream), "D2H pcm (direct)");
+  } else {
+    HIP_TRY(hipMemcpy2DAsync(host_dst, (size_t)row, t.d_pcm, PDMP3_FRAME_PCM_BYTES, (size_t)row, n, hipMemcpyDeviceToHost, t.stream),
+            "D2H pcm (direct, packed)");
+  }
+  return PDMP3_HIP_OK;
+}
+
+extern "C" int pdmp3_hip_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_host_alloc: out is NULL", hipSuccess);
+  *out = nullptr;
+  HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault), "hipHostMalloc");
+  return PDMP3_HIP_OK;
+}
+extern "C" void pdmp3_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
+extern "C" int pdmp3_hip_host_is_pinned(const void* p, size_t bytes) {
+  if (!p) return 0;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (a.type != hipMemoryTypeHost) return 0;
+  if (bytes > 1) {
+    hipPointerAttribute_t e;
+    if (hipPointerGetAttributes(&e, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (e.type != hipMemoryTypeHost) return 0;
+  }
+  return 1;
+}
+
+static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row);
 extern "C" int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_frames) {
+  return submit_records(hs, slot, n_frames, nullptr, PDMP3_FRAME_PCM_BYTES);
+}
+extern "C" int pdmp3_hip_stream_submit_to(pdmp3_hip_stream* hs, int slot, int n_frames, void* pinned_dst, int row_bytes) {
+  if (pinned_dst && row_bytes != PDMP3_FRAME_PCM_BYTES && row_bytes != PDMP3_FRAME_PCM_BYTES / 2)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_to: row_bytes must be 4608 or 2304", hipSuccess);
+  return submit_records(hs, slot, n_frames, pinned_dst, row_bytes);
+}
+static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row) {
   if (!SLOT_OK(hs, slot) || n_frames < 0 || n_frames > hs->max_frames)
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit: bad argument", hipSuccess);
   StreamSlot& t = hs->s[slot];
@@ -451,7 +495,8 @@ extern "C" int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_fra
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
   hs->have_state_ev = 1;
-  HIP_TRY(hipMemcpyAsync(t.h_pcm, t.d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDeviceToHost, t.stream), "D2H pcm");
+  rc = download_pcm(t, n, host_dst, row);
+  if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(t.done, t.stream), "record done event");
   t.busy = 1;
   return PDMP3_HIP_OK;
@@ -495,7 +540,16 @@ extern "C" uint8_t* pdmp3_hip_stream_slot_reservoir(pdmp3_hip_stream* hs, int sl
   return hs->s[slot].h_res;
 }
 
+static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row);
 extern "C" int pdmp3_hip_stream_submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames) {
+  return submit_bits(hs, slot, n_frames, nullptr, PDMP3_FRAME_PCM_BYTES);
+}
+extern "C" int pdmp3_hip_stream_submit_bits_to(pdmp3_hip_stream* hs, int slot, int n_frames, void* pinned_dst, int row_bytes) {
+  if (pinned_dst && row_bytes != PDMP3_FRAME_PCM_BYTES && row_bytes != PDMP3_FRAME_PCM_BYTES / 2)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_bits_to: row_bytes must be 4608 or 2304", hipSuccess);
+  return submit_bits(hs, slot, n_frames, pinned_dst, row_bytes);
+}
+static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row) {
   if (!SLOT_OK(hs, slot) || n_frames < 0 || n_frames > hs->max_frames)
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_bits: bad argument", hipSuccess);
   StreamSlot& t = hs->s[slot];
@@ -524,7 +578,8 @@ extern "C" int pdmp3_hip_stream_submit_bits(pdmp3_hip_stream* hs, int slot, int 
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
   hs->have_state_ev = 1;
-  HIP_TRY(hipMemcpyAsync(t.h_pcm, t.d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDeviceToHost, t.stream), "D2H pcm");
+  rc = download_pcm(t, n, host_dst, row);
+  if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(t.done, t.stream), "record done event");
   t.busy = 1;
   return PDMP3_HIP_OK;

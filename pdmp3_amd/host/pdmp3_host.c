@@ -872,6 +872,7 @@ typedef struct {                      /* a window that is on the GPU */
   int n, active, all_stereo;          /* all_stereo: 2 = every frame stereo, 1 = every frame mono, 0 = mixed */
   unsigned char* dst;                 /* where this window's PCM goes (caller memory) and how much room is left there */
   size_t dst_cap;
+  int direct;                         /* the GPU downloads straight to dst (pinned caller memory): nothing to copy */
   uint8_t* nch;
 } bulk_flight;
 
@@ -903,6 +904,7 @@ struct bulk {
   int16_t* rec_spectra; pdmp3_gc_side* rec_side; size_t rec_cap;
   unsigned char* pcm; size_t pcm_cap;
   size_t pcm_emitted;                 /* PCM bytes of all frames handed to stage C so far */
+  int pcm_pinned;                     /* the caller's PCM buffer is pinned host memory (pdmp3_hip_host_alloc) */
   int failed, busy;
   int carry;                          /* keep parse state (host handle / device sfstate) from the previous stream */
   /* bits mode: the engine calls of a window (H2D, kernels, D2H: ~40 us of driver time) are issued by a thread
@@ -911,7 +913,8 @@ struct bulk {
   int sub_started, sub_quit, sub_rc;
   pthread_mutex_t sub_mu;
   pthread_cond_t sub_cv, sub_done_cv;
-  int sub_slot[8], sub_n[8];
+  int sub_slot[8], sub_n[8], sub_row[8];
+  void* sub_dst[8];
   long long sub_head, sub_tail;       /* jobs enqueued / completed */
   size_t next_copy_row;               /* row size of the copy job bulk_collect last handed out */
   double t_submit, t_gpuwait, t_poolwait;   /* PDMP3_BULK_TRACE=1: where the scanning thread waits */
@@ -994,6 +997,7 @@ static int bulk_collect(struct bulk* b, int slot, const unsigned char** jsrc, un
   b->t_gpuwait += now_s() - t0;
   if (wrc != PDMP3_HIP_OK) return PDMP3_ERR;
   f->active = 0;
+  if (f->direct) return PDMP3_OK;
   const unsigned char* src = (const unsigned char*)pdmp3_hip_stream_slot_pcm(b->hs, slot);
   if (f->all_stereo == 2 || (f->all_stereo == 1 && jbytes)) {
     const size_t row = f->all_stereo == 2 ? 4608 : 2304;
@@ -1011,6 +1015,13 @@ static int bulk_collect(struct bulk* b, int slot, const unsigned char** jsrc, un
     off += fb;
   }
   return PDMP3_OK;
+}
+
+/* a window whose frames all have the same channel count and that fits its destination goes there directly when
+ * the destination is pinned */
+static void flight_plan(struct bulk* b, bulk_flight* f) {
+  const size_t row = f->all_stereo == 2 ? 4608 : 2304;
+  f->direct = b->pcm_pinned && f->all_stereo != 0 && f->dst && (size_t)f->n * row <= f->dst_cap;
 }
 
 /* stage C + D of the window the workers have just finished */
@@ -1035,7 +1046,8 @@ static int bulk_finish_b(struct bulk* b) {
     b->pcm_emitted += 2304u * nch;
   }
   if (f) {
-    if (pdmp3_hip_stream_submit(b->hs, w->slot, w->n) != PDMP3_HIP_OK) {
+    flight_plan(b, f);
+    if (pdmp3_hip_stream_submit_to(b->hs, w->slot, w->n, f->direct ? f->dst : NULL, f->all_stereo == 1 ? 2304 : 4608) != PDMP3_HIP_OK) {
       fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
       return PDMP3_ERR;
     }
@@ -1110,9 +1122,10 @@ static void* bulk_submitter(void* arg) {
     pthread_mutex_lock(&b->sub_mu);
     while (b->sub_tail == b->sub_head && !b->sub_quit) pthread_cond_wait(&b->sub_cv, &b->sub_mu);
     if (b->sub_tail == b->sub_head) { pthread_mutex_unlock(&b->sub_mu); return NULL; }
-    const int slot = b->sub_slot[b->sub_tail & 7], n = b->sub_n[b->sub_tail & 7];
+    const int slot = b->sub_slot[b->sub_tail & 7], n = b->sub_n[b->sub_tail & 7], row = b->sub_row[b->sub_tail & 7];
+    void* dst = b->sub_dst[b->sub_tail & 7];
     pthread_mutex_unlock(&b->sub_mu);
-    const int rc = pdmp3_hip_stream_submit_bits(b->hs, slot, n);
+    const int rc = pdmp3_hip_stream_submit_bits_to(b->hs, slot, n, dst, row);
     if (rc != PDMP3_HIP_OK) fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
     pthread_mutex_lock(&b->sub_mu);
     if (rc != PDMP3_HIP_OK) b->sub_rc = rc;
@@ -1121,9 +1134,10 @@ static void* bulk_submitter(void* arg) {
     pthread_mutex_unlock(&b->sub_mu);
   }
 }
-static void sub_enqueue(struct bulk* b, int slot, int n) {
+static void sub_enqueue(struct bulk* b, int slot, int n, void* dst, int row) {
   pthread_mutex_lock(&b->sub_mu);
   b->sub_slot[b->sub_head & 7] = slot; b->sub_n[b->sub_head & 7] = n;
+  b->sub_dst[b->sub_head & 7] = dst; b->sub_row[b->sub_head & 7] = row;
   b->sub_head++;
   pthread_cond_signal(&b->sub_cv);
   pthread_mutex_unlock(&b->sub_mu);
@@ -1173,7 +1187,8 @@ static int bits_close_window(struct bulk* b) {
       b->pcm_emitted += 2304u * f->nch[i];
     }
     const double t0 = now_s();
-    sub_enqueue(b, b->bits_slot, b->bits_n);
+    flight_plan(b, f);
+    sub_enqueue(b, b->bits_slot, b->bits_n, f->direct ? f->dst : NULL, f->all_stereo == 1 ? 2304 : 4608);
     b->t_submit += now_s() - t0;
     f->active = 1;
   }
@@ -1399,6 +1414,7 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
    * streams follow each other through the pipeline without a stop.  Host Huffman: the pipeline is idle here. */
   if (!b->bits_mode && !b->carry && pdmp3_hip_stream_reset(b->hs) != PDMP3_HIP_OK) return -1;
   b->pcm = pcm; b->pcm_cap = pcm_cap;
+  b->pcm_pinned = pcm_cap && pdmp3_hip_host_is_pinned(pcm, pcm_cap);
   const long long total = bulk_drive(b, mp3, n);
   int ok = !b->failed;
   if (b->bits_mode) ok = bits_close_window(b) == PDMP3_OK && ok;
@@ -1416,6 +1432,13 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
   if (total == PDMP3_BULK_REPLAY) return PDMP3_BULK_REPLAY;
   return ok ? total : -1;
 }
+
+/* PCM buffers in pinned host memory: the GPU downloads each window straight into them, the pool has nothing to copy */
+void* pdmp3_amd_pcm_alloc(size_t bytes) {
+  void* p = NULL;
+  return pdmp3_hip_host_alloc(bytes, &p) == PDMP3_HIP_OK ? p : NULL;
+}
+void pdmp3_amd_pcm_free(void* p) { pdmp3_hip_host_free(p); }
 
 /* Decode a whole stream.  Returns the PCM byte count pdmp3() writes for it (the first min(that, pcm_cap)
  * bytes are in `pcm`), or -1 on an engine failure.  rate / channels: format of the last header seen. */

@@ -258,3 +258,41 @@ def test_decoder_survives_a_declined_stream(oracle):
         b.close()
     assert_pcm_close(first, want, 1, "before")
     assert np.array_equal(again[0], first) and np.array_equal(again[1], first)
+
+
+@pytest.mark.parametrize("host_huffman", [False, True])
+def test_pinned_destination_is_written_directly(streams, host_huffman):
+    """PCM buffers from pdmp3_amd_pcm_alloc: windows are downloaded straight into them (mono packed by a 2-D copy,
+    mixed windows still through staging) -- same bytes as into ordinary memory"""
+    from pdmp3_amd import api
+    b = api.BulkDecoder(threads=2, window_frames=16, host_huffman=host_huffman)
+    ref = api.BulkDecoder(threads=2, window_frames=64)
+    bufs = []
+    try:
+        names = [k for k in streams if len(streams[k])]
+        want = {k: ref.decode(streams[k]) for k in names}
+        for k in names:                                    # synchronous
+            p = api.PinnedPCM(want[k].size + 64)
+            bufs.append(p)
+            p.array[:] = 0x5A5A
+            total, _, _ = b.decode_into(streams[k], p.array)
+            assert total == want[k].nbytes, k
+            assert np.array_equal(p.array[:want[k].size], want[k]), k
+            assert (p.array[want[k].size:] == 0x5A5A).all(), k          # nothing written past the stream's PCM
+        if not host_huffman:                               # back to back into one big pinned buffer
+            big = api.PinnedPCM(sum(w.size for w in want.values()))
+            bufs.append(big)
+            off = 0
+            for k in names:
+                b.decode_into_async(streams[k], big.array[off:off + max(want[k].size, 1)])
+                off += want[k].size
+            b.wait()
+            off = 0
+            for k in names:
+                assert np.array_equal(big.array[off:off + want[k].size], want[k]), k
+                off += want[k].size
+    finally:
+        b.close()
+        ref.close()
+        for p in bufs:
+            p.free()

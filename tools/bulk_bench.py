@@ -28,7 +28,8 @@ def c4(args, api):
     files = _c4_files(4096, 64, 12)
     files = [np.frombuffer(f, dtype=np.uint8) for f in files + files[:10]]
     sizes = [api.scan_buffer(f) for f in files]
-    outs = [np.zeros(max(b, 2) // 2, dtype=np.int16) for b, _ in sizes]
+    pins = [api.PinnedPCM(max(b, 2) // 2) for b, _ in sizes] if args.pinned else []
+    outs = [p.array for p in pins] if args.pinned else [np.zeros(max(b, 2) // 2, dtype=np.int16) for b, _ in sizes]
     plan = assign_files([len(f) for f in files], args.c4)
     import torch
     ngpu = max(1, min(args.gpus, torch.cuda.device_count()))
@@ -56,7 +57,8 @@ def c4(args, api):
     print(json.dumps({"workload": "C4: %d files, %d frames, mono/stereo/joint x 32/44.1/48 kHz x CBR/VBR x block mixes" % (len(files), frames),
                       "decoders": args.c4, "gpus": ngpu, "seconds": round(best, 4), "frames_per_s": round(frames / best, 1),
                       "mp3_bytes": int(sum(len(f) for f in files)), "pcm_bytes": int(sum(b for b, _ in sizes)),
-                      "mode": "host Huffman" if args.host_huffman else "device Huffman", "host_cpus": os.cpu_count()}))
+                      "mode": "host Huffman" if args.host_huffman else "device Huffman", "pcm": "pinned" if args.pinned else "pageable",
+                      "host_cpus": os.cpu_count()}))
 
 
 def main():
@@ -68,6 +70,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--c4", type=int, default=0, metavar="JOBS",
                     help="SURVEY 8d C4 instead: the mixed corpus (64 files x >= 4096 frames), JOBS decoders in parallel")
+    ap.add_argument("--pinned", action="store_true", help="PCM into pinned host buffers (pdmp3_amd_pcm_alloc): no host copy")
     ap.add_argument("--gpus", type=int, default=1, help="--c4: decoder j runs on GPU j %% GPUS")
     ap.add_argument("--host-huffman", action="store_true", help="scalefactors + Huffman on the host pool instead of the device")
     args = ap.parse_args()
@@ -86,7 +89,8 @@ def main():
     out = {"frames": frames, "mp3_bytes": len(mp3), "pcm_bytes": total, "packer_s": round(t_gen, 2),
            "scan_ms": round(t_scan * 1e3, 2), "scan_frames_per_s": round(frames / t_scan, 1), "host_cpus": os.cpu_count(),
            "runs": []}
-    pcm = np.empty(total // 2, dtype=np.int16)
+    pin = api.PinnedPCM(total // 2) if args.pinned else None
+    pcm = pin.array if pin else np.empty(total // 2, dtype=np.int16)
     for th in [int(x) for x in args.threads.split(",")]:
         b = api.BulkDecoder(threads=th, window_frames=args.window, parse_only=args.parse_only, host_huffman=args.host_huffman)
         best = None
@@ -101,7 +105,8 @@ def main():
             best = dt if best is None else min(best, dt)
         b.close()
         out["runs"].append({"threads": th, "seconds": round(best, 4), "frames_per_s": round(frames / best, 1),
-                            "x_realtime": round(frames / best / rt, 1), "mode": "parse" if args.parse_only else ("decode, host Huffman" if args.host_huffman else "decode, device Huffman")})
+                            "x_realtime": round(frames / best / rt, 1), "mode": "parse" if args.parse_only else ("decode, host Huffman" if args.host_huffman else "decode, device Huffman"),
+                            "pcm": "pinned" if args.pinned else "pageable"})
     print(json.dumps(out))
 
 
