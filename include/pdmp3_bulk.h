@@ -72,7 +72,8 @@ long long pdmp3_amd_bulk_decode(pdmp3_amd_bulk* b, const unsigned char* mp3, siz
 
 /* Optional: PCM buffers in pinned host memory.  When the `pcm` given to the decode calls lies in such a buffer the
  * GPU downloads every window straight into it (mono frames packed on the way) and the host never touches the
- * samples; any other memory works too, through a staging buffer and a copy by the pool. */
+ * samples; any other memory works too, through a staging buffer and a copy by the pool.  A DEVICE pointer (hipMalloc,
+ * a torch tensor) is accepted as `pcm` as well: the PCM then never leaves the GPU. */
 void* pdmp3_amd_pcm_alloc(size_t bytes);
 void pdmp3_amd_pcm_free(void* p);
 

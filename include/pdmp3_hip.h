@@ -237,12 +237,13 @@ pdmp3_frame_bits* pdmp3_hip_stream_slot_bits(pdmp3_hip_stream* hs, int slot);
 uint8_t* pdmp3_hip_stream_slot_reservoir(pdmp3_hip_stream* hs, int slot);
 /* like pdmp3_hip_stream_submit, from bits: H2D, unpack, merge, transforms, D2H of the PCM */
 int pdmp3_hip_stream_submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames);
-/* Pinned host memory for PCM that should not be copied twice: with a destination inside such an allocation the
- * _to forms below download a batch's PCM straight to it (row_bytes 4608, or 2304 to pack mono frames densely)
+/* Pinned host memory for PCM that should not be copied twice: with a destination inside such an allocation -- or in
+ * device memory, for consumers on the GPU -- the _to forms below move a batch's PCM straight to it (row_bytes 4608, or 2304 to pack mono frames densely)
  * instead of into the slot's staging buffer; pdmp3_hip_stream_wait() then means "it is there". */
 int pdmp3_hip_host_alloc(size_t bytes, void** out);
 void pdmp3_hip_host_free(void* p);
-int pdmp3_hip_host_is_pinned(const void* p, size_t bytes);          /* 1 if [p, p + bytes) is pinned host memory */
+int pdmp3_hip_host_is_pinned(const void* p, size_t bytes);          /* [p, p + bytes): 1 = pinned host memory, 2 = device memory
+                                                                       (both are valid _to destinations), 0 = neither */
 int pdmp3_hip_stream_submit_to(pdmp3_hip_stream* hs, int slot, int n_frames, void* pinned_dst, int row_bytes);
 int pdmp3_hip_stream_submit_bits_to(pdmp3_hip_stream* hs, int slot, int n_frames, void* pinned_dst, int row_bytes);
 

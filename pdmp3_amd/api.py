@@ -252,6 +252,20 @@ class BulkDecoder:
             raise RuntimeError("pdmp3_amd_bulk_decode_async: engine failure")
         return total, rate.value, ch.value
 
+    def decode_into_device(self, mp3, out_tensor, wait=True):
+        """PCM into a torch int16 tensor on the GPU (it never leaves the device).  Windows that mix mono and stereo
+        frames are not delivered to device destinations (streams do not change their channel count in practice)."""
+        a = _as_u8(mp3)
+        rate, ch = C.c_long(0), C.c_int(0)
+        f = self.lib.pdmp3_amd_bulk_decode if wait else self.lib.pdmp3_amd_bulk_decode_async
+        total = f(self.h, a.ctypes.data_as(C.c_void_p), len(mp3), C.c_void_p(out_tensor.data_ptr()),
+                  out_tensor.numel() * out_tensor.element_size(), C.byref(rate), C.byref(ch))
+        if total == -2:
+            raise RingReplay("the reference replays its input ring on this stream (no finite output)")
+        if total < 0:
+            raise RuntimeError("pdmp3_amd_bulk_decode: engine failure")
+        return total, rate.value, ch.value
+
     def wait(self):
         if self.lib.pdmp3_amd_bulk_wait(self.h) != 0:
             raise RuntimeError("pdmp3_amd_bulk_wait: engine failure")

@@ -436,17 +436,17 @@ extern "C" int16_t* pdmp3_hip_stream_spectra(pdmp3_hip_stream* hs) { return pdmp
 extern "C" pdmp3_gc_side* pdmp3_hip_stream_side(pdmp3_hip_stream* hs) { return pdmp3_hip_stream_slot_side(hs, 0); }
 extern "C" const int16_t* pdmp3_hip_stream_pcm(pdmp3_hip_stream* hs) { return pdmp3_hip_stream_slot_pcm(hs, 0); }
 
-// PCM of a batch back to the host: into the slot's pinned buffer, or -- when the caller hands over pinned memory of
-// its own (pdmp3_hip_host_alloc) -- straight to where it is wanted, `row` bytes per frame (4608; 2304 = mono frames
+// PCM of a batch to its destination: into the slot's pinned buffer, or -- when the caller hands over pinned host
+// memory (pdmp3_hip_host_alloc) or DEVICE memory of its own -- straight to where it is wanted, `row` bytes per frame (4608; 2304 = mono frames
 // packed densely out of their 4608-byte slots).
 static int download_pcm(StreamSlot& t, size_t n, void* host_dst, int row) {
   if (!host_dst) {
     HIP_TRY(hipMemcpyAsync(t.h_pcm, t.d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDeviceToHost, t.stream), "D2H pcm");
   } else if (row == PDMP3_FRAME_PCM_BYTES) {
-    HIP_TRY(hipMemcpyAsync(host_dst, t.d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDeviceToHost, t.stream), "D2H pcm (direct)");
+    HIP_TRY(hipMemcpyAsync(host_dst, t.d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDefault, t.stream), "pcm (direct)");
   } else {
-    HIP_TRY(hipMemcpy2DAsync(host_dst, (size_t)row, t.d_pcm, PDMP3_FRAME_PCM_BYTES, (size_t)row, n, hipMemcpyDeviceToHost, t.stream),
-            "D2H pcm (direct, packed)");
+    HIP_TRY(hipMemcpy2DAsync(host_dst, (size_t)row, t.d_pcm, PDMP3_FRAME_PCM_BYTES, (size_t)row, n, hipMemcpyDefault, t.stream),
+            "pcm (direct, packed)");
   }
   return PDMP3_HIP_OK;
 }
@@ -462,13 +462,13 @@ extern "C" int pdmp3_hip_host_is_pinned(const void* p, size_t bytes) {
   if (!p) return 0;
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  if (a.type != hipMemoryTypeHost) return 0;
+  if (a.type != hipMemoryTypeHost && a.type != hipMemoryTypeDevice) return 0;
   if (bytes > 1) {
     hipPointerAttribute_t e;
     if (hipPointerGetAttributes(&e, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    if (e.type != hipMemoryTypeHost) return 0;
+    if (e.type != a.type) return 0;
   }
-  return 1;
+  return a.type == hipMemoryTypeHost ? 1 : 2;
 }
 
 static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row);

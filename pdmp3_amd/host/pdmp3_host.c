@@ -904,7 +904,7 @@ struct bulk {
   int16_t* rec_spectra; pdmp3_gc_side* rec_side; size_t rec_cap;
   unsigned char* pcm; size_t pcm_cap;
   size_t pcm_emitted;                 /* PCM bytes of all frames handed to stage C so far */
-  int pcm_pinned;                     /* the caller's PCM buffer is pinned host memory (pdmp3_hip_host_alloc) */
+  int pcm_pinned;                     /* the caller's PCM buffer is pinned host memory (1) or device memory (2): direct target */
   int failed, busy;
   int carry;                          /* keep parse state (host handle / device sfstate) from the previous stream */
   /* bits mode: the engine calls of a window (H2D, kernels, D2H: ~40 us of driver time) are issued by a thread
@@ -1022,6 +1022,8 @@ static int bulk_collect(struct bulk* b, int slot, const unsigned char** jsrc, un
 static void flight_plan(struct bulk* b, bulk_flight* f) {
   const size_t row = f->all_stereo == 2 ? 4608 : 2304;
   f->direct = b->pcm_pinned && f->all_stereo != 0 && f->dst && (size_t)f->n * row <= f->dst_cap;
+  if (b->pcm_pinned == 2 && !f->direct) f->dst_cap = 0;   /* device memory the host cannot write: such a window is dropped
+                                                             (mixed mono / stereo window, or the tail that does not fit) */
 }
 
 /* stage C + D of the window the workers have just finished */

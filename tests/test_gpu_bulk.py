@@ -296,3 +296,34 @@ def test_pinned_destination_is_written_directly(streams, host_huffman):
         ref.close()
         for p in bufs:
             p.free()
+
+
+def test_pcm_stays_on_the_device(streams):
+    """a device pointer as destination (here a torch tensor): bitstream in host memory -> PCM in HBM, nothing comes back"""
+    import torch
+    from pdmp3_amd import api
+    b = api.BulkDecoder(threads=2, window_frames=32)
+    ref = api.BulkDecoder(threads=2, window_frames=64)
+    try:
+        for k in ("cbr320_js_441", "mono_32k_96", "vbr_48k_stereo_crc_tab33", "short_heavy_dual"):
+            want = ref.decode(streams[k])
+            out = torch.full((want.size + 32,), 0x5A5A, dtype=torch.int16, device="cuda")
+            total, rate, ch = b.decode_into_device(streams[k], out)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            assert total == want.nbytes, k
+            assert np.array_equal(got[:want.size], want), k
+            assert (got[want.size:] == 0x5A5A).all(), k
+        outs = []
+        for k in ("cbr128_js_441", "js_32k_256"):          # queued back to back
+            want = ref.decode(streams[k])
+            o = torch.zeros(want.size, dtype=torch.int16, device="cuda")
+            b.decode_into_device(streams[k], o, wait=False)
+            outs.append((k, o, want))
+        b.wait()
+        torch.cuda.synchronize()
+        for k, o, want in outs:
+            assert np.array_equal(o.cpu().numpy(), want), k
+    finally:
+        b.close()
+        ref.close()

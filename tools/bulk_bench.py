@@ -36,9 +36,14 @@ def c4(args, api):
     decs = [api.BulkDecoder(threads=2, window_frames=args.window, host_huffman=args.host_huffman, device=j % ngpu)
             for j in range(args.c4)]
 
+    douts = [torch.empty(max(b, 2) // 2, dtype=torch.int16, device="cuda:%d" % (0)) for b, _ in sizes] if args.device_out else None
+
     def work(j):
         for i in plan[j]:                                  # back to back, one wait at the end
-            got, _, _ = decs[j].decode_into_async(files[i], outs[i])
+            if douts is not None:
+                got, _, _ = decs[j].decode_into_device(files[i], douts[i], wait=False)
+            else:
+                got, _, _ = decs[j].decode_into_async(files[i], outs[i])
             assert got == sizes[i][0]
         decs[j].wait()
     best = None
@@ -57,7 +62,7 @@ def c4(args, api):
     print(json.dumps({"workload": "C4: %d files, %d frames, mono/stereo/joint x 32/44.1/48 kHz x CBR/VBR x block mixes" % (len(files), frames),
                       "decoders": args.c4, "gpus": ngpu, "seconds": round(best, 4), "frames_per_s": round(frames / best, 1),
                       "mp3_bytes": int(sum(len(f) for f in files)), "pcm_bytes": int(sum(b for b, _ in sizes)),
-                      "mode": "host Huffman" if args.host_huffman else "device Huffman", "pcm": "pinned" if args.pinned else "pageable",
+                      "mode": "host Huffman" if args.host_huffman else "device Huffman", "pcm": "device" if args.device_out else "pinned" if args.pinned else "pageable",
                       "host_cpus": os.cpu_count()}))
 
 
@@ -70,6 +75,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--c4", type=int, default=0, metavar="JOBS",
                     help="SURVEY 8d C4 instead: the mixed corpus (64 files x >= 4096 frames), JOBS decoders in parallel")
+    ap.add_argument("--device-out", action="store_true", help="--c4: PCM into device memory (torch tensors): it never leaves the GPU")
     ap.add_argument("--pinned", action="store_true", help="PCM into pinned host buffers (pdmp3_amd_pcm_alloc): no host copy")
     ap.add_argument("--gpus", type=int, default=1, help="--c4: decoder j runs on GPU j %% GPUS")
     ap.add_argument("--host-huffman", action="store_true", help="scalefactors + Huffman on the host pool instead of the device")
