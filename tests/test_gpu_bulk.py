@@ -298,11 +298,12 @@ def test_pinned_destination_is_written_directly(streams, host_huffman):
             p.free()
 
 
-def test_pcm_stays_on_the_device(streams):
+@pytest.mark.parametrize("host_huffman", [False, True])
+def test_pcm_stays_on_the_device(streams, host_huffman):
     """a device pointer as destination (here a torch tensor): bitstream in host memory -> PCM in HBM, nothing comes back"""
     import torch
     from pdmp3_amd import api
-    b = api.BulkDecoder(threads=2, window_frames=32)
+    b = api.BulkDecoder(threads=2, window_frames=32, host_huffman=host_huffman)
     ref = api.BulkDecoder(threads=2, window_frames=64)
     try:
         for k in ("cbr320_js_441", "mono_32k_96", "vbr_48k_stereo_crc_tab33", "short_heavy_dual"):
