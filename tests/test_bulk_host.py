@@ -106,8 +106,9 @@ def test_ring_replay_is_reported_not_looped():
 
 def test_corrupted_streams_match_the_oracle(oracle):
     """bit flips, byte splats, truncation: the host stage keeps giving the oracle's (= the reference's) records.
-    The one fenced difference: big_values > 288 makes the reference write past is[576]
-    and report a count1 above 576; the product stops at line 576 -- only that field may differ, only there."""
+    Streams in which a frame has big_values > 288 are not put to the oracle: the reference then writes past
+    is[576] and walks its band tables out of bounds (fenced in DESIGN.md 7) -- restated faithfully, the
+    oracle would do the same to this process."""
     from pdmp3_amd import api
     rs = np.random.RandomState(33)
     bases = [np.frombuffer(packer.generate(n_frames=90, seed=51, vbr=True, block_pct=(40, 10, 40, 10), mixed_pct=50), dtype=np.uint8),
@@ -117,7 +118,7 @@ def test_corrupted_streams_match_the_oracle(oracle):
     b = api.BulkDecoder(threads=2, window_frames=32, parse_only=True)
     streams = h8 = 0
     try:
-        for it in range(60):
+        for it in range(80):
             m = bases[it % 3].copy()
             kind = (it // 3) % 3
             for p in rs.randint(0, len(m), size=1 + rs.randint(0, 6 if kind == 0 else 150)):
@@ -129,21 +130,15 @@ def test_corrupted_streams_match_the_oracle(oracle):
                 sp, sd, nbytes = b.parse(m)
             except api.RingReplay:
                 continue
+            bits, _, _ = api.parse_bits(m)
+            if (bits["gc"]["big_values"] > 288).any():
+                h8 += 1
+                continue
             pcm_o, sp_o, sd_o = oracle.decode_buffer_like_cli(m.tobytes(), tap_frames=400)
             n = sp_o.shape[0]
             assert sp.shape[0] >= n and len(pcm_o) == nbytes, it
             assert np.array_equal(sp[:n], sp_o), it
-            bits, _, _ = api.parse_bits(m)
-            over = (bits["gc"]["big_values"][:n] > 288).any(axis=1)
-            ok = np.array([np.array_equal(sd[f:f + 1].view(np.uint8), sd_o[f:f + 1].view(np.uint8)) for f in range(n)])
-            assert not (~ok & ~over).any(), (it, np.nonzero(~ok & ~over)[0][:5])
-            for f in np.nonzero(~ok)[0]:                      # H8 frames: everything but count1 agrees
-                x, y = sd[f].copy(), sd_o[f].copy()
-                assert (y["count1"] > 576).any() and (x["count1"] <= 576).all()
-                x["count1"] = 0
-                y["count1"] = 0
-                assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (it, f)
-                h8 += 1
+            assert np.array_equal(sd[:n].view(np.uint8), sd_o.view(np.uint8)), it
             streams += 1
     finally:
         b.close()
