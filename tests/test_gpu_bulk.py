@@ -328,3 +328,50 @@ def test_pcm_stays_on_the_device(streams, host_huffman):
     finally:
         b.close()
         ref.close()
+
+
+def test_corrupted_streams_pcm_against_the_oracle(oracle):
+    """corrupted streams (without H8 frames, which the oracle cannot be given) end to end against the oracle's
+    transforms: +-1 LSB wherever the signal is within a few times full scale; where a flipped global_gain drives the
+    synthesis to 100x .. 4000x full scale the bar is the north-star float tolerance, 1e-5 of that amplitude"""
+    from pdmp3_amd import api
+    from util import pcm_tolerance
+    rs = np.random.RandomState(777)
+    bases = [np.frombuffer(packer.generate(n_frames=60, seed=500 + k, **kw), dtype=np.uint8) for k, kw in enumerate([
+        dict(vbr=True, block_pct=(40, 10, 40, 10), mixed_pct=50), dict(mode=1, mode_ext=2, bitrate_index=14, big_pct=200, gain=(100, 140)),
+        dict(sfreq=1, mode=0, mode_ext=0, crc=True, table33_pct=20), dict(mode=2, bitrate_index=12, block_pct=(10, 10, 70, 10))])]
+    dev = api.BulkDecoder(threads=2, window_frames=48)
+    streams = loud = 0
+    try:
+        for it in range(150):
+            m = bases[rs.randint(len(bases))].copy()
+            kind = rs.randint(3)
+            for p in rs.randint(0, len(m), size=1 + rs.randint(0, 4 if kind == 0 else 200)):
+                m[p] = rs.randint(0, 256) if kind == 2 else m[p] ^ (1 << rs.randint(0, 8))
+            m = np.ascontiguousarray(m)
+            try:
+                api.scan_buffer(m)
+            except api.RingReplay:
+                continue
+            bits, _, _ = api.parse_bits(m)
+            if (bits["gc"]["big_values"] > 288).any() or (((bits["frame"] >> 2) & 3) == 3).any():
+                continue                                   # H8, or a flipped header bit made a frame mono (layout below is stereo)
+            sp, sd = api.parse_like_cli(m.tobytes(), 200)
+            got = dev.decode(m)
+            n = got.size // 2304
+            if n == 0:
+                continue
+            want, st = oracle.decode(sp[:n], sd[:n], stages=True)
+            got = got.reshape(n, 2304)
+            d = np.abs(got.astype(np.int32) - want.astype(np.int32)).max(axis=1)
+            amp = np.abs(st[:, :, :, 3]).reshape(n, -1).max(axis=1)
+            hist = np.maximum.reduce([amp, np.roll(amp, 1), np.roll(amp, 2)])      # the polyphase history reaches back
+            hist[:2] = np.maximum(hist[:2], amp[:2].max())
+            quiet = hist < 1.0
+            assert (d[quiet] <= 1).all(), (it, np.nonzero(quiet & (d > 1))[0][:4])
+            assert d.max() <= pcm_tolerance(st[:, :, :, 3]), it
+            loud += int((~quiet).any())
+            streams += 1
+    finally:
+        dev.close()
+    assert streams > 80 and loud > 0
