@@ -34,11 +34,20 @@ __constant__ ConstBank c_bank;
 #endif
 constexpr int kWavesPerWg = PDMP3_WAVES_PER_WG;
 
+// Workgroup b is observed to run on XCD b % 8, each XCD with its own L2.  A chunk's halo is the tail of the chunk
+// before it, so neighbouring chunks should share an L2: XCD x gets the x-th contiguous eighth of the chunks
+// (bijective for any count).  Purely a placement choice -- nothing is communicated between workgroups.
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 template <bool DUMP>
 __global__ __launch_bounds__(64 * kWavesPerWg, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a, GlobalTables T, int n_chunks) {
   __shared__ WaveLds L[kWavesPerWg];
   const int w = threadIdx.x >> 6;
-  const int chunk = (int)blockIdx.x * kWavesPerWg + w;
+  const int n_wgs = (n_chunks + kWavesPerWg - 1) / kWavesPerWg;
+  const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * kWavesPerWg + w;
   if (chunk < n_chunks) run_chunk<DUMP>(a, T, (BankPtr)&c_bank, chunk, L[w]);
 }
 
