@@ -997,6 +997,9 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     }
   )
   PD_PHASE(ph_commit(lane, L, R))
+  // The band scales of a granule depend on its side info alone, which is in LDS one granule ahead: they are computed
+  // in the store phase of the granule before (here: of nothing), not in a phase of their own.
+  PD_PHASE(ph_scales(lane, L))
   unsigned long long acc[kProfSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = PD_CLOCK();
   acc[11] = tprev;                 // end of the per-wave setup
@@ -1021,15 +1024,12 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       }
     }
     PD_TICK(0)
-    PD_PHASE(
-      if (gr == 0 && (L.side[0][7] & PDMP3_FR_RESET)) state_zero(lane, R);
-      ph_scales(lane, L);
-    )
+    const bool reset_here = gr == 0 && (L.side[0][7] & PDMP3_FR_RESET);   // wave-uniform
     PD_TICK(1)
     float* dmp = DUMP ? a.stages + ((size_t)f * 16 + gr * 8) * 576 : nullptr;
 #if PD_MFMA
     if (g == g_peek) {                     // wave-uniform: lines 0..63, boundary sb 0 | 1, three IMDCT outputs
-      PD_PHASE(ph_requant<false, 1>(lane, L, cb, T, nullptr, nullptr))
+      PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<false, 1>(lane, L, cb, T, nullptr, nullptr))
       PD_TICK(2)
       PD_PHASE(
         if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
@@ -1039,7 +1039,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       PD_PHASE(ph_peek_tail(lane, L, R, T))
       PD_TICK(4)
     } else {
-      PD_PHASE(ph_requant<DUMP>(lane, L, cb, T, dmp, dmp + 576))
+      PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<DUMP>(lane, L, cb, T, dmp, dmp + 576))
       PD_TICK(2)
       PD_PHASE(
         // the next granule's HBM reads fly during this granule's transforms
@@ -1052,7 +1052,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     }
     PD_TICK(5)
 #else
-    PD_PHASE(ph_requant<DUMP>(lane, L, cb, T, dmp, dmp + 576))
+    PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<DUMP>(lane, L, cb, T, dmp, dmp + 576))
     PD_TICK(2)
     PD_PHASE(
       // the next granule's HBM reads fly during this granule's transforms
@@ -1077,7 +1077,10 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     if (g_next < g_end) {
       PD_PHASE(ph_commit(lane, L, R))
     }
-    PD_PHASE(ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, emit))
+    PD_PHASE(
+      ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, emit);
+      if (g_next < g_end) ph_scales(lane, L);        // next granule's (its side info was committed just above)
+    )
     PD_TICK(7)
   }
 #undef PD_TICK
