@@ -48,7 +48,9 @@
 // pins a VGPR value at this program point (keeps IR passes from sinking the
 // arithmetic that produced it past the scheduling fences)
 #define PD_PIN(x) asm volatile("" : "+v"(x))
+#define PD_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)     // wave-uniform: any lane
 #else
+#define PD_ANY(c) (true)
 #define PD_FN static inline
 #define PD_MFN inline
 #define PD_HD static inline
@@ -364,8 +366,13 @@ PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, f
     float pg0[NI], pg1[NI], ps0[NI], ps1[NI];
     PD_UNROLL for (int i = 0; i < NI; i++) { a0[i] = v0[i] < 0 ? -v0[i] : v0[i]; a1[i] = v1[i] < 0 ? -v1[i] : v1[i]; }
     PD_UNROLL for (int i = 0; i < NI; i++) {
-      pg0[i] = T.pow43[a0[i] >= kPow43Small ? (a0[i] > 8206 ? 8206 : a0[i]) : 0];
-      pg1[i] = T.pow43[a1[i] >= kPow43Small ? (a1[i] > 8206 ? 8206 : a1[i]) : 0];
+      // (wave-uniform skip: most groups of 64 lines hold no magnitude above the LDS copy's range, and a gather is
+      // a 64-bit address per lane plus a trip through the texture addresser even when every lane asks for [0])
+      pg0[i] = 0.0f; pg1[i] = 0.0f;
+      if (PD_ANY(a0[i] >= kPow43Small || a1[i] >= kPow43Small)) {
+        pg0[i] = T.pow43[a0[i] >= kPow43Small ? (a0[i] > 8206 ? 8206 : a0[i]) : 0];
+        pg1[i] = T.pow43[a1[i] >= kPow43Small ? (a1[i] > 8206 ? 8206 : a1[i]) : 0];
+      }
     }
     PD_UNROLL for (int i = 0; i < NI; i++) { ps0[i] = L.pow43s[a0[i] & (kPow43Small - 1)]; ps1[i] = L.pow43s[a1[i] & (kPow43Small - 1)]; }
     PD_UNROLL for (int i = 0; i < NI; i++) {
