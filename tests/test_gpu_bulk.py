@@ -22,7 +22,7 @@ def streams():
 
 
 @pytest.mark.parametrize("host_huffman", [False, True])
-@pytest.mark.parametrize("threads,window", [(4, 2048), (3, 5), (8, 32)])
+@pytest.mark.parametrize("threads,window", [(4, 2048), (3, 5), (8, 32), (1, 1)])
 def test_bulk_decode_matches_oracle_and_streaming_api(oracle, streams, threads, window, host_huffman):
     """host_huffman=False: scalefactors + Huffman + state merge on the device (submit_bits); True: on the host pool"""
     from pdmp3_amd import api
