@@ -295,12 +295,13 @@ static int search_header(pdmp3_handle* id) {
 /* ------------------------------------------------------------------------ */
 /* side info (P:1129-1200)                                                   */
 /* ------------------------------------------------------------------------ */
-static inline unsigned side_bits(pdmp3_handle* id, unsigned n) {   /* n <= 12 */
+/* bit cursor over side_vec, kept in registers while one frame's side info is parsed (pos in bits) */
+typedef struct { const uint8_t* base; unsigned pos; } side_cur;
+static inline unsigned side_bits(side_cur* c, unsigned n) {          /* n <= 12 */
   uint64_t w;
-  memcpy(&w, &id->side_vec[id->side_ptr & 63], 8);
-  w = __builtin_bswap64(w) << id->side_idx;
-  id->side_ptr += (id->side_idx + n) >> 3;
-  id->side_idx = (id->side_idx + n) & 7;
+  memcpy(&w, c->base + ((c->pos >> 3) & 63), 8);
+  w = __builtin_bswap64(w) << (c->pos & 7);
+  c->pos += n;
   return (unsigned)(w >> (64 - n));
 }
 
@@ -322,35 +323,38 @@ static void read_side_info(pdmp3_handle* id) {
   }
   if (got == nbytes) { id->side_ptr = 0; id->side_idx = 0; }   /* pointers move only on a full read (P:1576-1586) */
   side_info* S = &id->si;
-  S->main_data_begin = side_bits(id, 9);
-  (void)side_bits(id, nch == 1 ? 5 : 3);
+  side_cur sc = {id->side_vec, id->side_ptr * 8 + id->side_idx};
+  S->main_data_begin = side_bits(&sc, 9);
+  (void)side_bits(&sc, nch == 1 ? 5 : 3);
   for (unsigned ch = 0; ch < nch; ch++)
-    for (unsigned b = 0; b < 4; b++) S->scfsi[ch][b] = side_bits(id, 1);
+    for (unsigned b = 0; b < 4; b++) S->scfsi[ch][b] = side_bits(&sc, 1);
   for (unsigned gr = 0; gr < 2; gr++)
     for (unsigned ch = 0; ch < nch; ch++) {
-      S->part2_3_length[gr][ch] = side_bits(id, 12);
-      S->big_values[gr][ch] = side_bits(id, 9);
-      S->global_gain[gr][ch] = side_bits(id, 8);
-      S->scalefac_compress[gr][ch] = side_bits(id, 4);
-      S->win_switch[gr][ch] = side_bits(id, 1);
+      S->part2_3_length[gr][ch] = side_bits(&sc, 12);
+      S->big_values[gr][ch] = side_bits(&sc, 9);
+      S->global_gain[gr][ch] = side_bits(&sc, 8);
+      S->scalefac_compress[gr][ch] = side_bits(&sc, 4);
+      S->win_switch[gr][ch] = side_bits(&sc, 1);
       if (S->win_switch[gr][ch]) {
-        S->block_type[gr][ch] = side_bits(id, 2);
-        S->mixed[gr][ch] = side_bits(id, 1);
-        S->table_select[gr][ch][0] = side_bits(id, 5);
-        S->table_select[gr][ch][1] = side_bits(id, 5);
-        for (unsigned w = 0; w < 3; w++) S->subblock_gain[gr][ch][w] = side_bits(id, 3);
+        S->block_type[gr][ch] = side_bits(&sc, 2);
+        S->mixed[gr][ch] = side_bits(&sc, 1);
+        S->table_select[gr][ch][0] = side_bits(&sc, 5);
+        S->table_select[gr][ch][1] = side_bits(&sc, 5);
+        for (unsigned w = 0; w < 3; w++) S->subblock_gain[gr][ch][w] = side_bits(&sc, 3);
         S->region0_count[gr][ch] = (S->block_type[gr][ch] == 2 && !S->mixed[gr][ch]) ? 8 : 7;   /* implicit */
         S->region1_count[gr][ch] = 20 - S->region0_count[gr][ch];
       } else {
-        for (unsigned r = 0; r < 3; r++) S->table_select[gr][ch][r] = side_bits(id, 5);
-        S->region0_count[gr][ch] = side_bits(id, 4);
-        S->region1_count[gr][ch] = side_bits(id, 3);
+        for (unsigned r = 0; r < 3; r++) S->table_select[gr][ch][r] = side_bits(&sc, 5);
+        S->region0_count[gr][ch] = side_bits(&sc, 4);
+        S->region1_count[gr][ch] = side_bits(&sc, 3);
         S->block_type[gr][ch] = 0;             /* mixed / subblock_gain stay stale (H20) */
       }
-      S->preflag[gr][ch] = side_bits(id, 1);
-      S->scalefac_scale[gr][ch] = side_bits(id, 1);
-      S->count1table_select[gr][ch] = side_bits(id, 1);
+      S->preflag[gr][ch] = side_bits(&sc, 1);
+      S->scalefac_scale[gr][ch] = side_bits(&sc, 1);
+      S->count1table_select[gr][ch] = side_bits(&sc, 1);
     }
+  id->side_ptr = sc.pos >> 3;
+  id->side_idx = sc.pos & 7;
 }
 
 /* ------------------------------------------------------------------------ */
