@@ -2,36 +2,34 @@
 //
 // One 64-lane wavefront owns one CHUNK of consecutive frames of a stream and
 // walks it granule by granule; all inter-granule state lives on chip:
-//   * IMDCT overlap (the reference's `store[2][32][18]`, pdmp3.c:1755) in the
-//     VGPRs of the lane that owns (channel, subband),
+//   * IMDCT overlap (the reference's `store[2][32][18]`, pdmp3.c:1755) in VGPRs, in the C/D register layout of
+//     the matrix instruction that produces it,
 //   * the polyphase history (the reference's 1024-float V FIFO per channel,
 //     pdmp3.c:1983,2006) as the 2 x 15 DCT coefficients each lane will need
 //     again, also in VGPRs.
 // Stages per granule (reference stage it replaces, "P:n" = pdmp3.c line n):
-//   ph_commit   prefetched 2304 B int16 spectra + 2 side records -> LDS
-//   ph_scales   per-band requantisation scale 2^-(sfm*sf) * 2^(gain/4)   P:2127-2128, P:2144-2146
-//   ph_requant  |is|^(4/3) * scale, short-block reorder as a gather,
-//               MS / intensity stereo                                     P:1829, P:1786, P:1911
-//   ph_fetch    alias reduction fused into the IMDCT operand fetch        P:1706
-//   ph_imdct    18->36 (or 3 x 6->12) IMDCT with scalar-broadcast
-//               coefficients, window, overlap-add, frequency inversion    P:1649, P:1752, P:1738
-//   ph_dct32    32-point DCT-II (Lee) per time slot = the 64x32 matrixing
-//               folded by its cosine symmetries                           P:2010-2014
-//   ph_window   512-tap D window as 16 FMAs per sample against the slot
-//               history, float -> int16 exactly as P:2028-2031
-//   ph_store    coalesced PCM store
+//   ph_commit    prefetched 2304 B int16 spectra + 2 side records -> LDS
+//   ph_scales    per-band requantisation scale 2^-(sfm*sf) * 2^(gain/4)   P:2127-2128, P:2144-2146
+//   ph_requant   |is|^(4/3) * scale, short-block reorder as a gather,
+//                MS / intensity stereo                                     P:1829, P:1786, P:1911
+//   ph_antialias alias reduction in place                                  P:1706
+//   ph_mfma      18->36 (or 3 x 6->12) IMDCT, window, overlap-add, frequency inversion, and the 64x32 matrixing
+//                folded to 16x16 DCT halves -- all on v_mfma_f32_16x16x4_f32   P:1649, P:1752, P:1738, P:2010-2014
+//   ph_window    512-tap D window as 16 FMAs per sample against the slot
+//                history, float -> int16 exactly as P:2028-2031
+//   ph_store     PCM store
 //
-// The file is plain C++ that compiles for the device with hipcc AND for the
-// host with g++ (tests/host_emul): the host build runs each phase for lanes
-// 0..63 in turn and is used ONLY by the CPU test-suite to validate indexing
-// without a GPU.  It is not a product path.
+// ONE formulation, two builds: hipcc compiles this file for the device; g++ compiles THE SAME code for the
+// CPU test-suite (tests/host_emul), where the 64 lanes of a wave run as 64 cooperatively scheduled fibers and
+// the cross-lane operations (matrix instruction, lane shuffles, ballots, phase fences) are provided by the
+// test harness through the `pdmp3::emu` hooks declared below -- with the device's fragment layouts and the
+// device's arithmetic (k-ordered fmaf chains).  The host build is test infrastructure, not a product path.
 #pragma once
 
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
 #include "../../include/pdmp3_hip.h"
-#include "dct32_consts.h"
 
 #if defined(__HIPCC__)
 #define PD_FN __device__ __forceinline__
@@ -40,7 +38,6 @@
 // Built with -ffp-contract=off: a*b+c stays two roundings (as in the reference's
 // x86-64 build) unless PD_FMA is written out.
 #define PD_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
-#define PD_FMA_EXACT(a, b, c) __builtin_fmaf((a), (b), (c))
 #define PD_CLOCK() __builtin_amdgcn_s_memtime()
 #define PD_UNROLL _Pragma("unroll")
 #define PD_NOUNROLL _Pragma("nounroll")
@@ -49,35 +46,46 @@
 // arithmetic that produced it past the scheduling fences)
 #define PD_PIN(x) asm volatile("" : "+v"(x))
 #define PD_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)     // wave-uniform: any lane
+#define PD_LANE() ((int)(threadIdx.x & 63))
+#define PD_SHFL_XOR(v, m) __shfl_xor((v), (m))
+// A workgroup's waves never share a WaveLds: LDS operations of a wave execute in order, so the
+// phase hand-offs through LDS need no s_barrier and -- unlike __syncthreads() -- no
+// drain of the vector-memory counter: the next granule's prefetch loads and this
+// granule's PCM stores stay in flight across phases.  The wave barrier only stops
+// the compiler from moving memory operations across the phase boundary.
+#define PD_WAVE_SYNC()                                       \
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+  __builtin_amdgcn_wave_barrier();                          \
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
 #else
-#define PD_ANY(c) (true)
+namespace pdmp3 {
+namespace emu {   // provided by tests/host_emul/wave_emul.h: one wave = 64 fibers
+int lane();                                   // the calling fiber's lane
+void wave_sync();                             // returns when all 64 lanes have arrived
+float shfl_xor(float v, int mask);
+bool any(bool c);
+void mfma16(float a, float b, float* cd);     // v_mfma_f32_16x16x4_f32: cd[4] in and out
+void permlane32_swap(int* a, int* b);         // v_permlane32_swap_b32 vdst = a, src = b
+}  // namespace emu
+}  // namespace pdmp3
 #define PD_FN static inline
 #define PD_MFN inline
 #define PD_HD static inline
-#define PD_FMA(a, b, c) ((a) * (b) + (c))
-#define PD_FMA_EXACT(a, b, c) fmaf((a), (b), (c))   /* a true fused multiply-add is required */
+#define PD_FMA(a, b, c) __builtin_fmaf((a), (b), (c))   /* a true fused multiply-add, as on the device */
 #define PD_CLOCK() 0ull
 #define PD_UNROLL
 #define PD_NOUNROLL
 #define PD_SCHED_FENCE() ((void)0)
 #define PD_PIN(x) ((void)0)
-#endif
-
-// IMDCT and the polyphase matrixing on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32)
-// in the device build; the host (index-logic) build keeps the VALU formulation.
-#if defined(__HIPCC__) && !defined(PDMP3_NO_MFMA)
-#define PD_MFMA 1
-#else
-#define PD_MFMA 0
+#define PD_ANY(c) (::pdmp3::emu::any(c))
+#define PD_LANE() (::pdmp3::emu::lane())
+#define PD_SHFL_XOR(v, m) (::pdmp3::emu::shfl_xor((v), (m)))
+#define PD_WAVE_SYNC() ::pdmp3::emu::wave_sync()
 #endif
 
 namespace pdmp3 {
 
-#if PD_MFMA
 constexpr int kOvlRegs = 18;          // overlap: [ch][h][r] in MFMA C/D layout for p = 18 + j, plus p = 34, 35 of the lane's own (ch, sb)
-#else
-constexpr int kOvlRegs = 18;          // overlap of (ch, sb) in the lane that owns it
-#endif
 
 constexpr int kHaloGranules = 2;      // (f-1,gr0) (f-1,gr1): overlap depth 1, polyphase history 15 slots
 constexpr int kHaloGranulesH5 = 3;    // + (f-2,gr1) when (f-1,gr1,ch1) is a short block: its requantisation peeks at
@@ -88,9 +96,7 @@ constexpr int kPow43Small = 128;      // |is| below this come from the LDS copy 
 // Small tables; lives in __constant__ memory on the device so that
 // wave-uniform indices become scalar loads.
 struct ConstBank {
-  float c36p[18][18][2];  // cos_N36 (P:620-729) as [m][q][{p = q, p = q + 18}]
-  float c12t[12][6];      // cos_N12 (P:606-619) transposed to [p][m]
-  float c36x[4][18];      // cos_N36 columns p = 16, 17, 34, 35 as [q][m]   (MFMA build: the columns left to the VALU)
+  float c36x[4][18];      // cos_N36 (P:620-729) columns p = 16, 17, 34, 35 as [q][m]: the columns left to the VALU
   float s36x[4][18];      // the same columns of the short-block matrix (3 x 12-point IMDCT, win[2] folded in)
   float cs[8], ca[8];     // P:573-574
   float isr_l[16];        // is_ratio_l for is_pos 0..6 (P:2166-2172); [7] unused;
@@ -216,10 +222,8 @@ PD_FN void lane_init(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const Global
   L.pow43s[lane + 64] = T.pow43[lane + 64];
   for (int k = lane; k < 144; k += 64) (&L.win[0][0])[k] = T.win[k];
   if (lane < 4) L.peek[lane] = 1.0f;
-#if PD_MFMA
   for (int k = 0; k < 10; k++) R.bi[k] = T.frag_long[k * 64 + lane];
   for (int k = 0; k < 8; k++) R.bm[k] = T.frag_mat[k * 64 + lane];
-#endif
 }
 
 // the line tables of one sampling frequency (3 kinds x 576 u16 = 216 x 16 B)
@@ -244,16 +248,10 @@ PD_FN void state_load(int lane, LaneRegs& R, const float* st) {
 // (ch 1, sb) lanes) and its polyphase history; what a run of mono frames leaves untouched (P:1777, P:2126 are
 // indexed by channel)
 PD_FN void state_load_ch1(int lane, LaneRegs& R, const float* st) {
-#if PD_MFMA
   for (int m = 8; m < 16; m++) R.ovl[m] = st[m * 64 + lane];
-#endif
   if (lane >= 32) {
-#if PD_MFMA
     R.ovl[16] = st[16 * 64 + lane];
     R.ovl[17] = st[17 * 64 + lane];
-#else   // host test build: the lane (ch, sb) owns all 18 tails of its subband
-    for (int m = 0; m < kOvlRegs; m++) R.ovl[m] = st[m * 64 + lane];
-#endif
     for (int s = 0; s < kHistSlots; s++) {
       R.he[s] = st[(kOvlRegs + s) * 64 + lane];
       R.ho[s] = st[(kOvlRegs + kHistSlots + s) * 64 + lane];
@@ -458,115 +456,6 @@ PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, f
 }
 
 // ---------------------------------------------------------------------------
-// ph_fetch: IMDCT operand fetch with the alias-reduction butterflies folded in
-// ---------------------------------------------------------------------------
-template <bool DUMP>
-PD_FN void ph_fetch(int lane, const WaveLds& L, LaneRegs& R, BankPtr cb, float* dump2) {
-  const GranuleInfo g = granule_info(L);
-  const int ch = lane >> 5, sb = lane & 31;
-  if (ch >= g.nch) return;
-  const bool shrt = g.is_short(ch), mixed = g.is_mixed(ch);
-  const float* x = L.xr[ch];
-  float* in = R.in;
-  PD_UNROLL for (int m = 0; m < 18; m++) in[m] = x[18 * sb + m];
-  // P:1706-1732: butterflies across the boundary below (index sb) and above (sb+1)
-  const bool aa_lo = (sb >= 1) && (!shrt || (mixed && sb == 1));
-  const bool aa_hi = (sb <= 30) && (!shrt || (mixed && sb == 0));
-  if (aa_lo) {
-    PD_UNROLL for (int i = 0; i < 8; i++) {
-      const float lo = x[18 * sb - 1 - i];
-      in[i] = in[i] * cb->cs[i] + lo * cb->ca[i];                 // ub, P:1726
-    }
-  }
-  if (aa_hi) {
-    PD_UNROLL for (int i = 0; i < 8; i++) {
-      const float up = x[18 * (sb + 1) + i];
-      in[17 - i] = in[17 - i] * cb->cs[i] - up * cb->ca[i];       // lb, P:1725
-    }
-  }
-  if (DUMP) {
-    PD_UNROLL for (int m = 0; m < 18; m++) dump2[ch * 4 * 576 + 18 * sb + m] = in[m];
-  }
-}
-
-// ---------------------------------------------------------------------------
-// ph_imdct: 18 -> 36 IMDCT (or 3 x 6 -> 12), window, overlap-add, freq inversion
-// ---------------------------------------------------------------------------
-template <bool DUMP>
-PD_FN void ph_imdct(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, float* dump3) {
-  const GranuleInfo g = granule_info(L);
-  const int ch = lane >> 5, sb = lane & 31;
-  const bool active = ch < g.nch;
-  const bool mixed = g.is_mixed(ch);
-  const bool wsf = (g.flags(ch) & PDMP3_GC_WIN_SWITCH) != 0;
-  const float* in = R.in;
-  const int bt = (wsf && mixed && sb < 2) ? 0 : g.block_type(ch);   // P:1769-1771
-  const bool odd_sb = sb & 1;
-  float res[18], nov[18];
-  {
-    // Long transform, executed by every lane in straight-line code (lanes of a
-    // short-block channel discard it below): out[p] = (sum_m in[m] cos_N36[m][p]) * win[bt][p]
-    // (P:1689-1698), all 36 sums advance together, m ascending as in the
-    // reference.  The coefficients of one m are wave-uniform => scalar operands,
-    // fetched one unit (9 output pairs) ahead of their use; the fences keep the
-    // scheduler from clustering all 648 scalar loads up front (SGPR spills).
-    float lo[18], hi[18];
-    PD_UNROLL for (int q = 0; q < 18; q++) { lo[q] = 0.0f; hi[q] = 0.0f; }
-    float ca[18], cn[18];
-    const auto* cflat = &cb->c36p[0][0][0];
-    PD_UNROLL for (int k = 0; k < 18; k++) ca[k] = cflat[k];
-    PD_UNROLL for (int u = 0; u < 36; u += 2) {
-      const int m = u >> 1;
-      PD_UNROLL for (int k = 0; k < 18; k++) cn[k] = cflat[(u + 1) * 18 + k];
-      PD_UNROLL for (int q = 0; q < 9; q++) {
-        lo[q] = PD_FMA(in[m], ca[2 * q], lo[q]);
-        hi[q] = PD_FMA(in[m], ca[2 * q + 1], hi[q]);
-      }
-      PD_UNROLL for (int q = 0; q < 9; q++) { PD_PIN(lo[q]); PD_PIN(hi[q]); }
-      PD_SCHED_FENCE();
-      if (u + 2 < 36) {
-        PD_UNROLL for (int k = 0; k < 18; k++) ca[k] = cflat[(u + 2) * 18 + k];
-      }
-      PD_UNROLL for (int q = 0; q < 9; q++) {
-        lo[9 + q] = PD_FMA(in[m], cn[2 * q], lo[9 + q]);
-        hi[9 + q] = PD_FMA(in[m], cn[2 * q + 1], hi[9 + q]);
-      }
-      PD_UNROLL for (int q = 0; q < 9; q++) { PD_PIN(lo[9 + q]); PD_PIN(hi[9 + q]); }
-      PD_SCHED_FENCE();
-    }
-    const float* w = L.win[bt == 2 ? 0 : bt];
-    PD_UNROLL for (int q = 0; q < 18; q++) {
-      res[q] = lo[q] * w[q] + R.ovl[q];                                        // P:1775
-      nov[q] = hi[q] * w[q + 18];                                              // P:1776
-    }
-  }
-  if (g.is_short(0) || g.is_short(1)) {      // wave-uniform: some lanes need the 3 x 12-point transform
-    if (bt == 2) {
-      float raw[36];
-      PD_UNROLL for (int p = 0; p < 36; p++) raw[p] = 0.0f;
-      PD_UNROLL for (int wn = 0; wn < 3; wn++)                                 // P:1675-1685
-        PD_UNROLL for (int p = 0; p < 12; p++) {
-          float sum = 0.0f;
-          PD_UNROLL for (int m = 0; m < 6; m++) sum = PD_FMA(in[wn + 3 * m], cb->c12t[p][m], sum);
-          raw[6 * wn + p + 6] += sum * L.win[2][p];
-        }
-      PD_UNROLL for (int p = 0; p < 18; p++) { res[p] = raw[p] + R.ovl[p]; nov[p] = raw[p + 18]; }
-    }
-  }
-  // lanes of the unused channel of a mono frame keep their overlap (the state of
-  // channel 1 survives mono frames, as in the reference) and write a dead hyb row
-  PD_UNROLL for (int p = 0; p < 18; p++) {
-    R.ovl[p] = active ? nov[p] : R.ovl[p];
-    float y = res[p];
-    if (odd_sb && (p & 1)) y = -y;                                             // P:1738-1746
-    L.hyb[ch][p][sb] = y;
-    if (DUMP) { if (active) dump3[ch * 4 * 576 + 18 * sb + p] = y; }
-    if (lane == 0 && p < 3) L.peek[p] = y;                                     // H5 source
-  }
-}
-
-#if PD_MFMA
-// ---------------------------------------------------------------------------
 // MFMA formulation of IMDCT + matrixing (device build)
 //
 // v_mfma_f32_16x16x4_f32: lane l = (j = l & 15, kq = l >> 4) holds A[row j][k = kq], B[k = kq][col j] and
@@ -583,8 +472,17 @@ PD_FN void ph_imdct(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, float* dump3)
 //              registers ARE the A fragments (row = t = j, k = 4 kq + r arrives as k-step r) -- the hybrid output
 //              never goes through LDS and the matrixing costs 8 instead of 16 MFMAs per row tile.
 // ---------------------------------------------------------------------------
+#if defined(__HIPCC__)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 PD_FN f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#else
+typedef float f32x4 __attribute__((vector_size(16)));
+PD_FN f32x4 mfma16(float a, float b, f32x4 c) {
+  float cd[4] = {c[0], c[1], c[2], c[3]};
+  emu::mfma16(a, b, cd);
+  return (f32x4){cd[0], cd[1], cd[2], cd[3]};
+}
+#endif
 
 // alias reduction in place (P:1706-1732): lane (ch, sb) owns the boundary below subband sb
 PD_FN void ph_antialias(int lane, WaveLds& L, BankPtr cb, bool only_first = false) {   // only_first: boundary sb 0 | 1 alone
@@ -602,11 +500,6 @@ PD_FN void ph_antialias(int lane, WaveLds& L, BankPtr cb, bool only_first = fals
     x[18 * sb + i] = up[i] * cb->cs[i] + lo[i] * cb->ca[i];       // ub, P:1726
   }
 }
-
-#define PD_WAVE_SYNC()                                       \
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
-  __builtin_amdgcn_wave_barrier();                          \
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
 
 // The peek-only halo granule (run_chunk): all that is wanted from it are the three IMDCT tail values p = 18, 19, 20 of
 // (channel 0, subband 0) -- the overlap that the next granule's hybrid output (ch 0, sb 0, t 0..2) adds, which is what the
@@ -667,7 +560,7 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTa
     if (DUMP) { if (act) { dump3[cl * 4 * 576 + 18 * sb + 16] = o16; dump3[cl * 4 * 576 + 18 * sb + 17] = o17; } }
     // matrixing fold: x[k] +- x[31 - k]; subband 31 - sb of the same channel is lane ^ 31
     if (do_matrix) {
-      const float p16 = __shfl_xor(o16, 31), p17 = __shfl_xor(o17, 31);
+      const float p16 = PD_SHFL_XOR(o16, 31), p17 = PD_SHFL_XOR(o17, 31);
       if (sb < 16) {
         L.lo[0][2 * cl + 0][sb] = o16 + p16; L.lo[1][2 * cl + 0][sb] = o16 - p16;
         L.lo[0][2 * cl + 1][sb] = o17 + p17; L.lo[1][2 * cl + 1][sb] = o17 - p17;
@@ -762,47 +655,6 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTa
     }
   }
 }
-#endif  // PD_MFMA
-
-// ---------------------------------------------------------------------------
-// 32-point DCT-II, Lee's recursion:  X[k] = sum_n x[n] cos(pi (2n+1) k / 2N)
-// ---------------------------------------------------------------------------
-template <int N> struct LeeC;
-template <> struct LeeC<32> { static constexpr float v[16] = PDMP3_LEE32; };
-template <> struct LeeC<16> { static constexpr float v[8] = PDMP3_LEE16; };
-template <> struct LeeC<8> { static constexpr float v[4] = PDMP3_LEE8; };
-template <> struct LeeC<4> { static constexpr float v[2] = PDMP3_LEE4; };
-template <> struct LeeC<2> { static constexpr float v[1] = PDMP3_LEE2; };
-
-template <int N>
-PD_FN void dct2_lee(const float* in, float* out) {
-  if constexpr (N == 1) {
-    out[0] = in[0];
-  } else {
-    float a[N / 2], b[N / 2], A[N / 2], B[N / 2];
-    PD_UNROLL for (int n = 0; n < N / 2; n++) {
-      a[n] = in[n] + in[N - 1 - n];
-      b[n] = (in[n] - in[N - 1 - n]) * LeeC<N>::v[n];
-    }
-    dct2_lee<N / 2>(a, A);
-    dct2_lee<N / 2>(b, B);
-    PD_UNROLL for (int k = 0; k < N / 2; k++) {
-      out[2 * k] = A[k];
-      out[2 * k + 1] = (k + 1 < N / 2) ? B[k] + B[k + 1] : B[k];
-    }
-  }
-}
-
-PD_FN void ph_dct32(int lane, WaveLds& L) {
-  const GranuleInfo g = granule_info(L);
-  if (lane >= 18 * g.nch) return;
-  const int ch = lane / 18, t = lane - 18 * ch;
-  float x[32], c[32];
-  PD_UNROLL for (int j = 0; j < 32; j++) x[j] = L.hyb[ch][t][j];
-  dct2_lee<32>(x, c);
-  PD_UNROLL for (int n = 0; n < 32; n++) L.hyb[ch][t][n] = c[n];   // in place: the row now holds the slot's C[0..31]
-}
-
 // float -> int16 exactly as P:2028-2031 on x86-64 (cvttsd2si: out of range / NaN => INT32_MIN);
 // the f64 product of a binary32 and 32767 is exact, so this is bit-for-bit the reference's conversion
 PD_FN int pcm_from_sum(float sum) {
@@ -890,9 +742,7 @@ PD_FN int last_stereo_or_reset(const pdmp3_gc_side* side, int f_lo, int f_hi) {
 }
 
 // ---------------------------------------------------------------------------
-// One chunk = one wavefront.  PD_PHASE runs its body for every lane and then
-// synchronises: on the device `lane` is threadIdx.x and the barrier is a
-// (single-wave) __syncthreads(); the host test build loops lanes 0..63.
+// One chunk = one wavefront.
 // ---------------------------------------------------------------------------
 struct DecodeArgs {
   const int16_t* spectra;        // [n_frames][2][2][576]
@@ -909,36 +759,18 @@ struct DecodeArgs {
 
 constexpr int kProfSlots = 12;
 
-#if defined(__HIPCC__)
-#define PD_NLANES 1
-// A workgroup is ONE wavefront: LDS operations of a wave execute in order, so the
-// phase hand-offs through LDS need no s_barrier and -- unlike __syncthreads() -- no
-// drain of the vector-memory counter: the next granule's prefetch loads and this
-// granule's PCM stores stay in flight across phases.  The wave barrier only stops
-// the compiler from moving memory operations across the phase boundary.
+// PD_PHASE: a phase body, then the wave-level fence that orders its LDS traffic against the next phase's
+// (device: compiler-level only, see PD_WAVE_SYNC; host test build: every fiber of the wave arrives).
 #define PD_PHASE(...)                                   \
   {                                                     \
-    const int lane = threadIdx.x & 63;                  \
-    LaneRegs& R = Rs[0];                                \
-    (void)R; (void)lane;                                \
     __VA_ARGS__;                                        \
   }                                                     \
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-  __builtin_amdgcn_wave_barrier();                      \
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
-#define PD_NLANES 64
-#define PD_PHASE(...)                                   \
-  for (int lane = 0; lane < 64; ++lane) {               \
-    LaneRegs& R = Rs[lane];                             \
-    (void)R;                                            \
-    __VA_ARGS__;                                        \
-  }
-#endif
+  PD_WAVE_SYNC();
 
 template <bool DUMP, bool PROF = false>
 PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveLds& L) {
-  LaneRegs Rs[PD_NLANES];
+  LaneRegs R;
+  const int lane = PD_LANE();
   const unsigned long long t_wave_start = PROF ? PD_CLOCK() : 0ull;
   const int f0 = chunk * a.chunk_frames;
   int f1 = f0 + a.chunk_frames;
@@ -949,7 +781,6 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   // (26 lines, one subband, three IMDCT outputs; ph_peek_tail) unless it is also granule 0 of the batch, whose
   // state is the caller's
   int g_peek = -1;
-  (void)g_peek;              // (host test build: every halo granule is decoded in full)
   if (g_begin > 0) {
     // channel 1 of the granule just before the chunk: flags byte of its side record (wave-uniform)
     const uint8_t fl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(g_begin - 1) * 2 + 1)[3];
@@ -1032,9 +863,10 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     }
     PD_TICK(0)
     const bool reset_here = gr == 0 && (L.side[0][7] & PDMP3_FR_RESET);   // wave-uniform
+    // (read here, not next to its use: the commit phase below overwrites the side records with the next granule's)
+    const int nch_g = ((L.side[0][7] & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
     PD_TICK(1)
     float* dmp = DUMP ? a.stages + ((size_t)f * 16 + gr * 8) * 576 : nullptr;
-#if PD_MFMA
     if (g == g_peek) {                     // wave-uniform: lines 0..63, boundary sb 0 | 1, three IMDCT outputs
       PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<false, 1>(lane, L, cb, T, nullptr, nullptr))
       PD_TICK(2)
@@ -1058,29 +890,12 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       PD_TICK(4)
     }
     PD_TICK(5)
-#else
-    PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<DUMP>(lane, L, cb, T, dmp, dmp + 576))
-    PD_TICK(2)
-    PD_PHASE(
-      // the next granule's HBM reads fly during this granule's transforms
-      if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
-      ph_fetch<DUMP>(lane, L, R, cb, dmp + 2 * 576);
-    )
-    PD_TICK(3)
-    PD_PHASE(ph_imdct<DUMP>(lane, L, R, cb, dmp + 3 * 576))
-    PD_TICK(4)
-    if (emit || feeds_next) {
-      PD_PHASE(ph_dct32(lane, L))
-    }
-    PD_TICK(5)
-#endif
     if (emit || feeds_next) {
       PD_PHASE(ph_window(lane, L, R, emit))
     }
     PD_TICK(6)
     // the next granule is committed to LDS BEFORE this granule's PCM stores are issued: its prefetch
     // loads are older than those stores, so waiting for them never waits for a store
-    const int nch_g = ((L.side[0][7] & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
     if (g_next < g_end) {
       PD_PHASE(ph_commit(lane, L, R))
     }

@@ -43,13 +43,6 @@ inline const uint16_t* sfb_short_of(int sfreq) { return sfreq == 0 ? kSfbShort0 
 inline void build_host_tables(HostTables& H) {
   ConstBank& cb = H.cb;
   memset(&cb, 0, sizeof cb);
-  for (int m = 0; m < 18; m++)
-    for (int q = 0; q < 18; q++) {
-      cb.c36p[m][q][0] = kCosN36[m * 36 + q];
-      cb.c36p[m][q][1] = kCosN36[m * 36 + q + 18];
-    }
-  for (int m = 0; m < 6; m++)
-    for (int p = 0; p < 12; p++) cb.c12t[p][m] = kCosN12[m * 12 + p];
   for (int i = 0; i < 8; i++) { cb.cs[i] = kAliasCs[i]; cb.ca[i] = kAliasCa[i]; }
   for (int i = 0; i < 16; i++) {
     // pdmp3.c:2166-2172; is_pos == 6 is special-cased, 7 means "off", >= 8 is

@@ -40,13 +40,14 @@ def engine():
 
 @pytest.fixture(scope="session")
 def emul():
-    """Host build of the device pipeline (tests/host_emul): index-logic check only."""
+    """Host build of the device pipeline (tests/host_emul): the kernel's own source, one wave = 64 fibers."""
     import ctypes as C
     import subprocess
     d = os.path.join(ROOT, "tests", "host_emul")
     so = os.path.join(d, "libemul.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                           "-o", so, os.path.join(d, "emul.cpp")])
+    fma = ["-mfma"] if " fma " in open("/proc/cpuinfo").read() else []      # (else libm's fmaf: same results, slower)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"] + fma +
+                          ["-o", so, os.path.join(d, "emul.cpp")])
     lib = C.CDLL(so)
     lib.emul_state_floats.restype = C.c_size_t
     return lib

@@ -1,9 +1,10 @@
 // emul.cpp -- CPU build of pdmp3_amd/csrc/decode_core.h for the test-suite.
 //
-// TEST INFRASTRUCTURE.  Runs the device pipeline's phase functions lane by
-// lane on the host so that `pytest -m "not gpu"` can check the kernel's
-// indexing, table construction and chunk/halo logic against the oracle in a
+// TEST INFRASTRUCTURE.  Runs the device pipeline -- the same source the GPU runs, matrix-instruction fragment
+// layouts included -- as 64 fibers per wave (wave_emul.h) so that `pytest -m "not gpu"` can check the kernel's
+// indexing, table construction, fragment layouts and chunk/halo logic against the oracle in a
 // container without a GPU.  Never loaded by the product (pdmp3_amd/).
+#include "wave_emul.h"
 #include "../../pdmp3_amd/csrc/decode_core.h"
 #include "../../pdmp3_amd/csrc/host_tables.h"
 #include "../../pdmp3_amd/csrc/gen_core.h"
@@ -27,8 +28,9 @@ extern "C" int emul_decode_frames(const int16_t* spectra, const pdmp3_gc_side* s
   const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
   auto L = std::make_unique<WaveLds>();
   for (int c = 0; c < nchunks; ++c) {
-    if (stages) run_chunk<true>(a, T, &H.cb, c, *L);
-    else run_chunk<false>(a, T, &H.cb, c, *L);
+    WaveLds& Lr = *L;
+    if (stages) emu::run_wave([&] { run_chunk<true>(a, T, &H.cb, c, Lr); });
+    else emu::run_wave([&] { run_chunk<false>(a, T, &H.cb, c, Lr); });
   }
   if (state) std::copy(state_next.begin(), state_next.end(), state);
   return 0;
