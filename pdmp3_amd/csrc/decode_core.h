@@ -47,6 +47,9 @@
 #define PD_PIN(x) asm volatile("" : "+v"(x))
 #define PD_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)     // wave-uniform: any lane
 #define PD_LANE() ((int)(threadIdx.x & 63))
+// a value every lane holds alike, moved to a scalar register: conditions on it become scalar branches instead of
+// exec-masked regions, and loads under them can be hoisted
+#define PD_UNIFORM(x) __builtin_amdgcn_readfirstlane((int)(x))
 #define PD_SHFL_XOR(v, m) __shfl_xor((v), (m))
 // A workgroup's waves never share a WaveLds: LDS operations of a wave execute in order, so the
 // phase hand-offs through LDS need no s_barrier and -- unlike __syncthreads() -- no
@@ -79,6 +82,7 @@ void permlane32_swap(int* a, int* b);         // v_permlane32_swap_b32 vdst = a,
 #define PD_PIN(x) ((void)0)
 #define PD_ANY(c) (::pdmp3::emu::any(c))
 #define PD_LANE() (::pdmp3::emu::lane())
+#define PD_UNIFORM(x) ((int)(x))
 #define PD_SHFL_XOR(v, m) (::pdmp3::emu::shfl_xor((v), (m)))
 #define PD_WAVE_SYNC() ::pdmp3::emu::wave_sync()
 #endif
@@ -137,7 +141,7 @@ struct GlobalTables {
 // hyb rows are [slot t][33]: the DCT lane that owns slot t transforms its row in place.
 struct WaveLds {
   alignas(16) int16_t spec[2][576];     // committed one granule ahead (before the previous granule's PCM stores)
-  alignas(16) int16_t pcm[1152];
+  alignas(16) int16_t pcm[576];
   alignas(16) uint8_t side[2][128];
   float scale[2][64];
   union {
@@ -182,16 +186,19 @@ struct GranuleInfo {
 
 PD_FN GranuleInfo granule_info(const WaveLds& L) {
   GranuleInfo g;
-  const int fr = L.side[0][7];
+  // (the first dword of each record: count1 u16, global_gain, flags; byte 7: frame flags)
+  const uint32_t w0 = (uint32_t)PD_UNIFORM(*reinterpret_cast<const uint32_t*>(&L.side[0][0]));
+  const uint32_t w1 = (uint32_t)PD_UNIFORM(*reinterpret_cast<const uint32_t*>(&L.side[1][0]));
+  const int fr = PD_UNIFORM(L.side[0][7]);
   g.sfreq = fr & PDMP3_FR_SFREQ_MASK;
   if (g.sfreq > 2) g.sfreq = 2;
   g.mode = (fr & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT;
   g.mode_ext = (fr & PDMP3_FR_MODEEXT_MASK) >> PDMP3_FR_MODEEXT_SHIFT;
   g.nch = (g.mode == 3) ? 1 : 2;
-  g.count1_0 = L.side[0][0] | (L.side[0][1] << 8);
-  g.count1_1 = L.side[1][0] | (L.side[1][1] << 8);
-  g.flags0 = L.side[0][3];
-  g.flags1 = L.side[1][3];
+  g.count1_0 = (int)(w0 & 0xffffu);
+  g.count1_1 = (int)(w1 & 0xffffu);
+  g.flags0 = (int)(w0 >> 24);
+  g.flags1 = (int)(w1 >> 24);
   return g;
 }
 
@@ -667,46 +674,109 @@ PD_FN int pcm_from_sum(float sum) {
   return s;
 }
 
+// The same conversion for the 18 samples of a lane without binary64 (half-rate on the VALU, 5 instructions per
+// sample): truncation of the EXACT product sum * 32767 equals truncation of the binary32 product rounded TOWARD
+// ZERO (no integer lies strictly between a value and its round-toward-zero neighbour, integers below 2^24 being
+// representable), so the 18 multiplies run with the FP32 rounding mode switched to RTZ -- set and restored inside
+// one asm statement, the compiler never sees another mode.  Then: clamp to +-32767 in binary32 (exact), convert,
+// and the reference's wrap-around: a product at or beyond 2^31 (sum > 65538, the largest binary32 whose product
+// is still below 2^31) or a NaN comes out of cvttsd2si as INT32_MIN and is then clipped to -32767.
+PD_FN void pcm_convert18(const float* sum, int* out) {
+#if defined(__HIPCC__)
+  float p[18];
+  PD_UNROLL for (int t = 0; t < 18; t++) p[t] = sum[t];
+#define PD_M(n) "v_mul_f32 %" #n ", 0x46fffe00, %" #n "\n\t"
+  asm volatile(
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "s_nop 1\n\t"
+      PD_M(0) PD_M(1) PD_M(2) PD_M(3) PD_M(4) PD_M(5) PD_M(6) PD_M(7) PD_M(8)
+      PD_M(9) PD_M(10) PD_M(11) PD_M(12) PD_M(13) PD_M(14) PD_M(15) PD_M(16) PD_M(17)
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t"
+      "s_nop 1"
+      : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]),
+        "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15]), "+v"(p[16]), "+v"(p[17]));
+#undef PD_M
+  PD_UNROLL for (int t = 0; t < 18; t++) {
+    const int n = (int)__builtin_amdgcn_fmed3f(p[t], -32767.0f, 32767.0f);
+    out[t] = (sum[t] <= 65538.0f) ? n : -32767;
+  }
+#else
+  for (int t = 0; t < 18; t++) out[t] = pcm_from_sum(sum[t]);
+#endif
+}
+
+// v_permlane32_swap_b32: lanes 32..63 of a exchange with lanes 0..31 of b
+PD_FN void permlane32_swap(int& a, int& b) {
+#if defined(__HIPCC__)
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+  a = (int)r[0];
+  b = (int)r[1];
+#else
+  emu::permlane32_swap(&a, &b);
+#endif
+}
+
 // full = false (wave-uniform): the last halo granule -- only its slots 3..17 are wanted, as the next granule's history
-PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full) {
+PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int16_t* pcm_g) {
   const GranuleInfo g = granule_info(L);
   const int ch = lane >> 5, i = lane & 31;
-  if (ch >= g.nch) return;
+  const bool act = ch < g.nch;                 // (mono: lanes 32..63 idle, their history is channel 1's and stays)
   if (!full) {
-    PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
-      R.he[s] = L.hyb[ch][3 + s][R.idx_e];
-      R.ho[s] = L.hyb[ch][3 + s][R.idx_o];
+    if (act) {
+      PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
+        R.he[s] = L.hyb[ch][3 + s][R.idx_e];
+        R.ho[s] = L.hyb[ch][3 + s][R.idx_o];
+      }
     }
     return;
   }
-  // E[s], O[s]: the lane's two coefficients of slot s; s = 0..14 history, 15..32 this granule
-  float E[kHistSlots + 18], O[kHistSlots + 18];
-  PD_UNROLL for (int s = 0; s < kHistSlots; s++) { E[s] = R.he[s]; O[s] = R.ho[s]; }
-  PD_UNROLL for (int t = 0; t < 18; t++) {
-    E[kHistSlots + t] = L.hyb[ch][t][R.idx_e];
-    O[kHistSlots + t] = L.hyb[ch][t][R.idx_o];
-  }
-  int16_t out[18];
-  PD_UNROLL for (int t = 0; t < 18; t++) {
-    float sum = 0.0f;
-    PD_UNROLL for (int k = 0; k < 8; k++) {     // P:2021-2026: u[32j+i], j = 2k (age 2k), 2k+1 (age 2k+1)
-      sum = PD_FMA(R.we[k], E[kHistSlots + t - 2 * k], sum);
-      sum = PD_FMA(R.wo[k], O[kHistSlots + t - 2 * k - 1], sum);
+  int out[18];
+  if (act) {
+    // E[s], O[s]: the lane's two coefficients of slot s; s = 0..14 history, 15..32 this granule
+    float E[kHistSlots + 18], O[kHistSlots + 18];
+    PD_UNROLL for (int s = 0; s < kHistSlots; s++) { E[s] = R.he[s]; O[s] = R.ho[s]; }
+    PD_UNROLL for (int t = 0; t < 18; t++) {
+      E[kHistSlots + t] = L.hyb[ch][t][R.idx_e];
+      O[kHistSlots + t] = L.hyb[ch][t][R.idx_o];
     }
-    out[t] = (int16_t)pcm_from_sum(sum);
+    const float* we = R.we; const float* wo = R.wo;
+    float sum[18];
+    PD_UNROLL for (int t = 0; t < 18; t++) {
+      float acc = 0.0f;
+      PD_UNROLL for (int k = 0; k < 8; k++) {     // P:2021-2026: u[32j+i], j = 2k (age 2k), 2k+1 (age 2k+1)
+        acc = PD_FMA(we[k], E[kHistSlots + t - 2 * k], acc);
+        acc = PD_FMA(wo[k], O[kHistSlots + t - 2 * k - 1], acc);
+      }
+      sum[t] = acc;
+    }
+    PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = E[18 + s]; R.ho[s] = O[18 + s]; }
+    pcm_convert18(sum, out);
   }
-  PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = E[18 + s]; R.ho[s] = O[18 + s]; }
-  // pcm aliases spec, which is dead since ph_requant; hyb reads above are done
-  PD_UNROLL for (int t = 0; t < 18; t++) L.pcm[(t * 32 + i) * g.nch + ch] = out[t];
+  if (g.nch == 2) {
+    // Lanes i and i + 32 hold the left and the right value of the same sample.  For a pair of time slots (t, t + 1) one
+    // half exchange leaves lane i with L, R of sample (t, i) and lane i + 32 with L, R of sample (t + 1, i): every lane
+    // owns one interleaved sample-frame (P:2032-2041, P:2307-2345), lane l the dword 32 t + l of the granule.
+    // 9 stores of one dword per lane, 64 consecutive dwords per instruction.
+    uint32_t* dst = reinterpret_cast<uint32_t*>(pcm_g);
+    PD_UNROLL for (int q = 0; q < 9; q++) {
+      int a = out[2 * q], b = out[2 * q + 1];
+      permlane32_swap(a, b);
+      dst[64 * q + lane] = ((unsigned)a & 0xffffu) | ((unsigned)b << 16);
+    }
+  } else {
+    // mono (pcm aliases nothing live: spec is dead since ph_requant; hyb reads above are done)
+    if (act) { PD_UNROLL for (int t = 0; t < 18; t++) L.pcm[t * 32 + i] = (int16_t)out[t]; }
+  }
 }
 
-// PCM: granule = 576 sample-frames = 1152*nch bytes
+// PCM of a mono granule (576 samples = 1152 bytes) from the LDS staging buffer; stereo granules were stored by
+// ph_window straight from registers.
 PD_FN void ph_store(int lane, WaveLds& L, int nch, int16_t* pcm_g, bool emit) {
-  if (emit) {
-    const int n16 = (576 * 2 * nch) / 16;   // 144 or 72 chunks of 16 B
+  if (!emit) return;
+  if (nch != 2) {
     const Chunk16* src = reinterpret_cast<const Chunk16*>(L.pcm);
     Chunk16* dst = reinterpret_cast<Chunk16*>(pcm_g);
-    for (int c = lane; c < n16; c += 64) dst[c] = src[c];
+    for (int c = lane; c < 72; c += 64) dst[c] = src[c];
   }
 }
 
@@ -862,9 +932,10 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       }
     }
     PD_TICK(0)
-    const bool reset_here = gr == 0 && (L.side[0][7] & PDMP3_FR_RESET);   // wave-uniform
+    const int fr_here = PD_UNIFORM(L.side[0][7]);
+    const bool reset_here = gr == 0 && (fr_here & PDMP3_FR_RESET);
     // (read here, not next to its use: the commit phase below overwrites the side records with the next granule's)
-    const int nch_g = ((L.side[0][7] & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
+    const int nch_g = ((fr_here & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
     PD_TICK(1)
     float* dmp = DUMP ? a.stages + ((size_t)f * 16 + gr * 8) * 576 : nullptr;
     if (g == g_peek) {                     // wave-uniform: lines 0..63, boundary sb 0 | 1, three IMDCT outputs
@@ -891,7 +962,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     }
     PD_TICK(5)
     if (emit || feeds_next) {
-      PD_PHASE(ph_window(lane, L, R, emit))
+      PD_PHASE(ph_window(lane, L, R, emit, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g))
     }
     PD_TICK(6)
     // the next granule is committed to LDS BEFORE this granule's PCM stores are issued: its prefetch

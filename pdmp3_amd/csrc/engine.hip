@@ -206,49 +206,6 @@ extern "C" const char* pdmp3_hip_last_error(void) { return g_err; }
 
 extern "C" size_t pdmp3_hip_state_bytes(void) { return (size_t)kStateFloats * sizeof(float); }
 
-extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
-  if (!out) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_create: out is NULL", hipSuccess);
-  *out = nullptr;
-  HIP_TRY(hipSetDevice(device), "hipSetDevice");
-  HostTables H;
-  build_host_tables(H);
-  pdmp3_hip_ctx* c = (pdmp3_hip_ctx*)calloc(1, sizeof *c);
-  if (!c) return fail(PDMP3_HIP_ENOMEM, "calloc", hipSuccess);
-  c->device = device;
-  {
-    hipDeviceProp_t prop;
-    c->wave_slots = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-                        ? prop.multiProcessorCount * 4 * PDMP3_WAVES_PER_EU : 2048;
-  }
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_bank), &H.cb, sizeof(ConstBank)), "upload const bank");
-  if (!H.ldexp_forms_exact) {
-    free(c);
-    return fail(PDMP3_HIP_EDEVICE, "this host's libm pow() disagrees with the device's ldexp forms of 2^(k/4), 2^(-n/2)", hipSuccess);
-  }
-  HIP_TRY(hipMalloc(&c->d_pow43, H.pow43.size() * sizeof(float)), "hipMalloc pow43");
-  HIP_TRY(hipMalloc(&c->d_linetab, H.linetab.size() * sizeof(uint16_t)), "hipMalloc linetab");
-  HIP_TRY(hipMalloc(&c->d_win, H.win.size() * sizeof(float)), "hipMalloc win");
-  HIP_TRY(hipMemcpy(c->d_pow43, H.pow43.data(), H.pow43.size() * sizeof(float), hipMemcpyHostToDevice), "upload pow43");
-  HIP_TRY(hipMemcpy(c->d_linetab, H.linetab.data(), H.linetab.size() * sizeof(uint16_t), hipMemcpyHostToDevice), "upload linetab");
-  HIP_TRY(hipMemcpy(c->d_win, H.win.data(), H.win.size() * sizeof(float), hipMemcpyHostToDevice), "upload win");
-  HIP_TRY(hipMalloc(&c->d_frag, (10 + 10 + 8) * 64 * sizeof(float)), "hipMalloc frag");
-  HIP_TRY(hipMemcpy(c->d_frag, H.frag_long.data(), 10 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_long");
-  HIP_TRY(hipMemcpy(c->d_frag + 10 * 64, H.frag_short.data(), 10 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_short");
-  HIP_TRY(hipMemcpy(c->d_frag + 20 * 64, H.frag_mat.data(), 8 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_mat");
-  {
-    UnpackTables* U = new UnpackTables;
-    const bool ok = build_unpack_tables(*U);
-    hipError_t e = ok ? hipMalloc((void**)&c->d_unpack, sizeof(UnpackTables)) : hipSuccess;
-    if (ok && e == hipSuccess) e = hipMemcpy(c->d_unpack, U, sizeof(UnpackTables), hipMemcpyHostToDevice);
-    delete U;
-    if (!ok) return fail(PDMP3_HIP_EDEVICE, "Huffman lookup tables exceed kHuffLutMax", hipSuccess);
-    if (e != hipSuccess) return fail(PDMP3_HIP_EDEVICE, "upload unpack tables", e);
-  }
-  HIP_TRY(hipDeviceSynchronize(), "sync after uploads");
-  *out = c;
-  return PDMP3_HIP_OK;
-}
-
 extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -258,6 +215,54 @@ extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   (void)hipFree(c->d_frag);
   (void)hipFree(c->d_unpack);
   free(c);
+}
+
+extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
+  if (!out) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_create: out is NULL", hipSuccess);
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(device), "hipSetDevice");
+  HostTables H;
+  build_host_tables(H);
+  if (!H.ldexp_forms_exact)
+    return fail(PDMP3_HIP_EDEVICE, "this host's libm pow() disagrees with the device's ldexp forms of 2^(k/4), 2^(-n/2)", hipSuccess);
+  pdmp3_hip_ctx* c = (pdmp3_hip_ctx*)calloc(1, sizeof *c);
+  if (!c) return fail(PDMP3_HIP_ENOMEM, "calloc", hipSuccess);
+  c->device = device;
+  {
+    hipDeviceProp_t prop;
+    c->wave_slots = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                        ? prop.multiProcessorCount * 4 * PDMP3_WAVES_PER_EU : 2048;
+  }
+  // every failure from here on releases what was allocated so far (pdmp3_hip_destroy takes a partly built context)
+  UnpackTables* U = new UnpackTables;
+  const char* what = nullptr;
+  hipError_t e = hipSuccess;
+#define CREATE_STEP(call, text) if ((e = (call)) != hipSuccess) { what = text; break; }
+  do {
+    if (!build_unpack_tables(*U)) { what = "Huffman lookup tables exceed kHuffLutMax"; break; }
+    CREATE_STEP(hipMemcpyToSymbol(HIP_SYMBOL(c_bank), &H.cb, sizeof(ConstBank)), "upload const bank")
+    CREATE_STEP(hipMalloc(&c->d_pow43, H.pow43.size() * sizeof(float)), "hipMalloc pow43")
+    CREATE_STEP(hipMalloc(&c->d_linetab, H.linetab.size() * sizeof(uint16_t)), "hipMalloc linetab")
+    CREATE_STEP(hipMalloc(&c->d_win, H.win.size() * sizeof(float)), "hipMalloc win")
+    CREATE_STEP(hipMalloc(&c->d_frag, (10 + 10 + 8) * 64 * sizeof(float)), "hipMalloc frag")
+    CREATE_STEP(hipMalloc((void**)&c->d_unpack, sizeof(UnpackTables)), "hipMalloc unpack tables")
+    CREATE_STEP(hipMemcpy(c->d_pow43, H.pow43.data(), H.pow43.size() * sizeof(float), hipMemcpyHostToDevice), "upload pow43")
+    CREATE_STEP(hipMemcpy(c->d_linetab, H.linetab.data(), H.linetab.size() * sizeof(uint16_t), hipMemcpyHostToDevice), "upload linetab")
+    CREATE_STEP(hipMemcpy(c->d_win, H.win.data(), H.win.size() * sizeof(float), hipMemcpyHostToDevice), "upload win")
+    CREATE_STEP(hipMemcpy(c->d_frag, H.frag_long.data(), 10 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_long")
+    CREATE_STEP(hipMemcpy(c->d_frag + 10 * 64, H.frag_short.data(), 10 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_short")
+    CREATE_STEP(hipMemcpy(c->d_frag + 20 * 64, H.frag_mat.data(), 8 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_mat")
+    CREATE_STEP(hipMemcpy(c->d_unpack, U, sizeof(UnpackTables), hipMemcpyHostToDevice), "upload unpack tables")
+    CREATE_STEP(hipDeviceSynchronize(), "sync after uploads")
+  } while (0);
+#undef CREATE_STEP
+  delete U;
+  if (what) {
+    pdmp3_hip_destroy(c);
+    return fail(PDMP3_HIP_EDEVICE, what, e);
+  }
+  *out = c;
+  return PDMP3_HIP_OK;
 }
 
 // Frames per chunk (= per wave).  The kernel holds 2 waves per SIMD, so a launch runs in rounds of `slots` waves
@@ -288,6 +293,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: buffers must be 16-byte aligned", hipSuccess);
   if (n_frames == 0) return PDMP3_HIP_OK;
   hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(c->device), "hipSetDevice");     // (a bare call may come from a thread whose current device is another one)
   if (chunk_frames <= 0) chunk_frames = auto_chunk(n_frames, c->wave_slots);
   if (d_stages || chunk_frames > n_frames) chunk_frames = n_frames;
   const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
@@ -310,10 +316,17 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
   else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3((nchunks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, s, a, T, nchunks);
   else hipLaunchKernelGGL(k_decode<false>, dim3((nchunks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, s, a, T, nchunks);
-  HIP_TRY(hipGetLastError(), "launch k_decode");
-  if (d_state)
-    HIP_TRY(hipMemcpyAsync(d_state, d_state_tmp, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, s), "state copy");
-  if (own_tmp) HIP_TRY(hipFreeAsync(d_state_tmp, s), "hipFreeAsync state");
+  hipError_t e = hipGetLastError();
+  const char* what = "launch k_decode";
+  if (e == hipSuccess && d_state) {
+    what = "state copy";
+    e = hipMemcpyAsync(d_state, d_state_tmp, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, s);
+  }
+  if (own_tmp) {                                        // released on the failure paths too
+    const hipError_t ef = hipFreeAsync(d_state_tmp, s);
+    if (e == hipSuccess && ef != hipSuccess) { what = "hipFreeAsync state"; e = ef; }
+  }
+  if (e != hipSuccess) return fail(PDMP3_HIP_EDEVICE, what, e);
   return PDMP3_HIP_OK;
 }
 
@@ -615,6 +628,7 @@ extern "C" int pdmp3_hip_generate_frames(pdmp3_hip_ctx* ctx, uint64_t seed, int6
   if (!ctx || !d_spectra || !d_side || n_frames < 0)
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_generate_frames: bad argument", hipSuccess);
   if (n_frames == 0) return PDMP3_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
   hipLaunchKernelGGL(k_generate, dim3((unsigned)n_frames * 4u), dim3(64), 0, (hipStream_t)stream, seed, first_frame,
                      d_spectra, d_side);
   HIP_TRY(hipGetLastError(), "launch k_generate");
