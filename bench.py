@@ -328,6 +328,25 @@ def main():
                                  "includes": "host header/side-info/reservoir scan, H2D, k_unpack, k_merge, k_decode, D2H, copy to pageable memory"}
         except Exception as e:
             out["end_to_end"] = {"error": repr(e)}
+        # BASELINE configs[2] (C3) through the drop-in API itself: pdmp3_feed / pdmp3_read driven by a C loop
+        # (pdmp3_amd_stream_loop) at the reference driver's cadence (4096-byte feeds on PDMP3_NEED_MORE, 16 KiB reads),
+        # and with a caller that keeps the 16 KiB ring full.  One host thread, synchronous calls: a reported extra.
+        try:
+            nf = 20000
+            mp3s = np.frombuffer(packer.generate(n_frames=nf, seed=0xC3, sfreq=0, mode=1, mode_ext=2, bitrate_index=14), dtype=np.uint8)
+            res = {}
+            for key, (feed, read, eager) in (("reference_cadence", (4096, 16384, False)), ("ring_kept_full", (4096, 65536, True))):
+                api.stream_loop(mp3s[:200000], feed, read, eager, want_pcm=False)      # warm-up (engine, streams)
+                t0 = time.perf_counter()
+                nbytes, _ = api.stream_loop(mp3s, feed, read, eager, want_pcm=False)
+                dt_s = time.perf_counter() - t0
+                fr = nbytes / 4608.0
+                res[key] = {"frames_per_s": round(fr / dt_s, 1), "x_realtime": round(fr / dt_s / RT_FRAMES_PER_S, 1),
+                            "frames": int(fr), "seconds": round(dt_s, 4), "feed_bytes": feed, "read_bytes": read}
+            out["streaming_api"] = {"workload": "C3-style stream (44.1 kHz joint stereo 320 kbps CBR) through pdmp3_feed / pdmp3_read "
+                                                "(include/pdmp3.h), host Huffman, one thread, read-ahead batches of up to 16 frames", **res}
+        except Exception as e:
+            out["streaming_api"] = {"error": repr(e)}
     if cpu is not None:
         out["cpu_baseline"] = cpu
     print(json.dumps(out))

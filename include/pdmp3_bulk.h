@@ -101,6 +101,16 @@ pdmp3_amd_bulk* pdmp3_amd_bulk_new_parse_bits(void);
 long long pdmp3_amd_bulk_parse_bits(pdmp3_amd_bulk* b, const unsigned char* mp3, size_t n, pdmp3_frame_bits* bits,
                                     uint8_t* reservoir, size_t cap_frames, long long* pcm_bytes);
 
+/* The streaming API (include/pdmp3.h) driven from a memory buffer by a C loop: pdmp3_new, pdmp3_open_feed, then
+ * pdmp3_read(read_bytes) until PDMP3_ERR, with a pdmp3_feed of feed_bytes on every PDMP3_NEED_MORE -- the
+ * reference driver's loop (pdmp3.c:2564-2584; 4096 and 16384 there) with its two sizes as parameters.  eager != 0:
+ * the caller keeps the ring as full as feed_bytes-sized feeds allow instead of waiting for PDMP3_NEED_MORE, but never
+ * to the last byte (a ring filled exactly looks EMPTY to the reference, pdmp3.c:1062-1068, and so to this library).  At most
+ * `cap` bytes go to `out` (may be NULL); returns the PCM bytes the reads delivered, -1 without an engine.  For
+ * measuring the drop-in path without an interpreter in the loop (bench.py: streaming_api). */
+long long pdmp3_amd_stream_loop(const unsigned char* mp3, size_t n, unsigned char* out, size_t cap,
+                                size_t feed_bytes, size_t read_bytes, int eager);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,6 +190,10 @@ pdmp3_gc_side* pdmp3_hip_stream_slot_side(pdmp3_hip_stream* hs, int slot);
 const int16_t* pdmp3_hip_stream_slot_pcm(pdmp3_hip_stream* hs, int slot);
 /* enqueue H2D + transforms + D2H of the slot's first n_frames frames; returns at once */
 int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_frames);
+/* undo the slot's latest pdmp3_hip_stream_submit beyond its first keep_frames frames: the carried synthesis state
+ * (P:1755, P:1983) becomes what it was after frame keep_frames - 1 of that batch.  Blocks.  (pdmp3_read hands frames
+ * out in the reference's order; frames it decoded ahead that the reference turns out not to reach are taken back.) */
+int pdmp3_hip_stream_rewind(pdmp3_hip_stream* hs, int slot, int keep_frames);
 
 /* ------------------------------------------------------------------------
  * Bitstream-level input: scalefactor + Huffman decoding on the
@@ -244,6 +248,10 @@ int pdmp3_hip_host_alloc(size_t bytes, void** out);
 void pdmp3_hip_host_free(void* p);
 int pdmp3_hip_host_is_pinned(const void* p, size_t bytes);          /* [p, p + bytes): 1 = pinned host memory, 2 = device memory
                                                                        (both are valid _to destinations), 0 = neither */
+/* plain copy of `bytes` from host memory to a destination pdmp3_hip_host_is_pinned() classified (1 or 2); blocks until
+ * it is done.  The whole-stream decoder uses it for the windows that cannot go to a DEVICE destination directly
+ * (mixed mono / stereo frames, the clipped tail): they are staged in the slot's pinned buffer and copied from there. */
+int pdmp3_hip_copy_to_dest(void* dst, const void* src_host, size_t bytes);
 int pdmp3_hip_stream_submit_to(pdmp3_hip_stream* hs, int slot, int n_frames, void* pinned_dst, int row_bytes);
 int pdmp3_hip_stream_submit_bits_to(pdmp3_hip_stream* hs, int slot, int n_frames, void* pinned_dst, int row_bytes);
 

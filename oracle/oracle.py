@@ -128,6 +128,34 @@ class OracleStream:
     def close(self):
         self.L.orc_stream_delete(self.s)
 
+    # the seven API calls, with pdmp3_amd.api.Decoder's signatures
+    def open_feed(self):
+        return self.L.orc_stream_open_feed(self.s)
+
+    def feed(self, data: bytes):
+        buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+        return self.L.orc_stream_feed(self.s, buf, len(data))
+
+    def read(self, outsize):
+        out = (C.c_ubyte * outsize)()
+        done = C.c_size_t(0)
+        rc = self.L.orc_stream_read(self.s, out, outsize, C.byref(done))
+        return rc, bytes(out[:done.value])
+
+    def decode(self, data: bytes, outsize):
+        self.L.orc_stream_decode.argtypes = [_p, _p, C.c_size_t, _p, C.c_size_t, C.POINTER(C.c_size_t)]
+        buf = (C.c_ubyte * max(1, len(data))).from_buffer_copy(data or b"\0")
+        out = (C.c_ubyte * outsize)() if outsize else None
+        done = C.c_size_t(0)
+        rc = self.L.orc_stream_decode(self.s, buf, len(data), out, outsize, C.byref(done))
+        return rc, bytes(out[:done.value]) if outsize else b""
+
+    def getformat(self):
+        self.L.orc_stream_getformat.argtypes = [_p, C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        rate, ch, enc = C.c_long(0), C.c_int(0), C.c_int(0)
+        rc = self.L.orc_stream_getformat(self.s, C.byref(rate), C.byref(ch), C.byref(enc))
+        return rc, rate.value, ch.value, enc.value
+
     def decode_like_cli(self, mp3: bytes):
         self.L.orc_stream_open_feed(self.s)
         out, pos = [], 0

@@ -15,7 +15,7 @@ _LIB = None
 
 BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads",
                 "pdmp3_amd_scan_buffer", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_decode_async", "pdmp3_amd_bulk_wait", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
-                "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits", "pdmp3_amd_pcm_alloc", "pdmp3_amd_pcm_free"]
+                "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits", "pdmp3_amd_pcm_alloc", "pdmp3_amd_pcm_free", "pdmp3_amd_stream_loop"]
 
 # include/pdmp3_hip.h: pdmp3_gc_bits / pdmp3_frame_bits
 GC_BITS_DTYPE = np.dtype([("part2_3_length", "<u2"), ("big_values", "<u2"), ("global_gain", "u1"), ("scalefac_compress", "u1"),
@@ -142,6 +142,21 @@ class Decoder:
         return self.lib.pdmp3_amd_parse_available(self.h)
 
 
+def stream_loop(mp3, feed_bytes=4096, read_bytes=16384, eager=False, want_pcm=True):
+    """pdmp3_amd_stream_loop: the feed / read loop of the reference's driver run in C over a memory buffer.
+    -> (PCM bytes delivered, int16 array or None)"""
+    lib = load_library()
+    lib.pdmp3_amd_stream_loop.restype = C.c_longlong
+    lib.pdmp3_amd_stream_loop.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    a = _as_u8(mp3)
+    out = np.empty((len(a) // 96 + 8) * 2304, dtype=np.int16) if want_pcm else None
+    n = lib.pdmp3_amd_stream_loop(a.ctypes.data_as(C.c_void_p), len(a), out.ctypes.data_as(C.c_void_p) if want_pcm else None,
+                                  out.nbytes if want_pcm else 0, feed_bytes, read_bytes, int(eager))
+    if n < 0:
+        raise RuntimeError("pdmp3_amd_stream_loop: no transform engine")
+    return n, (out[:n // 2] if want_pcm else None)
+
+
 def decode_like_cli(mp3: bytes, dec: "Decoder" = None):
     """The CLI driver loop pdmp3() (pdmp3.c:2552-2587) over a memory buffer."""
     own = dec is None
@@ -253,8 +268,9 @@ class BulkDecoder:
         return total, rate.value, ch.value
 
     def decode_into_device(self, mp3, out_tensor, wait=True):
-        """PCM into a torch int16 tensor on the GPU (it never leaves the device).  Windows that mix mono and stereo
-        frames are not delivered to device destinations (streams do not change their channel count in practice)."""
+        """PCM into a torch int16 tensor on the GPU.  Windows of one channel count go from the engine's buffer to the
+        tensor without leaving the device; a window that mixes mono and stereo frames, or the one the tensor ends in,
+        is staged in pinned host memory and copied from there."""
         a = _as_u8(mp3)
         rate, ch = C.c_long(0), C.c_int(0)
         f = self.lib.pdmp3_amd_bulk_decode if wait else self.lib.pdmp3_amd_bulk_decode_async

@@ -367,6 +367,7 @@ struct pdmp3_hip_stream {
   int have_state_ev;
   float* d_state;
   float* d_state_tmp;
+  float* d_state_prev;       // d_state as it was before the latest submit of decoded records (pdmp3_hip_stream_rewind)
   uint16_t* d_sfstate;       // [2][256]: scalefactors / count1 carried from frame to frame (unpack_core.h), double-buffered
   int sf_cur;
   int have_bits;
@@ -388,6 +389,7 @@ extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
   if (hs->ev_state) (void)hipEventDestroy(hs->ev_state);
   (void)hipFree(hs->d_state);
   (void)hipFree(hs->d_state_tmp);
+  (void)hipFree(hs->d_state_prev);
   free(hs);
 }
 
@@ -417,6 +419,7 @@ extern "C" int pdmp3_hip_stream_create_slots(pdmp3_hip_ctx* ctx, int max_frames,
   HS_TRY(hipEventCreateWithFlags(&hs->ev_state, hipEventDisableTiming), "hipEventCreate");
   HS_TRY(hipMalloc((void**)&hs->d_state, pdmp3_hip_state_bytes()), "hipMalloc state");
   HS_TRY(hipMalloc((void**)&hs->d_state_tmp, pdmp3_hip_state_bytes()), "hipMalloc state");
+  HS_TRY(hipMalloc((void**)&hs->d_state_prev, pdmp3_hip_state_bytes()), "hipMalloc state");
   HS_TRY(hipMemsetAsync(hs->d_state, 0, pdmp3_hip_state_bytes(), hs->s[0].stream), "memset state");
   HS_TRY(hipStreamSynchronize(hs->s[0].stream), "sync");
 #undef HS_TRY
@@ -493,6 +496,13 @@ extern "C" int pdmp3_hip_host_is_pinned(const void* p, size_t bytes) {
   return a.type == hipMemoryTypeHost ? 1 : 2;
 }
 
+extern "C" int pdmp3_hip_copy_to_dest(void* dst, const void* src_host, size_t bytes) {
+  if (!bytes) return PDMP3_HIP_OK;
+  if (!dst || !src_host) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_copy_to_dest: NULL", hipSuccess);
+  HIP_TRY(hipMemcpy(dst, src_host, bytes, hipMemcpyDefault), "copy to destination");
+  return PDMP3_HIP_OK;
+}
+
 static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row);
 extern "C" int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_frames) {
   return submit_records(hs, slot, n_frames, nullptr, PDMP3_FRAME_PCM_BYTES);
@@ -513,6 +523,7 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
   HIP_TRY(hipMemcpyAsync(t.d_spectra, t.h_spectra, n * PDMP3_FRAME_SPECTRA_BYTES, hipMemcpyHostToDevice, t.stream), "H2D spectra");
   HIP_TRY(hipMemcpyAsync(t.d_side, t.h_side, n * PDMP3_FRAME_SIDE_BYTES, hipMemcpyHostToDevice, t.stream), "H2D side");
   if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
+  HIP_TRY(hipMemcpyAsync(hs->d_state_prev, hs->d_state, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, t.stream), "keep the state");
   int rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp);
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
@@ -531,6 +542,27 @@ extern "C" int pdmp3_hip_stream_wait(pdmp3_hip_stream* hs, int slot) {
   HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
   HIP_TRY(hipEventSynchronize(t.done), "event sync");
   t.busy = 0;
+  return PDMP3_HIP_OK;
+}
+
+// Undo the slot's latest pdmp3_hip_stream_submit beyond its first keep_frames frames: the carried synthesis state
+// becomes what it was after frame keep_frames - 1 of that batch (the state before the batch, then the kept frames
+// again -- their records are still in the slot's device buffers).  Blocks until done.
+extern "C" int pdmp3_hip_stream_rewind(pdmp3_hip_stream* hs, int slot, int keep_frames) {
+  if (!SLOT_OK(hs, slot) || keep_frames < 0 || keep_frames > hs->max_frames)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_rewind: bad argument", hipSuccess);
+  HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
+  StreamSlot& t = hs->s[slot];
+  HIP_TRY(hipStreamSynchronize(t.stream), "stream sync");
+  t.busy = 0;
+  HIP_TRY(hipMemcpyAsync(hs->d_state, hs->d_state_prev, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, t.stream), "restore the state");
+  if (keep_frames) {
+    const int rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, keep_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp);
+    if (rc != PDMP3_HIP_OK) return rc;
+  }
+  HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
+  hs->have_state_ev = 1;
+  HIP_TRY(hipStreamSynchronize(t.stream), "stream sync");
   return PDMP3_HIP_OK;
 }
 

@@ -114,6 +114,16 @@ typedef struct {
   uint16_t sf_s_set[2][2];           /* bit sfb: scalefac_s[gr][ch][sfb][0..2] were read */
 } main_out;
 
+/* everything a frame's parse can change (read_ahead below undoes frames with it) */
+typedef struct {
+  size_t processed; unsigned istart;
+  frame_header hdr; side_info si;
+  uint8_t scalefac_l[2][2][21]; uint8_t scalefac_s[2][2][12][3]; uint16_t count1[2][2];
+  uint8_t main_vec[2048 + 16]; unsigned main_top;
+  uint8_t side_vec[64 + 8]; unsigned side_ptr, side_idx;
+  int new_header, need_reset, tap_n;
+} parse_snap;
+
 struct pdmp3_handle {
   /* input ring, P:126-128 */
   size_t processed;
@@ -136,6 +146,18 @@ struct pdmp3_handle {
   unsigned side_ptr, side_idx;
   int new_header;                  /* P:147 */
   int need_reset;                  /* hsynth_init / synth_init, P:134-135 */
+  int ring_short;                  /* set whenever a parse step found fewer bytes in the ring than it wanted */
+  /* Read-ahead of pdmp3_read (see read_ahead below).  The parser above may be AHEAD of the stream position the
+   * reference would have at this point of the call sequence; what the API shows is the logical view: */
+  size_t l_processed;              /* id->processed of the reference */
+  unsigned l_istart;               /* id->istart of the reference: pdmp3_feed's free space, the 1152-byte rule */
+  frame_header l_hdr;              /* g_frame_header of the reference: pdmp3_getformat, the partial-frame cursor */
+  int l_new_header;                /* id->new_header of the reference */
+  struct ra_entry {                /* a frame parsed and sent to the engine but not handed out yet */
+    size_t processed_after; unsigned istart_after; frame_header hdr; uint8_t nch, nh;
+  } ra[BATCH_MAX];
+  int ra_head, ra_n, ra_inflight;  /* ra_inflight: the batch is still on the GPU */
+  parse_snap ra_before[BATCH_MAX]; /* the parser as it was before each of these frames */
   /* engine */
   pdmp3_hip_stream* hs;
   int host_only;                   /* test hook: parse without an engine (no decode possible) */
@@ -199,9 +221,12 @@ void pdmp3_amd_set_tap(pdmp3_handle* id, int16_t* spectra, pdmp3_gc_side* side, 
 }
 int pdmp3_amd_tap_count(const pdmp3_handle* id) { return id->tap_n; }
 
+static int ra_rollback(pdmp3_handle* id);      /* read-ahead of pdmp3_read, below */
+
 /* P:2360 */
 void pdmp3_delete(pdmp3_handle* id) {
   if (!id) return;
+  if (id->ra_inflight && id->hs) (void)pdmp3_hip_stream_wait(id->hs, 0);
   if (id->hs) pdmp3_hip_stream_destroy(id->hs);
   free(id);
 }
@@ -209,7 +234,9 @@ void pdmp3_delete(pdmp3_handle* id) {
 /* P:2369-2384 */
 int pdmp3_open_feed(pdmp3_handle* id) {
   if (!id) return PDMP3_ERR;
+  if (ra_rollback(id) != PDMP3_OK) return PDMP3_ERR;   /* (what survives open_feed is the parse state of the reference's position) */
   id->ostart = 0; id->istart = 0; id->iend = 0; id->processed = 0; id->new_header = 0;
+  id->l_istart = 0; id->l_processed = 0; id->l_new_header = 0;
   id->need_reset = 1;
   id->main_top = 0;
   return PDMP3_OK;
@@ -221,11 +248,20 @@ int pdmp3_open_feed(pdmp3_handle* id) {
 static unsigned ring_filled(const pdmp3_handle* id) {
   return (id->istart <= id->iend) ? (id->iend - id->istart) : (INBUF_SIZE - id->istart + id->iend);
 }
-static unsigned ring_free(const pdmp3_handle* id) {
-  return (id->iend < id->istart) ? (id->istart - id->iend) : (INBUF_SIZE - id->iend + id->istart);
+/* the same two as the reference's caller sees them (the parser may have read ahead, see read_ahead) */
+static unsigned ring_filled_logical(const pdmp3_handle* id) {
+  return (id->l_istart <= id->iend) ? (id->iend - id->l_istart) : (INBUF_SIZE - id->l_istart + id->iend);
+}
+static unsigned ring_free_logical(const pdmp3_handle* id) {
+  return (id->iend < id->l_istart) ? (id->l_istart - id->iend) : (INBUF_SIZE - id->iend + id->l_istart);
+}
+/* the parser stands where the reference stands (nothing read ahead): used by the paths that drive it directly */
+static inline void sync_logical(pdmp3_handle* id) {
+  id->l_istart = id->istart; id->l_processed = id->processed; id->l_hdr = id->hdr;
+  if (!id->l_new_header && id->new_header) id->l_new_header = 1;
 }
 static inline unsigned ring_byte(pdmp3_handle* id) {
-  if (id->istart == id->iend) return BYTE_EOF;
+  if (id->istart == id->iend) { id->ring_short = 1; return BYTE_EOF; }
   unsigned v = id->in[id->istart++];
   if (id->istart == INBUF_SIZE) id->istart = 0;
   id->processed++;
@@ -235,10 +271,10 @@ static inline unsigned ring_byte(pdmp3_handle* id) {
 /* P:2391-2423: all-or-nothing copy into the ring */
 int pdmp3_feed(pdmp3_handle* id, const unsigned char* in, size_t size) {
   if (!(id && in && size)) return PDMP3_ERR;
-  if (size > (size_t)ring_free(id)) return PDMP3_NO_SPACE;
+  if (size > (size_t)ring_free_logical(id)) return PDMP3_NO_SPACE;
   size_t first;
-  if (id->iend < id->istart) {
-    first = id->istart - id->iend;
+  if (id->iend < id->l_istart) {
+    first = id->l_istart - id->iend;
     if (size < first) first = size;
     memcpy(id->in + id->iend, in, first);
     id->iend += (unsigned)first;
@@ -248,6 +284,9 @@ int pdmp3_feed(pdmp3_handle* id, const unsigned char* in, size_t size) {
     if (first) { memcpy(id->in + id->iend, in, first); id->iend += (unsigned)first; size -= first; }
     if (size) { memcpy(id->in, in + first, size); id->iend = (unsigned)size; }
   }
+  /* a feed that fills the ring exactly leaves iend == istart, which the reference reads as EMPTY (P:1062-1068): it
+   * will not get to the frames read ahead before its next feeds have overwritten them */
+  if (id->ra_head != id->ra_n && id->iend == id->l_istart && ra_rollback(id) != PDMP3_OK) return PDMP3_ERR;
   return PDMP3_OK;
 }
 
@@ -289,6 +328,7 @@ static int search_header(pdmp3_handle* id) {
     id->processed = pos;
     if (++tries > 1152) return PDMP3_ERR;
   }
+  if (!(id->hdr.layer == 3 && (res == PDMP3_OK || res == PDMP3_NEW_FORMAT))) id->ring_short = 1;   /* left by the fill test */
   return res;
 }
 
@@ -313,6 +353,7 @@ static void read_side_info(pdmp3_handle* id) {
   const unsigned nch = id->hdr.mode == 3 ? 1 : 2, nbytes = nch == 1 ? 17 : 32;
   unsigned got = ring_filled(id);
   if (got > nbytes) got = nbytes;
+  else if (got < nbytes) id->ring_short = 1;
   {
     unsigned first = INBUF_SIZE - id->istart;
     if (first > got) first = got;
@@ -375,7 +416,7 @@ static int fill_reservoir(pdmp3_handle* id, unsigned size, unsigned begin) {
   const size_t off = (size_t)(dst - id->main_vec);
   unsigned n = off >= sizeof id->main_vec ? 0 : (unsigned)(sizeof id->main_vec - off);
   if (n > size) n = size;
-  if (n > ring_filled(id)) n = ring_filled(id);
+  if (n > ring_filled(id)) { n = ring_filled(id); id->ring_short = 1; }
   unsigned first = INBUF_SIZE - id->istart;
   if (first > n) first = n;
   memcpy(dst, id->in + id->istart, first);
@@ -687,7 +728,7 @@ static void emit_records(pdmp3_handle* id, const frame_header* H, const side_inf
 
 /* P:2307-2345: hand out up to buflen bytes of the frame under the cursor */
 static size_t drain_frame(pdmp3_handle* id, unsigned char* out, size_t buflen) {
-  const unsigned nch = id->hdr.mode == 3 ? 1 : 2;          /* the CURRENT header's channel count, as in the reference */
+  const unsigned nch = id->l_hdr.mode == 3 ? 1 : 2;        /* the CURRENT header's channel count, as in the reference */
   const unsigned bps = 2 * nch;
   size_t n = buflen / bps;
   if (n > 1152u - id->ostart) n = 1152u - id->ostart;
@@ -703,84 +744,218 @@ static size_t drain_frame(pdmp3_handle* id, unsigned char* out, size_t buflen) {
 struct bulk;
 static int bulk_push(struct bulk* b);             /* snapshot the frame read_frame_staged just staged */
 
-/* With `sink` the call only does what touches the input ring and the output cursor: main data decoding,
- * the transforms and the PCM copy are the sink's business (bulk path below), byte counts are the same. */
-static int read_impl(pdmp3_handle* id, unsigned char* outmemory, size_t outsize, size_t* done, struct bulk* sink) {
+/* The whole-stream decoder's form of the read loop (`sink`): the call only does what touches the input ring and the
+ * output cursor; main data decoding, the transforms and the PCM copy are the sink's business (bulk path below),
+ * byte counts are the same.  The parser is never ahead here. */
+static int read_impl_sink(pdmp3_handle* id, size_t outsize, size_t* done, struct bulk* sink) {
+  *done = 0;
+  int res = PDMP3_ERR;
+  if (id->ostart) {                               /* rest of the frame a previous call could not fit */
+    const size_t n = drain_frame(id, NULL, outsize);
+    *done = n; outsize -= n;
+    res = PDMP3_OK;
+  }
+  while (outsize) {
+    if (ring_filled(id) < 1152) { res = PDMP3_NEED_MORE; break; }      /* H10 */
+    const size_t pos = id->processed;
+    const unsigned mark = id->istart;
+    res = read_frame_staged(id);
+    if (res != PDMP3_OK && res != PDMP3_NEW_FORMAT) {   /* failed: rewind to the frame start (P:2459-2462) */
+      id->processed = pos; id->istart = mark;
+      sync_logical(id);
+      break;
+    }
+    sync_logical(id);
+    if (bulk_push(sink) != PDMP3_OK) return PDMP3_ERR;
+    id->last_nch = id->hdr.mode == 3 ? 1 : 2;
+    const size_t n = drain_frame(id, NULL, outsize);      /* (the cursor is NOT reset for a new frame: P:2307-2345) */
+    outsize -= n; *done += n;
+  }
+  if (id->l_new_header == 1 && res == PDMP3_OK) res = PDMP3_NEW_FORMAT;
+  return res;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Read-ahead.  pdmp3_read is synchronous per call (P:2431-2481): it parses   */
+/* and decodes as many frames as the caller's buffer takes.  A GPU batch of   */
+/* the three or four frames a 16 KiB buffer takes is all launch latency, so   */
+/* when the parser has to parse a frame anyway it goes on through EVERY       */
+/* complete frame the ring already holds and the engine decodes them as one   */
+/* batch; later calls hand those frames out without parsing or launching.     */
+/*                                                                            */
+/* What the caller can observe must not change, so the handle keeps two       */
+/* views of the stream: the parser's (istart, processed, hdr, new_header:     */
+/* possibly ahead) and the reference's (l_*: what P:2431-2481 would have      */
+/* consumed by now) -- pdmp3_feed's free space, the 1152-byte rule (H10),     */
+/* pdmp3_getformat and the return codes use the second.  A frame is parsed    */
+/* ahead only if the reference is certain to parse it to the same result      */
+/* later: at least 1152 bytes are buffered behind its start NOW (more can     */
+/* only be fed), the parse succeeded, and no step of it found the ring short  */
+/* of bytes (ring_short) -- bytes fed later cannot change it then.  The       */
+/* first frame of a batch is the one the reference parses in this very call:  */
+/* its failures keep their side effects (H9: the reservoir keeps the bytes,   */
+/* the ring is rewound); a frame read ahead that fails is undone completely   */
+/* (snapshot) and left for the call in which the reference gets to it.        */
+/* ------------------------------------------------------------------------ */
+static void snap_save(const pdmp3_handle* id, parse_snap* p) {
+  p->processed = id->processed; p->istart = id->istart; p->hdr = id->hdr; p->si = id->si;
+  memcpy(p->scalefac_l, id->scalefac_l, sizeof p->scalefac_l);
+  memcpy(p->scalefac_s, id->scalefac_s, sizeof p->scalefac_s);
+  memcpy(p->count1, id->count1, sizeof p->count1);
+  memcpy(p->main_vec, id->main_vec, sizeof p->main_vec); p->main_top = id->main_top;
+  memcpy(p->side_vec, id->side_vec, sizeof p->side_vec); p->side_ptr = id->side_ptr; p->side_idx = id->side_idx;
+  p->new_header = id->new_header; p->need_reset = id->need_reset; p->tap_n = id->tap_n;
+}
+static void snap_restore(pdmp3_handle* id, const parse_snap* p) {
+  id->processed = p->processed; id->istart = p->istart; id->hdr = p->hdr; id->si = p->si;
+  memcpy(id->scalefac_l, p->scalefac_l, sizeof p->scalefac_l);
+  memcpy(id->scalefac_s, p->scalefac_s, sizeof p->scalefac_s);
+  memcpy(id->count1, p->count1, sizeof p->count1);
+  memcpy(id->main_vec, p->main_vec, sizeof p->main_vec); id->main_top = p->main_top;
+  memcpy(id->side_vec, p->side_vec, sizeof p->side_vec); id->side_ptr = p->side_ptr; id->side_idx = p->side_idx;
+  id->new_header = p->new_header; id->need_reset = p->need_reset; id->tap_n = p->tap_n;
+}
+
+static void ra_push(pdmp3_handle* id) {
+  struct ra_entry* e = &id->ra[id->ra_n++];
+  e->processed_after = id->processed; e->istart_after = id->istart; e->hdr = id->hdr;
+  e->nch = (uint8_t)(id->hdr.mode == 3 ? 1 : 2);
+  e->nh = (uint8_t)(id->new_header != 0);
+}
+
+/* Take back the frames read ahead but not handed out: the parser returns to the reference's position, the engine's
+ * synthesis state to the last frame handed out.  Needed when the reference will NOT find what was read ahead: a
+ * feed that fills the ring exactly makes it look empty to the reference (iend == istart, P:1062-1068), whose next
+ * feeds then overwrite the unread frames; pdmp3_open_feed keeps the parse state of ITS position (H4-H6). */
+static int ra_rollback(pdmp3_handle* id) {
+  if (id->ra_head == id->ra_n) return PDMP3_OK;
+  snap_restore(id, &id->ra_before[id->ra_head]);
+  int rc = PDMP3_OK;
+  if (id->hs && pdmp3_hip_stream_rewind(id->hs, 0, id->ra_head) != PDMP3_HIP_OK) {
+    fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
+    rc = PDMP3_ERR;
+  }
+  id->ra_head = id->ra_n = id->ra_inflight = 0;
+  return rc;
+}
+
+/* Parse the frame the reference parses now and, behind it, every frame that qualifies; send them to the engine.
+ * Called with nothing read ahead (parser == logical view).  Returns the code of the FIRST frame's Read_Frame. */
+static int read_ahead(pdmp3_handle* id) {
+  static _Thread_local int16_t scratch_sp[BATCH_MAX * 2304];      /* parse-only test handles: records go nowhere */
+  static _Thread_local pdmp3_gc_side scratch_sd[BATCH_MAX * 4];
+  int16_t* spectra = id->hs ? pdmp3_hip_stream_spectra(id->hs) : scratch_sp;
+  pdmp3_gc_side* side = id->hs ? pdmp3_hip_stream_side(id->hs) : scratch_sd;
+  id->ra_head = id->ra_n = 0;
+  const size_t pos = id->processed;
+  const unsigned mark = id->istart;
+  snap_save(id, &id->ra_before[0]);
+  int res = read_frame(id, spectra);
+  if (res != PDMP3_OK && res != PDMP3_NEW_FORMAT) {       /* failed: rewind to the frame start (P:2459-2462) */
+    id->processed = pos; id->istart = mark;
+    sync_logical(id);                                     /* (the header it read stays, as in the reference) */
+    return res;
+  }
+  emit_records(id, &id->hdr, &id->si, id->need_reset, spectra, side);
+  id->need_reset = 0;
+  ra_push(id);
+  const int cap = getenv("PDMP3_NO_READAHEAD") ? 1 : BATCH_MAX;
+  while (id->ra_n < cap) {
+    /* bytes behind the parser, counted from the reference's cursor (a cursor that has crossed the end of the ring
+     * while pdmp3_feed has iend parked there, P:2410-2417, sees the ring full of its own stale bytes) */
+    const size_t ahead = id->processed - id->l_processed;
+    const unsigned have = ring_filled_logical(id);
+    const unsigned avail = have > ahead ? (unsigned)(have - ahead) : 0;
+    if (avail < 1152) break;                              /* H10: the reference would not attempt it yet */
+    parse_snap* snapp = &id->ra_before[id->ra_n];
+    snap_save(id, snapp);
+#define snap (*snapp)
+    id->ring_short = 0;
+    int16_t* sp = spectra + (size_t)id->ra_n * 2304;
+    const int r = read_frame(id, sp);
+    /* undone unless it succeeded on bytes that were all there */
+    if ((r != PDMP3_OK && r != PDMP3_NEW_FORMAT) || id->ring_short || id->processed - snap.processed > avail) {
+      snap_restore(id, &snap);
+      break;
+    }
+#undef snap
+    emit_records(id, &id->hdr, &id->si, id->need_reset, sp, side + (size_t)id->ra_n * 4);
+    id->need_reset = 0;
+    ra_push(id);
+  }
+  if (id->hs) {
+    if (pdmp3_hip_stream_submit(id->hs, 0, id->ra_n) != PDMP3_HIP_OK) {
+      fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
+      id->ra_n = 0;
+      return PDMP3_ERR;
+    }
+    id->ra_inflight = 1;
+  }
+  return res;
+}
+
+/* pdmp3_read (P:2431-2481) */
+static int read_impl(pdmp3_handle* id, unsigned char* outmemory, size_t outsize, size_t* done) {
   *done = 0;
   int res = PDMP3_ERR;
   if (id->ostart) {                               /* rest of the frame a previous call could not fit */
     const size_t n = drain_frame(id, outmemory, outsize);
-    *done = n; outsize -= n;
-    if (outmemory) outmemory += n;
+    *done = n; outsize -= n; outmemory += n;
     res = PDMP3_OK;
   }
   while (outsize) {
-    /* 1. host stage: parse as many frames as the caller's buffer will take
-     *    (one frame needs >= 1152 buffered bytes to be attempted, H10) */
-    int16_t* spectra = id->hs ? pdmp3_hip_stream_spectra(id->hs) : NULL;
-    pdmp3_gc_side* side = id->hs ? pdmp3_hip_stream_side(id->hs) : NULL;
-    int16_t scratch_sp[2304];
-    pdmp3_gc_side scratch_sd[4];
-    unsigned nchs[BATCH_MAX];
-    int nb = 0, stop = 0;
-    size_t budget = outsize;
-    while (budget && nb < BATCH_MAX) {
-      if (ring_filled(id) < 1152) { res = PDMP3_NEED_MORE; stop = 1; break; }
-      const size_t pos = id->processed;
-      const unsigned mark = id->istart;
-      int16_t* sp = spectra ? spectra + (size_t)nb * 2304 : scratch_sp;
-      res = sink ? read_frame_staged(id) : read_frame(id, sp);
-      if (res != PDMP3_OK && res != PDMP3_NEW_FORMAT) {   /* failed: rewind to the frame start (P:2459-2462) */
-        id->processed = pos; id->istart = mark;
-        stop = 1;
+    if (id->ra_head == id->ra_n) {                /* nothing read ahead: the reference's own step */
+      if (ring_filled_logical(id) < 1152) { res = PDMP3_NEED_MORE; break; }      /* H10 */
+      res = read_ahead(id);
+      if (id->ra_n == 0) {
+        if (res == PDMP3_OK || res == PDMP3_NEW_FORMAT) return PDMP3_ERR;        /* engine failure */
         break;
       }
-      if (sink) {
-        if (bulk_push(sink) != PDMP3_OK) return PDMP3_ERR;
-      } else {
-        emit_records(id, &id->hdr, &id->si, id->need_reset, sp, side ? side + (size_t)nb * 4 : scratch_sd);
-        id->need_reset = 0;
+    } else {
+      if (ring_filled_logical(id) < 1152) {       /* (cannot be after a plain feed; the net under ra_rollback's cases) */
+        if (ra_rollback(id) != PDMP3_OK) return PDMP3_ERR;
+        res = PDMP3_NEED_MORE;
+        break;
       }
-      nchs[nb] = id->hdr.mode == 3 ? 1 : 2;
-      const size_t fbytes = 2304u * nchs[nb];
-      budget -= budget < fbytes ? budget : fbytes;
-      nb++;
+      res = PDMP3_OK;                             /* Read_Frame of a frame read ahead: it succeeded */
     }
-    /* 2. transforms on the GPU, one batch */
-    if (nb) {
-      const int16_t* pcm = NULL;
-      if (!sink) {
-        if (!id->hs) return PDMP3_ERR;            /* parse-only handle: cannot decode */
-        if (pdmp3_hip_stream_decode(id->hs, nb) != PDMP3_HIP_OK) {
-          fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
-          return PDMP3_ERR;
-        }
-        pcm = pdmp3_hip_stream_pcm(id->hs);
+    /* Decode_L3 + Convert_Frame_S16 of the frame at the head */
+    const struct ra_entry* e = &id->ra[id->ra_head];
+    if (!id->hs && !id->host_only) return PDMP3_ERR;
+    if (id->ra_inflight) {
+      if (pdmp3_hip_stream_wait(id->hs, 0) != PDMP3_HIP_OK) {
+        fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
+        return PDMP3_ERR;
       }
-      for (int k = 0; k < nb; k++) {
-        const size_t fbytes = 2304u * nchs[k];
-        if (outsize >= fbytes && k < nb - 1) {    /* whole frame fits: copy straight through */
-          if (pcm) { memcpy(outmemory, pcm + (size_t)k * 2304, fbytes); outmemory += fbytes; }
-          outsize -= fbytes; *done += fbytes;
-        } else {                                  /* last frame of the batch: may be partial */
-          if (pcm) memcpy(id->last_pcm, pcm + (size_t)k * 2304, fbytes);
-          id->last_nch = nchs[k];
-          id->ostart = 0;
-          const size_t n = drain_frame(id, pcm ? outmemory : NULL, outsize);
-          if (pcm) outmemory += n;
-          outsize -= n; *done += n;
-        }
-      }
+      id->ra_inflight = 0;
     }
-    if (stop) break;
+    id->l_processed = e->processed_after; id->l_istart = e->istart_after; id->l_hdr = e->hdr;
+    if (!id->l_new_header && e->nh) id->l_new_header = 1;
+    const size_t fbytes = 2304u * e->nch;
+    const int16_t* pcm = id->hs ? pdmp3_hip_stream_pcm(id->hs) + (size_t)id->ra_head * 2304 : NULL;
+    id->ra_head++;
+    if (pcm && id->ostart == 0 && outsize >= fbytes) {    /* whole frame fits: copy straight through */
+      memcpy(outmemory, pcm, fbytes);
+      outmemory += fbytes; outsize -= fbytes; *done += fbytes;
+      id->last_nch = e->nch;
+    } else {
+      /* Convert_Frame_S16 (P:2307-2345) starts at the cursor it finds: a new frame does not reset it.  (The cursor
+       * is not 0 here only after a call whose buffer ended inside a sample-frame -- 1..3 stray bytes -- which makes
+       * the reference decode and drop frames; the new frame is then handed out from that sample on.) */
+      if (pcm) memcpy(id->last_pcm, pcm, fbytes);
+      else memset(id->last_pcm, 0, fbytes);       /* parse-only test handle: silence */
+      id->last_nch = e->nch;
+      const size_t n = drain_frame(id, outmemory, outsize);
+      outmemory += n; outsize -= n; *done += n;
+    }
   }
-  if (id->new_header == 1 && res == PDMP3_OK) res = PDMP3_NEW_FORMAT;
+  if (id->l_new_header == 1 && res == PDMP3_OK) res = PDMP3_NEW_FORMAT;
   return res;
 }
 
 int pdmp3_read(pdmp3_handle* id, unsigned char* outmemory, size_t outsize, size_t* done) {
   if (!(id && outmemory && outsize && done)) return PDMP3_ERR;
-  return read_impl(id, outmemory, outsize, done, NULL);
+  return read_impl(id, outmemory, outsize, done);
 }
 
 /* parse-only variant of the read loop for host-logic tests: parses every frame
@@ -793,16 +968,17 @@ int pdmp3_amd_parse_available(pdmp3_handle* id) {
     const size_t pos = id->processed;
     const unsigned mark = id->istart;
     res = read_frame(id, sp);
-    if (res != PDMP3_OK && res != PDMP3_NEW_FORMAT) { id->processed = pos; id->istart = mark; return res; }
+    if (res != PDMP3_OK && res != PDMP3_NEW_FORMAT) { id->processed = pos; id->istart = mark; sync_logical(id); return res; }
     emit_records(id, &id->hdr, &id->si, id->need_reset, sp, sd);
     id->need_reset = 0;
+    sync_logical(id);
   }
   return PDMP3_NEED_MORE;
 }
 
 /* P:2491-2520 */
 int pdmp3_decode(pdmp3_handle* id, const unsigned char* in, size_t insize, unsigned char* out, size_t outsize, size_t* done) {
-  size_t take = ring_free(id);
+  size_t take = ring_free_logical(id);
   *done = 0;
   if (take > insize) take = insize;               /* the surplus is silently dropped (H16) */
   int res = pdmp3_feed(id, in, take);
@@ -811,12 +987,13 @@ int pdmp3_decode(pdmp3_handle* id, const unsigned char* in, size_t insize, unsig
     size_t got;
     res = pdmp3_read(id, out, outsize, &got);
     *done = got;
-  } else if (id->processed == 0) {                /* probe: peek at the first header, then rewind */
-    const size_t pos = id->processed;
+  } else if (id->l_processed == 0) {              /* probe: peek at the first header, then rewind */
+    const size_t pos = id->processed;             /* (nothing is read ahead before the first frame is handed out) */
     const unsigned mark = id->istart;
     res = search_header(id);
     id->processed = pos; id->istart = mark;
-    if (id->new_header == 1) res = PDMP3_NEW_FORMAT;
+    sync_logical(id);
+    if (id->l_new_header == 1) res = PDMP3_NEW_FORMAT;
   }
   return res;
 }
@@ -825,9 +1002,10 @@ int pdmp3_decode(pdmp3_handle* id, const unsigned char* in, size_t insize, unsig
 int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) {
   if (!(id && rate && channels && encoding)) return PDMP3_ERR;
   *encoding = PDMP3_ENC_SIGNED_16;
-  *rate = (long)kSampleRates[id->hdr.sfreq];
-  *channels = id->hdr.mode == 3 ? 1 : 2;
+  *rate = (long)kSampleRates[id->l_hdr.sfreq];
+  *channels = id->l_hdr.mode == 3 ? 1 : 2;
   id->new_header = -1;
+  id->l_new_header = -1;
   return PDMP3_OK;
 }
 
@@ -1003,20 +1181,31 @@ static int bulk_collect(struct bulk* b, int slot, const unsigned char** jsrc, un
   f->active = 0;
   if (f->direct) return PDMP3_OK;
   const unsigned char* src = (const unsigned char*)pdmp3_hip_stream_slot_pcm(b->hs, slot);
-  if (f->all_stereo == 2 || (f->all_stereo == 1 && jbytes)) {
+  const int to_device = b->pcm_pinned == 2;       /* memory the host cannot write: copies go through the engine */
+  if (f->all_stereo == 2 || (f->all_stereo == 1 && jbytes && !to_device)) {
     const size_t row = f->all_stereo == 2 ? 4608 : 2304;
     size_t n = (size_t)f->n * row;
     if (n > f->dst_cap) n = f->dst_cap;
     if (!n) return PDMP3_OK;
+    if (to_device) return pdmp3_hip_copy_to_dest(f->dst, src, n) == PDMP3_HIP_OK ? PDMP3_OK : PDMP3_ERR;
     if (jbytes) { *jsrc = src; *jdst = f->dst; *jbytes = n; b->next_copy_row = row; }
     else memcpy(f->dst, src, n);
     return PDMP3_OK;
   }
+  /* frames of both kinds (or mono frames without the pool): frame by frame, runs of equal frames as one copy */
   size_t off = 0;
-  for (int i = 0; i < f->n; i++) {
+  for (int i = 0; i < f->n;) {
     const size_t fb = 2304u * f->nch[i];
-    if (off < f->dst_cap) memcpy(f->dst + off, src + (size_t)i * 4608, fb < f->dst_cap - off ? fb : f->dst_cap - off);
-    off += fb;
+    int k = i + 1;
+    if (fb == 4608) while (k < f->n && f->nch[k] == 2) k++;       /* stereo frames are dense in the slot */
+    const size_t run = (size_t)(k - i) * fb;
+    if (off < f->dst_cap) {
+      const size_t n = run < f->dst_cap - off ? run : f->dst_cap - off;
+      if (to_device) { if (pdmp3_hip_copy_to_dest(f->dst + off, src + (size_t)i * 4608, n) != PDMP3_HIP_OK) return PDMP3_ERR; }
+      else memcpy(f->dst + off, src + (size_t)i * 4608, n);
+    }
+    off += run;
+    i = k;
   }
   return PDMP3_OK;
 }
@@ -1026,8 +1215,8 @@ static int bulk_collect(struct bulk* b, int slot, const unsigned char** jsrc, un
 static void flight_plan(struct bulk* b, bulk_flight* f) {
   const size_t row = f->all_stereo == 2 ? 4608 : 2304;
   f->direct = b->pcm_pinned && f->all_stereo != 0 && f->dst && (size_t)f->n * row <= f->dst_cap;
-  if (b->pcm_pinned == 2 && !f->direct) f->dst_cap = 0;   /* device memory the host cannot write: such a window is dropped
-                                                             (mixed mono / stereo window, or the tail that does not fit) */
+  /* (a window that cannot go there directly -- mixed mono / stereo frames, or the tail that does not fit -- is staged in
+   * the slot's pinned buffer and copied by bulk_collect, through the engine when the destination is device memory) */
 }
 
 /* stage C + D of the window the workers have just finished */
@@ -1237,7 +1426,7 @@ static long long bulk_drive(struct bulk* b, const unsigned char* mp3, size_t n) 
   pdmp3_open_feed(id);
   size_t fed = 0, done, total = 0;
   int res;
-  while ((res = read_impl(id, NULL, INBUF_SIZE, &done, b)) != PDMP3_ERR) {
+  while ((res = read_impl_sink(id, INBUF_SIZE, &done, b)) != PDMP3_ERR) {
     total += done;
     /* More bytes consumed than were ever fed: the ring is being replayed.  pdmp3_feed parks iend AT INBUF_SIZE
      * when a feed ends exactly at the end of the ring (P:2410-2417); a frame that then ends exactly there (only
@@ -1531,6 +1720,47 @@ static void cli_stream_file(pdmp3_handle* id, const char* filename, FILE* fp) {
       (void)pdmp3_feed(id, in, n);
     }
   }
+}
+
+/* The streaming API driven from a memory buffer, in C (include/pdmp3_bulk.h): pdmp3_new, pdmp3_open_feed, then
+ * pdmp3_read(read_bytes) until PDMP3_ERR, feeding feed_bytes on PDMP3_NEED_MORE -- the reference driver's loop
+ * (P:2564-2584) with its two sizes as parameters (4096 / 16384 there).  eager != 0: the caller keeps the ring as full
+ * as feed_bytes-sized feeds allow instead of waiting for PDMP3_NEED_MORE. */
+long long pdmp3_amd_stream_loop(const unsigned char* mp3, size_t n, unsigned char* out, size_t cap,
+                                size_t feed_bytes, size_t read_bytes, int eager) {
+  if (!mp3 || !feed_bytes || !read_bytes) return -1;
+  pdmp3_handle* id = pdmp3_new(NULL, NULL);
+  if (!id) return -1;
+  unsigned char* buf = (unsigned char*)malloc(read_bytes);
+  if (!buf) { pdmp3_delete(id); return -1; }
+  pdmp3_open_feed(id);
+  size_t fed = 0, done, total = 0;
+  int res;
+  for (;;) {
+    if (eager)
+      while (fed < n) {
+        const size_t take = n - fed < feed_bytes ? n - fed : feed_bytes;
+        /* never to the last byte: a ring filled exactly looks EMPTY to the reference (iend == istart, P:1062-1068)
+         * and the next feeds would overwrite it -- a caller of the real API has to keep count for this itself */
+        if (take >= ring_free_logical(id) || pdmp3_feed(id, mp3 + fed, take) != PDMP3_OK) break;
+        fed += take;
+      }
+    res = pdmp3_read(id, buf, read_bytes, &done);
+    if (res == PDMP3_ERR) break;
+    if (out && total < cap) memcpy(out + total, buf, done < cap - total ? done : cap - total);
+    total += done;
+    if (res == PDMP3_NEED_MORE) {
+      if (fed >= n) break;
+      if (!eager) {
+        const size_t take = n - fed < feed_bytes ? n - fed : feed_bytes;
+        (void)pdmp3_feed(id, mp3 + fed, take);
+        fed += take;
+      }
+    }
+  }
+  free(buf);
+  pdmp3_delete(id);
+  return (long long)total;
 }
 
 /* Same contract as the reference's driver: every named file is decoded to interleaved int16 and appended to

@@ -111,3 +111,41 @@ def test_two_handles_do_not_share_state(oracle):
         assert len(got) == len(want)
         assert_pcm_close(_as16(got), _as16(want), 1, what)
     oa.close(); ob.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_call_sequences_on_the_gpu(oracle, seed):
+    """the read-ahead inside pdmp3_read is invisible: random feed / read / decode / getformat / open_feed sequences,
+    every return code, byte count and PCM byte (+-1 LSB) against the oracle's restatement of the reference's API --
+    including the sequences that make the library take frames back (a feed that fills the ring exactly, open_feed)"""
+    import stream_replay
+    from oracle.oracle import OracleStream
+    from pdmp3_amd import api
+    for name, mp3 in stream_replay.streams():
+        dec = api.Decoder()
+        orc = OracleStream(oracle)
+        try:
+            stream_replay.replay(1000 * seed + len(name), mp3, dec, orc, compare_pcm=True)
+        finally:
+            dec.close()
+            orc.close()
+
+
+def test_stream_loop_in_c_matches_the_cli_loop(oracle):
+    """pdmp3_amd_stream_loop (the driver's loop in C: what bench.py times as streaming_api), at the reference's cadence
+    and with eager feeds / other buffer sizes: same bytes as the reference's loop on the oracle"""
+    from oracle.oracle import OracleStream
+    from pdmp3_amd import api
+    mp3 = packer.generate(n_frames=500, seed=77, sfreq=0, mode=1, mode_ext=2, bitrate_index=14)
+    o = OracleStream(oracle)
+    want = _as16(o.decode_like_cli(mp3))
+    o.close()
+    n, got = api.stream_loop(mp3)
+    assert n == want.nbytes
+    assert_pcm_close(got, want, 1, "reference cadence")
+    for feed, read, eager in ((4096, 16384, True), (1000, 4608, True), (15000, 65536, True), (8192, 100000, False)):
+        n2, got2 = api.stream_loop(mp3, feed, read, eager)
+        # other cadences deliver the same frames except for the tail rule (H10: a frame is attempted only with 1152
+        # bytes buffered), which depends on how the end of the file is fed
+        k = min(got2.size, want.size)
+        assert k >= want.size - 2 * 2304 * 2 and np.array_equal(got2[:k], got[:k]), (feed, read, eager)

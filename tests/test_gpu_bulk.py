@@ -330,6 +330,41 @@ def test_pcm_stays_on_the_device(streams, host_huffman):
         ref.close()
 
 
+@pytest.mark.parametrize("host_huffman", [False, True])
+def test_device_destination_takes_mixed_windows_and_clipped_tails(host_huffman):
+    """windows that cannot be downloaded straight into a DEVICE destination -- mono and stereo frames in one window,
+    or a destination that ends inside a window -- are staged and copied, never dropped"""
+    import torch
+    from pdmp3_amd import api
+    parts = [dict(n_frames=9, seed=31, bitrate_index=9), dict(n_frames=11, seed=32, mode=3, bitrate_index=7),
+             dict(n_frames=2, seed=33, mode=1, mode_ext=2, bitrate_index=11, block_pct=(10, 10, 70, 10)),
+             dict(n_frames=27, seed=34, mode=3, bitrate_index=7),
+             dict(n_frames=40, seed=35, mode=1, mode_ext=2, bitrate_index=11, block_pct=(10, 10, 70, 10))]
+    mp3 = b"".join(packer.generate(**p) for p in parts)
+    b = api.BulkDecoder(threads=2, window_frames=16, host_huffman=host_huffman)
+    ref = api.BulkDecoder(threads=2, window_frames=64)
+    try:
+        want = ref.decode(mp3)
+        out = torch.full((want.size + 32,), 0x5A5A, dtype=torch.int16, device="cuda")
+        total, rate, ch = b.decode_into_device(mp3, out)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert total == want.nbytes
+        assert np.array_equal(got[:want.size], want)
+        assert (got[want.size:] == 0x5A5A).all()
+        # a destination that ends in the middle of a window (and of a frame): the prefix that fits is delivered
+        short = want.size - 16 * 2304 - 1000
+        out = torch.full((short + 64,), 0x5A5A, dtype=torch.int16, device="cuda")
+        b.decode_into_device(mp3, out[:short])
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:short], want[:short])
+        assert (got[short:] == 0x5A5A).all()
+    finally:
+        b.close()
+        ref.close()
+
+
 def test_corrupted_streams_pcm_against_the_oracle(oracle):
     """corrupted streams (without H8 frames, which the oracle cannot be given) end to end against the oracle's
     transforms: +-1 LSB wherever the signal is within a few times full scale; where a flipped global_gain drives the
