@@ -300,7 +300,24 @@ def main():
             "fp32_tflops": round(nb * ALGO_FLOP_PER_FRAME / (ms * 1e-3) / 1e12, 2),
             "fp32_frac": round(nb * ALGO_FLOP_PER_FRAME / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
         }
-        del sp2, sd2, pcm2
+        # float PCM (pdmp3_hip_decode_frames_f32): 3584 algorithmic bytes per granule-channel
+        # (1152 spectra + 128 side + 2304 float PCM) = 14336 per stereo frame
+        pcmf = torch.empty((nb, 2304), dtype=torch.float32, device=eng.tdev)
+        for _ in range(2):
+            eng.decode_f32(sp2, sd2, pcmf, chunk_frames=args.chunk)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            eng.decode_f32(sp2, sd2, pcmf, chunk_frames=args.chunk)
+        b.record()
+        torch.cuda.synchronize()
+        msf = a.elapsed_time(b) / reps
+        achf = nb * 14336 / (msf * 1e-3) / 1e9
+        out["roofline_float_pcm"] = {"frames": nb, "avg_launch_ms": round(msf, 4), "frames_per_s": round(nb / (msf * 1e-3), 1),
+                                     "algorithmic_bytes_per_frame": 14336, "achieved": round(achf, 2), "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": round(achf / HBM_PEAK_GBS, 5), "kernel": "k_decode<false, true>"}
+        del sp2, sd2, pcm2, pcmf
 
     if world == 1 and not args.no_e2e:
         # beside the hot-path metric: the same path fed from a bitstream in host memory to PCM in host memory (host scan ->

@@ -46,6 +46,15 @@ int pdmp3_decode(pdmp3_handle* id, const unsigned char* in, size_t insize,
                  unsigned char* out, size_t outsize, size_t* done);
 int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding);
 
+/* Output encoding (NOT in the reference, which has int16 only).  PDMP3_ENC_FLOAT_32 -- libmpg123's
+ * value for 32-bit float -- makes pdmp3_read / pdmp3_decode deliver interleaved native float, full scale +-1.0,
+ * unclipped: the binary32 synthesis sum that pdmp3.c:2028-2031 would scale by 32767, truncate and clip, so the
+ * int16 output is exactly clip(trunc(float * 32767)).  Sizes count bytes as before (8 per stereo sample-frame).
+ * Takes effect at once; frames decoded but not handed out yet are decoded again.  pdmp3_getformat reports it.
+ * Returns PDMP3_ERR for any other encoding. */
+#define PDMP3_ENC_FLOAT_32 0x200
+int pdmp3_amd_set_encoding(pdmp3_handle* id, int encoding);
+
 /* CLI driver: NULL-terminated list of .mp3 paths ("-" = stdin); writes
  * <first file>.raw (interleaved native-endian int16), as the reference's
  * OUTPUT_RAW build does (pdmp3.c:2236-2257).  A leading "/dev/dsp*" argument

@@ -126,6 +126,21 @@ int pdmp3_hip_decode_frames(pdmp3_hip_ctx* ctx,
                             int chunk_frames,
                             void* stream);
 
+/* Float PCM (not in the reference, whose only output is int16): the same decode, but what is stored is
+ * the binary32 synthesis sum that P:2028-2031 scale by 32767, truncate and clip -- full scale is +-1.0, nothing is
+ * clipped.  d_pcm: device, float; frame f occupies floats [f*2304, f*2304+2304), interleaved L, R (mono frames: the
+ * first 1152).  The int16 output of pdmp3_hip_decode_frames is exactly clip(trunc(these * 32767)), which is how the
+ * float form is pinned to the reference.  State and chunking as above (the two forms may alternate on one state). */
+#define PDMP3_FRAME_PCM_F32_BYTES (1152 * 2 * 4)
+int pdmp3_hip_decode_frames_f32(pdmp3_hip_ctx* ctx,
+                                const int16_t* d_spectra,
+                                const pdmp3_gc_side* d_side,
+                                int n_frames,
+                                void* d_state,
+                                float* d_pcm,
+                                int chunk_frames,
+                                void* stream);
+
 /* Same, additionally dumping float32 stage outputs for parity tests
  * (d_stages: float [n_frames][2][2][4][576]; stage 0 = after requantize +
  * reorder, 1 = after stereo, 2 = after antialias, 3 = after hybrid synthesis
@@ -190,6 +205,10 @@ pdmp3_gc_side* pdmp3_hip_stream_slot_side(pdmp3_hip_stream* hs, int slot);
 const int16_t* pdmp3_hip_stream_slot_pcm(pdmp3_hip_stream* hs, int slot);
 /* enqueue H2D + transforms + D2H of the slot's first n_frames frames; returns at once */
 int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_frames);
+/* PCM of pdmp3_hip_stream_submit / _decode as float from now on (on != 0; see pdmp3_hip_decode_frames_f32) or as
+ * int16 again.  Call with nothing in flight: the slots' PCM buffers are re-allocated (9216 bytes per frame for float)
+ * and the pdmp3_hip_stream_*pcm accessors return the new ones, to be read as float.  Not for the _to / _bits forms. */
+int pdmp3_hip_stream_set_f32(pdmp3_hip_stream* hs, int on);
 /* undo the slot's latest pdmp3_hip_stream_submit beyond its first keep_frames frames: the carried synthesis state
  * (P:1755, P:1983) becomes what it was after frame keep_frames - 1 of that batch.  Blocks.  (pdmp3_read hands frames
  * out in the reference's order; frames it decoded ahead that the reference turns out not to reach are taken back.) */

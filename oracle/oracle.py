@@ -52,6 +52,7 @@ class Oracle:
         self.lib = C.CDLL(os.path.join(_HERE, "liboracle.so"))
         L = self.lib
         L.orc_decode_frames.argtypes = [_p, _p, _p, C.c_int, _p, _p]
+        L.orc_decode_frames_f32.argtypes = [_p, _p, _p, C.c_int, _p, _p, _p]
         L.orc_generate_frames.argtypes = [C.c_uint64, C.c_int64, C.c_int, _p, _p]
         L.orc_table_pow43.restype = C.POINTER(C.c_float)
         L.orc_table_nwin.restype = C.POINTER(C.c_float)
@@ -79,6 +80,18 @@ class Oracle:
         stg = np.zeros((n, 2, 2, 4, 576), dtype=np.float32) if stages else None
         self.lib.orc_decode_frames(_ptr(state), _ptr(spectra), _ptr(side), n, _ptr(pcm), _ptr(stg))
         return (pcm, stg) if stages else pcm
+
+    def decode_f32(self, spectra, side, state=None):
+        """-> (int16 PCM, float PCM): the float is the binary32 `sum` of P:2028, i.e. int16 = clip(trunc(sum * 32767))"""
+        n = spectra.shape[0]
+        spectra = np.ascontiguousarray(spectra, dtype=np.int16)
+        side = np.ascontiguousarray(side)
+        if state is None:
+            state = self.new_state()
+        pcm = np.zeros((n, 2304), dtype=np.int16)
+        f32 = np.zeros((n, 2304), dtype=np.float32)
+        self.lib.orc_decode_frames_f32(_ptr(state), _ptr(spectra), _ptr(side), n, _ptr(pcm), _ptr(f32), None)
+        return pcm, f32
 
     def time_decode(self, spectra, side, reps=1):
         n = spectra.shape[0]

@@ -303,7 +303,7 @@ static inline int32_t cvt_trunc_x86(double d) {
 
 /* P:1978-2045 L3_Subband_Synthesis.  out[] is the reference's `outdata`
  * (id->out[gr]): ch0 in the high half, ch1 OR-ed into the low half. */
-static void stage_subband(frame_ws* w, orc_synth* st, unsigned gr, unsigned ch, uint32_t out[576]) {
+static void stage_subband(frame_ws* w, orc_synth* st, unsigned gr, unsigned ch, uint32_t out[576], float* fsum) {
   float u_vec[512], s_vec[32], sum;
   float* v = st->v_vec[ch];
   const float* x = w->is[gr][ch];
@@ -325,6 +325,7 @@ static void stage_subband(frame_ws* w, orc_synth* st, unsigned gr, unsigned ch, 
     for (i = 0; i < 32; i++) {
       sum = 0.0;
       for (j = 0; j < 16; j++) sum += u_vec[(j << 5) + i];
+      if (fsum) fsum[32 * ss + i] = sum;                    /* the binary32 `sum` of P:2028, before the scaling */
       int32_t samp = cvt_trunc_x86(sum * 32767.0);
       if (samp > 32767) samp = 32767;
       else if (samp < -32767) samp = -32767;
@@ -368,9 +369,17 @@ static void unpack_frame(frame_ws* w, const int16_t* spectra, const pdmp3_gc_sid
 
 int orc_decode_frames(orc_synth* st, const int16_t* spectra, const pdmp3_gc_side* side,
                       int n_frames, int16_t* pcm, float* stages) {
+  return orc_decode_frames_f32(st, spectra, side, n_frames, pcm, NULL, stages);
+}
+
+/* the same, also handing out the synthesis sums P:2028 turns into int16: pcm_f32 (nullable), interleaved like pcm,
+ * 2304 floats per frame (mono: first 1152); pcm (nullable) */
+int orc_decode_frames_f32(orc_synth* st, const int16_t* spectra, const pdmp3_gc_side* side,
+                          int n_frames, int16_t* pcm, float* pcm_f32, float* stages) {
   build_tables();
   frame_ws* w = (frame_ws*)malloc(sizeof *w);
   uint32_t out[2][576];
+  float fs[2][2][576];
   for (int f = 0; f < n_frames; f++) {
     const pdmp3_gc_side* sd = side + (size_t)f * 4;
     unpack_frame(w, spectra + (size_t)f * 2304, sd);
@@ -393,11 +402,18 @@ int orc_decode_frames(orc_synth* st, const int16_t* spectra, const pdmp3_gc_side
         stage_hybrid(w, st, gr, ch);
         stage_freqinv(w, gr, ch);
         if (stg) memcpy(stg + ((gr * 2 + ch) * 4 + 3) * 576, w->is[gr][ch], 576 * 4);
-        stage_subband(w, st, gr, ch, out[gr]);
+        stage_subband(w, st, gr, ch, out[gr], fs[gr][ch]);
       }
     }
     /* P:2307-2345 Convert_Frame_S16 for a whole frame */
+    if (pcm_f32) {
+      float* of = pcm_f32 + (size_t)f * 2304;
+      for (unsigned gr = 0; gr < 2; gr++)
+        for (unsigned i = 0; i < 576; i++)
+          for (unsigned ch = 0; ch < w->nch; ch++) of[(gr * 576 + i) * w->nch + ch] = fs[gr][ch][i];
+    }
     int16_t* o = pcm + (size_t)f * 2304;
+    if (pcm)
     for (unsigned gr = 0; gr < 2; gr++)
       for (unsigned i = 0; i < 576; i++) {
         uint32_t v = out[gr][i];

@@ -42,6 +42,12 @@ int orc_decode_frames(orc_synth* st, const int16_t* spectra,
                       const pdmp3_gc_side* side, int n_frames,
                       int16_t* pcm, float* stages);
 
+/* the same, also handing out the binary32 synthesis sums that P:2028-2031 scale, truncate and clip into int16
+ * (float PCM): pcm_f32 (nullable) interleaved like pcm, 2304 floats per frame; pcm nullable too */
+int orc_decode_frames_f32(orc_synth* st, const int16_t* spectra,
+                          const pdmp3_gc_side* side, int n_frames,
+                          int16_t* pcm, float* pcm_f32, float* stages);
+
 /* SURVEY 8d synthetic generator (C2/C5), integer-only. */
 void orc_generate_frames(uint64_t seed, int64_t first_frame, int n_frames,
                          int16_t* spectra, pdmp3_gc_side* side);

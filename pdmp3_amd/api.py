@@ -24,7 +24,8 @@ GC_BITS_DTYPE = np.dtype([("part2_3_length", "<u2"), ("big_values", "<u2"), ("gl
 FRAME_BITS_DTYPE = np.dtype([("frame", "u1"), ("scfsi", "u1", (2,)), ("reserved", "u1", (13,)), ("gc", GC_BITS_DTYPE, (4,))])
 RESERVOIR_BYTES = 2064
 API_EXPORTS = ["pdmp3_new", "pdmp3_delete", "pdmp3_open_feed", "pdmp3_feed", "pdmp3_read",
-               "pdmp3_decode", "pdmp3_getformat", "pdmp3"]
+               "pdmp3_decode", "pdmp3_getformat", "pdmp3", "pdmp3_amd_set_encoding"]
+PDMP3_ENC_SIGNED_16, PDMP3_ENC_FLOAT_32 = 0xD0, 0x200
 
 
 def library_path():
@@ -49,6 +50,7 @@ def load_library():
     lib.pdmp3_read.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.pdmp3_decode.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.pdmp3_getformat.argtypes = [vp, C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.pdmp3_amd_set_encoding.argtypes = [vp, C.c_int]
     lib.pdmp3_amd_new_parse_only.restype = vp
     lib.pdmp3_amd_set_tap.argtypes = [vp, vp, vp, C.c_int]
     lib.pdmp3_amd_tap_count.argtypes = [vp]
@@ -127,6 +129,9 @@ class Decoder:
         rate, ch, enc = C.c_long(0), C.c_int(0), C.c_int(0)
         rc = self.lib.pdmp3_getformat(self.h, C.byref(rate), C.byref(ch), C.byref(enc))
         return rc, rate.value, ch.value, enc.value
+
+    def set_encoding(self, enc):
+        return self.lib.pdmp3_amd_set_encoding(self.h, enc)
 
     def set_tap(self, cap_frames):
         self._tap_sp = np.zeros((cap_frames, 2, 2, 576), dtype=np.int16)

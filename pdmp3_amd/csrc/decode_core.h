@@ -203,6 +203,7 @@ PD_FN GranuleInfo granule_info(const WaveLds& L) {
 }
 
 PD_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+PD_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 // ---------------------------------------------------------------------------
 // chunk prologue: per-lane constants, LDS copies of hot tables
@@ -717,7 +718,8 @@ PD_FN void permlane32_swap(int& a, int& b) {
 }
 
 // full = false (wave-uniform): the last halo granule -- only its slots 3..17 are wanted, as the next granule's history
-PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int16_t* pcm_g) {
+template <bool F32>
+PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int16_t* pcm_g, float* pcmf_g) {
   const GranuleInfo g = granule_info(L);
   const int ch = lane >> 5, i = lane & 31;
   const bool act = ch < g.nch;                 // (mono: lanes 32..63 idle, their history is channel 1's and stays)
@@ -750,7 +752,26 @@ PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int16_t* pcm_
       sum[t] = acc;
     }
     PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = E[18 + s]; R.ho[s] = O[18 + s]; }
-    pcm_convert18(sum, out);
+    if (F32) {
+      // float PCM: the binary32 `sum` of P:2028 itself, before the scaling to int16
+      PD_UNROLL for (int t = 0; t < 18; t++) out[t] = (int)f2u(sum[t]);
+    } else pcm_convert18(sum, out);
+  }
+  if (F32) {
+    if (g.nch == 2) {
+      // same pairing as below; a lane then owns one interleaved sample-frame of two floats: 8-byte stores,
+      // 64 consecutive sample-frames per instruction
+      PD_UNROLL for (int q = 0; q < 9; q++) {
+        int a = out[2 * q], b = out[2 * q + 1];
+        permlane32_swap(a, b);
+        float* d = pcmf_g + 2 * (64 * q + lane);
+        d[0] = u2f((uint32_t)a);
+        d[1] = u2f((uint32_t)b);
+      }
+    } else if (act) {
+      PD_UNROLL for (int t = 0; t < 18; t++) pcmf_g[32 * t + i] = u2f((uint32_t)out[t]);
+    }
+    return;
   }
   if (g.nch == 2) {
     // Lanes i and i + 32 hold the left and the right value of the same sample.  For a pair of time slots (t, t + 1) one
@@ -818,6 +839,7 @@ struct DecodeArgs {
   const int16_t* spectra;        // [n_frames][2][2][576]
   const pdmp3_gc_side* side;     // [n_frames][2][2]
   int16_t* pcm;                  // 2304 int16 per frame
+  float* pcm_f32;                // F32 kernels: 2304 floats per frame instead (the sums of P:2028, unscaled)
   const float* state_in;         // kStateFloats or null (read by chunk 0)
   float* state_out;              // kStateFloats or null (written by the last chunk; must not alias state_in
                                  // when there is more than one chunk)
@@ -837,7 +859,7 @@ constexpr int kProfSlots = 12;
   }                                                     \
   PD_WAVE_SYNC();
 
-template <bool DUMP, bool PROF = false>
+template <bool DUMP, bool PROF = false, bool F32 = false>
 PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveLds& L) {
   LaneRegs R;
   const int lane = PD_LANE();
@@ -962,7 +984,8 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     }
     PD_TICK(5)
     if (emit || feeds_next) {
-      PD_PHASE(ph_window(lane, L, R, emit, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g))
+      PD_PHASE(ph_window<F32>(lane, L, R, emit, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g,
+                                F32 ? a.pcm_f32 + (size_t)f * 2304 + gr * 576 * nch_g : nullptr))
     }
     PD_TICK(6)
     // the next granule is committed to LDS BEFORE this granule's PCM stores are issued: its prefetch
@@ -971,7 +994,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       PD_PHASE(ph_commit(lane, L, R))
     }
     PD_PHASE(
-      ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, emit);
+      if (!F32) ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, emit);
       if (g_next < g_end) ph_scales(lane, L);        // next granule's (its side info was committed just above)
     )
     PD_TICK(7)

@@ -42,13 +42,14 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-template <bool DUMP>
+// F32: float PCM (the sums of P:2028 unscaled, DecodeArgs::pcm_f32) instead of int16
+template <bool DUMP, bool F32 = false>
 __global__ __launch_bounds__(64 * kWavesPerWg, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a, GlobalTables T, int n_chunks) {
   __shared__ WaveLds L[kWavesPerWg];
   const int w = threadIdx.x >> 6;
   const int n_wgs = (n_chunks + kWavesPerWg - 1) / kWavesPerWg;
   const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * kWavesPerWg + w;
-  if (chunk < n_chunks) run_chunk<DUMP>(a, T, (BankPtr)&c_bank, chunk, L[w]);
+  if (chunk < n_chunks) run_chunk<DUMP, false, F32>(a, T, (BankPtr)&c_bank, chunk, L[w]);
 }
 
 // same kernel with shader-clock stamps after every phase (tools/phase_profile.py)
@@ -284,12 +285,12 @@ static int auto_chunk(int n_frames, int slots) {
 // pdmp3_hip_decode_frames call takes a stream-ordered allocation so that calls on different HIP streams never share it.
 static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3_gc_side* d_side, int n_frames,
                          void* d_state, int16_t* d_pcm, float* d_stages, int chunk_frames, void* stream,
-                         unsigned long long* d_prof = nullptr, float* d_state_tmp = nullptr) {
+                         unsigned long long* d_prof = nullptr, float* d_state_tmp = nullptr, float* d_pcm_f32 = nullptr) {
   if (!c || n_frames < 0) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: bad argument", hipSuccess);
   if (n_frames == 0) return PDMP3_HIP_OK;
-  if (!d_spectra || !d_side || !d_pcm)
+  if (!d_spectra || !d_side || !(d_pcm || d_pcm_f32))
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: NULL buffer", hipSuccess);
-  if (((uintptr_t)d_spectra | (uintptr_t)d_side | (uintptr_t)d_pcm) & 15)
+  if (((uintptr_t)d_spectra | (uintptr_t)d_side | (uintptr_t)d_pcm | (uintptr_t)d_pcm_f32) & 15)
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: buffers must be 16-byte aligned", hipSuccess);
   if (n_frames == 0) return PDMP3_HIP_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -301,6 +302,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.spectra = d_spectra;
   a.side = d_side;
   a.pcm = d_pcm;
+  a.pcm_f32 = d_pcm_f32;
   a.state_in = (const float*)d_state;
   bool own_tmp = false;
   if (d_state && !d_state_tmp) {
@@ -315,6 +317,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64};
   if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
   else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3((nchunks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, s, a, T, nchunks);
+  else if (d_pcm_f32) hipLaunchKernelGGL((k_decode<false, true>), dim3((nchunks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, s, a, T, nchunks);
   else hipLaunchKernelGGL(k_decode<false>, dim3((nchunks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, s, a, T, nchunks);
   hipError_t e = hipGetLastError();
   const char* what = "launch k_decode";
@@ -333,6 +336,12 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
 extern "C" int pdmp3_hip_decode_frames(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,
                                        int n_frames, void* d_state, int16_t* d_pcm, int chunk_frames, void* stream) {
   return launch_decode(ctx, d_spectra, d_side, n_frames, d_state, d_pcm, nullptr, chunk_frames, stream);
+}
+
+extern "C" int pdmp3_hip_decode_frames_f32(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,
+                                           int n_frames, void* d_state, float* d_pcm, int chunk_frames, void* stream) {
+  if (!d_pcm) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames_f32: d_pcm is NULL", hipSuccess);
+  return launch_decode(ctx, d_spectra, d_side, n_frames, d_state, nullptr, nullptr, chunk_frames, stream, nullptr, nullptr, d_pcm);
 }
 
 extern "C" int pdmp3_hip_decode_frames_stages(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,
@@ -371,6 +380,7 @@ struct pdmp3_hip_stream {
   uint16_t* d_sfstate;       // [2][256]: scalefactors / count1 carried from frame to frame (unpack_core.h), double-buffered
   int sf_cur;
   int have_bits;
+  int f32;                   // PCM as float (pdmp3_hip_stream_set_f32): the slots' PCM buffers hold 9216 bytes per frame
 };
 
 extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
@@ -503,6 +513,28 @@ extern "C" int pdmp3_hip_copy_to_dest(void* dst, const void* src_host, size_t by
   return PDMP3_HIP_OK;
 }
 
+// PCM of the record-level submits (pdmp3_hip_stream_submit / _decode) as float from now on (on != 0) or int16 again.
+// Call with nothing in flight; the slots' PCM buffers are re-allocated.  The accessors return the same pointers'
+// new values, to be read as float: frame f at floats [f*2304, f*2304+2304).
+extern "C" int pdmp3_hip_stream_set_f32(pdmp3_hip_stream* hs, int on) {
+  if (!hs) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_set_f32: NULL", hipSuccess);
+  on = on ? 1 : 0;
+  if (hs->f32 == on) return PDMP3_HIP_OK;
+  HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
+  int rc = drain_slots(hs);
+  if (rc != PDMP3_HIP_OK) return rc;
+  const size_t bytes = (size_t)hs->max_frames * (on ? PDMP3_FRAME_PCM_F32_BYTES : PDMP3_FRAME_PCM_BYTES);
+  for (int i = 0; i < hs->n_slots; ++i) {
+    StreamSlot& t = hs->s[i];
+    (void)hipHostFree(t.h_pcm); t.h_pcm = nullptr;
+    (void)hipFree(t.d_pcm); t.d_pcm = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&t.h_pcm, bytes, hipHostMallocDefault), "hipHostMalloc pcm");
+    HIP_TRY(hipMalloc((void**)&t.d_pcm, bytes), "hipMalloc pcm");
+  }
+  hs->f32 = on;
+  return PDMP3_HIP_OK;
+}
+
 static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row);
 extern "C" int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_frames) {
   return submit_records(hs, slot, n_frames, nullptr, PDMP3_FRAME_PCM_BYTES);
@@ -524,11 +556,15 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
   HIP_TRY(hipMemcpyAsync(t.d_side, t.h_side, n * PDMP3_FRAME_SIDE_BYTES, hipMemcpyHostToDevice, t.stream), "H2D side");
   if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
   HIP_TRY(hipMemcpyAsync(hs->d_state_prev, hs->d_state, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, t.stream), "keep the state");
-  int rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp);
+  if (hs->f32 && host_dst) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_to: not with float PCM", hipSuccess);
+  int rc = hs->f32
+      ? launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm)
+      : launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp);
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
   hs->have_state_ev = 1;
-  rc = download_pcm(t, n, host_dst, row);
+  if (hs->f32) HIP_TRY(hipMemcpyAsync(t.h_pcm, t.d_pcm, n * PDMP3_FRAME_PCM_F32_BYTES, hipMemcpyDeviceToHost, t.stream), "D2H pcm");
+  else rc = download_pcm(t, n, host_dst, row);
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(t.done, t.stream), "record done event");
   t.busy = 1;
@@ -557,7 +593,9 @@ extern "C" int pdmp3_hip_stream_rewind(pdmp3_hip_stream* hs, int slot, int keep_
   t.busy = 0;
   HIP_TRY(hipMemcpyAsync(hs->d_state, hs->d_state_prev, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, t.stream), "restore the state");
   if (keep_frames) {
-    const int rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, keep_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp);
+    const int rc = hs->f32
+        ? launch_decode(hs->ctx, t.d_spectra, t.d_side, keep_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm)
+        : launch_decode(hs->ctx, t.d_spectra, t.d_side, keep_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp);
     if (rc != PDMP3_HIP_OK) return rc;
   }
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");

@@ -25,7 +25,7 @@ FRAME_SIDE_BYTES = 512
 
 EXPORTS = [
     "pdmp3_hip_create", "pdmp3_hip_destroy", "pdmp3_hip_last_error", "pdmp3_hip_state_bytes",
-    "pdmp3_hip_decode_frames", "pdmp3_hip_decode_frames_stages", "pdmp3_hip_generate_frames",
+    "pdmp3_hip_decode_frames", "pdmp3_hip_decode_frames_f32", "pdmp3_hip_decode_frames_stages", "pdmp3_hip_generate_frames",
     "pdmp3_host_generate_frames",
     "pdmp3_hip_stream_create", "pdmp3_hip_stream_destroy", "pdmp3_hip_stream_reset", "pdmp3_hip_stream_spectra",
     "pdmp3_hip_stream_side", "pdmp3_hip_stream_pcm", "pdmp3_hip_stream_decode",
@@ -65,6 +65,7 @@ def load_library():
     lib.pdmp3_hip_last_error.restype = C.c_char_p
     lib.pdmp3_hip_state_bytes.restype = C.c_size_t
     lib.pdmp3_hip_decode_frames.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp]
+    lib.pdmp3_hip_decode_frames_f32.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp]
     lib.pdmp3_hip_decode_frames_stages.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     lib.pdmp3_hip_generate_frames.argtypes = [vp, u64, i64, i32, vp, vp, vp]
     lib.pdmp3_host_generate_frames.argtypes = [u64, i64, i32, vp, vp]
@@ -145,6 +146,13 @@ class Engine:
         self._check(self.lib.pdmp3_hip_decode_frames(
             self.h, spectra.data_ptr(), side.data_ptr(), n,
             state.data_ptr() if state is not None else None, pcm.data_ptr(), int(chunk_frames), self._stream()))
+
+    def decode_f32(self, spectra, side, pcm_f32, n_frames=None, state=None, chunk_frames=0):
+        """float PCM (pdmp3_hip_decode_frames_f32): pcm_f32 = float32 tensor, 2304 floats per frame"""
+        n = int(spectra.shape[0]) if n_frames is None else int(n_frames)
+        self._check(self.lib.pdmp3_hip_decode_frames_f32(
+            self.h, spectra.data_ptr(), side.data_ptr(), n,
+            state.data_ptr() if state is not None else None, pcm_f32.data_ptr(), int(chunk_frames), self._stream()))
 
     def decode_stages(self, spectra, side, pcm, stages, state=None):
         n = int(spectra.shape[0])

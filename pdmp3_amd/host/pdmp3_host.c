@@ -131,7 +131,8 @@ struct pdmp3_handle {
   unsigned char in[INBUF_SIZE];
   /* output cursor into the last decoded frame, P:127 (ostart), P:129 (out) */
   unsigned ostart;
-  int16_t last_pcm[2304];
+  int16_t last_pcm[2304 * 2];      /* (as float when enc_f32: 2304 floats) */
+  int enc_f32;                     /* pdmp3_amd_set_encoding: PCM as float (not in the reference) */
   unsigned last_nch;
   /* parse state that survives frames (the reference never clears it) */
   frame_header hdr;
@@ -729,7 +730,7 @@ static void emit_records(pdmp3_handle* id, const frame_header* H, const side_inf
 /* P:2307-2345: hand out up to buflen bytes of the frame under the cursor */
 static size_t drain_frame(pdmp3_handle* id, unsigned char* out, size_t buflen) {
   const unsigned nch = id->l_hdr.mode == 3 ? 1 : 2;        /* the CURRENT header's channel count, as in the reference */
-  const unsigned bps = 2 * nch;
+  const unsigned bps = (id->enc_f32 ? 4 : 2) * nch;
   size_t n = buflen / bps;
   if (n > 1152u - id->ostart) n = 1152u - id->ostart;
   if (out) memcpy(out, (const unsigned char*)id->last_pcm + (size_t)id->ostart * bps, n * bps);
@@ -931,8 +932,9 @@ static int read_impl(pdmp3_handle* id, unsigned char* outmemory, size_t outsize,
     }
     id->l_processed = e->processed_after; id->l_istart = e->istart_after; id->l_hdr = e->hdr;
     if (!id->l_new_header && e->nh) id->l_new_header = 1;
-    const size_t fbytes = 2304u * e->nch;
-    const int16_t* pcm = id->hs ? pdmp3_hip_stream_pcm(id->hs) + (size_t)id->ra_head * 2304 : NULL;
+    const size_t fbytes = (id->enc_f32 ? 4608u : 2304u) * e->nch;
+    const unsigned char* pcm = id->hs ? (const unsigned char*)pdmp3_hip_stream_pcm(id->hs) +
+                                            (size_t)id->ra_head * (id->enc_f32 ? 9216u : 4608u) : NULL;
     id->ra_head++;
     if (pcm && id->ostart == 0 && outsize >= fbytes) {    /* whole frame fits: copy straight through */
       memcpy(outmemory, pcm, fbytes);
@@ -998,10 +1000,26 @@ int pdmp3_decode(pdmp3_handle* id, const unsigned char* in, size_t insize, unsig
   return res;
 }
 
+/* include/pdmp3.h: float output (not in the reference) */
+int pdmp3_amd_set_encoding(pdmp3_handle* id, int encoding) {
+  if (!id || (encoding != PDMP3_ENC_SIGNED_16 && encoding != PDMP3_ENC_FLOAT_32)) return PDMP3_ERR;
+  const int want = encoding == PDMP3_ENC_FLOAT_32;
+  if (want == id->enc_f32) return PDMP3_OK;
+  if (ra_rollback(id) != PDMP3_OK) return PDMP3_ERR;          /* frames read ahead were decoded in the other format */
+  if (id->ostart) {                                            /* the frame under the cursor was, too: convert what is left */
+    const unsigned nch = id->l_hdr.mode == 3 ? 1 : 2;
+    if (want) { float* f = (float*)id->last_pcm; for (int k = (int)(1152 * nch) - 1; k >= 0; k--) f[k] = (float)id->last_pcm[k] / 32767.0f; }
+    else { const float* f = (const float*)id->last_pcm; for (unsigned k = 0; k < 1152 * nch; k++) { float v = f[k] * 32767.0f; id->last_pcm[k] = (int16_t)(v > 32767.0f ? 32767 : v < -32767.0f ? -32767 : (int)v); } }
+  }
+  if (id->hs && pdmp3_hip_stream_set_f32(id->hs, want) != PDMP3_HIP_OK) return PDMP3_ERR;
+  id->enc_f32 = want;
+  return PDMP3_OK;
+}
+
 /* P:2526-2535 */
 int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) {
   if (!(id && rate && channels && encoding)) return PDMP3_ERR;
-  *encoding = PDMP3_ENC_SIGNED_16;
+  *encoding = id->enc_f32 ? PDMP3_ENC_FLOAT_32 : PDMP3_ENC_SIGNED_16;
   *rate = (long)kSampleRates[id->l_hdr.sfreq];
   *channels = id->l_hdr.mode == 3 ? 1 : 2;
   id->new_header = -1;

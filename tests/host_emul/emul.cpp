@@ -24,13 +24,33 @@ extern "C" int emul_decode_frames(const int16_t* spectra, const pdmp3_gc_side* s
   if (stages) chunk_frames = n_frames;
   // like engine.hip: the kernel writes the new state to scratch (any chunk may read the old one), then it is copied
   std::vector<float> state_next(kStateFloats);
-  DecodeArgs a{spectra, side, pcm, state, state ? state_next.data() : nullptr, stages, n_frames, chunk_frames, nullptr};
+  DecodeArgs a{spectra, side, pcm, nullptr, state, state ? state_next.data() : nullptr, stages, n_frames, chunk_frames, nullptr};
   const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
   auto L = std::make_unique<WaveLds>();
   for (int c = 0; c < nchunks; ++c) {
     WaveLds& Lr = *L;
     if (stages) emu::run_wave([&] { run_chunk<true>(a, T, &H.cb, c, Lr); });
     else emu::run_wave([&] { run_chunk<false>(a, T, &H.cb, c, Lr); });
+  }
+  if (state) std::copy(state_next.begin(), state_next.end(), state);
+  return 0;
+}
+
+// float PCM form (pdmp3_hip_decode_frames_f32)
+extern "C" int emul_decode_frames_f32(const int16_t* spectra, const pdmp3_gc_side* side, int n_frames,
+                                      float* state, float* pcm, int chunk_frames) {
+  static HostTables H;
+  static bool ready = false;
+  if (!ready) { build_host_tables(H); ready = true; }
+  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data()};
+  if (chunk_frames <= 0) chunk_frames = n_frames;
+  std::vector<float> state_next(kStateFloats);
+  DecodeArgs a{spectra, side, nullptr, pcm, state, state ? state_next.data() : nullptr, nullptr, n_frames, chunk_frames, nullptr};
+  const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
+  auto L = std::make_unique<WaveLds>();
+  for (int c = 0; c < nchunks; ++c) {
+    WaveLds& Lr = *L;
+    emu::run_wave([&] { run_chunk<false, false, true>(a, T, &H.cb, c, Lr); });
   }
   if (state) std::copy(state_next.begin(), state_next.end(), state);
   return 0;

@@ -149,3 +149,34 @@ def test_stream_loop_in_c_matches_the_cli_loop(oracle):
         # bytes buffered), which depends on how the end of the file is fed
         k = min(got2.size, want.size)
         assert k >= want.size - 2 * 2304 * 2 and np.array_equal(got2[:k], got[:k]), (feed, read, eager)
+
+
+def test_float_encoding_through_the_api(oracle):
+    """pdmp3_amd_set_encoding(PDMP3_ENC_FLOAT_32): pdmp3_read delivers the unscaled synthesis sums as float (8 bytes per
+    stereo sample-frame); against the oracle's floats for the records the oracle parses from the same bytes; switching
+    back mid-stream gives the int16 stream again"""
+    from pdmp3_amd import api
+    mp3 = packer.generate(n_frames=120, seed=91, sfreq=0, mode=1, mode_ext=2, bitrate_index=12, block_pct=(55, 15, 15, 15))
+    pcm16, sp, sd = oracle.decode_buffer_like_cli(mp3, tap_frames=200)
+    _, want = oracle.decode_f32(sp, sd)
+    want = want.reshape(-1)
+    d = api.Decoder()
+    assert d.set_encoding(0x123) == api.PDMP3_ERR
+    assert d.set_encoding(api.PDMP3_ENC_FLOAT_32) == 0
+    out, pos, half = [], 0, False
+    while True:
+        rc, pcm = d.read(10000)                           # (not a multiple of the frame size: the cursor is exercised)
+        if rc == api.PDMP3_ERR:
+            break
+        out.append(pcm)
+        if rc == api.PDMP3_NEED_MORE:
+            chunk = mp3[pos:pos + 4096]
+            if not chunk:
+                break
+            d.feed(chunk)
+            pos += len(chunk)
+    assert d.getformat()[3] == api.PDMP3_ENC_FLOAT_32
+    d.close()
+    got = np.frombuffer(b"".join(out), dtype=np.float32)
+    assert got.size == want.size == len(pcm16) // 2
+    assert float(np.abs(got - want).max()) <= 1e-5 * max(1.0, float(np.abs(want).max()))

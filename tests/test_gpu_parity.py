@@ -199,3 +199,47 @@ def test_gpu_channel1_state_survives_mono_runs(engine, oracle, chunk):
         st.zero_()
         parts = [gpu_decode(engine, sp[a:b], sd[a:b], chunk=chunk, state=st) for a, b in zip(cuts[:-1], cuts[1:])]
         assert np.array_equal(np.concatenate(parts), whole), cuts
+
+
+@pytest.mark.parametrize("name", list(corpus.CASES))
+def test_gpu_float_pcm(engine, oracle, name):
+    """float PCM (pdmp3_hip_decode_frames_f32): the synthesis sums before P:2028's scaling, against the
+    oracle's (whose int16 = clip(trunc(float * 32767)) is the reference's, bit for bit): 1e-5 absolute, relative to
+    the amplitude where a corpus drives the synthesis beyond full scale; int16 form and float form agree"""
+    import torch
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    n = g["pcm"].shape[0]
+    sp, sd = corpus.case(name, n=n)
+    _, want = oracle.decode_f32(sp, sd)
+    dsp, dsd = engine.upload(sp, sd)
+    out = torch.zeros((n, 2304), dtype=torch.float32, device=engine.tdev)
+    engine.decode_f32(dsp, dsd, out, chunk_frames=3)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    tol = 1e-5 * max(1.0, float(np.abs(want).max()))
+    assert float(np.abs(got - want).max()) <= tol, name
+    q = np.clip(np.trunc(got.astype(np.float64) * 32767.0), -32767, 32767)
+    q[got > 65538.0] = -32767                      # P:2028-2031 on x86-64: the wrap-around of cvttsd2si
+    nch = nch_of(sd)
+    assert np.array_equal(q[:, :1152 * nch].astype(np.int16), gpu_decode(engine, sp, sd, chunk=3)[:, :1152 * nch]), name
+
+
+def test_gpu_float_pcm_c2(engine, oracle):
+    import torch
+    n = 2048
+    spectra, side, _ = engine.alloc_frames(n)
+    engine.generate(C2_SEED, 0, n, spectra, side)
+    out = torch.zeros((n, 2304), dtype=torch.float32, device=engine.tdev)
+    engine.decode_f32(spectra, side, out)
+    torch.cuda.synchronize()
+    sp, sd = oracle.generate(C2_SEED, 0, 96)
+    _, want = oracle.decode_f32(sp, sd)
+    got = out[:96].cpu().numpy()
+    assert float(np.abs(got - want).max()) <= 1e-5 * max(1.0, float(np.abs(want).max()))
+    pcm = torch.zeros((n, 2304), dtype=torch.int16, device=engine.tdev)
+    engine.decode(spectra, side, pcm)
+    torch.cuda.synchronize()
+    f = out.cpu().numpy().astype(np.float64)
+    q = np.clip(np.trunc(f * 32767.0), -32767, 32767)
+    q[f > 65538.0] = -32767
+    assert np.array_equal(q.astype(np.int16), pcm.cpu().numpy())

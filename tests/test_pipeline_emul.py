@@ -101,3 +101,30 @@ def test_emul_channel1_state_across_batches(oracle, emul):
             st[:] = 0
             out = [emul_decode(emul, sp[a:b], sd[a:b], chunk, st) for a, b in zip(cuts[:-1], cuts[1:])]
             assert np.array_equal(np.concatenate(out), whole), (chunk, cuts)
+
+
+def test_oracle_float_pcm_is_what_the_int16_comes_from(oracle):
+    """float output is pinned through its quantisation: the oracle's int16 PCM -- bit-exact against the compiled
+    reference (test_oracle.py) -- is clip(trunc(float * 32767)) of the float it hands out (P:2028-2031)"""
+    sp, sd = oracle.generate(C2_SEED, 0, 24)
+    pcm, f32 = oracle.decode_f32(sp, sd)
+    assert np.array_equal(pcm, oracle.decode(sp, sd))
+    q = np.clip(np.trunc(f32.astype(np.float64) * 32767.0), -32767, 32767).astype(np.int16)
+    assert np.array_equal(q, pcm)
+    assert np.abs(f32).max() > 0.5
+
+
+@pytest.mark.parametrize("name", ["ms_long_441", "mono_441", "ms_short_heavy_480", "ms_loud_clip"])
+def test_emul_float_pcm(oracle, emul, name):
+    """pdmp3_hip_decode_frames_f32 on the host build: 1e-5 absolute (north_star's float tolerance; relative to the
+    amplitude where the signal is driven beyond full scale), chunked == unchunked"""
+    sp, sd = corpus.case(name, n=8)
+    _, want = oracle.decode_f32(sp, sd)
+    n = sp.shape[0]
+    got = np.zeros((n, 2304), np.float32)
+    emul.emul_decode_frames_f32(_p(sp), _p(sd), n, None, _p(got), 0)
+    tol = 1e-5 * max(1.0, float(np.abs(want).max()))
+    assert float(np.abs(got - want).max()) <= tol
+    got2 = np.zeros((n, 2304), np.float32)
+    emul.emul_decode_frames_f32(_p(sp), _p(sd), n, None, _p(got2), 3)
+    assert np.array_equal(got, got2)
