@@ -10,10 +10,13 @@ polyphase -> int16 PCM) over one batch of synthetic input that is already
 resident in HBM.  Workload at N = 1 is BASELINE.json configs[1] (SURVEY 8d
 "C2"): one stream of 2048 stereo 44.1 kHz frames = 4096 pre-Huffman-decoded
 granules (x 2 channels), integer-only generator, seed 0x5EED0000C2.  At N > 1
-the stream is N x 2048 frames long and rank r decodes frames [2048 r, 2048 (r+1))
-from a 2-frame halo: no data-path collective, weak scaling.  The
-one exchange of the path -- the final PCM gather to rank 0 over RCCL -- runs
-once after the timed region and is reported as `gather_ms`.
+the workload is BASELINE.json configs[4] (SURVEY 8d "C5") at N ranks: one stream
+of N x 125 000 frames (seed 0x5EED0000C5, counter-based: every rank generates its
+own shard on its GPU), rank r decodes frames [125000 r, 125000 (r+1)) from a
+2-frame halo: no data-path collective, fixed work per GPU (weak
+scaling).  The one exchange of the path -- the final PCM gather to rank 0 over
+RCCL, 576 MB per rank -- runs once after the timed region and is reported as
+`gather_ms` / `gather_GBps`.
 
 Prints ONE JSON line (rank 0).
 """
@@ -28,6 +31,8 @@ sys.path.insert(0, ROOT)
 
 SEED_C2 = 0x5EED0000C2
 FRAMES_PER_GPU = 2048                 # C2: 4096 granules
+SEED_C5 = 0x5EED0000C5
+SHARD_FRAMES = 125000                 # C5: 1 000 000 frames on 8 GPUs
 ALGO_BYTES_PER_FRAME = 9728           # 4 gc x (1152 B spectra + 128 B side + 1152 B PCM)
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_FLOP_PER_FRAME = 552e3           # direct-form flops of one stereo frame (41.5 k IMDCT + 91.6 k polyphase + ~5 k per gc)
@@ -141,7 +146,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--chunk", type=int, default=0, help="frames per workgroup chunk (0 = engine default)")
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0: 2048 = C2 at 1 GPU, 125000 = the C5 shard at N > 1)")
+    ap.add_argument("--dump-gathered", default="", help="N > 1, rank 0: write the gathered PCM (int16 .npy) here (tests)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-all-seconds", type=float, default=6.0, help="all-host-cores leg of the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -181,11 +187,12 @@ def main():
     coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     eng = pdmp3_amd.Engine(dev_index)
-    n = args.frames
+    n = args.frames or (FRAMES_PER_GPU if world == 1 else SHARD_FRAMES)
+    seed = SEED_C2 if world == 1 else SEED_C5
     halo = 2 if rank > 0 else 0
     first = rank * n - halo
     spectra, side, pcm = eng.alloc_frames(n + halo)
-    eng.generate(SEED_C2, first, n + halo, spectra, side)
+    eng.generate(seed, first, n + halo, spectra, side)
     torch.cuda.synchronize()
 
     def step():
@@ -217,8 +224,12 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        # the path's one exchange: final PCM gather to rank 0 (RCCL over xGMI), outside the timed region
+        # the path's one exchange: final PCM gather to rank 0 (RCCL over xGMI: grouped point-to-point, the root's
+        # ingress links in parallel), outside the timed region.  A one-element gather first: communicator set-up
+        # is not part of the exchange.
         mine = pcm[halo:].contiguous().view(torch.uint8).to(coll_dev)   # RCCL has no int16: gather the PCM as bytes
+        tiny = mine[:16].clone()
+        dist.gather(tiny, [torch.empty_like(tiny) for _ in range(world)] if rank == 0 else None, dst=0)
         bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
         torch.cuda.synchronize()
         dist.barrier()
@@ -226,6 +237,10 @@ def main():
         dist.gather(mine, bufs, dst=0)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        gather_bytes = int(mine.numel()) * (world - 1)                  # what crosses links into rank 0
+        if rank == 0 and args.dump_gathered:
+            import numpy as np
+            np.save(args.dump_gathered, torch.cat([b.cpu() for b in bufs]).numpy().view(np.int16).reshape(-1, 2304))
     else:
         gather_ms = None
 
@@ -253,10 +268,12 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "C2 (BASELINE configs[1]): %d stereo frames = %d granules per GPU per step, "
-                        "pre-Huffman-decoded spectra resident in HBM, one stream sharded by frame range "
-                        "with a 2-frame halo" % (n, 2 * n),
-            "frames_per_gpu": n, "granules_per_gpu": 2 * n, "seed": hex(SEED_C2),
+            "workload": ("C2 (BASELINE configs[1]): %d stereo frames = %d granules per GPU per step, "
+                         "pre-Huffman-decoded spectra resident in HBM, one stream" % (n, 2 * n)) if world == 1 else
+                        ("C5 (BASELINE configs[4]) at %d GPUs: one stream of %d stereo frames, %d per GPU per step (shards by "
+                         "frame range with a 2-frame halo), spectra generated on each GPU and resident in HBM; PCM gathered "
+                         "to rank 0 over RCCL after the timed region" % (world, n * world, n)),
+            "frames_per_gpu": n, "granules_per_gpu": 2 * n, "seed": hex(seed),
             "chunk_frames": args.chunk or "auto", "sharding": "frame-range x%d, no data-path collective" % world,
         },
         "x_realtime": round(fps / RT_FRAMES_PER_S, 1),
@@ -276,6 +293,9 @@ def main():
                             "dtype": "f32 (v_mfma_f32_16x16x4_f32 + VALU)"}
     if gather_ms is not None:
         out["gather_ms"] = round(gather_ms, 3)
+        out["gather_bytes"] = gather_bytes
+        out["gather_GBps"] = round(gather_bytes / (gather_ms * 1e-3) / 1e9, 2)
+        out["gather_backend"] = "rccl" if backend == "nccl" else backend
 
     if args.big and world == 1:
         # kernel quality at throughput size (SURVEY 8d C5 shard scale), outside the timed region

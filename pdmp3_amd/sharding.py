@@ -8,6 +8,12 @@ decode loop.  Whole files (independent streams, config C4) are dealt
 largest-first to the least loaded rank.  The one exchange of the path is the
 final PCM gather to rank 0.
 """
+# The fixed halo covers a stream whose channel count does not change inside it (C5 is all stereo; a file of a corpus
+# is decoded whole by one rank).  Across a run of MONO frames channel 1's state is the last stereo frame's, however
+# far back that is: inside one launch the kernel looks for it itself (decode_core.h: pre-halo), but it cannot look
+# in front of the records it is given -- a shard boundary right after mono frames of a stream that also has stereo
+# frames would start channel 1 from zero.  Shard such streams at frames where the channel count is settled (or
+# decode them through the whole-stream decoder, which carries the state from window to window).
 HALO_FRAMES = 2
 
 

@@ -1,0 +1,67 @@
+"""The multi-GPU paths exercised on the ONE GPU of the test box: bench.py's N = 2 code path (two ranks sharing GPU 0,
+gloo instead of RCCL -- the launch line, sharding, halo and gather are the ones the 8-GPU run uses), and a C4-style
+corpus dealt over per-device decoders (pdmp3_amd_bulk_new_on), which degrade to device 0 twice here."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tools.packer import packer
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_gathered_pcm_equals_unsharded(engine, tmp_path):
+    import torch
+    n = 3000
+    out = str(tmp_path / "gathered.npy")
+    env = dict(os.environ, PDMP3_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--frames", str(n), "--dump-gathered", out]
+    # a fresh child process (never an exec from this process, which has initialised the GPU)
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_gpu"] == n
+    assert d["gather_bytes"] == n * 4608 and d["gather_ms"] > 0 and d["value"] > 0
+    got = np.load(out)
+    assert got.shape == (2 * n, 2304)
+    spectra, side, pcm = engine.alloc_frames(2 * n)
+    engine.generate(0x5EED0000C5, 0, 2 * n, spectra, side)
+    engine.decode(spectra, side, pcm)
+    torch.cuda.synchronize()
+    assert np.array_equal(got, pcm.cpu().numpy()), "sharded + gathered PCM differs from the unsharded decode"
+
+
+def test_corpus_dealt_over_devices(oracle):
+    """C4's partitioning (whole files per GPU, largest first) through per-device decoders"""
+    import torch
+    from pdmp3_amd import api
+    from pdmp3_amd.sharding import assign_files
+    kinds = [dict(sfreq=0, mode=1, mode_ext=2, bitrate_index=14), dict(sfreq=1, mode=3, bitrate_index=7),
+             dict(sfreq=2, mode=0, mode_ext=0, vbr=True, block_pct=(40, 10, 40, 10), mixed_pct=50),
+             dict(sfreq=0, mode=2, bitrate_index=12, block_pct=(10, 10, 70, 10))]
+    files = [packer.generate(n_frames=40 + 13 * k, seed=900 + k, **kinds[k % 4]) for k in range(10)]
+    ndev = max(1, torch.cuda.device_count())
+    devices = [0, 1 % ndev]                            # two "GPUs": the second one is device 0 again on a 1-GPU box
+    groups = assign_files([len(f) for f in files], len(devices))
+    decs = [api.BulkDecoder(threads=2, window_frames=64, device=d) for d in devices]
+    try:
+        outs = {}
+        for dec, grp in zip(decs, groups):
+            for i, pcm in zip(grp, dec.decode_many([files[i] for i in grp])):
+                outs[i] = pcm
+    finally:
+        for dec in decs:
+            dec.close()
+    assert sorted(outs) == list(range(len(files)))
+    for i, f in enumerate(files):
+        want = np.frombuffer(oracle.decode_buffer_like_cli(f), dtype=np.int16)
+        assert outs[i].shape == want.shape and np.abs(outs[i].astype(np.int32) - want).max() <= 1, i
