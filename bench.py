@@ -344,7 +344,7 @@ def main():
         # device Huffman -> transforms; PCIe both ways and the host stages included).  A reported extra, never `value`.
         try:
             import numpy as np
-            from tools.packer import packer
+            from pdmp3_amd.packer import packer
             from pdmp3_amd import api
             nf = 40000
             mp3 = np.frombuffer(packer.generate(n_frames=nf, seed=0xC3, sfreq=0, mode=1, mode_ext=2, bitrate_index=14), dtype=np.uint8)

@@ -12,11 +12,18 @@
  *   pdmp3_read       pdmp3.c:2431     pdmp3_decode     pdmp3.c:2491
  *   pdmp3_getformat  pdmp3.c:2526     pdmp3            pdmp3.c:2540
  *
- * Differences by design: the handle is opaque (the reference exposes its
- * struct, pdmp3.c:124-148, but no caller touches it); synthesis state is per
- * handle instead of process-global; the handle starts zeroed
- * (H13).  There is no CPU decode path: pdmp3_new() returns NULL (and sets
- * *error when given) if no HIP device / engine library is available.
+ * Differences by design:
+ *   1. the handle is opaque (the reference publishes its struct, pdmp3.c:124-148, but no caller in its tree or of
+ *      its API touches a field; this library's handle holds pinned staging, queue state and device objects);
+ *   2. there is no PDMP3_HEADER_ONLY mode (pdmp3.c:161: `#define PDMP3_HEADER_ONLY` + `#include "pdmp3.c"` to get
+ *      the declarations without the code): this header plays that role, the code is a shared library;
+ *   3. the Huffman table index `hufftables g_huffman_main[34]`, which the reference exports by accident
+ *      (pdmp3.c:535, missing `static`), is not exported: the library's code books are derived tables with another
+ *      layout (pdmp3_amd/csrc/tables_data.h);
+ *   4. synthesis state is per handle instead of process-global; the handle starts zeroed (H13);
+ *   5. additions, all prefixed pdmp3_amd_: float output below, whole-stream decoding in pdmp3_bulk.h.
+ * There is no CPU decode path: pdmp3_new() returns NULL (and sets *error when given) if no HIP device / engine
+ * library is available.
  */
 #ifndef PDMP3_H
 #define PDMP3_H

@@ -111,6 +111,11 @@ long long pdmp3_amd_bulk_parse_bits(pdmp3_amd_bulk* b, const unsigned char* mp3,
 long long pdmp3_amd_stream_loop(const unsigned char* mp3, size_t n, unsigned char* out, size_t cap,
                                 size_t feed_bytes, size_t read_bytes, int eager);
 
+/* A PCM buffer as a RIFF/WAVE file: interleaved int16 (float32 = 0) or 32-bit float (float32 != 0; the output of
+ * pdmp3_amd_set_encoding(PDMP3_ENC_FLOAT_32)).  The reference's only sink is the raw writer (pdmp3.c:2236-2257); the
+ * CLI driver writes "<first name>.wav" instead of ".raw" when PDMP3_CLI_WAV=1 is set.  PDMP3_OK or PDMP3_ERR. */
+int pdmp3_amd_write_wav(const char* path, const void* pcm, size_t bytes, long rate, int channels, int float32);
+
 #ifdef __cplusplus
 }
 #endif

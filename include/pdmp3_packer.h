@@ -1,0 +1,52 @@
+/*
+ * pdmp3_packer.h -- MPEG-1 Layer III bitstream generator (pdmp3_amd/packer/libpacker.so).
+ *
+ * Not part of the reference (which has no encoder and ships no test data): the generator of the stream-level
+ * workloads of SURVEY 8d -- C1 (one 128 kbps file), C3 (one hour at 320 kbps), C4 (the mixed corpus) -- in a box
+ * without network.  Every stream is syntactically valid MPEG-1 Layer III as the reference parses it (appendix A of
+ * SURVEY.md): frame sync and header (CBR with ISO padding, or VBR), optional CRC word, side info with scfsi, long /
+ * start / short / stop / mixed blocks, scalefactors, big-value pairs from every code book incl. linbits, count1 quads
+ * from both tables (the reference mis-points table 33: table33_pct), and a bit reservoir (main_data_begin up to 511).
+ * The spectra are synthetic (the C2 generator's distribution), so the audio is noise: what a stream decodes TO is
+ * defined by the reference decoder, the generator only guarantees validity and variety.  Deterministic in cfg.
+ *
+ * Command line: python -m pdmp3_amd.packer {c1|c3|c4|custom} OUTDIR [...]  (writes the files and a manifest.json
+ * with sizes and SHA-256).  32 kHz streams should stay at or below 224 kbps (index 12): 256 kbps gives 1152-byte
+ * frames, which drive the reference into replaying its input ring (include/pdmp3_bulk.h, PDMP3_BULK_REPLAY).
+ */
+#ifndef PDMP3_PACKER_H
+#define PDMP3_PACKER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pk_cfg {
+  uint64_t seed;
+  int sfreq;            /* 0 = 44.1k, 1 = 48k, 2 = 32k */
+  int mode;             /* 0 stereo, 1 joint, 2 dual, 3 mono */
+  int mode_ext;         /* bit1 MS, bit0 intensity */
+  int bitrate_index;    /* 1..14; used when vbr == 0 */
+  int vbr;              /* 1: bitrate_index drawn per frame from [vbr_lo, vbr_hi] */
+  int vbr_lo, vbr_hi;
+  int crc;              /* 1: protection_bit = 0, 2 CRC bytes follow the header */
+  int block_pct[4];     /* percentages of block types 0,1,2,3 */
+  int mixed_pct;        /* of the short blocks */
+  int reservoir;        /* 1: let main data run ahead into earlier frames */
+  int table33_pct;      /* count1table_select = 1 (reference H1) */
+  int fill_pct;         /* how much of the available bits to use, e.g. 90 */
+  int big_pct;          /* chance (per 1000) that a big_values pair uses the linbits range */
+  int gain_lo, gain_hi; /* global_gain range */
+} pk_cfg;
+
+/* Writes n_frames frames into out (capacity cap bytes; n_frames * 1500 + 4096 always suffices) and returns the
+ * number of bytes written, 0 if cap is too small or cfg is invalid. */
+size_t pk_generate(const pk_cfg* cfg, int n_frames, uint8_t* out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -15,7 +15,7 @@ _LIB = None
 
 BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads",
                 "pdmp3_amd_scan_buffer", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_decode_async", "pdmp3_amd_bulk_wait", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
-                "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits", "pdmp3_amd_pcm_alloc", "pdmp3_amd_pcm_free", "pdmp3_amd_stream_loop"]
+                "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits", "pdmp3_amd_pcm_alloc", "pdmp3_amd_pcm_free", "pdmp3_amd_stream_loop", "pdmp3_amd_write_wav"]
 
 # include/pdmp3_hip.h: pdmp3_gc_bits / pdmp3_frame_bits
 GC_BITS_DTYPE = np.dtype([("part2_3_length", "<u2"), ("big_values", "<u2"), ("global_gain", "u1"), ("scalefac_compress", "u1"),

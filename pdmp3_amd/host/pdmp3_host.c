@@ -1705,21 +1705,77 @@ long long pdmp3_amd_bulk_parse_bits(struct bulk* b, const unsigned char* mp3, si
 /* ------------------------------------------------------------------------ */
 /* CLI driver (P:2540-2589) with the raw sink (P:2236-2257)                   */
 /* ------------------------------------------------------------------------ */
-static void write_raw(const char* filename, const unsigned char* data, size_t nbytes) {
-  static int fd = -2;                             /* opened once, for the FIRST file name only, like the reference */
-  if (fd == -2) {
-    if (strcmp(filename, "-")) {
-      char name[1024];
-      snprintf(name, sizeof name, "%s.raw", filename);
-      fd = open(name, O_WRONLY | O_CREAT, 0666);  /* no O_TRUNC, like the reference */
-      if (fd == -1) { perror(name); exit(-1); }
-    } else fd = 1;
-  }
+/* RIFF/WAVE header for interleaved PCM: 16-bit integer (format 1) or 32-bit float (format 3); data_bytes = 0xffffffff
+ * when the length is not known yet (a pipe) */
+static void wav_header(unsigned char h[44], long rate, int channels, int float32, uint32_t data_bytes) {
+  const uint32_t bps = float32 ? 4 : 2, align = bps * (uint32_t)channels;
+  const uint32_t riff = data_bytes == 0xffffffffu ? 0xffffffffu : data_bytes + 36;
+#define LE32(p, v) ((p)[0] = (unsigned char)(v), (p)[1] = (unsigned char)((v) >> 8), (p)[2] = (unsigned char)((v) >> 16), (p)[3] = (unsigned char)((v) >> 24))
+#define LE16(p, v) ((p)[0] = (unsigned char)(v), (p)[1] = (unsigned char)((v) >> 8))
+  memcpy(h, "RIFF", 4); LE32(h + 4, riff); memcpy(h + 8, "WAVEfmt ", 8); LE32(h + 16, 16u);
+  LE16(h + 20, float32 ? 3u : 1u); LE16(h + 22, (uint32_t)channels); LE32(h + 24, (uint32_t)rate);
+  LE32(h + 28, (uint32_t)rate * align); LE16(h + 32, align); LE16(h + 34, bps * 8);
+  memcpy(h + 36, "data", 4); LE32(h + 40, data_bytes);
+#undef LE32
+#undef LE16
+}
+
+/* include/pdmp3_bulk.h: a whole PCM buffer as a .wav file */
+int pdmp3_amd_write_wav(const char* path, const void* pcm, size_t bytes, long rate, int channels, int float32) {
+  if (!path || (!pcm && bytes) || rate <= 0 || channels < 1 || channels > 2 || bytes > 0xfffffff0u) return PDMP3_ERR;
+  FILE* f = fopen(path, "wb");
+  if (!f) return PDMP3_ERR;
+  unsigned char h[44];
+  wav_header(h, rate, channels, float32, (uint32_t)bytes);
+  int ok = fwrite(h, 1, 44, f) == 44 && (bytes == 0 || fwrite(pcm, 1, bytes, f) == bytes);
+  ok = (fclose(f) == 0) && ok;
+  return ok ? PDMP3_OK : PDMP3_ERR;
+}
+
+/* The driver's sink.  Default: the reference's OUTPUT_RAW writer (P:2236-2257) -- "<first name>.raw", opened once for
+ * the FIRST file name only, O_CREAT without O_TRUNC, "-" = stdout.  PDMP3_CLI_WAV=1: the same samples as
+ * "<first name>.wav" (truncated, 44-byte header with the first stream's rate and channel count, sizes filled in when
+ * the driver is done; to stdout with unknown-length sizes). */
+static int g_out_fd = -2, g_out_wav = 0;
+static uint64_t g_out_bytes = 0;
+static long g_out_rate = 44100;
+static int g_out_ch = 2;
+
+static void write_all(int fd, const unsigned char* data, size_t nbytes) {
   size_t off = 0;
   while (off < nbytes) {
     ssize_t w = write(fd, data + off, nbytes - off);
     if (w <= 0) { fputs("Unable to write raw data\n", stderr); exit(-1); }
     off += (size_t)w;
+  }
+}
+
+static void write_raw(const char* filename, const unsigned char* data, size_t nbytes, long rate, int channels) {
+  if (g_out_fd == -2) {
+    const char* w = getenv("PDMP3_CLI_WAV");
+    g_out_wav = w && *w && *w != '0';
+    if (strcmp(filename, "-")) {
+      char name[1024];
+      snprintf(name, sizeof name, g_out_wav ? "%s.wav" : "%s.raw", filename);
+      g_out_fd = open(name, O_WRONLY | O_CREAT | (g_out_wav ? O_TRUNC : 0), 0666);  /* raw: no O_TRUNC, like the reference */
+      if (g_out_fd == -1) { perror(name); exit(-1); }
+    } else g_out_fd = 1;
+    if (g_out_wav) {
+      unsigned char h[44];
+      g_out_rate = rate > 0 ? rate : 44100; g_out_ch = channels == 1 ? 1 : 2;
+      wav_header(h, g_out_rate, g_out_ch, 0, 0xffffffffu);
+      write_all(g_out_fd, h, 44);
+    }
+  }
+  write_all(g_out_fd, data, nbytes);
+  g_out_bytes += nbytes;
+}
+
+static void finish_output(void) {
+  if (g_out_fd >= 0 && g_out_wav && g_out_fd != 1 && g_out_bytes <= 0xfffffff0u && lseek(g_out_fd, 0, SEEK_SET) == 0) {
+    unsigned char h[44];
+    wav_header(h, g_out_rate, g_out_ch, 0, (uint32_t)g_out_bytes);
+    write_all(g_out_fd, h, 44);
   }
 }
 
@@ -1730,7 +1786,7 @@ static void cli_stream_file(pdmp3_handle* id, const char* filename, FILE* fp) {
   size_t done;
   int res;
   while ((res = pdmp3_read(id, out, INBUF_SIZE, &done)) != PDMP3_ERR) {
-    write_raw(filename, out, done);
+    if (done) write_raw(filename, out, done, (long)kSampleRates[id->l_hdr.sfreq], id->l_hdr.mode == 3 ? 1 : 2);
     if (res == PDMP3_NEED_MORE) {
       unsigned char in[4096];
       const size_t n = fread(in, 1, sizeof in, fp);
@@ -1820,9 +1876,10 @@ void pdmp3(char* const* mp3s) {
       unsigned char* pcm = (unsigned char*)malloc((size_t)total + 1);
       if (!b || !pcm) { fputs("Cannot open stream API (no transform engine)\n", stderr); exit(0); }
       b->carry = bulk_used;                       /* first file: fresh state, like the reference's new handle */
-      const long long got = pdmp3_amd_bulk_decode(b, data, (size_t)size, pcm, (size_t)total, NULL, NULL);
+      long rate = 0; int ch = 0;
+      const long long got = pdmp3_amd_bulk_decode(b, data, (size_t)size, pcm, (size_t)total, &rate, &ch);
       if (got != total) { fputs("pdmp3: engine failure\n", stderr); exit(-1); }
-      write_raw(filename, pcm, (size_t)total);
+      if (total) write_raw(filename, pcm, (size_t)total, rate, ch);
       free(pcm);
       bulk_used = 1;
     } else {
@@ -1833,6 +1890,7 @@ void pdmp3(char* const* mp3s) {
     free(data);
     if (fp != stdin) fclose(fp);
   }
+  finish_output();
   if (b) pdmp3_amd_bulk_delete(b);
   pdmp3_delete(id);
 }

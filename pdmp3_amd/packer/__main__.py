@@ -1,10 +1,10 @@
 """Corpus generator for the bitstream-level workloads of SURVEY.md 8d (there is no network for real files):
 
-  python -m tools.packer c1 out/            one 44.1 kHz stereo 128 kbps CBR file
-  python -m tools.packer c3 out/            1 h of 44.1 kHz joint stereo 320 kbps CBR (137 813 frames, ~144 MB)
-  python -m tools.packer c4 out/            the mixed corpus: {mono, stereo, joint-MS} x {32, 44.1, 48 kHz} x
+  python -m pdmp3_amd.packer c1 out/            one 44.1 kHz stereo 128 kbps CBR file
+  python -m pdmp3_amd.packer c3 out/            1 h of 44.1 kHz joint stereo 320 kbps CBR (137 813 frames, ~144 MB)
+  python -m pdmp3_amd.packer c4 out/            the mixed corpus: {mono, stereo, joint-MS} x {32, 44.1, 48 kHz} x
                                             {CBR, VBR} x {long, start/short/stop, mixed}, 64 files x >= 4096 frames
-  python -m tools.packer custom out/ --frames 500 --sfreq 1 --mode 3 --vbr ...
+  python -m pdmp3_amd.packer custom out/ --frames 500 --sfreq 1 --mode 3 --vbr ...
 
 Every file is a valid MPEG-1 Layer III stream (frame sync, side info, bit reservoir with main_data_begin, scale-
 factors, Huffman-coded spectra from all code books incl. linbits and both count1 tables); the spectra are synthetic
@@ -36,7 +36,7 @@ def c4_specs(frames=4096):
 
 
 def main():
-    ap = argparse.ArgumentParser(prog="python -m tools.packer", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap = argparse.ArgumentParser(prog="python -m pdmp3_amd.packer", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("what", choices=["c1", "c3", "c4", "custom"])
     ap.add_argument("outdir")
     ap.add_argument("--frames", type=int, default=0)

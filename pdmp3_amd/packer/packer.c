@@ -1,5 +1,6 @@
 /*
- * packer.c -- synthetic MPEG-1 Layer III bitstream generator (TEST TOOL).
+ * packer.c -- MPEG-1 Layer III bitstream generator (include/pdmp3_packer.h; SURVEY 8f #3: the corpus generator of
+ * the stream-level workloads, `python -m pdmp3_amd.packer`).
  *
  * There is no MP3 encoder in this image and no network, so the corpora for the
  * stream-level configs are made here: syntactically valid
@@ -14,25 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../../pdmp3_amd/csrc/tables_data.h"
-
-typedef struct pk_cfg {
-  uint64_t seed;
-  int sfreq;            /* 0 = 44.1k, 1 = 48k, 2 = 32k */
-  int mode;             /* 0 stereo, 1 joint, 2 dual, 3 mono */
-  int mode_ext;         /* bit1 MS, bit0 intensity */
-  int bitrate_index;    /* 1..14; used when vbr == 0 */
-  int vbr;              /* 1: bitrate_index drawn per frame from [vbr_lo, vbr_hi] */
-  int vbr_lo, vbr_hi;
-  int crc;              /* 1: protection_bit = 0, 2 CRC bytes follow the header */
-  int block_pct[4];     /* percentages of block types 0,1,2,3 */
-  int mixed_pct;        /* of the short blocks */
-  int reservoir;        /* 1: let main data run ahead into earlier frames */
-  int table33_pct;      /* count1table_select = 1 (reference H1) */
-  int fill_pct;         /* how much of the available bits to use, e.g. 90 */
-  int big_pct;          /* chance (per 1000) that a big_values pair uses the linbits range */
-  int gain_lo, gain_hi; /* global_gain range */
-} pk_cfg;
+#include "../../include/pdmp3_packer.h"
+#include "../csrc/tables_data.h"
 
 /* ---------- rng ---------- */
 static uint64_t rng_state;

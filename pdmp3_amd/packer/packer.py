@@ -1,4 +1,4 @@
-"""ctypes wrapper of the synthetic Layer-III bitstream generator (test tool)."""
+"""ctypes wrapper of the Layer-III bitstream generator (include/pdmp3_packer.h, pdmp3_amd/packer/libpacker.so)."""
 import ctypes as C
 import os
 import subprocess

@@ -4,7 +4,7 @@ every byte count must agree call by call -- the read-ahead inside pdmp3_read (pd
 invisible.  Used by the CPU suite (parse-only handle: codes and counts) and the GPU suite (PCM as well)."""
 import numpy as np
 
-from tools.packer import packer
+from pdmp3_amd.packer import packer
 
 
 _BITRATES = [0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320]

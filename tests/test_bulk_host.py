@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from tests.test_host_stage import STREAMS, _records_equal
-from tools.packer import packer
+from pdmp3_amd.packer import packer
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 

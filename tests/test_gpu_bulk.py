@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from tools.packer import packer
+from pdmp3_amd.packer import packer
 from util import assert_pcm_close
 from test_bulk_host import _streams
 

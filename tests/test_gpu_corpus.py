@@ -17,7 +17,7 @@ import time
 import numpy as np
 import pytest
 
-from tools.packer import packer
+from pdmp3_amd.packer import packer
 from util import assert_pcm_close
 
 pytestmark = pytest.mark.gpu
@@ -151,6 +151,37 @@ def test_cli_writes_raw(oracle, tmp_path):
     want = oracle.decode_buffer_like_cli(mp3)
     assert len(got) == len(want)
     assert_pcm_close(_as16(got), _as16(want), 1, "CLI")
+
+
+@pytest.mark.parametrize("streaming", ["0", "1"])
+def test_cli_writes_wav(oracle, tmp_path, streaming):
+    """PDMP3_CLI_WAV=1: the same samples as <file>.wav, header with the stream's rate and channel count (the
+    reference's only sink is the raw writer, pdmp3.c:2236-2257); and pdmp3_amd_write_wav for buffers, int16 and float"""
+    import ctypes as C
+    import wave
+    from pdmp3_amd import api
+    mp3 = packer.generate(n_frames=90, seed=0xC7, sfreq=1, mode=3, bitrate_index=8)       # 48 kHz mono
+    path = tmp_path / "m.mp3"
+    path.write_bytes(mp3)
+    cli = os.path.join(ROOT, "pdmp3_amd", "pdmp3_cli")
+    subprocess.check_call([cli, str(path)], timeout=120, env=dict(os.environ, PDMP3_CLI_WAV="1", PDMP3_CLI_STREAMING=streaming))
+    want = oracle.decode_buffer_like_cli(mp3)
+    with wave.open(str(tmp_path / "m.mp3.wav"), "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 48000)
+        assert w.getnframes() == len(want) // 2
+        got = w.readframes(w.getnframes())
+    assert_pcm_close(_as16(got), _as16(want), 1, "wav")
+    lib = api.load_library()
+    lib.pdmp3_amd_write_wav.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_long, C.c_int, C.c_int]
+    out = str(tmp_path / "buf.wav").encode()
+    pcm = np.frombuffer(want, dtype=np.int16)
+    assert lib.pdmp3_amd_write_wav(out, pcm.ctypes.data_as(C.c_void_p), pcm.nbytes, 48000, 1, 0) == 0
+    with wave.open(out.decode(), "rb") as w:
+        assert w.readframes(w.getnframes()) == want
+    f32 = (pcm.astype(np.float32) / 32767.0)
+    assert lib.pdmp3_amd_write_wav(out, f32.ctypes.data_as(C.c_void_p), f32.nbytes, 48000, 1, 1) == 0
+    raw = open(out.decode(), "rb").read()
+    assert raw[20:22] == b"\x03\x00" and raw[34:36] == b"\x20\x00" and raw[44:] == f32.tobytes()
 
 
 def test_cli_several_files_one_handle(oracle, tmp_path):

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from tools.packer import packer
+from pdmp3_amd.packer import packer
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

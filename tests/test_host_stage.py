@@ -1,7 +1,7 @@
 """Host stage of the product (pdmp3_amd/host/pdmp3_host.c: ring, header sync,
 side info, bit reservoir, scalefactors, table-driven Huffman, record
 emission) against the oracle's bitstream front end, on the real clip and on
-packer-made streams (tools/packer).  No GPU involved: the parse-only handle
+packer-made streams (pdmp3_amd/packer).  No GPU involved: the parse-only handle
 taps the gc records the engine would be given.  Bar: records bit-identical.
 
 Where oracle/_ref is present the same streams also pin the ORACLE front end to
@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from tools.packer import packer
+from pdmp3_amd.packer import packer
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 

@@ -67,7 +67,7 @@ def test_emul_generator(oracle, emul):
 def _mode_switch_records():
     """stereo / mono / stereo runs, incl. single stereo frames between mono runs (records from the host parser)"""
     from pdmp3_amd import api
-    from tools.packer import packer
+    from pdmp3_amd.packer import packer
     parts = [dict(n_frames=9, seed=31, bitrate_index=9), dict(n_frames=11, seed=32, mode=3, bitrate_index=7),
              dict(n_frames=2, seed=33, mode=1, mode_ext=2, bitrate_index=11, block_pct=(10, 10, 70, 10)),
              dict(n_frames=7, seed=34, mode=3, bitrate_index=7),

@@ -9,7 +9,7 @@ import pytest
 
 from test_bulk_host import _streams
 from test_host_stage import _records_equal
-from tools.packer import packer
+from pdmp3_amd.packer import packer
 
 
 def _p(a):

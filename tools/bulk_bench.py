@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1, help="--c4: decoder j runs on GPU j %% GPUS")
     ap.add_argument("--host-huffman", action="store_true", help="scalefactors + Huffman on the host pool instead of the device")
     args = ap.parse_args()
-    from tools.packer import packer
+    from pdmp3_amd.packer import packer
     from pdmp3_amd import api
     if args.c4:
         return c4(args, api)
