@@ -132,7 +132,13 @@ def measured_traffic(frames, n_halo):
     if not files or frames != FRAMES_PER_GPU or n_halo:
         return None, None
     try:
+        import hashlib
         d = json.load(open(files[-1]))
+        h = hashlib.sha256()
+        for f in ("pdmp3_amd/csrc/decode_core.h", "pdmp3_amd/csrc/engine.hip"):
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        if d.get("kernel_source_sha16") != h.hexdigest()[:16]:
+            return None, "stale: %s was measured on another version of the kernel" % os.path.basename(files[-1])
         fetch_kb = d["fetch"]["per_dispatch"]["FETCH_SIZE"]
         write_kb = d["write"]["per_dispatch"]["WRITE_SIZE"]
         return int((2.0 * fetch_kb + write_kb) * 1024), os.path.basename(files[-1])
@@ -280,7 +286,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "k_decode<false>", "avg_launch_ms": round(kern_ms, 5),
+            "kernel": "k_decode<false, false>", "avg_launch_ms": round(kern_ms, 5),
             "algorithmic_bytes_per_launch": launch_bytes,
         },
     }

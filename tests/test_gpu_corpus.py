@@ -1,8 +1,7 @@
 """Stream-level BASELINE configs on the GPU box:
 
   configs[2] (C3)  feed/read streaming of a long 44.1 kHz stereo 320 kbps CBR stream, host Huffman +
-                   GPU transforms (default: 20 000 frames ~ 8.7 min of audio; PDMP3_FULL_C3=1 runs the
-                   full hour, 137 813 frames, ~144 MB)
+                   GPU transforms: the full hour, 137 813 frames, ~144 MB (PDMP3_SHORT_C3=1 runs 20 000 frames)
   configs[3] (C4)  mixed corpus: mono / stereo / joint-MS x 32 / 44.1 / 48 kHz x CBR+VBR x long /
                    start-short-stop / mixed blocks, files dealt to ranks largest-first
   CLI             pdmp3_cli (the reference's main.c contract) writing <file>.raw
@@ -29,18 +28,23 @@ def _as16(b):
 
 
 def test_c3_long_stream(oracle):
+    """BASELINE configs[2] at full size: one hour (137 813 frames) of 44.1 kHz joint stereo 320 kbps CBR through the
+    drop-in API's feed / read loop (PDMP3_SHORT_C3=1: 20 000 frames)"""
     from pdmp3_amd import api
-    n = 137813 if os.environ.get("PDMP3_FULL_C3") else 20000
+    n = 20000 if os.environ.get("PDMP3_SHORT_C3") else 137813
     mp3 = packer.generate(n_frames=n, seed=0xC3, sfreq=0, mode=1, mode_ext=2, bitrate_index=14)
     assert abs(len(mp3) / n - 1044.9) < 0.2                     # 320 kbps CBR with ISO padding
     t0 = time.time()
-    got = api.decode_like_cli(mp3)
+    nbytes, got16 = api.stream_loop(mp3)                        # pdmp3_feed / pdmp3_read at the reference driver's cadence, in C
     dt = time.time() - t0
+    got = got16.tobytes()
+    head = api.decode_like_cli(mp3[:3000 * 1045])               # the same loop driven from Python
+    assert head[:2900 * 4608] == got[:2900 * 4608]
     want = oracle.decode_buffer_like_cli(mp3)
     assert len(got) == len(want) >= (n - 3) * 4608
     dmax, ndiff = assert_pcm_close(_as16(got), _as16(want), 1, "C3")
     fps = (len(got) / 4608) / dt
-    print("C3: %d frames in %.2f s = %.0f frames/s = %.0fx real time (python ctypes loop included); "
+    print("C3: %d frames in %.2f s = %.0f frames/s = %.0fx real time (feed/read loop in C); "
           "max diff %d LSB in %.3f%% of samples" % (len(got) // 4608, dt, fps, fps / 38.28125, dmax, 100.0 * ndiff / (len(got) // 2)))
     assert fps / 38.28125 >= 50, "north_star: >= 50x real time"
     # the same bytes through the whole-stream decoder (device Huffman, then host Huffman): identical PCM, bit for bit

@@ -40,6 +40,11 @@ for d in sorted(glob.glob(os.path.join(out, "*", "p_counter_collection.csv"))):
         agg[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
     n = max(1, len(disp))
     summary[name] = {"dispatches": n, "per_dispatch": {k: v / n for k, v in sorted(agg.items())}}
+import hashlib
+h = hashlib.sha256()
+for f in ("pdmp3_amd/csrc/decode_core.h", "pdmp3_amd/csrc/engine.hip"):
+    h.update(open(f, "rb").read())
+summary["kernel_source_sha16"] = h.hexdigest()[:16]      # bench.py quotes `traffic` only for the kernel it was measured on
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
 PY
