@@ -101,6 +101,12 @@ pdmp3_amd_bulk* pdmp3_amd_bulk_new_parse_bits(void);
 long long pdmp3_amd_bulk_parse_bits(pdmp3_amd_bulk* b, const unsigned char* mp3, size_t n, pdmp3_frame_bits* bits,
                                     uint8_t* reservoir, size_t cap_frames, long long* pcm_bytes);
 
+/* The same in the compact form the engine is actually given (include/pdmp3_hip.h, pdmp3_row_desc): side info, row
+ * descriptors and the pool, as ONE window holding the whole stream (host tests: the rows rebuilt from it must be the
+ * snapshots of pdmp3_amd_bulk_parse_bits).  pool_cap: capacity of `pool`; *pool_bytes: what was used. */
+long long pdmp3_amd_bulk_parse_pool(pdmp3_amd_bulk* b, const unsigned char* mp3, size_t n, pdmp3_frame_bits* bits,
+                                    pdmp3_row_desc* desc, uint8_t* pool, size_t pool_cap, size_t cap_frames, size_t* pool_bytes);
+
 /* The streaming API (include/pdmp3.h) driven from a memory buffer by a C loop: pdmp3_new, pdmp3_open_feed, then
  * pdmp3_read(read_bytes) until PDMP3_ERR, with a pdmp3_feed of feed_bytes on every PDMP3_NEED_MORE -- the
  * reference driver's loop (pdmp3.c:2564-2584; 4096 and 16384 there) with its two sizes as parameters.  eager != 0:

@@ -274,6 +274,38 @@ int pdmp3_hip_copy_to_dest(void* dst, const void* src_host, size_t bytes);
 int pdmp3_hip_stream_submit_to(pdmp3_hip_stream* hs, int slot, int n_frames, void* pinned_dst, int row_bytes);
 int pdmp3_hip_stream_submit_bits_to(pdmp3_hip_stream* hs, int slot, int n_frames, void* pinned_dst, int row_bytes);
 
+/* Compact form of the same input.  A frame's reservoir buffer is the last main_data_begin bytes of what was there
+ * before plus the frame's own main data (Get_Main_Data, P:1096-1122), so consecutive snapshots overlap almost
+ * entirely: instead of 2064 bytes per frame the host uploads a POOL -- the main-data bytes of the window's frames,
+ * each appended once, in stream order -- and a descriptor per frame, and the device rebuilds the rows
+ * (k_rows; unpack_core.h row_byte) before k_unpack reads them.  Byte j of frame f's buffer is
+ *     pool[row_off(f) + j]                 j <  top(f)       written by this frame's Get_Main_Data
+ *     pool[row_off(g) + j]                 j >= top(f)       left there by frame g, the nearest earlier frame of the
+ *                                                            same SEGMENT with top(g) > j (the reference never clears
+ *                                                            g_main_data_vec: corrupt streams read those bytes); g is
+ *                                                            found along the `up` links, each to a larger top
+ *     pool[s_off + j]                      no such frame     the buffer as it was before the segment began
+ * A segment is a run of frames over which "the buffer's valid bytes are the tail of the pool" holds; it starts with a
+ * 2064-byte image of the buffer (at s_off) followed by a copy of its last bytes, and a new one starts at every
+ * window and after anything irregular (reservoir underflow H9, short reads H18).  A frame whose buffer does not fit
+ * the rule carries its own image: row_off = s_off, top = 2064.  ~1.1 KB per frame up instead of 2144. */
+typedef struct pdmp3_row_desc {
+  uint32_t row_off;                         /* pool offset of byte 0 of the frame's buffer            */
+  uint32_t s_off;                           /* pool offset of its segment's 2064-byte image            */
+  uint16_t top;                             /* bytes [0, top) come from row_off                        */
+  uint16_t back;                            /* frames before this one in its segment                   */
+  uint16_t up;                              /* distance (in frames) to the nearest earlier frame of the
+                                             * segment with a larger top; 0 = none (the image at s_off) */
+  uint16_t reserved;
+} pdmp3_row_desc;                           /* 16 bytes */
+pdmp3_row_desc* pdmp3_hip_stream_slot_rowdesc(pdmp3_hip_stream* hs, int slot);
+uint8_t* pdmp3_hip_stream_slot_pool(pdmp3_hip_stream* hs, int slot);       /* = pdmp3_hip_stream_slot_reservoir's memory */
+#define PDMP3_POOL_SLACK_BYTES 8192         /* a window of ONE frame still takes a segment start + its frame + an image */
+size_t pdmp3_hip_stream_pool_bytes(const pdmp3_hip_stream* hs);            /* capacity of a slot's pool:
+                                                                            * max_frames * 2064 + PDMP3_POOL_SLACK_BYTES */
+/* like pdmp3_hip_stream_submit_bits_to, from the slot's bits, descriptors and the first pool_bytes of its pool */
+int pdmp3_hip_stream_submit_pool_to(pdmp3_hip_stream* hs, int slot, int n_frames, size_t pool_bytes, void* pinned_dst, int row_bytes);
+
 /* test hook: the gc records the device built for the slot's last submit_bits (after pdmp3_hip_stream_wait) */
 int pdmp3_hip_stream_fetch_records(pdmp3_hip_stream* hs, int slot, int n_frames, int16_t* spectra, pdmp3_gc_side* side);
 /* block until the slot's PCM is in its pinned buffer (no-op if nothing is in flight) */

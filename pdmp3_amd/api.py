@@ -15,7 +15,7 @@ _LIB = None
 
 BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads",
                 "pdmp3_amd_scan_buffer", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_decode_async", "pdmp3_amd_bulk_wait", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
-                "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits", "pdmp3_amd_pcm_alloc", "pdmp3_amd_pcm_free", "pdmp3_amd_stream_loop", "pdmp3_amd_write_wav"]
+                "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits", "pdmp3_amd_bulk_parse_pool", "pdmp3_amd_pcm_alloc", "pdmp3_amd_pcm_free", "pdmp3_amd_stream_loop", "pdmp3_amd_write_wav"]
 
 # include/pdmp3_hip.h: pdmp3_gc_bits / pdmp3_frame_bits
 GC_BITS_DTYPE = np.dtype([("part2_3_length", "<u2"), ("big_values", "<u2"), ("global_gain", "u1"), ("scalefac_compress", "u1"),
@@ -344,6 +344,31 @@ def parse_bits(mp3):
     if n < 0:
         raise RuntimeError("pdmp3_amd_bulk_parse_bits failed")
     return bits[:n], res[:n], pcm_bytes.value
+
+
+ROW_DESC_DTYPE = np.dtype([("row_off", "<u4"), ("s_off", "<u4"), ("top", "<u2"), ("back", "<u2"), ("up", "<u2"), ("reserved", "<u2")])
+
+
+def parse_pool(mp3):
+    """Stage A alone in the compact form the engine is given: (bits, row descriptors, pool).  No GPU."""
+    lib = load_library()
+    _, frames = scan_buffer(mp3)
+    cap = frames + 1
+    bits = np.zeros(cap, dtype=FRAME_BITS_DTYPE)
+    desc = np.zeros(cap, dtype=ROW_DESC_DTYPE)
+    pool = np.zeros(cap * 2064 + 16384, dtype=np.uint8)
+    a = _as_u8(mp3)
+    h = lib.pdmp3_amd_bulk_new_parse_bits()
+    used = C.c_size_t(0)
+    lib.pdmp3_amd_bulk_parse_pool.restype = C.c_longlong
+    lib.pdmp3_amd_bulk_parse_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                              C.c_size_t, C.POINTER(C.c_size_t)]
+    n = lib.pdmp3_amd_bulk_parse_pool(h, a.ctypes.data_as(C.c_void_p), len(mp3), bits.ctypes.data_as(C.c_void_p),
+                                      desc.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p), pool.nbytes, cap, C.byref(used))
+    lib.pdmp3_amd_bulk_delete(h)
+    if n < 0:
+        raise RuntimeError("pdmp3_amd_bulk_parse_pool failed")
+    return bits[:n], desc[:n], pool[:used.value]
 
 
 class PinnedPCM:

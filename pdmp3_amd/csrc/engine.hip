@@ -119,6 +119,13 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
   }
 }
 
+// reservoir rows from the pool (unpack_core.h row_word): one workgroup per frame, a 4-byte word per thread and trip
+__global__ __launch_bounds__(128) void k_rows(const pdmp3_row_desc* desc, const uint8_t* pool, uint8_t* rows) {
+  const pdmp3_row_desc* d = desc + blockIdx.x;
+  uint32_t* out = reinterpret_cast<uint32_t*>(rows + (size_t)blockIdx.x * kRowBytes);
+  for (int w = threadIdx.x; w < kRowBytes / 4; w += 128) out[w] = row_word(d, pool, 4u * (unsigned)w);
+}
+
 // inclusive "last lane that has a value" scan over the wave; lanes without any take `carry`.  (has, 16-bit value) in
 // one register, Hillis-Steele inside each row of 16 lanes with DPP row shifts, then the two row broadcasts of the
 // classic GCN wave scan -- 6 cross-lane moves at VALU rate.  (With __shfl_up = ds_bpermute the 24 dependent LDS round
@@ -366,6 +373,7 @@ struct StreamSlot {
   // bitstream-level input (allocated on first use)
   pdmp3_frame_bits* h_bits; uint8_t* h_res;                       // pinned
   pdmp3_frame_bits* d_bits; uint8_t* d_res; GcRaw* d_raw;
+  pdmp3_row_desc* h_desc; pdmp3_row_desc* d_desc; uint8_t* d_pool;   // compact bits input: pinned descriptors; the pool is h_res
   int busy;
 };
 struct pdmp3_hip_stream {
@@ -392,8 +400,8 @@ extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
     if (t.done) (void)hipEventDestroy(t.done);
     (void)hipHostFree(t.h_spectra); (void)hipHostFree(t.h_side); (void)hipHostFree(t.h_pcm);
     (void)hipFree(t.d_spectra); (void)hipFree(t.d_side); (void)hipFree(t.d_pcm);
-    (void)hipHostFree(t.h_bits); (void)hipHostFree(t.h_res);
-    (void)hipFree(t.d_bits); (void)hipFree(t.d_res); (void)hipFree(t.d_raw);
+    (void)hipHostFree(t.h_bits); (void)hipHostFree(t.h_res); (void)hipHostFree(t.h_desc);
+    (void)hipFree(t.d_bits); (void)hipFree(t.d_res); (void)hipFree(t.d_raw); (void)hipFree(t.d_desc); (void)hipFree(t.d_pool);
   }
   (void)hipFree(hs->d_sfstate);
   if (hs->ev_state) (void)hipEventDestroy(hs->ev_state);
@@ -612,10 +620,13 @@ static int ensure_bits(pdmp3_hip_stream* hs) {
   for (int i = 0; i < hs->n_slots; ++i) {
     StreamSlot& t = hs->s[i];
     HIP_TRY(hipHostMalloc((void**)&t.h_bits, n * sizeof(pdmp3_frame_bits), hipHostMallocDefault), "hipHostMalloc bits");
-    HIP_TRY(hipHostMalloc((void**)&t.h_res, n * PDMP3_RESERVOIR_BYTES + 16, hipHostMallocDefault), "hipHostMalloc reservoir");
+    HIP_TRY(hipHostMalloc((void**)&t.h_res, n * PDMP3_RESERVOIR_BYTES + PDMP3_POOL_SLACK_BYTES + 16, hipHostMallocDefault), "hipHostMalloc reservoir");
     HIP_TRY(hipMalloc((void**)&t.d_bits, n * sizeof(pdmp3_frame_bits)), "hipMalloc bits");
     HIP_TRY(hipMalloc((void**)&t.d_res, n * PDMP3_RESERVOIR_BYTES + 16), "hipMalloc reservoir");
     HIP_TRY(hipMalloc((void**)&t.d_raw, n * 4 * sizeof(GcRaw)), "hipMalloc raw");
+    HIP_TRY(hipHostMalloc((void**)&t.h_desc, n * sizeof(pdmp3_row_desc), hipHostMallocDefault), "hipHostMalloc row descriptors");
+    HIP_TRY(hipMalloc((void**)&t.d_desc, n * sizeof(pdmp3_row_desc)), "hipMalloc row descriptors");
+    HIP_TRY(hipMalloc((void**)&t.d_pool, n * PDMP3_RESERVOIR_BYTES + PDMP3_POOL_SLACK_BYTES + 16), "hipMalloc pool");
   }
   HIP_TRY(hipMalloc((void**)&hs->d_sfstate, 2 * 256 * sizeof(uint16_t)), "hipMalloc sfstate");
   HIP_TRY(hipMemset(hs->d_sfstate, 0, 2 * 256 * sizeof(uint16_t)), "memset sfstate");
@@ -632,7 +643,21 @@ extern "C" uint8_t* pdmp3_hip_stream_slot_reservoir(pdmp3_hip_stream* hs, int sl
   return hs->s[slot].h_res;
 }
 
-static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row);
+extern "C" pdmp3_row_desc* pdmp3_hip_stream_slot_rowdesc(pdmp3_hip_stream* hs, int slot) {
+  if (!SLOT_OK(hs, slot) || ensure_bits(hs) != PDMP3_HIP_OK) return nullptr;
+  return hs->s[slot].h_desc;
+}
+extern "C" uint8_t* pdmp3_hip_stream_slot_pool(pdmp3_hip_stream* hs, int slot) { return pdmp3_hip_stream_slot_reservoir(hs, slot); }
+extern "C" size_t pdmp3_hip_stream_pool_bytes(const pdmp3_hip_stream* hs) { return hs ? (size_t)hs->max_frames * PDMP3_RESERVOIR_BYTES + PDMP3_POOL_SLACK_BYTES : 0; }
+
+static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row, size_t pool_bytes = 0);
+extern "C" int pdmp3_hip_stream_submit_pool_to(pdmp3_hip_stream* hs, int slot, int n_frames, size_t pool_bytes, void* pinned_dst, int row_bytes) {
+  if (pinned_dst && row_bytes != PDMP3_FRAME_PCM_BYTES && row_bytes != PDMP3_FRAME_PCM_BYTES / 2)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_pool_to: row_bytes must be 4608 or 2304", hipSuccess);
+  if (!pool_bytes || !hs || pool_bytes > pdmp3_hip_stream_pool_bytes(hs))
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_pool_to: bad pool size", hipSuccess);
+  return submit_bits(hs, slot, n_frames, pinned_dst, row_bytes, pool_bytes);
+}
 extern "C" int pdmp3_hip_stream_submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames) {
   return submit_bits(hs, slot, n_frames, nullptr, PDMP3_FRAME_PCM_BYTES);
 }
@@ -641,7 +666,7 @@ extern "C" int pdmp3_hip_stream_submit_bits_to(pdmp3_hip_stream* hs, int slot, i
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_bits_to: row_bytes must be 4608 or 2304", hipSuccess);
   return submit_bits(hs, slot, n_frames, pinned_dst, row_bytes);
 }
-static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row) {
+static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row, size_t pool_bytes) {
   if (!SLOT_OK(hs, slot) || n_frames < 0 || n_frames > hs->max_frames)
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_bits: bad argument", hipSuccess);
   StreamSlot& t = hs->s[slot];
@@ -652,6 +677,12 @@ static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_
   HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
   const size_t n = (size_t)n_frames;
   HIP_TRY(hipMemcpyAsync(t.d_bits, t.h_bits, n * sizeof(pdmp3_frame_bits), hipMemcpyHostToDevice, t.stream), "H2D bits");
+  if (pool_bytes) {           // compact input: pool + descriptors up, rows rebuilt on the device
+    HIP_TRY(hipMemcpyAsync(t.d_pool, t.h_res, pool_bytes, hipMemcpyHostToDevice, t.stream), "H2D pool");
+    HIP_TRY(hipMemcpyAsync(t.d_desc, t.h_desc, n * sizeof(pdmp3_row_desc), hipMemcpyHostToDevice, t.stream), "H2D row descriptors");
+    hipLaunchKernelGGL(k_rows, dim3((unsigned)n_frames), dim3(128), 0, t.stream, t.d_desc, t.d_pool, t.d_res);
+    HIP_TRY(hipGetLastError(), "launch k_rows");
+  } else
   HIP_TRY(hipMemcpyAsync(t.d_res, t.h_res, n * PDMP3_RESERVOIR_BYTES, hipMemcpyHostToDevice, t.stream), "H2D reservoir");
   {
     int blocks = (n_frames + kUnpackRows - 1) / kUnpackRows;

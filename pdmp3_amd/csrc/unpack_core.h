@@ -74,6 +74,28 @@ static_assert(sizeof(GcRaw) == 80, "GcRaw layout");
 constexpr int kMergeSlots = 84 + 144 + 4;          // scalefac_l, scalefac_s, count1
 
 // ---------------------------------------------------------------------------
+// reservoir rows from the pool (include/pdmp3_hip.h: pdmp3_row_desc).  d points at the frame's descriptor inside the
+// window's array: d[-k] is the k-th frame before it.
+// ---------------------------------------------------------------------------
+PD_HD uint8_t row_byte(const pdmp3_row_desc* d, const uint8_t* pool, unsigned j) {
+  while (d->top <= j) {                           // up the skyline of the segment: every hop has a larger top
+    if (!d->up) return pool[d->s_off + j];
+    d -= d->up;
+  }
+  return pool[d->row_off + j];
+}
+PD_HD uint32_t row_word(const pdmp3_row_desc* d, const uint8_t* pool, unsigned j) {   // bytes j .. j + 3, little-endian
+  while (d->top <= j) {
+    if (!d->up) { uint32_t v; __builtin_memcpy(&v, pool + d->s_off + j, 4); return v; }   // (the image is 2064 bytes: j + 3 is inside)
+    d -= d->up;
+  }
+  if (d->top >= j + 4) { uint32_t v; __builtin_memcpy(&v, pool + d->row_off + j, 4); return v; }
+  uint32_t v = 0;                                 // the word straddles a boundary: byte by byte
+  for (int q = 0; q < 4; q++) v |= (uint32_t)row_byte(d, pool, j + q) << (8 * q);
+  return v;
+}
+
+// ---------------------------------------------------------------------------
 // bit reader over one reservoir row (same windows as pdmp3_host.c peek32 / peek64)
 // ---------------------------------------------------------------------------
 struct BitPos {

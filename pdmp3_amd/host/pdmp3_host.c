@@ -148,6 +148,13 @@ struct pdmp3_handle {
   int new_header;                  /* P:147 */
   int need_reset;                  /* hsynth_init / synth_init, P:134-135 */
   int ring_short;                  /* set whenever a parse step found fewer bytes in the ring than it wanted */
+  /* Whole-stream decoding (bulk_drive) reads a stream that is in memory anyway: the ring is then only its index
+   * arithmetic (istart / iend / processed move exactly as with real feeds) and the bytes come from the buffer:
+   * the ring slot ring_filled() places before the write index holds stream byte vfed - ring_filled(), stale slots
+   * of a replayed ring included (`processed` is no position: the header search resets it, P:1322-1340). */
+  const unsigned char* vsrc;
+  size_t vfed;                     /* bytes fed so far in virtual mode */
+  struct bulk* pool_sink;          /* bits mode with an engine: Get_Main_Data appends to the window's pool (fill_reservoir_pool) */
   /* Read-ahead of pdmp3_read (see read_ahead below).  The parser above may be AHEAD of the stream position the
    * reference would have at this point of the call sequence; what the API shows is the logical view: */
   size_t l_processed;              /* id->processed of the reference */
@@ -263,10 +270,24 @@ static inline void sync_logical(pdmp3_handle* id) {
 }
 static inline unsigned ring_byte(pdmp3_handle* id) {
   if (id->istart == id->iend) { id->ring_short = 1; return BYTE_EOF; }
-  unsigned v = id->in[id->istart++];
+  unsigned v = id->vsrc ? id->vsrc[id->vfed - ring_filled(id)] : id->in[id->istart];
+  id->istart++;
   if (id->istart == INBUF_SIZE) id->istart = 0;
   id->processed++;
   return v;
+}
+
+/* n bytes (n <= ring_filled) from the read index to dst; the read index moves past them */
+static inline void ring_take(pdmp3_handle* id, uint8_t* dst, unsigned n) {
+  if (id->vsrc) memcpy(dst, id->vsrc + id->vfed - ring_filled(id), n);
+  else {
+    unsigned first = INBUF_SIZE - id->istart;
+    if (first > n) first = n;
+    memcpy(dst, id->in + id->istart, first);
+    memcpy(dst + first, id->in, n - first);
+  }
+  id->istart = (id->istart + n) % INBUF_SIZE;
+  id->processed += n;
 }
 
 /* P:2391-2423: all-or-nothing copy into the ring */
@@ -274,16 +295,18 @@ int pdmp3_feed(pdmp3_handle* id, const unsigned char* in, size_t size) {
   if (!(id && in && size)) return PDMP3_ERR;
   if (size > (size_t)ring_free_logical(id)) return PDMP3_NO_SPACE;
   size_t first;
+  const int real = id->vsrc == NULL;             /* (virtual ring: the same index arithmetic, no bytes moved) */
+  if (!real) id->vfed += size;
   if (id->iend < id->l_istart) {
     first = id->l_istart - id->iend;
     if (size < first) first = size;
-    memcpy(id->in + id->iend, in, first);
+    if (real) memcpy(id->in + id->iend, in, first);
     id->iend += (unsigned)first;
   } else {
     first = INBUF_SIZE - id->iend;
     if (size < first) first = size;
-    if (first) { memcpy(id->in + id->iend, in, first); id->iend += (unsigned)first; size -= first; }
-    if (size) { memcpy(id->in, in + first, size); id->iend = (unsigned)size; }
+    if (first) { if (real) memcpy(id->in + id->iend, in, first); id->iend += (unsigned)first; size -= first; }
+    if (size) { if (real) memcpy(id->in, in + first, size); id->iend = (unsigned)size; }
   }
   /* a feed that fills the ring exactly leaves iend == istart, which the reference reads as EMPTY (P:1062-1068): it
    * will not get to the frames read ahead before its next feeds have overwritten them */
@@ -355,14 +378,7 @@ static void read_side_info(pdmp3_handle* id) {
   unsigned got = ring_filled(id);
   if (got > nbytes) got = nbytes;
   else if (got < nbytes) id->ring_short = 1;
-  {
-    unsigned first = INBUF_SIZE - id->istart;
-    if (first > got) first = got;
-    memcpy(id->side_vec, id->in + id->istart, first);
-    memcpy(id->side_vec + first, id->in, got - first);
-    id->istart = (id->istart + got) % INBUF_SIZE;
-    id->processed += got;
-  }
+  ring_take(id, id->side_vec, got);
   if (got == nbytes) { id->side_ptr = 0; id->side_idx = 0; }   /* pointers move only on a full read (P:1576-1586) */
   side_info* S = &id->si;
   side_cur sc = {id->side_vec, id->side_ptr * 8 + id->side_idx};
@@ -418,12 +434,7 @@ static int fill_reservoir(pdmp3_handle* id, unsigned size, unsigned begin) {
   unsigned n = off >= sizeof id->main_vec ? 0 : (unsigned)(sizeof id->main_vec - off);
   if (n > size) n = size;
   if (n > ring_filled(id)) { n = ring_filled(id); id->ring_short = 1; }
-  unsigned first = INBUF_SIZE - id->istart;
-  if (first > n) first = n;
-  memcpy(dst, id->in + id->istart, first);
-  memcpy(dst + first, id->in, n - first);
-  id->istart = (id->istart + n) % INBUF_SIZE;
-  id->processed += n;
+  ring_take(id, dst, n);
   return ok ? PDMP3_OK : PDMP3_NEED_MORE;
 }
 
@@ -648,6 +659,8 @@ static void apply_main(pdmp3_handle* id, const frame_header* H, const main_out* 
     }
 }
 
+static int fill_reservoir_pool(pdmp3_handle* id, unsigned size, unsigned begin);   /* bulk pipeline, below */
+
 /* P:1346-1374: sizes + bit reservoir; the frame's bytes leave the ring here */
 static int stage_main_data(pdmp3_handle* id) {
   const unsigned nch = id->hdr.mode == 3 ? 1 : 2;
@@ -655,6 +668,7 @@ static int stage_main_data(pdmp3_handle* id) {
   if (fb > 2000) return PDMP3_ERR;
   unsigned size = fb - (nch == 1 ? 17 : 32) - 4;
   if (id->hdr.protection == 0) size -= 2;
+  if (id->pool_sink) return fill_reservoir_pool(id, size, id->si.main_data_begin);
   return fill_reservoir(id, size, id->si.main_data_begin);
 }
 
@@ -1084,6 +1098,16 @@ struct bulk {
   pdmp3_frame_bits* bits_dst; uint8_t* res_dst;   /* where stage A writes the current window (bits mode) */
   int bits_n, bits_slot, bits_open;
   pdmp3_frame_bits* rec_bits; uint8_t* rec_res;   /* parse-only bits mode: caller memory */
+  /* compact bits input (include/pdmp3_hip.h: pdmp3_row_desc): res_dst is the window's pool */
+  int pool_mode;                      /* 1: rows go up as pool + descriptors; 0: as 2064-byte snapshots */
+  pdmp3_row_desc* desc_dst;
+  size_t pool_tail, pool_cap;
+  int seg_first;                      /* index in the window of the first frame of the current segment */
+  uint32_t seg_s_off;
+  int need_segment;                   /* id->main_vec is the live buffer: the next regular frame starts a segment */
+  uint32_t cur_row_off; unsigned cur_top; int cur_explicit, cur_staged;   /* what the frame just staged leaves for its descriptor */
+  int sky[RESERVOIR_BYTES + 1], sky_n;            /* frames of the segment no later frame has topped yet (pdmp3_row_desc.up) */
+  pdmp3_row_desc* rec_desc; size_t rec_pool_cap;  /* parse-only pool mode (host tests): caller memory, one window */
   bulk_window win[2];
   int cur;                            /* window stage A is filling */
   bulk_window* in_b;                  /* window the workers hold, or NULL */
@@ -1114,6 +1138,7 @@ struct bulk {
   pthread_mutex_t sub_mu;
   pthread_cond_t sub_cv, sub_done_cv;
   int sub_slot[8], sub_n[8], sub_row[8];
+  size_t sub_pool[8];                 /* pool bytes of the window (0: snapshot rows) */
   void* sub_dst[8];
   long long sub_head, sub_tail;       /* jobs enqueued / completed */
   size_t next_copy_row;               /* row size of the copy job bulk_collect last handed out */
@@ -1337,8 +1362,10 @@ static void* bulk_submitter(void* arg) {
     if (b->sub_tail == b->sub_head) { pthread_mutex_unlock(&b->sub_mu); return NULL; }
     const int slot = b->sub_slot[b->sub_tail & 7], n = b->sub_n[b->sub_tail & 7], row = b->sub_row[b->sub_tail & 7];
     void* dst = b->sub_dst[b->sub_tail & 7];
+    const size_t pool = b->sub_pool[b->sub_tail & 7];
     pthread_mutex_unlock(&b->sub_mu);
-    const int rc = pdmp3_hip_stream_submit_bits_to(b->hs, slot, n, dst, row);
+    const int rc = pool ? pdmp3_hip_stream_submit_pool_to(b->hs, slot, n, pool, dst, row)
+                        : pdmp3_hip_stream_submit_bits_to(b->hs, slot, n, dst, row);
     if (rc != PDMP3_HIP_OK) fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
     pthread_mutex_lock(&b->sub_mu);
     if (rc != PDMP3_HIP_OK) b->sub_rc = rc;
@@ -1347,10 +1374,10 @@ static void* bulk_submitter(void* arg) {
     pthread_mutex_unlock(&b->sub_mu);
   }
 }
-static void sub_enqueue(struct bulk* b, int slot, int n, void* dst, int row) {
+static void sub_enqueue(struct bulk* b, int slot, int n, void* dst, int row, size_t pool_bytes) {
   pthread_mutex_lock(&b->sub_mu);
   b->sub_slot[b->sub_head & 7] = slot; b->sub_n[b->sub_head & 7] = n;
-  b->sub_dst[b->sub_head & 7] = dst; b->sub_row[b->sub_head & 7] = row;
+  b->sub_dst[b->sub_head & 7] = dst; b->sub_row[b->sub_head & 7] = row; b->sub_pool[b->sub_head & 7] = pool_bytes;
   b->sub_head++;
   pthread_cond_signal(&b->sub_cv);
   pthread_mutex_unlock(&b->sub_mu);
@@ -1369,9 +1396,11 @@ static int sub_drain(struct bulk* b) {            /* every enqueued window has b
 static int bits_open_window(struct bulk* b) {
   b->bits_n = 0;
   b->bits_open = 1;
+  b->pool_tail = 0; b->need_segment = 1; b->seg_first = 0; b->cur_explicit = 0; b->cur_staged = 0; b->sky_n = 0;
   if (!b->hs) {                                   /* parse only: one "window" = the caller's arrays */
     b->bits_dst = b->rec_bits;
     b->res_dst = b->rec_res;
+    b->desc_dst = b->rec_desc; b->pool_cap = b->rec_pool_cap;
     return PDMP3_OK;
   }
   b->bits_slot = (int)(b->windows % BULK_SLOTS);
@@ -1381,11 +1410,75 @@ static int bits_open_window(struct bulk* b) {
   if (nbytes) bulk_start_b(b, NULL, src, dst, nbytes);
   b->bits_dst = pdmp3_hip_stream_slot_bits(b->hs, b->bits_slot);
   b->res_dst = pdmp3_hip_stream_slot_reservoir(b->hs, b->bits_slot);
+  if (b->pool_mode) {
+    b->desc_dst = pdmp3_hip_stream_slot_rowdesc(b->hs, b->bits_slot);
+    b->pool_cap = pdmp3_hip_stream_pool_bytes(b->hs);
+    if (!b->desc_dst) return PDMP3_ERR;
+  }
   return b->bits_dst && b->res_dst ? PDMP3_OK : PDMP3_ERR;
+}
+
+/* ---- compact bits input: the window's pool (include/pdmp3_hip.h, pdmp3_row_desc) ----
+ * While a segment runs, id->main_vec is NOT updated: it keeps the buffer as it was when the segment began (that image
+ * is in the pool at seg_s_off), and "the buffer's valid bytes [0, main_top) are the last main_top bytes of the pool"
+ * holds.  pool_materialize() brings main_vec up to date again from the segment's frames (the same rule the device
+ * applies, unpack_core.h row_byte): before anything irregular touches the buffer, and when the window closes. */
+static void pool_materialize(struct bulk* b) {
+  pdmp3_handle* id = b->id;
+  if (b->need_segment) return;                    /* main_vec is live */
+  unsigned covered = 0;
+  if (b->sky_n)                                   /* the last frame, then up its links: each hop has a larger top */
+    for (const pdmp3_row_desc* d = &b->desc_dst[b->sky[b->sky_n - 1]];; d -= d->up) {
+      memcpy(id->main_vec + covered, b->res_dst + d->row_off + covered, d->top - covered);
+      covered = d->top;
+      if (!d->up) break;
+    }
+  b->need_segment = 1;
+}
+
+/* room for a segment start (2064 + 511), a frame's main data (< 2000) and an explicit image (2064) */
+#define POOL_ROOM 6700u
+_Static_assert(POOL_ROOM <= PDMP3_POOL_SLACK_BYTES, "a fresh window has room for its first frame");
+
+/* Get_Main_Data (P:1096-1122) of the frame being staged, into the pool.  Same return codes and the same effect on
+ * main_top and the ring as fill_reservoir. */
+static int fill_reservoir_pool(pdmp3_handle* id, unsigned size, unsigned begin) {
+  struct bulk* b = id->pool_sink;
+  if (!b->bits_open && bits_open_window(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
+  if (b->cur_staged) { b->failed = 1; return PDMP3_ERR; }   /* (every frame staged here is pushed: the pool is the only copy) */
+  const int regular = begin <= id->main_top && size <= ring_filled(id) && begin + size <= sizeof id->main_vec;
+  if (!regular) {
+    /* reservoir underflow (H9), a frame the ring does not hold completely (H18), or more bytes than the buffer
+     * takes: the reference's buffer arithmetic on the real buffer; a frame that is decoded all the same carries its
+     * own image of the result */
+    pool_materialize(b);
+    b->cur_explicit = 1;
+    return fill_reservoir(id, size, begin);
+  }
+  if (b->need_segment) {                          /* the buffer as it is now, then its valid tail once more */
+    const unsigned h = id->main_top < 511 ? id->main_top : 511;
+    b->seg_s_off = (uint32_t)b->pool_tail;
+    memcpy(b->res_dst + b->pool_tail, id->main_vec, RESERVOIR_BYTES);
+    b->pool_tail += RESERVOIR_BYTES;
+    memcpy(b->res_dst + b->pool_tail, id->main_vec + id->main_top - h, h);
+    b->pool_tail += h;
+    b->seg_first = b->bits_n;
+    b->sky_n = 0;
+    b->need_segment = 0;
+  }
+  b->cur_row_off = (uint32_t)(b->pool_tail - begin);
+  b->cur_top = begin + size;
+  b->cur_explicit = 0;
+  b->cur_staged = 1;
+  ring_take(id, b->res_dst + b->pool_tail, size);
+  b->pool_tail += size;
+  id->main_top = begin + size;
+  return PDMP3_OK;
 }
 
 static int bits_close_window(struct bulk* b) {
   if (!b->bits_open) return PDMP3_OK;
+  if (b->pool_mode) pool_materialize(b);          /* the next window starts from the live buffer */
   b->bits_open = 0;
   if (!b->bits_n) return PDMP3_OK;
   if (b->hs) {
@@ -1401,7 +1494,7 @@ static int bits_close_window(struct bulk* b) {
     }
     const double t0 = now_s();
     flight_plan(b, f);
-    sub_enqueue(b, b->bits_slot, b->bits_n, f->direct ? f->dst : NULL, f->all_stereo == 1 ? 2304 : 4608);
+    sub_enqueue(b, b->bits_slot, b->bits_n, f->direct ? f->dst : NULL, f->all_stereo == 1 ? 2304 : 4608, b->pool_mode ? b->pool_tail : 0);
     b->t_submit += now_s() - t0;
     f->active = 1;
   }
@@ -1416,9 +1509,29 @@ static int bits_push(struct bulk* b) {
   const int i = b->bits_n++;
   fill_frame_bits(id, &b->bits_dst[i], b->frames == 1 && !b->carry);   /* a fresh handle's parse state is zero */
   id->need_reset = 0;
-  memcpy(b->res_dst + (size_t)i * RESERVOIR_BYTES, id->main_vec, RESERVOIR_BYTES);
+  if (b->pool_mode) {
+    pdmp3_row_desc* d = &b->desc_dst[i];
+    b->cur_staged = 0;
+    if (b->cur_explicit) {                        /* its own image of the buffer (main_vec is live here) */
+      d->row_off = d->s_off = (uint32_t)b->pool_tail;
+      d->top = RESERVOIR_BYTES; d->back = 0; d->up = 0; d->reserved = 0;
+      memcpy(b->res_dst + b->pool_tail, id->main_vec, RESERVOIR_BYTES);
+      b->pool_tail += RESERVOIR_BYTES;
+      b->cur_explicit = 0;
+    } else {
+      d->row_off = b->cur_row_off; d->s_off = b->seg_s_off;
+      d->top = (uint16_t)b->cur_top; d->back = (uint16_t)(i - b->seg_first); d->reserved = 0;
+      /* previous frame of the segment with a larger top: the skyline seen from this frame (a stack of strictly
+       * decreasing tops, so never deeper than 2064) */
+      while (b->sky_n && b->desc_dst[b->sky[b->sky_n - 1]].top <= d->top) b->sky_n--;
+      d->up = (uint16_t)(b->sky_n ? i - b->sky[b->sky_n - 1] : 0);
+      b->sky[b->sky_n++] = i;
+    }
+  } else memcpy(b->res_dst + (size_t)i * RESERVOIR_BYTES, id->main_vec, RESERVOIR_BYTES);
   if (b->hs) b->flight[b->bits_slot].nch[i] = (uint8_t)(id->hdr.mode == 3 ? 1 : 2);
-  if (b->hs && b->bits_n == b->cap && bits_close_window(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
+  const int full = b->bits_n == b->cap || (b->pool_mode && b->pool_tail + POOL_ROOM > b->pool_cap);
+  if (b->hs && full && bits_close_window(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
+  if (!b->hs && b->pool_mode && b->pool_tail + POOL_ROOM > b->pool_cap) { b->failed = 1; return PDMP3_ERR; }
   return PDMP3_OK;
 }
 
@@ -1442,6 +1555,7 @@ static int bulk_push(struct bulk* b) {
 static long long bulk_drive(struct bulk* b, const unsigned char* mp3, size_t n) {
   pdmp3_handle* id = b->id;
   pdmp3_open_feed(id);
+  id->vsrc = mp3; id->vfed = 0;                   /* the ring's bytes are the buffer's: only its indices move */
   size_t fed = 0, done, total = 0;
   int res;
   while ((res = read_impl_sink(id, INBUF_SIZE, &done, b)) != PDMP3_ERR) {
@@ -1452,14 +1566,21 @@ static long long bulk_drive(struct bulk* b, const unsigned char* mp3, size_t n) 
      * looks full of its own stale contents (P:1464-1474).  The reference -- and pdmp3_read / pdmp3(), which keep
      * its behaviour -- then emit the last 16 KiB again, often forever.  There is no finite reference output to
      * match, so the whole-stream entry points stop here. */
-    if (id->processed > fed) { b->failed = 2; return PDMP3_BULK_REPLAY; }
+    if (id->processed > fed) { id->vsrc = NULL; b->failed = 2; return PDMP3_BULK_REPLAY; }
     if (res == PDMP3_NEED_MORE) {
       size_t take = n - fed < 4096 ? n - fed : 4096;
       if (!take) break;
+      if (id->vsrc && take > ring_free_logical(id)) {
+        /* the CLI drops a feed the ring has no room for (H16, after an underflow's NEED_MORE): from here on the ring's
+         * bytes are no longer the buffer's at `processed` -- give the ring its real contents and go on with copies */
+        for (unsigned k = 0, f = ring_filled(id); k < f; k++) id->in[(id->istart + k) % INBUF_SIZE] = id->vsrc[id->vfed - f + k];
+        id->vsrc = NULL;
+      }
       (void)pdmp3_feed(id, mp3 + fed, take);
       fed += take;
     }
   }
+  id->vsrc = NULL;
   return (long long)total;
 }
 
@@ -1544,6 +1665,8 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
       if (!b->flight[i].nch) { pdmp3_amd_bulk_delete(b); return NULL; }
     }
     if (bits_mode) {
+      const char* snap = getenv("PDMP3_BULK_SNAPSHOT_ROWS");          /* 1: the 2064-byte-per-frame form of the input */
+      b->pool_mode = !(snap && *snap && *snap != '0');
       pthread_mutex_init(&b->sub_mu, NULL); pthread_cond_init(&b->sub_cv, NULL); pthread_cond_init(&b->sub_done_cv, NULL);
       if (pthread_create(&b->sub_th, NULL, bulk_submitter, b) != 0) { pdmp3_amd_bulk_delete(b); return NULL; }
       b->sub_started = 1;
@@ -1581,6 +1704,7 @@ static void bulk_begin(struct bulk* b) {
     memset(id, 0, sizeof *id);
     id->host_only = 1;
   }
+  id->pool_sink = b->pool_mode ? b : NULL;
   /* (windows, flights, a running copy job: the pipeline keeps going across streams) */
   b->win[b->cur].n = 0;
   b->frames = 0; b->pcm_emitted = 0; b->count_only = 0; b->failed = 0;
@@ -1698,6 +1822,22 @@ long long pdmp3_amd_bulk_parse_bits(struct bulk* b, const unsigned char* mp3, si
   b->rec_bits = bits; b->rec_res = res; b->rec_cap = cap_frames;
   const long long total = bulk_drive(b, mp3, n);
   if (pcm_bytes) *pcm_bytes = total;
+  if (total == PDMP3_BULK_REPLAY) return PDMP3_BULK_REPLAY;
+  return b->failed ? -1 : b->frames;
+}
+
+/* the same in the compact form (include/pdmp3_hip.h: pdmp3_row_desc): side info, row descriptors and the pool of ONE
+ * window that holds the whole stream (host tests of the pool rule against the snapshot rows) */
+long long pdmp3_amd_bulk_parse_pool(struct bulk* b, const unsigned char* mp3, size_t n, pdmp3_frame_bits* bits,
+                                    pdmp3_row_desc* desc, uint8_t* pool, size_t pool_cap, size_t cap_frames, size_t* pool_bytes) {
+  if (!b || b->hs || !b->bits_mode || (!mp3 && n)) return -1;
+  b->pool_mode = 1;
+  bulk_begin(b);
+  b->rec_bits = bits; b->rec_res = pool; b->rec_desc = desc; b->rec_pool_cap = pool_cap; b->rec_cap = cap_frames;
+  const long long total = bulk_drive(b, mp3, n);
+  if (b->bits_open) pool_materialize(b);
+  if (pool_bytes) *pool_bytes = b->pool_tail;
+  b->pool_mode = 0; b->id->pool_sink = NULL;
   if (total == PDMP3_BULK_REPLAY) return PDMP3_BULK_REPLAY;
   return b->failed ? -1 : b->frames;
 }

@@ -96,3 +96,12 @@ extern "C" int emul_unpack_frames(const pdmp3_frame_bits* bits, const uint8_t* r
   return (int)U->n_lut;
 }
 
+
+// reservoir rows from the pool (unpack_core.h row_word: what k_rows runs per frame)
+extern "C" void emul_rows(const pdmp3_row_desc* desc, const uint8_t* pool, int n_frames, uint8_t* rows) {
+  for (int f = 0; f < n_frames; ++f)
+    for (unsigned w = 0; w < PDMP3_RESERVOIR_BYTES / 4; ++w) {
+      const uint32_t v = row_word(desc + f, pool, 4 * w);
+      memcpy(rows + (size_t)f * PDMP3_RESERVOIR_BYTES + 4 * w, &v, 4);
+    }
+}

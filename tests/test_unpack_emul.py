@@ -129,3 +129,61 @@ def test_newstream_flag_restarts_the_parse_state(emul, streams):
         assert np.array_equal(sp, np.concatenate([a[0] for a in alone]))
         assert np.array_equal(sd.view(np.uint8), np.concatenate([a[1] for a in alone]).view(np.uint8))
     assert not (sd["frame"] & 0x80).any()              # the flag stays out of the gc records
+
+
+def _corrupt(rs, base, kind):
+    m = np.frombuffer(base, dtype=np.uint8).copy()
+    for p in rs.randint(0, len(m), size=1 + rs.randint(0, 4 if kind == 0 else 120)):
+        m[p] = rs.randint(0, 256) if kind == 2 else m[p] ^ (1 << rs.randint(0, 8))
+    return np.ascontiguousarray(m)
+
+
+def test_pool_rows_are_the_snapshot_rows(emul):
+    """the compact bits input (pdmp3_row_desc + pool): rows rebuilt by the device's rule (row_word, here on the host)
+    are byte for byte the 2064-byte reservoir snapshots -- stale bytes beyond main_top included -- on clean streams
+    (CBR, VBR with small frames: long look-backs), truncated ones and corrupted ones (underflows H9, resyncs)"""
+    from pdmp3_amd import api
+    rs = np.random.RandomState(11)
+    bases = [packer.generate(n_frames=300, seed=21, sfreq=0, mode=1, mode_ext=2, bitrate_index=14),
+             packer.generate(n_frames=400, seed=22, sfreq=2, mode=3, vbr=True, vbr_lo=1, vbr_hi=6),
+             packer.generate(n_frames=250, seed=23, sfreq=1, mode=0, mode_ext=0, vbr=True, block_pct=(40, 10, 40, 10), crc=True),
+             packer.generate(n_frames=200, seed=24, sfreq=0, mode=1, mode_ext=2, bitrate_index=2)]
+    streams = [np.frombuffer(b, dtype=np.uint8) for b in bases] + [np.frombuffer(bases[0][:-700], dtype=np.uint8)]
+    for it in range(60):
+        streams.append(_corrupt(rs, bases[rs.randint(len(bases))], rs.randint(3)))
+    # reservoir underflows on purpose (H9): main_data_begin = 511 in every 7th frame of streams with small frames
+    for base in (packer.generate(n_frames=300, seed=31, sfreq=0, mode=1, mode_ext=2, bitrate_index=5),
+                 packer.generate(n_frames=300, seed=32, sfreq=1, mode=3, bitrate_index=3)):
+        m = np.frombuffer(base, dtype=np.uint8).copy()
+        pos, k = 0, 0
+        while pos + 6 < len(m):
+            h = int.from_bytes(m[pos:pos + 4].tobytes(), "big")
+            if k % 7 == 3:
+                m[pos + 4] = 0xFF
+                m[pos + 5] |= 0x80
+            pos += 144 * [0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320][(h >> 12) & 15] * 1000 // \
+                [44100, 48000, 32000][(h >> 10) & 3] + ((h >> 9) & 1)
+            k += 1
+        streams.append(m)
+    checked = explicit = segments = parsed = 0
+    for m in streams:
+        try:
+            bits, res, _ = api.parse_bits(m)
+        except (api.RingReplay, RuntimeError):
+            continue
+        bits2, desc, pool = api.parse_pool(m)
+        assert len(bits2) == len(bits) and np.array_equal(bits2.view(np.uint8), bits.view(np.uint8))
+        if len(bits) == 0:
+            continue
+        rows = np.zeros((len(bits), 2064), dtype=np.uint8)
+        emul.emul_rows(desc.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p), len(bits), rows.ctypes.data_as(C.c_void_p))
+        bad = np.nonzero((rows != res).any(axis=1))[0]
+        assert bad.size == 0, (len(bits), bad[:5], desc[bad[:2]])
+        checked += len(bits)
+        parsed += 1
+        explicit += int((desc["top"] == 2064).sum())
+        segments += int((desc["back"] == 0).sum())
+    # segments restarted by reservoir underflows, not only one per stream (a frame that is decoded after an irregular
+    # fill -- H18, an explicit image -- needs a frame longer than 1152 bytes cut short: those streams take the ring-replay path)
+    assert checked > 5000 and segments >= parsed + 8
+    print("rows %d, segments %d, explicit images %d" % (checked, segments, explicit))
