@@ -154,6 +154,10 @@ struct pdmp3_handle {
    * of a replayed ring included (`processed` is no position: the header search resets it, P:1322-1340). */
   const unsigned char* vsrc;
   size_t vfed;                     /* bytes fed so far in virtual mode */
+  /* whole-stream decoding in bits mode: the side info goes straight into the engine's record (read_side_info_bits);
+   * fb_cur is valid for the frame just parsed when fb_valid is set */
+  int side_to_bits, fb_valid;
+  pdmp3_frame_bits fb_cur;
   struct bulk* pool_sink;          /* bits mode with an engine: Get_Main_Data appends to the window's pool (fill_reservoir_pool) */
   /* Read-ahead of pdmp3_read (see read_ahead below).  The parser above may be AHEAD of the stream position the
    * reference would have at this point of the call sequence; what the API shows is the logical view: */
@@ -319,6 +323,11 @@ int pdmp3_feed(pdmp3_handle* id, const unsigned char* in, size_t size) {
 /* ------------------------------------------------------------------------ */
 static int read_header(pdmp3_handle* id) {
   unsigned b[4];
+  if (id->vsrc && ring_filled(id) >= 4) {         /* (virtual ring: the four bytes lie in a row) */
+    uint8_t q[4];
+    ring_take(id, q, 4);
+    b[0] = q[0]; b[1] = q[1]; b[2] = q[2]; b[3] = q[3];
+  } else
   for (int i = 0; i < 4; i++) b[i] = ring_byte(id);
   if (b[0] == BYTE_EOF || b[1] == BYTE_EOF || b[2] == BYTE_EOF || b[3] == BYTE_EOF) return PDMP3_ERR;
   uint32_t h = (b[0] << 24) | (b[1] << 16) | (b[2] << 8) | b[3];
@@ -369,8 +378,12 @@ static inline unsigned side_bits(side_cur* c, unsigned n) {          /* n <= 12 
   return (unsigned)(w >> (64 - n));
 }
 
-static unsigned frame_bytes(const frame_header* H) {   /* P:1135-1138 */
-  return 144u * kBitratesL3[H->bitrate_index] / kSampleRates[H->sfreq] + H->padding;
+static unsigned frame_bytes(const frame_header* H) {   /* P:1135-1138; the 42 quotients there are, computed once */
+  static uint16_t q[15][3];
+  if (!q[1][0])
+    for (unsigned b = 1; b < 15; b++)
+      for (unsigned f = 0; f < 3; f++) q[b][f] = (uint16_t)(144u * kBitratesL3[b] / kSampleRates[f]);
+  return q[H->bitrate_index][H->sfreq] + H->padding;
 }
 
 static void read_side_info(pdmp3_handle* id) {
@@ -413,6 +426,68 @@ static void read_side_info(pdmp3_handle* id) {
     }
   id->side_ptr = sc.pos >> 3;
   id->side_idx = sc.pos & 7;
+}
+
+/* The same parse (P:1129-1200) for a frame whose side info the ring holds completely, written as the engine's
+ * pdmp3_frame_bits in one go: the whole-stream decoder's scan is one host thread, and field-by-field parsing into
+ * side_info plus the repacking (fill_frame_bits) was two thirds of its time per frame.  A granule-channel is 59 bits:
+ * 34 fixed, 22 that depend on window_switching, 3 flags.  What the reference leaves stale from earlier frames is kept
+ * in `si` exactly as read_side_info keeps it (H20: table_select[2] and subblock_gain are not written by every frame),
+ * so frames parsed by either function can follow each other. */
+static inline uint64_t side_word(const uint8_t* base, unsigned pos) {   /* >= 57 valid bits from bit `pos`, at the top */
+  uint64_t w;
+  memcpy(&w, base + (pos >> 3), 8);
+  return __builtin_bswap64(w) << (pos & 7);
+}
+static void read_side_info_bits(pdmp3_handle* id) {
+  static const uint8_t rev4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+  const unsigned nch = id->hdr.mode == 3 ? 1 : 2, nbytes = nch == 1 ? 17 : 32;
+  ring_take(id, id->side_vec, nbytes);
+  id->side_ptr = 0; id->side_idx = 0;
+  side_info* S = &id->si;
+  pdmp3_frame_bits* fb = &id->fb_cur;
+  const uint8_t* v = id->side_vec;
+  memset(fb, 0, sizeof *fb);
+  const uint64_t head = side_word(v, 0);
+  S->main_data_begin = (unsigned)(head >> 55);
+  unsigned pos;
+  if (nch == 1) { fb->scfsi[0] = rev4[(head >> 46) & 15]; pos = 18; }
+  else { fb->scfsi[0] = rev4[(head >> 48) & 15]; fb->scfsi[1] = rev4[(head >> 44) & 15]; pos = 20; }
+  for (unsigned gr = 0; gr < 2; gr++)
+    for (unsigned ch = 0; ch < nch; ch++, pos += 59) {
+      const uint64_t x = side_word(v, pos);
+      const unsigned tail = (unsigned)(side_word(v, pos + 56) >> 61);     /* preflag, scalefac_scale, count1table_select */
+      pdmp3_gc_bits* g = &fb->gc[gr * 2 + ch];
+      g->part2_3_length = (uint16_t)(x >> 52);
+      g->big_values = (uint16_t)((x >> 43) & 0x1ff);
+      g->global_gain = (uint8_t)(x >> 35);
+      g->scalefac_compress = (uint8_t)((x >> 31) & 15);
+      const unsigned ws = (unsigned)(x >> 30) & 1, y = (unsigned)(x >> 8) & 0x3fffff;
+      unsigned flags = ((tail & 2) ? PDMP3_GC_SCALEFAC_SCALE : 0) | ((tail & 4) ? PDMP3_GC_PREFLAG : 0);
+      if (ws) {
+        const unsigned bt = y >> 20, mixed = (y >> 19) & 1;
+        flags |= PDMP3_GC_WIN_SWITCH | (bt << PDMP3_GC_BLOCK_TYPE_SHIFT) | (mixed ? PDMP3_GC_MIXED : 0);
+        S->mixed[gr][ch] = mixed;
+        g->table_select[0] = (uint8_t)((y >> 14) & 31);
+        g->table_select[1] = (uint8_t)((y >> 9) & 31);
+        g->table_select[2] = (uint8_t)S->table_select[gr][ch][2];          /* stale */
+        for (unsigned w = 0; w < 3; w++) g->subblock_gain[w] = (uint8_t)(S->subblock_gain[gr][ch][w] = (y >> (6 - 3 * w)) & 7);
+        g->region0_count = (bt == 2 && !mixed) ? 8 : 7;
+        g->region1_count = (uint8_t)(20 - g->region0_count);
+      } else {
+        g->table_select[0] = (uint8_t)(y >> 17);
+        g->table_select[1] = (uint8_t)((y >> 12) & 31);
+        g->table_select[2] = (uint8_t)(S->table_select[gr][ch][2] = (y >> 7) & 31);
+        for (unsigned w = 0; w < 3; w++) g->subblock_gain[w] = (uint8_t)S->subblock_gain[gr][ch][w];   /* stale */
+        g->region0_count = (uint8_t)((y >> 3) & 15);
+        g->region1_count = (uint8_t)(y & 7);
+      }
+      g->flags = (uint8_t)flags;
+      g->count1table_select = (uint8_t)(tail & 1);
+    }
+  id->side_ptr = pos >> 3;
+  id->side_idx = pos & 7;
+  id->fb_valid = 1;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -680,7 +755,11 @@ static int read_frame_staged(pdmp3_handle* id) {
     if (ring_byte(id) != BYTE_EOF) (void)ring_byte(id);
   }
   if (id->hdr.layer != 3) return PDMP3_ERR;
-  if (frame_bytes(&id->hdr) <= 2000) read_side_info(id);
+  id->fb_valid = 0;
+  if (frame_bytes(&id->hdr) <= 2000) {
+    if (id->side_to_bits && ring_filled(id) >= 32) read_side_info_bits(id);
+    else read_side_info(id);
+  }
   return stage_main_data(id);
 }
 
@@ -744,8 +823,8 @@ static void emit_records(pdmp3_handle* id, const frame_header* H, const side_inf
 /* P:2307-2345: hand out up to buflen bytes of the frame under the cursor */
 static size_t drain_frame(pdmp3_handle* id, unsigned char* out, size_t buflen) {
   const unsigned nch = id->l_hdr.mode == 3 ? 1 : 2;        /* the CURRENT header's channel count, as in the reference */
-  const unsigned bps = (id->enc_f32 ? 4 : 2) * nch;
-  size_t n = buflen / bps;
+  const unsigned sh = (id->enc_f32 ? 2 : 1) + (nch - 1), bps = 1u << sh;
+  size_t n = buflen >> sh;
   if (n > 1152u - id->ostart) n = 1152u - id->ostart;
   if (out) memcpy(out, (const unsigned char*)id->last_pcm + (size_t)id->ostart * bps, n * bps);
   id->ostart += (unsigned)n;
@@ -1106,6 +1185,12 @@ struct bulk {
   uint32_t seg_s_off;
   int need_segment;                   /* id->main_vec is the live buffer: the next regular frame starts a segment */
   uint32_t cur_row_off; unsigned cur_top; int cur_explicit, cur_staged;   /* what the frame just staged leaves for its descriptor */
+  /* The frames' main data is not copied by the scanning thread (it is memory-bound there: two thirds of its time per
+   * frame): stage A only notes where the bytes are in the caller's stream and where they go in the pool, and the
+   * submitter thread copies them just before the window goes up (pool_gather).  What the scanner itself needs from
+   * the pool before that -- a few KB per window, pool_materialize -- it copies early (pool_ensure). */
+  struct pool_copy { const uint8_t* src; uint32_t dst, n; } *gath[BULK_SLOTS], *gath_cur;
+  int gath_n;
   int sky[RESERVOIR_BYTES + 1], sky_n;            /* frames of the segment no later frame has topped yet (pdmp3_row_desc.up) */
   pdmp3_row_desc* rec_desc; size_t rec_pool_cap;  /* parse-only pool mode (host tests): caller memory, one window */
   bulk_window win[2];
@@ -1139,6 +1224,7 @@ struct bulk {
   pthread_cond_t sub_cv, sub_done_cv;
   int sub_slot[8], sub_n[8], sub_row[8];
   size_t sub_pool[8];                 /* pool bytes of the window (0: snapshot rows) */
+  int sub_gath[8];                    /* entries of the slot's copy list */
   void* sub_dst[8];
   long long sub_head, sub_tail;       /* jobs enqueued / completed */
   size_t next_copy_row;               /* row size of the copy job bulk_collect last handed out */
@@ -1354,6 +1440,10 @@ static void fill_frame_bits(const pdmp3_handle* id, pdmp3_frame_bits* fb, int ne
     }
 }
 
+/* the main data a window's frames left in the caller's stream, into its pool (entries the scanner needed early have n = 0) */
+static void pool_gather(uint8_t* pool, const struct pool_copy* g, int n) {
+  for (int i = 0; i < n; i++) if (g[i].n) memcpy(pool + g[i].dst, g[i].src, g[i].n);
+}
 static void* bulk_submitter(void* arg) {
   struct bulk* b = (struct bulk*)arg;
   for (;;) {
@@ -1363,7 +1453,9 @@ static void* bulk_submitter(void* arg) {
     const int slot = b->sub_slot[b->sub_tail & 7], n = b->sub_n[b->sub_tail & 7], row = b->sub_row[b->sub_tail & 7];
     void* dst = b->sub_dst[b->sub_tail & 7];
     const size_t pool = b->sub_pool[b->sub_tail & 7];
+    const int gn = b->sub_gath[b->sub_tail & 7];
     pthread_mutex_unlock(&b->sub_mu);
+    if (pool) pool_gather(pdmp3_hip_stream_slot_pool(b->hs, slot), b->gath[slot], gn);
     const int rc = pool ? pdmp3_hip_stream_submit_pool_to(b->hs, slot, n, pool, dst, row)
                         : pdmp3_hip_stream_submit_bits_to(b->hs, slot, n, dst, row);
     if (rc != PDMP3_HIP_OK) fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
@@ -1374,10 +1466,11 @@ static void* bulk_submitter(void* arg) {
     pthread_mutex_unlock(&b->sub_mu);
   }
 }
-static void sub_enqueue(struct bulk* b, int slot, int n, void* dst, int row, size_t pool_bytes) {
+static void sub_enqueue(struct bulk* b, int slot, int n, void* dst, int row, size_t pool_bytes, int gath_n) {
   pthread_mutex_lock(&b->sub_mu);
   b->sub_slot[b->sub_head & 7] = slot; b->sub_n[b->sub_head & 7] = n;
   b->sub_dst[b->sub_head & 7] = dst; b->sub_row[b->sub_head & 7] = row; b->sub_pool[b->sub_head & 7] = pool_bytes;
+  b->sub_gath[b->sub_head & 7] = gath_n;
   b->sub_head++;
   pthread_cond_signal(&b->sub_cv);
   pthread_mutex_unlock(&b->sub_mu);
@@ -1397,10 +1490,16 @@ static int bits_open_window(struct bulk* b) {
   b->bits_n = 0;
   b->bits_open = 1;
   b->pool_tail = 0; b->need_segment = 1; b->seg_first = 0; b->cur_explicit = 0; b->cur_staged = 0; b->sky_n = 0;
+  b->gath_n = 0;
   if (!b->hs) {                                   /* parse only: one "window" = the caller's arrays */
     b->bits_dst = b->rec_bits;
     b->res_dst = b->rec_res;
     b->desc_dst = b->rec_desc; b->pool_cap = b->rec_pool_cap;
+    if (b->pool_mode) {
+      free(b->gath[0]);
+      b->gath_cur = b->gath[0] = (struct pool_copy*)malloc((b->rec_cap + 1) * sizeof(struct pool_copy));
+      if (!b->gath_cur) return PDMP3_ERR;
+    }
     return PDMP3_OK;
   }
   b->bits_slot = (int)(b->windows % BULK_SLOTS);
@@ -1413,7 +1512,8 @@ static int bits_open_window(struct bulk* b) {
   if (b->pool_mode) {
     b->desc_dst = pdmp3_hip_stream_slot_rowdesc(b->hs, b->bits_slot);
     b->pool_cap = pdmp3_hip_stream_pool_bytes(b->hs);
-    if (!b->desc_dst) return PDMP3_ERR;
+    b->gath_cur = b->gath[b->bits_slot];
+    if (!b->desc_dst || !b->gath_cur) return PDMP3_ERR;
   }
   return b->bits_dst && b->res_dst ? PDMP3_OK : PDMP3_ERR;
 }
@@ -1423,12 +1523,21 @@ static int bits_open_window(struct bulk* b) {
  * is in the pool at seg_s_off), and "the buffer's valid bytes [0, main_top) are the last main_top bytes of the pool"
  * holds.  pool_materialize() brings main_vec up to date again from the segment's frames (the same rule the device
  * applies, unpack_core.h row_byte): before anything irregular touches the buffer, and when the window closes. */
+/* pool bytes [lo, hi) are needed now: the copies that are still only noted and touch them (the list is in pool order) */
+static void pool_ensure(struct bulk* b, size_t lo, size_t hi) {
+  for (int i = b->gath_n - 1; i >= 0; i--) {
+    struct pool_copy* g = &b->gath_cur[i];
+    if ((size_t)g->dst + g->n <= lo && g->n) break;           /* (entries done earlier have n = 0: keep looking) */
+    if (g->n && g->dst < hi) { memcpy(b->res_dst + g->dst, g->src, g->n); g->n = 0; }
+  }
+}
 static void pool_materialize(struct bulk* b) {
   pdmp3_handle* id = b->id;
   if (b->need_segment) return;                    /* main_vec is live */
   unsigned covered = 0;
   if (b->sky_n)                                   /* the last frame, then up its links: each hop has a larger top */
     for (const pdmp3_row_desc* d = &b->desc_dst[b->sky[b->sky_n - 1]];; d -= d->up) {
+      pool_ensure(b, (size_t)d->row_off + covered, (size_t)d->row_off + d->top);
       memcpy(id->main_vec + covered, b->res_dst + d->row_off + covered, d->top - covered);
       covered = d->top;
       if (!d->up) break;
@@ -1470,7 +1579,12 @@ static int fill_reservoir_pool(pdmp3_handle* id, unsigned size, unsigned begin) 
   b->cur_top = begin + size;
   b->cur_explicit = 0;
   b->cur_staged = 1;
-  ring_take(id, b->res_dst + b->pool_tail, size);
+  if (id->vsrc) {                                 /* the bytes stay where they are for now (pool_gather) */
+    struct pool_copy* g = &b->gath_cur[b->gath_n++];
+    g->src = id->vsrc + id->vfed - ring_filled(id); g->dst = (uint32_t)b->pool_tail; g->n = size;
+    id->istart = (id->istart + size) % INBUF_SIZE;
+    id->processed += size;
+  } else ring_take(id, b->res_dst + b->pool_tail, size);
   b->pool_tail += size;
   id->main_top = begin + size;
   return PDMP3_OK;
@@ -1494,7 +1608,7 @@ static int bits_close_window(struct bulk* b) {
     }
     const double t0 = now_s();
     flight_plan(b, f);
-    sub_enqueue(b, b->bits_slot, b->bits_n, f->direct ? f->dst : NULL, f->all_stereo == 1 ? 2304 : 4608, b->pool_mode ? b->pool_tail : 0);
+    sub_enqueue(b, b->bits_slot, b->bits_n, f->direct ? f->dst : NULL, f->all_stereo == 1 ? 2304 : 4608, b->pool_mode ? b->pool_tail : 0, b->gath_n);
     b->t_submit += now_s() - t0;
     f->active = 1;
   }
@@ -1507,6 +1621,12 @@ static int bits_push(struct bulk* b) {
   if (!b->bits_open && bits_open_window(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
   if (!b->hs && (size_t)b->frames > b->rec_cap) { b->failed = 1; return PDMP3_ERR; }
   const int i = b->bits_n++;
+  if (id->fb_valid) {                             /* read_side_info_bits has built the record */
+    const frame_header* H = &id->hdr;
+    id->fb_cur.frame = (uint8_t)((H->sfreq & 3) | (H->mode << PDMP3_FR_MODE_SHIFT) | (H->mode_ext << PDMP3_FR_MODEEXT_SHIFT) |
+                                 (id->need_reset ? PDMP3_FR_RESET : 0) | (b->frames == 1 && !b->carry ? PDMP3_FR_NEWSTREAM : 0));
+    b->bits_dst[i] = id->fb_cur;
+  } else
   fill_frame_bits(id, &b->bits_dst[i], b->frames == 1 && !b->carry);   /* a fresh handle's parse state is zero */
   id->need_reset = 0;
   if (b->pool_mode) {
@@ -1604,7 +1724,7 @@ void pdmp3_amd_bulk_delete(struct bulk* b) {
     pthread_mutex_destroy(&b->sub_mu); pthread_cond_destroy(&b->sub_cv); pthread_cond_destroy(&b->sub_done_cv);
   }
   for (int i = 0; i < 2; i++) { free(b->win[i].jobs); free(b->win[i].outs); }
-  for (int i = 0; i < BULK_SLOTS; i++) free(b->flight[i].nch);
+  for (int i = 0; i < BULK_SLOTS; i++) { free(b->flight[i].nch); free(b->gath[i]); }
   if (b->hs) pdmp3_hip_stream_destroy(b->hs);
   free(b->id);
   free(b);
@@ -1662,7 +1782,8 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
     }
     for (int i = 0; i < BULK_SLOTS; i++) {
       b->flight[i].nch = (uint8_t*)malloc((size_t)b->cap);
-      if (!b->flight[i].nch) { pdmp3_amd_bulk_delete(b); return NULL; }
+      b->gath[i] = (struct pool_copy*)malloc(((size_t)b->cap + 1) * sizeof(struct pool_copy));
+      if (!b->flight[i].nch || !b->gath[i]) { pdmp3_amd_bulk_delete(b); return NULL; }
     }
     if (bits_mode) {
       const char* snap = getenv("PDMP3_BULK_SNAPSHOT_ROWS");          /* 1: the 2064-byte-per-frame form of the input */
@@ -1705,6 +1826,7 @@ static void bulk_begin(struct bulk* b) {
     id->host_only = 1;
   }
   id->pool_sink = b->pool_mode ? b : NULL;
+  id->side_to_bits = b->bits_mode && !getenv("PDMP3_BULK_SLOW_SIDE_INFO");
   /* (windows, flights, a running copy job: the pipeline keeps going across streams) */
   b->win[b->cur].n = 0;
   b->frames = 0; b->pcm_emitted = 0; b->count_only = 0; b->failed = 0;
@@ -1760,6 +1882,7 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
     ok = ok && bulk_finish_b(b) == PDMP3_OK;
   }
   if (drain || !b->bits_mode || !ok) ok = bulk_drain(b) == PDMP3_OK && ok;
+  else if (b->pool_mode) ok = sub_drain(b) == PDMP3_OK && ok;      /* the submitter has taken the main data out of `mp3` */
   if (rate) *rate = (long)kSampleRates[b->id->hdr.sfreq];
   if (channels) *channels = b->id->hdr.mode == 3 ? 1 : 2;
   if (getenv("PDMP3_BULK_TRACE")) {
@@ -1835,7 +1958,7 @@ long long pdmp3_amd_bulk_parse_pool(struct bulk* b, const unsigned char* mp3, si
   bulk_begin(b);
   b->rec_bits = bits; b->rec_res = pool; b->rec_desc = desc; b->rec_pool_cap = pool_cap; b->rec_cap = cap_frames;
   const long long total = bulk_drive(b, mp3, n);
-  if (b->bits_open) pool_materialize(b);
+  if (b->bits_open) { pool_materialize(b); pool_gather(pool, b->gath_cur, b->gath_n); }
   if (pool_bytes) *pool_bytes = b->pool_tail;
   b->pool_mode = 0; b->id->pool_sink = NULL;
   if (total == PDMP3_BULK_REPLAY) return PDMP3_BULK_REPLAY;
