@@ -1167,6 +1167,7 @@ typedef struct {                      /* a window that is on the GPU */
   size_t dst_cap;
   int direct;                         /* the GPU downloads straight to dst (pinned caller memory): nothing to copy */
   uint8_t* nch;
+  long long sub_seq;                  /* its place in the submitter's queue */
 } bulk_flight;
 
 struct bulk {
@@ -1229,6 +1230,7 @@ struct bulk {
   long long sub_head, sub_tail;       /* jobs enqueued / completed */
   size_t next_copy_row;               /* row size of the copy job bulk_collect last handed out */
   double t_submit, t_gpuwait, t_poolwait;   /* PDMP3_BULK_TRACE=1: where the scanning thread waits */
+  double t_sub_gather, t_sub_call, t_drive, t_subwait, t_tail;          /* ... and what the submitter thread spends on the main-data copies / the engine calls */
 };
 
 static void* bulk_worker(void* arg) {
@@ -1455,10 +1457,13 @@ static void* bulk_submitter(void* arg) {
     const size_t pool = b->sub_pool[b->sub_tail & 7];
     const int gn = b->sub_gath[b->sub_tail & 7];
     pthread_mutex_unlock(&b->sub_mu);
+    const double t0 = now_s();
     if (pool) pool_gather(pdmp3_hip_stream_slot_pool(b->hs, slot), b->gath[slot], gn);
+    const double t1 = now_s();
     const int rc = pool ? pdmp3_hip_stream_submit_pool_to(b->hs, slot, n, pool, dst, row)
                         : pdmp3_hip_stream_submit_bits_to(b->hs, slot, n, dst, row);
     if (rc != PDMP3_HIP_OK) fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
+    b->t_sub_gather += t1 - t0; b->t_sub_call += now_s() - t1;
     pthread_mutex_lock(&b->sub_mu);
     if (rc != PDMP3_HIP_OK) b->sub_rc = rc;
     b->sub_tail++;
@@ -1466,14 +1471,24 @@ static void* bulk_submitter(void* arg) {
     pthread_mutex_unlock(&b->sub_mu);
   }
 }
-static void sub_enqueue(struct bulk* b, int slot, int n, void* dst, int row, size_t pool_bytes, int gath_n) {
+static long long sub_enqueue(struct bulk* b, int slot, int n, void* dst, int row, size_t pool_bytes, int gath_n) {
   pthread_mutex_lock(&b->sub_mu);
+  const long long seq = b->sub_head;
   b->sub_slot[b->sub_head & 7] = slot; b->sub_n[b->sub_head & 7] = n;
   b->sub_dst[b->sub_head & 7] = dst; b->sub_row[b->sub_head & 7] = row; b->sub_pool[b->sub_head & 7] = pool_bytes;
   b->sub_gath[b->sub_head & 7] = gath_n;
   b->sub_head++;
   pthread_cond_signal(&b->sub_cv);
   pthread_mutex_unlock(&b->sub_mu);
+  return seq;
+}
+static int sub_wait_seq(struct bulk* b, long long seq) {   /* window number `seq` of the queue has been handed to the GPU */
+  if (!b->sub_started) return PDMP3_OK;
+  pthread_mutex_lock(&b->sub_mu);
+  while (b->sub_tail <= seq) pthread_cond_wait(&b->sub_done_cv, &b->sub_mu);
+  const int rc = b->sub_rc;
+  pthread_mutex_unlock(&b->sub_mu);
+  return rc == PDMP3_HIP_OK ? PDMP3_OK : PDMP3_ERR;
 }
 static int sub_drain(struct bulk* b) {            /* every enqueued window has been handed to the GPU */
   if (!b->sub_started) return PDMP3_OK;
@@ -1504,7 +1519,12 @@ static int bits_open_window(struct bulk* b) {
   }
   b->bits_slot = (int)(b->windows % BULK_SLOTS);
   const unsigned char* src; unsigned char* dst; size_t nbytes;
-  if (b->flight[b->bits_slot].active && sub_drain(b) != PDMP3_OK) return PDMP3_ERR;   /* (long done: 3 windows ago) */
+  if (b->flight[b->bits_slot].active) {           /* (long done: 3 windows ago) */
+    const double t0 = now_s();
+    const int rc = sub_wait_seq(b, b->flight[b->bits_slot].sub_seq);   /* (not the windows queued after it) */
+    b->t_subwait += now_s() - t0;
+    if (rc != PDMP3_OK) return PDMP3_ERR;
+  }
   if (bulk_collect(b, b->bits_slot, &src, &dst, &nbytes) != PDMP3_OK) return PDMP3_ERR;
   if (nbytes) bulk_start_b(b, NULL, src, dst, nbytes);
   b->bits_dst = pdmp3_hip_stream_slot_bits(b->hs, b->bits_slot);
@@ -1608,7 +1628,7 @@ static int bits_close_window(struct bulk* b) {
     }
     const double t0 = now_s();
     flight_plan(b, f);
-    sub_enqueue(b, b->bits_slot, b->bits_n, f->direct ? f->dst : NULL, f->all_stereo == 1 ? 2304 : 4608, b->pool_mode ? b->pool_tail : 0, b->gath_n);
+    f->sub_seq = sub_enqueue(b, b->bits_slot, b->bits_n, f->direct ? f->dst : NULL, f->all_stereo == 1 ? 2304 : 4608, b->pool_mode ? b->pool_tail : 0, b->gath_n);
     b->t_submit += now_s() - t0;
     f->active = 1;
   }
@@ -1874,7 +1894,10 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
   if (!b->bits_mode && !b->carry && pdmp3_hip_stream_reset(b->hs) != PDMP3_HIP_OK) return -1;
   b->pcm = pcm; b->pcm_cap = pcm_cap;
   b->pcm_pinned = pcm_cap && pdmp3_hip_host_is_pinned(pcm, pcm_cap);
+  const double t_in = now_s();
   const long long total = bulk_drive(b, mp3, n);
+  const double t_driven = now_s();
+  b->t_drive += t_driven - t_in;
   int ok = !b->failed;
   if (b->bits_mode) ok = bits_close_window(b) == PDMP3_OK && ok;
   else {
@@ -1883,11 +1906,14 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
   }
   if (drain || !b->bits_mode || !ok) ok = bulk_drain(b) == PDMP3_OK && ok;
   else if (b->pool_mode) ok = sub_drain(b) == PDMP3_OK && ok;      /* the submitter has taken the main data out of `mp3` */
+  b->t_tail += now_s() - t_driven;
   if (rate) *rate = (long)kSampleRates[b->id->hdr.sfreq];
   if (channels) *channels = b->id->hdr.mode == 3 ? 1 : 2;
   if (getenv("PDMP3_BULK_TRACE")) {
-    fprintf(stderr, "bulk trace: submit %.2f ms, gpu wait %.2f ms, pool wait %.2f ms (cumulative)\n", b->t_submit * 1e3,
-            b->t_gpuwait * 1e3, b->t_poolwait * 1e3);
+    fprintf(stderr, "bulk trace: scan loop %.2f ms (of it waiting for the submitter %.2f ms), tail %.2f ms (cumulative)\n",
+            b->t_drive * 1e3, b->t_subwait * 1e3, b->t_tail * 1e3);
+    fprintf(stderr, "bulk trace: submit %.2f ms, gpu wait %.2f ms, pool wait %.2f ms; submitter: copies %.2f ms, engine calls %.2f ms (cumulative)\n",
+            b->t_submit * 1e3, b->t_gpuwait * 1e3, b->t_poolwait * 1e3, b->t_sub_gather * 1e3, b->t_sub_call * 1e3);
   }
   if (total == PDMP3_BULK_REPLAY) return PDMP3_BULK_REPLAY;
   return ok ? total : -1;
