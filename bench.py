@@ -352,7 +352,7 @@ def main():
             import numpy as np
             from pdmp3_amd.packer import packer
             from pdmp3_amd import api
-            nf = 40000
+            nf = 137813                                      # BASELINE configs[2] (C3): one hour of audio
             mp3 = np.frombuffer(packer.generate(n_frames=nf, seed=0xC3, sfreq=0, mode=1, mode_ext=2, bitrate_index=14), dtype=np.uint8)
             total, frames = api.scan_buffer(mp3)
             pcm_out = np.empty(total // 2, dtype=np.int16)

@@ -191,7 +191,7 @@ const int16_t* pdmp3_hip_stream_pcm(pdmp3_hip_stream* hs);
 int pdmp3_hip_stream_decode(pdmp3_hip_stream* hs, int n_frames);
 
 /* Pipelined form for bulk decoding of one long stream (the C3 / C4 corpora of
- * SURVEY 8d): `n_slots` (1..4) independent staging slots of `max_frames` frames.
+ * SURVEY 8d): `n_slots` (1..8) independent staging slots of `max_frames` frames.
  * While the host fills slot w+1, slot w is uploading / running / downloading.
  * Batches are decoded in SUBMIT order, each from the synthesis state the
  * previous one left (the same carry Decode_L3's static buffers give the

@@ -364,7 +364,7 @@ extern "C" int pdmp3_hip_decode_frames_stages(pdmp3_hip_ctx* ctx, const int16_t*
 // HIP stream (H2D -> k_decode -> D2H), so slot w+1's upload overlaps slot w's kernel and download over the
 // two PCIe directions; the kernels themselves are chained in submit order through `ev_state` because each one
 // starts from the synthesis state its predecessor left (and they share the stream's d_state_tmp).
-constexpr int kMaxSlots = 4;
+constexpr int kMaxSlots = 8;
 struct StreamSlot {
   hipStream_t stream;
   hipEvent_t done;

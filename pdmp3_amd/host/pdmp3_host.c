@@ -1138,7 +1138,7 @@ int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) 
 /*   D  GPU, async   pdmp3_hip_stream_submit(); the PCM of window w-2 is     */
 /*                   copied out while w-1 is on the GPU and w is in B.       */
 /* ------------------------------------------------------------------------ */
-#define BULK_SLOTS 3
+#define BULK_SLOTS 6
 #include <time.h>
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 #define PDMP3_BULK_REPLAY (-2)         /* see bulk_drive */
@@ -1499,7 +1499,7 @@ static int sub_drain(struct bulk* b) {            /* every enqueued window has b
   return rc == PDMP3_HIP_OK ? PDMP3_OK : PDMP3_ERR;
 }
 
-/* make the slot of window `windows` writable: its previous occupant (window - 3) must be off the GPU; its PCM
+/* make the slot of window `windows` writable: its previous occupant (window - BULK_SLOTS) must be off the GPU; its PCM
  * goes home on the worker pool while stage A fills the slot's input side */
 static int bits_open_window(struct bulk* b) {
   b->bits_n = 0;
@@ -1519,7 +1519,7 @@ static int bits_open_window(struct bulk* b) {
   }
   b->bits_slot = (int)(b->windows % BULK_SLOTS);
   const unsigned char* src; unsigned char* dst; size_t nbytes;
-  if (b->flight[b->bits_slot].active) {           /* (long done: 3 windows ago) */
+  if (b->flight[b->bits_slot].active) {           /* (long done: BULK_SLOTS windows ago) */
     const double t0 = now_s();
     const int rc = sub_wait_seq(b, b->flight[b->bits_slot].sub_seq);   /* (not the windows queued after it) */
     b->t_subwait += now_s() - t0;
