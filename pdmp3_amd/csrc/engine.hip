@@ -68,8 +68,9 @@ __global__ __launch_bounds__(64) void k_generate(uint64_t seed, int64_t first, i
 // ---------------------------------------------------------------------------
 // main-data decoding on the device (unpack_core.h)
 // ---------------------------------------------------------------------------
-constexpr int kUnpackThreads = 64;                      // one wave = 16 frames per pass
-constexpr int kUnpackRows = kUnpackThreads / 4;
+constexpr int kUnpackLanes = 64;                        // one wave = 16 frames per pass decodes ...
+constexpr int kUnpackThreads = 256;                     // ... four bring the tables and the rows into LDS and zero the output
+constexpr int kUnpackRows = kUnpackLanes / 4;
 constexpr int kRowBytes = PDMP3_RESERVOIR_BYTES;
 // LDS row stride in 32-bit words, chosen ODD: the 64 lanes read their rows at about the same offset at the same
 // time, and with the natural stride (516 words) that is 8 of the 32 banks for the whole wave
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
     }
     __syncthreads();
     const int fl = threadIdx.x >> 2, g = threadIdx.x & 3;
-    if (fl < nrows) {
+    if (threadIdx.x < kUnpackLanes && fl < nrows) {
       const size_t idx = (size_t)(f0 + fl) * 4 + g;
       unpack_gc(U, U.lut, reinterpret_cast<const uint8_t*>(rows + fl * kRowStrideW),
                 *reinterpret_cast<const pdmp3_frame_bits*>(fbits + fl * kFrameBitsW), g, spectra + idx * 576, side + idx,

@@ -129,25 +129,46 @@ PD_HD uint64_t peek64(const BitPos& b) {
   return s ? (two << s) | (uint64_t)(d2 >> (32 - s)) : two;
 }
 
-// Short fields in a row (scalefactors): one window serves as many of them as it has bits for, instead of one LDS round
-// trip each.  Same per-call decision as get_bits: past kFastLimit the byte-wise clamped window.
-struct FieldWin {
-  uint64_t w;
-  unsigned avail;
+// The same bits out of REGISTERS: d0, d1 are the row's big-endian words pos >> 5 and the next one, nx the word after
+// them, already on its way from LDS.  A code word (<= 19 bits) or the linbits and signs that follow it (<= 28 bits) are
+// one funnel shift of d0:d1, and rw_step() after each of the two moves the window by at most one word, taking the
+// word asked for a step earlier -- its LDS latency passes under the table lookup instead of in front of every symbol
+// (peek64: three loads and ~a hundred cycles of waiting per symbol, in a loop that is one dependent chain per lane).
+// Valid while the iteration began at pos <= kFastLimit: the last word touched is then 8 bytes past the row at most.
+struct RegWin {
+  const uint32_t* row;
+  uint32_t d0, d1, nx;
+  unsigned wi;
 };
-PD_HD unsigned get_field(BitPos& b, FieldWin& fw, unsigned n) {   // n <= 16
+PD_HD void rw_open(RegWin& r, const uint8_t* buf, unsigned pos) {
+  r.row = reinterpret_cast<const uint32_t*>(buf);
+  r.wi = pos >> 5;
+  if (r.wi > kFastLimit / 32) r.wi = kFastLimit / 32;      // (a position out there is never read through the window)
+  r.d0 = __builtin_bswap32(r.row[r.wi]);
+  r.d1 = __builtin_bswap32(r.row[r.wi + 1]);
+  r.nx = r.row[r.wi + 2];
+}
+PD_HD uint32_t rw_peek(const RegWin& r, unsigned pos) {     // 32 bits from bit `pos` (pos >> 5 == r.wi)
+  const unsigned s = pos & 31;
+  return (uint32_t)(((((uint64_t)r.d0) << 32) | r.d1) >> (32 - s));   // one 64-bit shift (32 - s is 1..32: no branch for s = 0)
+}
+PD_HD void rw_step(RegWin& r, unsigned pos) {               // pos has moved by < 32 bits since the last step
+  const bool adv = (pos >> 5) != r.wi;
+  const uint32_t sw = __builtin_bswap32(r.nx);
+  r.d0 = adv ? r.d1 : r.d0;
+  r.d1 = adv ? sw : r.d1;
+  r.wi = pos >> 5;
+  r.nx = r.row[r.wi + 2];
+}
+
+// Short fields in a row (scalefactors).  Same per-call decision as get_bits: past kFastLimit the byte-wise clamped window.
+PD_HD unsigned get_field(BitPos& b, RegWin& r, unsigned n) {   // n <= 16
   if (!n) return 0;
-  if (b.pos > kFastLimit) {
-    fw.avail = 0;
-    const unsigned v = peek32(b) >> (32 - n);
-    b.pos += n;
-    return v;
-  }
-  if (fw.avail < n) { fw.w = peek64(b); fw.avail = 64; }
-  const unsigned v = (unsigned)(fw.w >> (64 - n));
-  fw.w <<= n;
-  fw.avail -= n;
+  unsigned v;
+  if (b.pos > kFastLimit) v = peek32(b) >> (32 - n);
+  else v = rw_peek(r, b.pos) >> (32 - n);
   b.pos += n;
+  if (b.pos <= kFastLimit + 32) rw_step(r, b.pos);
   return v;
 }
 
@@ -236,44 +257,48 @@ PD_COLD unsigned unpack_pairs_slow(const uint32_t* lut, BitPos& b, int base0, in
 // code words (0, 4, 14) reads no bits and leaves its (pre-zeroed) lines alone.  The loop body is branch-free apart
 // from that: second-level lookup, linbits and sign bits are selects (64 lanes decode 64 different streams -- every
 // data-dependent branch is taken by some lane anyway, and its overhead by all).
-PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& b, const pdmp3_gc_bits& s, unsigned e0,
-                            unsigned e1, unsigned nbig, int16_t* is) {
+PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& b, RegWin& r, const pdmp3_gc_bits& s,
+                            unsigned e0, unsigned e1, unsigned nbig, int16_t* is) {
   int base_r[3];
   unsigned lin_r[3];
-  for (int r = 0; r < 3; r++) {
-    const unsigned tn = s.table_select[r];
+  for (int k = 0; k < 3; k++) {
+    const unsigned tn = s.table_select[k];
     const int book = U.book_of_table[tn];
-    base_r[r] = book < 0 ? -1 : (int)U.book_base[book];
-    lin_r[r] = U.linbits[tn];
+    base_r[k] = book < 0 ? -1 : (int)U.book_base[book];
+    lin_r[k] = U.linbits[tn];
   }
   unsigned pos = 0;
   for (; pos < nbig && b.pos <= kFastLimit; pos += 2) {
     const int base = pos < e0 ? base_r[0] : pos < e1 ? base_r[1] : base_r[2];
     const unsigned linbits = pos < e0 ? lin_r[0] : pos < e1 ? lin_r[1] : lin_r[2];
     if (base < 0) continue;
-    const uint64_t w = peek64(b);
-    const unsigned i1 = (unsigned)base + (unsigned)(w >> (64 - kHuffFirstBits));
-    const uint32_t e1st = lut[i1];
+    // the code word: <= 19 bits
+    const uint32_t w = rw_peek(r, b.pos);
+    const uint32_t e1st = lut[(unsigned)base + (w >> (32 - kHuffFirstBits))];
     const bool link = (e1st & 0x80000000u) != 0;
-    const unsigned sb = (e1st >> 24) & 0x1f;                                   // 1..11 when link
-    // (v >> 1) >> (63 - n) == v >> (64 - n) for n = 1..63 and 0 for n = 0: no shift by 64
     uint32_t e = e1st;
-    if (link) e = lut[(e1st & 0xffffffu) + (unsigned)(((w << kHuffFirstBits) >> 1) >> (63 - sb))];   // only books deeper than 8 bits
-    unsigned used = (link ? (unsigned)kHuffFirstBits : 0u) + ((e >> 8) & 0xff);
+    if (link) {                                    // only books deeper than 8 bits; sub_bits is 1..11
+      const unsigned sb = (e1st >> 24) & 0x1f;
+      e = lut[(e1st & 0xffffffu) + ((w << kHuffFirstBits) >> (32 - sb))];
+    }
+    b.pos += (link ? (unsigned)kHuffFirstBits : 0u) + ((e >> 8) & 0xff);
+    rw_step(r, b.pos);
+    // linbits and signs of both values: <= 28 bits.  (v >> 1) >> (31 - n) == v >> (32 - n) for n = 1..31 and 0 for n = 0
+    uint32_t w2 = rw_peek(r, b.pos);
     int x = (int)((e >> 4) & 15), y = (int)(e & 15);
     const unsigned lbx = (x == 15) ? linbits : 0;
-    x += (int)(((w << used) >> 1) >> (63 - lbx));
-    used += lbx;
-    const bool nx = x != 0 && ((w << used) >> 63) != 0;
-    used += x != 0;
-    x = nx ? -x : x;
+    x += (int)((w2 >> 1) >> (31 - lbx));
+    w2 <<= lbx;
+    const unsigned nzx = x != 0;
+    x = (nzx && (w2 >> 31)) ? -x : x;
+    w2 <<= nzx;
     const unsigned lby = (y == 15) ? linbits : 0;
-    y += (int)(((w << used) >> 1) >> (63 - lby));
-    used += lby;
-    const bool ny = y != 0 && ((w << used) >> 63) != 0;
-    used += y != 0;
-    y = ny ? -y : y;
-    b.pos += used;
+    y += (int)((w2 >> 1) >> (31 - lby));
+    w2 <<= lby;
+    const unsigned nzy = y != 0;
+    y = (nzy && (w2 >> 31)) ? -y : y;
+    b.pos += lbx + nzx + lby + nzy;
+    rw_step(r, b.pos);
     store_pair(is, pos, x, y);
   }
   if (pos < nbig) pos = unpack_pairs_slow(lut, b, base_r[0], base_r[1], base_r[2], lin_r[0], lin_r[1], lin_r[2], e0, e1, nbig, pos, is);
@@ -341,17 +366,18 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
   const unsigned slen1 = U.slen[s.scalefac_compress * 2], slen2 = U.slen[s.scalefac_compress * 2 + 1];
   const bool wsf = (s.flags & PDMP3_GC_WIN_SWITCH) != 0;
   const unsigned bt = (s.flags & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT;
-  FieldWin fw{0, 0};
+  RegWin r;
+  rw_open(r, res, b.pos);
   if (wsf && bt == 2) {
     unsigned first_short = 0;
     if (s.flags & PDMP3_GC_MIXED) {
-      for (unsigned sfb = 0; sfb < 8; sfb++) raw->sf_l[sfb] = (uint8_t)get_field(b, fw, slen1);
+      for (unsigned sfb = 0; sfb < 8; sfb++) raw->sf_l[sfb] = (uint8_t)get_field(b, r, slen1);
       raw->sf_l_set = 0xffu;
       first_short = 3;
     }
     unsigned set = 0;
     for (unsigned sfb = first_short; sfb < 12; sfb++) {
-      for (unsigned w = 0; w < 3; w++) raw->sf_s[sfb * 3 + w] = (uint8_t)get_field(b, fw, sfb < 6 ? slen1 : slen2);
+      for (unsigned w = 0; w < 3; w++) raw->sf_s[sfb * 3 + w] = (uint8_t)get_field(b, r, sfb < 6 ? slen1 : slen2);
       set |= 1u << sfb;
     }
     raw->sf_s_set = (uint16_t)set;
@@ -360,7 +386,7 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
     for (unsigned g4 = 0; g4 < 4; g4++) {
       const unsigned lo = g4 ? 1 + 5 * g4 : 0, hi = 6 + 5 * g4, nb = g4 < 2 ? slen1 : slen2;
       if (gr == 1 && (F.scfsi[ch] >> g4 & 1)) copy |= 1u << g4;
-      else for (unsigned sfb = lo; sfb < hi; sfb++) { raw->sf_l[sfb] = (uint8_t)get_field(b, fw, nb); set |= 1u << sfb; }
+      else for (unsigned sfb = lo; sfb < hi; sfb++) { raw->sf_l[sfb] = (uint8_t)get_field(b, r, nb); set |= 1u << sfb; }
     }
     raw->sf_l_set = set;
     raw->sf_l_copy = (uint8_t)copy;
@@ -381,21 +407,24 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
   if (e0 > nbig) e0 = nbig;
   if (e1 > nbig) e1 = nbig;
   if (e1 < e0) e1 = e0;
-  unsigned pos = unpack_pairs(U, lut, b, s, e0, e1, nbig, spectra_gc);
+  unsigned pos = unpack_pairs(U, lut, b, r, s, e0, e1, nbig, spectra_gc);
   // count1 region: table 32 or the reference's mis-pointed table 33 (H1); both books are <= 8 bits deep
   const unsigned qbase = U.book_base[U.book_of_table[32 + s.count1table_select]];
   while (pos <= 572 && b.pos <= end && b.pos <= kFastLimit) {     // both count1 books are <= 8 bits deep: one lookup
-    const uint64_t w = peek64(b);
-    const uint32_t e = lut[qbase + (unsigned)(w >> (64 - kHuffFirstBits))];
-    unsigned used = (e >> 8) & 0xff;
+    uint32_t w = rw_peek(r, b.pos);                // code (<= 6 bits) and up to four signs
+    const uint32_t e = lut[qbase + (w >> (32 - kHuffFirstBits))];
+    const unsigned len = (e >> 8) & 0xff;
+    w <<= len;
+    unsigned used = len;
     int q[4];
     for (int k = 0; k < 4; k++) {                  // v w x y: a sign bit follows each nonzero one
-      const bool nz = ((e >> (3 - k)) & 1) != 0;
-      const bool neg = nz && ((w << used) >> 63) != 0;
+      const unsigned nz = (e >> (3 - k)) & 1;
+      q[k] = (nz && (w >> 31)) ? -1 : (int)nz;
+      w <<= nz;
       used += nz;
-      q[k] = neg ? -1 : (int)nz;
     }
     b.pos += used;
+    rw_step(r, b.pos);
     store_pair(spectra_gc, pos, q[0], q[1]);
     store_pair(spectra_gc, pos + 2, q[2], q[3]);
     pos += 4;
