@@ -146,19 +146,21 @@ PD_HD void rw_open(RegWin& r, const uint8_t* buf, unsigned pos) {
   if (r.wi > kFastLimit / 32) r.wi = kFastLimit / 32;      // (a position out there is never read through the window)
   r.d0 = __builtin_bswap32(r.row[r.wi]);
   r.d1 = __builtin_bswap32(r.row[r.wi + 1]);
-  r.nx = r.row[r.wi + 2];
+  r.nx = 0;
 }
 PD_HD uint32_t rw_peek(const RegWin& r, unsigned pos) {     // 32 bits from bit `pos` (pos >> 5 == r.wi)
   const unsigned s = pos & 31;
   return (uint32_t)(((((uint64_t)r.d0) << 32) | r.d1) >> (32 - s));   // one 64-bit shift (32 - s is 1..32: no branch for s = 0)
 }
-PD_HD void rw_step(RegWin& r, unsigned pos) {               // pos has moved by < 32 bits since the last step
+// ask for the word after the window; rw_step() takes it.  Kept apart so that no load is in flight across a loop's
+// back edge (the compiler then waits for it at the loop head) and the lookup's wait covers this one too.
+PD_HD void rw_ask(RegWin& r) { r.nx = r.row[r.wi + 2]; }
+PD_HD void rw_step(RegWin& r, unsigned pos) {               // pos has moved by < 32 bits since rw_ask()
   const bool adv = (pos >> 5) != r.wi;
   const uint32_t sw = __builtin_bswap32(r.nx);
   r.d0 = adv ? r.d1 : r.d0;
   r.d1 = adv ? sw : r.d1;
   r.wi = pos >> 5;
-  r.nx = r.row[r.wi + 2];
 }
 
 // Short fields in a row (scalefactors).  Same per-call decision as get_bits: past kFastLimit the byte-wise clamped window.
@@ -166,7 +168,7 @@ PD_HD unsigned get_field(BitPos& b, RegWin& r, unsigned n) {   // n <= 16
   if (!n) return 0;
   unsigned v;
   if (b.pos > kFastLimit) v = peek32(b) >> (32 - n);
-  else v = rw_peek(r, b.pos) >> (32 - n);
+  else { rw_ask(r); v = rw_peek(r, b.pos) >> (32 - n); }
   b.pos += n;
   if (b.pos <= kFastLimit + 32) rw_step(r, b.pos);
   return v;
@@ -273,6 +275,7 @@ PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& 
     const unsigned linbits = pos < e0 ? lin_r[0] : pos < e1 ? lin_r[1] : lin_r[2];
     if (base < 0) continue;
     // the code word: <= 19 bits
+    rw_ask(r);
     const uint32_t w = rw_peek(r, b.pos);
     const uint32_t e1st = lut[(unsigned)base + (w >> (32 - kHuffFirstBits))];
     const bool link = (e1st & 0x80000000u) != 0;
@@ -283,6 +286,7 @@ PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& 
     }
     b.pos += (link ? (unsigned)kHuffFirstBits : 0u) + ((e >> 8) & 0xff);
     rw_step(r, b.pos);
+    rw_ask(r);
     // linbits and signs of both values: <= 28 bits.  (v >> 1) >> (31 - n) == v >> (32 - n) for n = 1..31 and 0 for n = 0
     uint32_t w2 = rw_peek(r, b.pos);
     int x = (int)((e >> 4) & 15), y = (int)(e & 15);
@@ -411,6 +415,7 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
   // count1 region: table 32 or the reference's mis-pointed table 33 (H1); both books are <= 8 bits deep
   const unsigned qbase = U.book_base[U.book_of_table[32 + s.count1table_select]];
   while (pos <= 572 && b.pos <= end && b.pos <= kFastLimit) {     // both count1 books are <= 8 bits deep: one lookup
+    rw_ask(r);
     uint32_t w = rw_peek(r, b.pos);                // code (<= 6 bits) and up to four signs
     const uint32_t e = lut[qbase + (w >> (32 - kHuffFirstBits))];
     const unsigned len = (e >> 8) & 0xff;
