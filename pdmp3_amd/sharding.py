@@ -8,13 +8,16 @@ decode loop.  Whole files (independent streams, config C4) are dealt
 largest-first to the least loaded rank.  The one exchange of the path is the
 final PCM gather to rank 0.
 """
-# The fixed halo covers a stream whose channel count does not change inside it (C5 is all stereo; a file of a corpus
-# is decoded whole by one rank).  Across a run of MONO frames channel 1's state is the last stereo frame's, however
-# far back that is: inside one launch the kernel looks for it itself (decode_core.h: pre-halo), but it cannot look
-# in front of the records it is given -- a shard boundary right after mono frames of a stream that also has stereo
-# frames would start channel 1 from zero.  Shard such streams at frames where the channel count is settled (or
-# decode them through the whole-stream decoder, which carries the state from window to window).
+# The fixed halo covers a stream whose channel count does not change around the cut (C5 is all stereo; a file of a
+# corpus is decoded whole by one rank).  Across a run of MONO frames channel 1's state is the last stereo frame's,
+# however far back that is: inside one launch the kernel looks for it itself (decode_core.h: pre-halo), but it cannot
+# look in front of the records it is given.  So when the frame before a cut is mono, the shard starts further back:
+# at the frame in front of the last stereo frame (what the kernel's pre-halo wants to see), or at that frame itself
+# when it carries PDMP3_FR_RESET.  Pass the per-frame flag bytes (pdmp3_gc_side.frame of any record of the frame) for
+# that; without them the halo is the fixed one.
 HALO_FRAMES = 2
+
+_FR_MODE_SHIFT, _FR_RESET = 2, 0x40           # include/pdmp3_hip.h: PDMP3_FR_MODE_SHIFT, PDMP3_FR_RESET
 
 
 def frame_range(n_frames, rank, world):
@@ -25,11 +28,33 @@ def frame_range(n_frames, rank, world):
     return lo, hi
 
 
-def shard_with_halo(n_frames, rank, world, halo=HALO_FRAMES):
+def halo_start(lo, frame_flags=None, halo=HALO_FRAMES):
+    """First frame a shard that emits frames from `lo` on has to decode (cf. last_stereo_or_reset in decode_core.h)."""
+    first = max(0, lo - halo)
+    if frame_flags is None or lo <= 0:
+        return first
+
+    def mono(f):
+        return ((int(frame_flags[f]) >> _FR_MODE_SHIFT) & 3) == 3
+
+    def reset(f):
+        return bool(int(frame_flags[f]) & _FR_RESET)
+
+    if not mono(lo - 1) or reset(lo - 1):
+        return first
+    f = lo - 2
+    while f >= 0 and mono(f) and not reset(f):
+        f -= 1
+    if f < 0 or mono(f):                      # no stereo frame back to the start / a mono RESET frame: channel 1 is zero
+        return first
+    return min(first, f if (reset(f) or f == 0) else f - 1)
+
+
+def shard_with_halo(n_frames, rank, world, halo=HALO_FRAMES, frame_flags=None):
     """(first_frame_to_decode, n_frames_to_decode, n_halo_frames_to_discard)."""
     lo, hi = frame_range(n_frames, rank, world)
-    h = min(halo, lo)
-    return lo - h, (hi - lo) + h, h
+    first = halo_start(lo, frame_flags, halo)
+    return first, hi - first, lo - first
 
 
 def assign_files(sizes, world):

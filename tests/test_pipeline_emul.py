@@ -103,6 +103,28 @@ def test_emul_channel1_state_across_batches(oracle, emul):
             assert np.array_equal(np.concatenate(out), whole), (chunk, cuts)
 
 
+def test_shard_cut_after_mono_frames_reaches_back_to_the_last_stereo_frame(emul):
+    """pdmp3_amd.sharding.halo_start: a shard whose cut follows mono frames starts in front of the last stereo frame,
+    so that channel 1 is what that frame left (the kernel's pre-halo finds it inside the shard); with the fixed
+    2-frame halo alone some of these cuts come out wrong -- the test must bite"""
+    from pdmp3_amd.sharding import halo_start
+    sp, sd = _mode_switch_records()
+    n = sp.shape[0]
+    flags = sd["frame"][:, 0, 0] if sd["frame"].ndim == 3 else sd["frame"].reshape(n, -1)[:, 0]
+    whole = emul_decode(emul, sp, sd, 0)
+    fixed_fails = 0
+    for lo in range(1, n):
+        first = halo_start(lo, flags)
+        assert 0 <= first <= max(0, lo - 2) or first == 0
+        part = emul_decode(emul, sp[first:], sd[first:], 3)[lo - first:]
+        assert np.array_equal(part, whole[lo:]), (lo, first)
+        f2 = max(0, lo - 2)
+        if first != f2 and not np.array_equal(emul_decode(emul, sp[f2:], sd[f2:], 3)[lo - f2:], whole[lo:]):
+            fixed_fails += 1
+    assert fixed_fails > 0
+    assert halo_start(lo, None) == lo - 2 and halo_start(0, flags) == 0
+
+
 def test_oracle_float_pcm_is_what_the_int16_comes_from(oracle):
     """float output is pinned through its quantisation: the oracle's int16 PCM -- bit-exact against the compiled
     reference (test_oracle.py) -- is clip(trunc(float * 32767)) of the float it hands out (P:2028-2031)"""
