@@ -42,7 +42,7 @@ typedef struct bulk pdmp3_amd_bulk;
 
 /* threads <= 0: one worker per usable CPU (affinity and cgroup quota; at most 64; 4 with device Huffman, where the
  * pool only copies PCM out).  window_frames <= 0:
- * 2048 frames per GPU batch.  Returns NULL when there is no transform engine
+ * 2048 frames per GPU batch (at most 32768).  Returns NULL when there is no transform engine
  * (no CPU fallback). */
 pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
 /* host_huffman = 0 (what pdmp3_amd_bulk_new gives unless PDMP3_BULK_HOST_HUFFMAN=1 is set): the host only runs

@@ -1666,6 +1666,7 @@ static int bits_push(struct bulk* b) {
       while (b->sky_n && b->desc_dst[b->sky[b->sky_n - 1]].top <= d->top) b->sky_n--;
       d->up = (uint16_t)(b->sky_n ? i - b->sky[b->sky_n - 1] : 0);
       b->sky[b->sky_n++] = i;
+      if (i - b->seg_first >= 65000) pool_materialize(b);   /* (`back` / `up` are 16 bits: a very long window starts a new segment) */
     }
   } else memcpy(b->res_dst + (size_t)i * RESERVOIR_BYTES, id->main_vec, RESERVOIR_BYTES);
   if (b->hs) b->flight[b->bits_slot].nch[i] = (uint8_t)(id->hdr.mode == 3 ? 1 : 2);
@@ -1780,6 +1781,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
     if (bits_mode && threads > 4) threads = 4;   /* the pool only copies PCM out */
   }
   if (window_frames <= 0) window_frames = 2048;
+  if (window_frames > 32768) window_frames = 32768;
   struct bulk* b = (struct bulk*)calloc(1, sizeof *b);
   if (!b) return NULL;
   b->cap = window_frames;

@@ -187,3 +187,17 @@ def test_pool_rows_are_the_snapshot_rows(emul):
     # fill -- H18, an explicit image -- needs a frame longer than 1152 bytes cut short: those streams take the ring-replay path)
     assert checked > 5000 and segments >= parsed + 8
     print("rows %d, segments %d, explicit images %d" % (checked, segments, explicit))
+
+
+def test_pool_window_longer_than_the_link_fields(emul):
+    """`back` / `up` of pdmp3_row_desc are 16 bits: a window of more than 65000 frames (only the parse hook makes one; the
+    engine's windows are capped at 32768) starts a new segment, rows unchanged"""
+    from pdmp3_amd import api
+    mp3 = np.frombuffer(packer.generate(n_frames=67000, seed=5, sfreq=2, mode=3, bitrate_index=1), dtype=np.uint8)
+    bits, res, _ = api.parse_bits(mp3)
+    bits2, desc, pool = api.parse_pool(mp3)
+    assert len(bits) > 66000 and np.array_equal(bits2.view(np.uint8), bits.view(np.uint8))
+    assert int((desc["back"] == 0).sum()) == 2 and int(desc["back"].max()) == 65000
+    rows = np.zeros((len(bits), 2064), dtype=np.uint8)
+    emul.emul_rows(desc.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p), len(bits), rows.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(rows, res)
