@@ -60,6 +60,16 @@
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
   __builtin_amdgcn_wave_barrier();                          \
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
+// chained chunks: a wave hands its frame's closing state to the wave of the next frame through global memory.  The two
+// waves may sit on different XCDs, whose L2s are not coherent for ordinary accesses.  Device-scope release / acquire
+// FENCES write back / invalidate a whole L2 here (tried: the C2 launch went from 37 to 98 us), so the state travels in
+// device-scope relaxed ATOMIC accesses (sc1: written through, read past the reader's L1), ordered against the flag by
+// the wave's own vector-memory counter; nothing else is flushed.  (A second path through the shared L2 for waves of
+// the same XCD -- ordinary stores, an earlier flag -- was no faster.)  The waiting wave sleeps between polls.
+#define PD_STORE_DEVICE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define PD_LOAD_DEVICE(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define PD_VMEM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define PD_SLEEP() __builtin_amdgcn_s_sleep(4)
 #else
 namespace pdmp3 {
 namespace emu {   // provided by tests/host_emul/wave_emul.h: one wave = 64 fibers
@@ -85,6 +95,11 @@ void permlane32_swap(int* a, int* b);         // v_permlane32_swap_b32 vdst = a,
 #define PD_UNIFORM(x) ((int)(x))
 #define PD_SHFL_XOR(v, m) (::pdmp3::emu::shfl_xor((v), (m)))
 #define PD_WAVE_SYNC() ::pdmp3::emu::wave_sync()
+// (the host build runs the waves one after the other in frame order: a flag is always set before it is waited for)
+#define PD_STORE_DEVICE(p, v) (*(p) = (v))
+#define PD_LOAD_DEVICE(p) (*(p))
+#define PD_VMEM_DRAIN() ::pdmp3::emu::wave_sync()
+#define PD_SLEEP() __builtin_trap()        /* the host build runs the waves in frame order: nothing is ever waited for */
 #endif
 
 namespace pdmp3 {
@@ -136,7 +151,7 @@ struct GlobalTables {
   const float* frag_mat;    // [2 even/odd][4 k-steps]: 16 x 16 halves of the 32-point DCT-II, rows in register order
 };
 
-// LDS per wave (~12.3 KB).  Buffers whose lifetimes do not overlap share storage:
+// LDS per wave (~16.9 KB).  Buffers whose lifetimes do not overlap share storage:
 //   xr   (ph_requant .. ph_fetch)           | hyb  (ph_imdct .. ph_window)
 // hyb rows are [slot t][33]: the DCT lane that owns slot t transforms its row in place.
 struct WaveLds {
@@ -153,6 +168,7 @@ struct WaveLds {
   alignas(16) uint16_t ltab[3][576];
   float peek[4];
   float lo[2][4][16];       // MFMA build: even / odd folded time slots 16, 17: [a|b][2 ch + (t - 16)][k]
+  float park[18][64];       // chained chunks: granule 0's hybrid outputs until the frame before has been transformed
 };
 
 typedef uint32_t Chunk16 __attribute__((vector_size(16)));   // one 16-byte global/LDS access
@@ -249,6 +265,28 @@ PD_FN void state_load(int lane, LaneRegs& R, const float* st) {
   for (int s = 0; s < kHistSlots; s++) {
     R.he[s] = st[(kOvlRegs + s) * 64 + lane];
     R.ho[s] = st[(kOvlRegs + kHistSlots + s) * 64 + lane];
+  }
+}
+
+// chained chunks: the state a frame leaves, for the wave of the next frame (see PD_STORE_DEVICE above);
+// *flag == epoch once it is all there.  (Tried instead: every value with the epoch in one 8-byte access, no flag and no
+// drain -- the readers' retries of 24 KB each made the launch 30 % slower.)
+PD_FN void chain_publish(int lane, const LaneRegs& R, float* st, unsigned* flag, unsigned epoch) {
+  for (int m = 0; m < kOvlRegs; m++) PD_STORE_DEVICE(&st[m * 64 + lane], R.ovl[m]);
+  for (int s = 0; s < kHistSlots; s++) {
+    PD_STORE_DEVICE(&st[(kOvlRegs + s) * 64 + lane], R.he[s]);
+    PD_STORE_DEVICE(&st[(kOvlRegs + kHistSlots + s) * 64 + lane], R.ho[s]);
+  }
+  PD_VMEM_DRAIN();
+  if (lane == 0) PD_STORE_DEVICE(flag, epoch);
+}
+PD_FN void chain_take(int lane, LaneRegs& R, const float* st, const unsigned* flag, unsigned epoch) {
+  while ((unsigned)PD_UNIFORM(PD_LOAD_DEVICE(flag)) != epoch) PD_SLEEP();
+  asm volatile("" ::: "memory");
+  for (int m = 0; m < kOvlRegs; m++) R.ovl[m] = PD_LOAD_DEVICE(&st[m * 64 + lane]);
+  for (int s = 0; s < kHistSlots; s++) {
+    R.he[s] = PD_LOAD_DEVICE(&st[(kOvlRegs + s) * 64 + lane]);
+    R.ho[s] = PD_LOAD_DEVICE(&st[(kOvlRegs + kHistSlots + s) * 64 + lane]);
   }
 }
 
@@ -526,9 +564,14 @@ PD_FN void ph_peek_tail(int lane, const WaveLds& L, LaneRegs& R, const GlobalTab
   R.ovl[0] = y;
 }
 
-template <bool DUMP>
+// MODE (chained chunks, run_chunk_chained): 0 = the whole phase; kPark = the same, and the hybrid outputs -- computed
+// against whatever R.ovl holds (zero there) -- are also left in park[18][64] (indexed like R.ovl); kFromPark = no IMDCT:
+// the outputs are park[] plus the overlap tails R.ovl now holds (sign as below: -(a + b) == (-a) + (-b) exactly), then
+// the matrixing as usual; R.ovl is left alone.
+constexpr int kPark = 1, kFromPark = 2;
+template <bool DUMP, int MODE = 0>
 PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTables& T, float* dump2, float* dump3,
-                   bool do_matrix) {   // do_matrix (wave-uniform) = false: a halo granule whose polyphase input nobody reads
+                   bool do_matrix, float* park = nullptr) {   // do_matrix (wave-uniform) = false: a halo granule whose polyphase input nobody reads
   const GranuleInfo g = granule_info(L);
   const int j = lane & 15, kq = lane >> 4;
   if (DUMP) {   // stage 2 = lines after alias reduction
@@ -544,6 +587,11 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTa
   {
     const int cl = lane >> 5, sb = lane & 31;
     const bool act = cl < g.nch;
+    float o16, o17;
+    if (MODE == kFromPark) {
+      o16 = park[16 * 64 + lane] + R.ovl[16];
+      o17 = park[17 * 64 + lane] + ((sb & 1) ? -R.ovl[17] : R.ovl[17]);
+    } else {
     const bool lwsf = (g.flags(cl) & PDMP3_GC_WIN_SWITCH) != 0;
     const bool llow = lwsf && g.is_mixed(cl) && sb < 2;
     const bool lshort = g.is_short(cl) && !llow;
@@ -561,10 +609,12 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTa
         PD_UNROLL for (int q = 0; q < 4; q++) ys[q] = PD_FMA(in[m], cb->s36x[q][m], ys[q]);
       PD_UNROLL for (int q = 0; q < 4; q++) y[q] = lshort ? ys[q] : y[q];
     }
-    float o16 = y[0] + R.ovl[16], o17 = y[1] + R.ovl[17];                 // P:1775
+    o16 = y[0] + R.ovl[16]; o17 = y[1] + R.ovl[17];                       // P:1775
     R.ovl[16] = act ? y[2] : R.ovl[16];                                   // P:1776
     R.ovl[17] = act ? y[3] : R.ovl[17];
     if (sb & 1) o17 = -o17;                                               // P:1738-1746
+    if (MODE == kPark) { park[16 * 64 + lane] = o16; park[17 * 64 + lane] = o17; }
+    }
     if (DUMP) { if (act) { dump3[cl * 4 * 576 + 18 * sb + 16] = o16; dump3[cl * 4 * 576 + 18 * sb + 17] = o17; } }
     // matrixing fold: x[k] +- x[31 - k]; subband 31 - sb of the same channel is lane ^ 31
     if (do_matrix) {
@@ -580,6 +630,18 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTa
   PD_UNROLL for (int cc = 0; cc < 2; cc++) {
     const int ch = 1 - cc;
     if (ch < g.nch) {                    // wave-uniform
+      float outa[8];
+      if (MODE == kFromPark) {
+        PD_UNROLL for (int h = 0; h < 2; h++)
+          PD_UNROLL for (int r = 0; r < 4; r++) {
+            const int oi = ch * 8 + h * 4 + r;
+            const int sb = h ? 31 - (4 * kq + r) : 4 * kq + r;
+            const bool flip = (sb & 1) && (j & 1);
+            const float o = park[oi * 64 + lane] + (flip ? -R.ovl[oi] : R.ovl[oi]);
+            outa[h * 4 + r] = o;
+            if (ch == 0 && h == 0 && r == 0 && kq == 0 && j < 3) L.peek[j] = o;
+          }
+      } else {
       const bool shrt = g.is_short(ch);
       const bool wsf = (g.flags(ch) & PDMP3_GC_WIN_SWITCH) != 0;
       const bool mixrows = wsf && g.is_mixed(ch);        // subbands 0, 1 use window/transform 0 (P:1769-1771)
@@ -612,7 +674,6 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTa
       const float* w0 = L.win[0];
       const float wb1 = wb[j], wb2 = wb[18 + j];
       const float w01 = w0[j], w02 = w0[18 + j];
-      float outa[8];
       PD_UNROLL for (int h = 0; h < 2; h++)
         PD_UNROLL for (int r = 0; r < 4; r++) {
           const bool lowrow = mixrows && h == 0 && kq == 0 && r < 2;      // subbands 0, 1 (first tile, rows 0, 1)
@@ -627,9 +688,11 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTa
           const int sb = h ? 31 - (4 * kq + r) : 4 * kq + r;              // subband of this row (tile 1 is reversed)
           if ((sb & 1) && (j & 1)) o = -o;                                // P:1738-1746: odd subband, odd sample
           outa[h * 4 + r] = o;
+          if (MODE == kPark) park[oi * 64 + lane] = o;
           if (DUMP) dump3[ch * 4 * 576 + 18 * sb + j] = o;
           if (ch == 0 && h == 0 && r == 0 && kq == 0 && j < 3) L.peek[j] = o;   // H5 source: (ch 0, sb 0, t 0..2)
         }
+      }
       // matrixing of time slots t = j (rows) of this channel: butterflies, then even / odd 16 x 16 products
       if (do_matrix) {
         f32x4 me = (f32x4){0, 0, 0, 0}, mo = (f32x4){0, 0, 0, 0};
@@ -717,48 +780,19 @@ PD_FN void permlane32_swap(int& a, int& b) {
 #endif
 }
 
-// full = false (wave-uniform): the last halo granule -- only its slots 3..17 are wanted, as the next granule's history
+// the 18 sums of a lane (P:2028) -> PCM of the granule: conversion, channel pairing, stores
 template <bool F32>
-PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int16_t* pcm_g, float* pcmf_g) {
-  const GranuleInfo g = granule_info(L);
-  const int ch = lane >> 5, i = lane & 31;
-  const bool act = ch < g.nch;                 // (mono: lanes 32..63 idle, their history is channel 1's and stays)
-  if (!full) {
-    if (act) {
-      PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
-        R.he[s] = L.hyb[ch][3 + s][R.idx_e];
-        R.ho[s] = L.hyb[ch][3 + s][R.idx_o];
-      }
-    }
-    return;
-  }
+PD_FN void pcm_emit(int lane, WaveLds& L, int nch, bool act, const float* sum, int16_t* pcm_g, float* pcmf_g) {
+  const int i = lane & 31;
   int out[18];
   if (act) {
-    // E[s], O[s]: the lane's two coefficients of slot s; s = 0..14 history, 15..32 this granule
-    float E[kHistSlots + 18], O[kHistSlots + 18];
-    PD_UNROLL for (int s = 0; s < kHistSlots; s++) { E[s] = R.he[s]; O[s] = R.ho[s]; }
-    PD_UNROLL for (int t = 0; t < 18; t++) {
-      E[kHistSlots + t] = L.hyb[ch][t][R.idx_e];
-      O[kHistSlots + t] = L.hyb[ch][t][R.idx_o];
-    }
-    const float* we = R.we; const float* wo = R.wo;
-    float sum[18];
-    PD_UNROLL for (int t = 0; t < 18; t++) {
-      float acc = 0.0f;
-      PD_UNROLL for (int k = 0; k < 8; k++) {     // P:2021-2026: u[32j+i], j = 2k (age 2k), 2k+1 (age 2k+1)
-        acc = PD_FMA(we[k], E[kHistSlots + t - 2 * k], acc);
-        acc = PD_FMA(wo[k], O[kHistSlots + t - 2 * k - 1], acc);
-      }
-      sum[t] = acc;
-    }
-    PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = E[18 + s]; R.ho[s] = O[18 + s]; }
     if (F32) {
       // float PCM: the binary32 `sum` of P:2028 itself, before the scaling to int16
       PD_UNROLL for (int t = 0; t < 18; t++) out[t] = (int)f2u(sum[t]);
     } else pcm_convert18(sum, out);
   }
   if (F32) {
-    if (g.nch == 2) {
+    if (nch == 2) {
       // same pairing as below; a lane then owns one interleaved sample-frame of two floats: 8-byte stores,
       // 64 consecutive sample-frames per instruction
       PD_UNROLL for (int q = 0; q < 9; q++) {
@@ -773,7 +807,7 @@ PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int16_t* pcm_
     }
     return;
   }
-  if (g.nch == 2) {
+  if (nch == 2) {
     // Lanes i and i + 32 hold the left and the right value of the same sample.  For a pair of time slots (t, t + 1) one
     // half exchange leaves lane i with L, R of sample (t, i) and lane i + 32 with L, R of sample (t + 1, i): every lane
     // owns one interleaved sample-frame (P:2032-2041, P:2307-2345), lane l the dword 32 t + l of the granule.
@@ -788,6 +822,76 @@ PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int16_t* pcm_
     // mono (pcm aliases nothing live: spec is dead since ph_requant; hyb reads above are done)
     if (act) { PD_UNROLL for (int t = 0; t < 18; t++) L.pcm[t * 32 + i] = (int16_t)out[t]; }
   }
+}
+
+// full = false (wave-uniform): the last halo granule -- only its slots 3..17 are wanted, as the next granule's history
+template <bool F32>
+PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int16_t* pcm_g, float* pcmf_g) {
+  const GranuleInfo g = granule_info(L);
+  const int ch = lane >> 5;
+  const bool act = ch < g.nch;                 // (mono: lanes 32..63 idle, their history is channel 1's and stays)
+  if (!full) {
+    if (act) {
+      PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
+        R.he[s] = L.hyb[ch][3 + s][R.idx_e];
+        R.ho[s] = L.hyb[ch][3 + s][R.idx_o];
+      }
+    }
+    return;
+  }
+  float sum[18];
+  if (act) {
+    // E[s], O[s]: the lane's two coefficients of slot s; s = 0..14 history, 15..32 this granule
+    float E[kHistSlots + 18], O[kHistSlots + 18];
+    PD_UNROLL for (int s = 0; s < kHistSlots; s++) { E[s] = R.he[s]; O[s] = R.ho[s]; }
+    PD_UNROLL for (int t = 0; t < 18; t++) {
+      E[kHistSlots + t] = L.hyb[ch][t][R.idx_e];
+      O[kHistSlots + t] = L.hyb[ch][t][R.idx_o];
+    }
+    const float* we = R.we; const float* wo = R.wo;
+    PD_UNROLL for (int t = 0; t < 18; t++) {
+      float acc = 0.0f;
+      PD_UNROLL for (int k = 0; k < 8; k++) {     // P:2021-2026: u[32j+i], j = 2k (age 2k), 2k+1 (age 2k+1)
+        acc = PD_FMA(we[k], E[kHistSlots + t - 2 * k], acc);
+        acc = PD_FMA(wo[k], O[kHistSlots + t - 2 * k - 1], acc);
+      }
+      sum[t] = acc;
+    }
+    PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = E[18 + s]; R.ho[s] = O[18 + s]; }
+  }
+  pcm_emit<F32>(lane, L, g.nch, act, sum, pcm_g, pcmf_g);
+}
+
+// Chained chunks (run_chunk_chained): the window sums of a stereo granule whose history is not there yet.  Every sum is
+// ONE chain of 16 FMAs from the newest slot to the oldest; the terms that read this granule's own slots come first --
+// that part is done now (partial sums to part[18][64], global scratch), the rest (ph_window_rest) when the granule
+// before it has been transformed: same operations in the same order, bit for bit what ph_window computes.
+PD_FN void ph_window_first(int lane, const WaveLds& L, const LaneRegs& R, float* part) {
+  const int ch = lane >> 5;
+  float E[18], O[18];
+  PD_UNROLL for (int t = 0; t < 18; t++) { E[t] = L.hyb[ch][t][R.idx_e]; O[t] = L.hyb[ch][t][R.idx_o]; }
+  PD_UNROLL for (int t = 0; t < 18; t++) {
+    float acc = 0.0f;
+    PD_UNROLL for (int k = 0; k < 8; k++) {
+      if (t - 2 * k >= 0) acc = PD_FMA(R.we[k], E[t - 2 * k], acc);
+      if (t - 2 * k - 1 >= 0) acc = PD_FMA(R.wo[k], O[t - 2 * k - 1], acc);
+    }
+    part[t * 64 + lane] = acc;
+  }
+}
+// R.he / R.ho = slots 3..17 of the granule before (what ph_window left); stereo granules only
+template <bool F32>
+PD_FN void ph_window_rest(int lane, WaveLds& L, const LaneRegs& R, const float* part, int16_t* pcm_g, float* pcmf_g) {
+  float sum[18];
+  PD_UNROLL for (int t = 0; t < 18; t++) {
+    float acc = part[t * 64 + lane];
+    PD_UNROLL for (int k = 0; k < 8; k++) {
+      if (t - 2 * k < 0) acc = PD_FMA(R.we[k], R.he[kHistSlots + t - 2 * k], acc);
+      if (t - 2 * k - 1 < 0) acc = PD_FMA(R.wo[k], R.ho[kHistSlots + t - 2 * k - 1], acc);
+    }
+    sum[t] = acc;
+  }
+  pcm_emit<F32>(lane, L, 2, true, sum, pcm_g, pcmf_g);
 }
 
 // PCM of a mono granule (576 samples = 1152 bytes) from the LDS staging buffer; stereo granules were stored by
@@ -847,6 +951,12 @@ struct DecodeArgs {
   int n_frames;
   int chunk_frames;
   unsigned long long* prof;      // PROF builds: [n_chunks][kProfSlots] shader-clock ticks per phase
+  // chained chunks (chunk_frames == 1, run_chunk_chained): [n_frames][kStateFloats] states after every frame,
+  // [n_frames][18][64] partial window sums, one flag per frame (== chain_epoch once the frame's state is there)
+  float* chain_state;
+  float* chain_part;
+  unsigned* chain_flag;
+  unsigned chain_epoch;          // 0: chunks are independent (halo), as described above
 };
 
 constexpr int kProfSlots = 12;
@@ -1014,6 +1124,129 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   if (last && a.state_out) {
     PD_PHASE(state_store(lane, R, a.state_out))
   }
+  if (!DUMP && !PROF && a.chain_epoch) {
+    // a chained launch (one frame per chunk) in which this frame took the independent path: the wave of the next frame
+    // may be waiting for the state it leaves (stereo frames publish theirs, mono frames are skipped by their successors)
+    const uint8_t fbl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f1 - 1) * 4)[7];
+    if (((fbl & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3) {
+      PD_PHASE(chain_publish(lane, R, a.chain_state + (size_t)(f1 - 1) * kStateFloats, a.chain_flag + (f1 - 1), a.chain_epoch))
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Chained chunks: one frame per wave WITHOUT a halo (launches of up to one round of waves, where the halo is half of
+// every wave's work).  What frame f needs from frame f - 1 -- the IMDCT tails of its second granule and slots 3..17 of
+// that granule's matrixing output -- depends on frame f - 1's own spectra only (that is why a two-granule halo can
+// re-derive it), so no wave waits for a chain: every wave first does all the work that does not need its
+// predecessor, publishes its own closing state, and only then takes its predecessor's:
+//   A  granule 0: requantise .. IMDCT; its hybrid outputs are parked in LDS (computed against zero tails)
+//   B  granule 1 completely (its overlap partner is granule 0, in registers) up to the matrixing; its window sums as
+//      the frame's closing state -> chain_state[f], flag[f]; its window sums as far as they read its own slots
+//   C  wait for flag[f - 1]; R.ovl / R.he / R.ho = chain_state[f - 1]   (frame 0 / a RESET frame: the caller's / zero)
+//   D  granule 0: parked outputs + tails, matrixing, window, PCM     E  granule 1: the rest of its window sums, PCM
+// Same operations in the same order as run_chunk on the same frames: bit-identical PCM (tests compare).
+// The H5 corner -- granule 1 / channel 1 is a short block, its requantisation reads three hybrid outputs of granule
+// 0, which need the tails -- is served by the peek-only pass of run_chunk on the granule before the frame.
+// Taken by stereo frames whose predecessor's state is available that way: frame 0, a RESET frame, or a stereo frame
+// before it (mono frames, and stereo frames after mono ones, take run_chunk and publish at its end).
+// ---------------------------------------------------------------------------
+template <bool F32>
+PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int f, WaveLds& L, bool have_prev, bool h5) {
+  LaneRegs R;
+  const int lane = PD_LANE();
+  const int g0 = 2 * f, g1 = 2 * f + 1;
+  const bool pre = h5 && have_prev;              // wave-uniform: the peek-only pass on granule g0 - 1
+  const int g_first = pre ? g0 - 1 : g0;
+  int cur_sfreq = reinterpret_cast<const uint8_t*>(a.side + (size_t)g_first * 2)[7] & PDMP3_FR_SFREQ_MASK;
+  if (cur_sfreq > 2) cur_sfreq = 2;
+  PD_PHASE(
+    ph_prefetch(lane, R, a.spectra + (size_t)g_first * 1152, a.side + (size_t)g_first * 2);
+    load_linetab(lane, L, T, cur_sfreq);
+    lane_init(lane, L, R, cb, T);
+  )
+  PD_PHASE(ph_commit(lane, L, R))
+  PD_PHASE(ph_scales(lane, L))
+  float tail3 = 0.0f;                            // lanes 0..2: IMDCT tail p = 18 + lane of (channel 0, subband 0) of the granule before
+  if (pre) {
+      PD_PHASE(ph_requant<false, 1>(lane, L, cb, T, nullptr, nullptr))
+    PD_PHASE(
+      ph_prefetch(lane, R, a.spectra + (size_t)g0 * 1152, a.side + (size_t)g0 * 2);
+      ph_antialias(lane, L, cb, true);
+    )
+    PD_PHASE(ph_peek_tail(lane, L, R, T))
+    tail3 = R.ovl[0];
+    R.ovl[0] = 0.0f;
+    PD_PHASE(ph_commit(lane, L, R))
+    PD_PHASE(ph_scales(lane, L))
+    int sf = L.side[0][7] & PDMP3_FR_SFREQ_MASK;
+    if (sf > 2) sf = 2;
+    if (sf != cur_sfreq) {
+      PD_PHASE(load_linetab(lane, L, T, sf))
+      cur_sfreq = sf;
+    }
+  } else if (h5 && a.state_in && f == 0 && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET)) {
+    tail3 = a.state_in[lane];                    // ovl[0] of the caller's state (lanes 0..2 are the ones that use it)
+  }
+  // ---- A
+  PD_LAUNDER(cb);
+  PD_PHASE(ph_requant<false>(lane, L, cb, T, nullptr, nullptr))
+  PD_PHASE(
+    ph_prefetch(lane, R, a.spectra + (size_t)g1 * 1152, a.side + (size_t)g1 * 2);
+    ph_antialias(lane, L, cb);
+  )
+  PD_PHASE(ph_mfma<false, kPark>(lane, L, R, cb, T, nullptr, nullptr, false, &L.park[0][0]))
+  PD_PHASE(if (h5 && lane < 3) L.peek[lane] += tail3)
+  PD_PHASE(ph_commit(lane, L, R))
+  PD_PHASE(ph_scales(lane, L))
+  // ---- B
+  PD_LAUNDER(cb);
+  PD_PHASE(ph_requant<false>(lane, L, cb, T, nullptr, nullptr))
+  PD_PHASE(ph_antialias(lane, L, cb))
+  PD_PHASE(ph_mfma<false, 0>(lane, L, R, cb, T, nullptr, nullptr, true))
+  float* part = a.chain_part + (size_t)f * (18 * 64);
+  PD_PHASE(ph_window<F32>(lane, L, R, false, nullptr, nullptr))
+  PD_PHASE(
+    if (f == a.n_frames - 1 && a.state_out) state_store(lane, R, a.state_out);
+    chain_publish(lane, R, a.chain_state + (size_t)f * kStateFloats, a.chain_flag + f, a.chain_epoch);
+  )
+  PD_PHASE(ph_window_first(lane, L, R, part))      // (after the hand-over: useful work while the state travels, and its
+                                                   //  stores are not waited for by the publisher: 39 -> 33 us)
+  // ---- C
+  if (have_prev) {
+    PD_PHASE(chain_take(lane, R, a.chain_state + (size_t)(f - 1) * kStateFloats, a.chain_flag + (f - 1), a.chain_epoch))
+  } else if (f == 0 && a.state_in && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET)) {
+    PD_PHASE(state_load(lane, R, a.state_in))
+  } else {
+    PD_PHASE(state_zero(lane, R))
+  }
+  // ---- D
+  PD_PHASE(ph_mfma<false, kFromPark>(lane, L, R, cb, T, nullptr, nullptr, true, &L.park[0][0]))
+  PD_PHASE(ph_window<F32>(lane, L, R, true, a.pcm + (size_t)f * 2304, F32 ? a.pcm_f32 + (size_t)f * 2304 : nullptr))
+  // ---- E
+  PD_PHASE(ph_window_rest<F32>(lane, L, R, part, a.pcm + (size_t)f * 2304 + 1152, F32 ? a.pcm_f32 + (size_t)f * 2304 + 1152 : nullptr))
+}
+
+// one frame per chunk: which of the two ways this frame goes (wave-uniform facts from the side records)
+template <bool F32>
+PD_FN void run_frame(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int f, WaveLds& L) {
+  if (a.chain_epoch) {
+    const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)f * 4)[7];
+    const bool stereo = ((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
+    const bool fresh = f == 0 || (fb & PDMP3_FR_RESET);       // its input state is the caller's / zero
+    bool prev_stereo = false;
+    if (!fresh) {
+      const uint8_t pb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f - 1) * 4)[7];
+      prev_stereo = ((pb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
+    }
+    if (stereo && (fresh || prev_stereo)) {
+      const uint8_t fl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(2 * f + 1) * 2 + 1)[3];
+      const bool h5 = (fl & PDMP3_GC_WIN_SWITCH) && ((fl & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
+      run_chunk_chained<F32>(a, T, cb, f, L, !fresh, h5);
+      return;
+    }
+  }
+  run_chunk<false, false, F32>(a, T, cb, f, L);
 }
 
 }  // namespace pdmp3

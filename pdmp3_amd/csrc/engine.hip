@@ -18,6 +18,8 @@
 #include "gen_core.h"
 #include "host_tables.h"
 #include "unpack_core.h"
+#include <mutex>
+#include <new>
 
 using namespace pdmp3;
 
@@ -49,7 +51,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg, PDMP3_WAVES_PER_EU) void k_decode
   const int w = threadIdx.x >> 6;
   const int n_wgs = (n_chunks + kWavesPerWg - 1) / kWavesPerWg;
   const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * kWavesPerWg + w;
-  if (chunk < n_chunks) run_chunk<DUMP, false, F32>(a, T, (BankPtr)&c_bank, chunk, L[w]);
+  if (chunk >= n_chunks) return;
+  if (!DUMP && a.chain_epoch) run_frame<F32>(a, T, (BankPtr)&c_bank, chunk, L[w]);   // one frame per chunk, no halo (decode_core.h)
+  else run_chunk<DUMP, false, F32>(a, T, (BankPtr)&c_bank, chunk, L[w]);
 }
 
 // same kernel with shader-clock stamps after every phase (tools/phase_profile.py)
@@ -188,6 +192,19 @@ __global__ __launch_bounds__(64) void k_merge(const GcRaw* raw, const pdmp3_fram
   if (lane == 0) state_out[t] = (uint16_t)carry;
 }
 
+// Scratch of a chained launch (DecodeArgs::chain_*): launches on one HIP stream are ordered and share a buffer,
+// launches on different streams never do.
+struct ChainBuf {
+  hipStream_t stream;
+  bool used;
+  int cap;                  // frames
+  unsigned epoch;           // of the last launch that used it; flags of older launches are smaller, never equal
+  float* state;
+  float* part;
+  unsigned* flag;
+};
+constexpr int kChainBufs = 32;
+
 struct pdmp3_hip_ctx {
   int device;
   int wave_slots;           // waves of k_decode the device holds at once (CUs x 4 SIMDs x 2)
@@ -196,6 +213,9 @@ struct pdmp3_hip_ctx {
   uint16_t* d_linetab;
   float* d_win;
   float* d_frag;            // frag_long [10][64] | frag_short [10][64] | frag_mat [8][64]
+  bool chain_on;            // PDMP3_HIP_CHAIN=0 switches the chained form of one-frame-per-chunk launches off
+  std::mutex chain_mu;
+  ChainBuf chain[kChainBufs];
 };
 
 static thread_local char g_err[256] = "";
@@ -223,7 +243,8 @@ extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   (void)hipFree(c->d_win);
   (void)hipFree(c->d_frag);
   (void)hipFree(c->d_unpack);
-  free(c);
+  for (ChainBuf& b : c->chain) { (void)hipFree(b.state); (void)hipFree(b.part); (void)hipFree(b.flag); }
+  delete c;
 }
 
 extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
@@ -234,9 +255,13 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
   build_host_tables(H);
   if (!H.ldexp_forms_exact)
     return fail(PDMP3_HIP_EDEVICE, "this host's libm pow() disagrees with the device's ldexp forms of 2^(k/4), 2^(-n/2)", hipSuccess);
-  pdmp3_hip_ctx* c = (pdmp3_hip_ctx*)calloc(1, sizeof *c);
-  if (!c) return fail(PDMP3_HIP_ENOMEM, "calloc", hipSuccess);
+  pdmp3_hip_ctx* c = new (std::nothrow) pdmp3_hip_ctx();      // (value-initialised: every pointer null)
+  if (!c) return fail(PDMP3_HIP_ENOMEM, "new", hipSuccess);
   c->device = device;
+  {
+    const char* e = getenv("PDMP3_HIP_CHAIN");
+    c->chain_on = !(e && *e == '0');
+  }
   {
     hipDeviceProp_t prop;
     c->wave_slots = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -288,6 +313,41 @@ static int auto_chunk(int n_frames, int slots) {
   return (int)(L < 1 ? 1 : L);
 }
 
+// The scratch of a chained launch of n_frames frames on stream s, or null (then the chunks stay independent).
+static ChainBuf* chain_get(pdmp3_hip_ctx* c, hipStream_t s, int n_frames) {
+  std::lock_guard<std::mutex> lock(c->chain_mu);
+  ChainBuf* b = nullptr;
+  for (ChainBuf& x : c->chain) if (x.used && x.stream == s) { b = &x; break; }
+  if (!b) for (ChainBuf& x : c->chain) if (!x.used) { b = &x; b->used = true; b->stream = s; b->cap = 0; b->epoch = 0; break; }
+  if (!b) return nullptr;
+  if (b->cap < n_frames) {                                 // (stream-ordered: earlier launches on s are done with the old one)
+    if (b->state) (void)hipFreeAsync(b->state, s);
+    if (b->part) (void)hipFreeAsync(b->part, s);
+    if (b->flag) (void)hipFreeAsync(b->flag, s);
+    b->state = b->part = nullptr; b->flag = nullptr; b->cap = 0;
+    const int cap = n_frames < 256 ? 256 : n_frames;
+    if (hipMallocAsync((void**)&b->state, (size_t)cap * kStateFloats * sizeof(float), s) != hipSuccess ||
+        hipMallocAsync((void**)&b->part, (size_t)cap * 18 * 64 * sizeof(float), s) != hipSuccess ||
+        hipMallocAsync((void**)&b->flag, (size_t)cap * sizeof(unsigned), s) != hipSuccess ||
+        hipMemsetAsync(b->flag, 0, (size_t)cap * sizeof(unsigned), s) != hipSuccess) {
+      (void)hipGetLastError();
+      if (b->state) (void)hipFreeAsync(b->state, s);
+      if (b->part) (void)hipFreeAsync(b->part, s);
+      if (b->flag) (void)hipFreeAsync(b->flag, s);
+      b->state = b->part = nullptr; b->flag = nullptr;
+      return nullptr;
+    }
+    b->cap = cap;
+    b->epoch = 0;
+  }
+  if (b->epoch == 0xffffffffu) {                           // (never in practice: flags start over)
+    if (hipMemsetAsync(b->flag, 0, (size_t)b->cap * sizeof(unsigned), s) != hipSuccess) return nullptr;
+    b->epoch = 0;
+  }
+  b->epoch++;
+  return b;
+}
+
 // d_state_tmp: where the kernel leaves the new state before it is copied over d_state (chunk 0 and the channel-1
 // pre-halo read the OLD state while the last chunk writes the new one).  Streams own one; a bare
 // pdmp3_hip_decode_frames call takes a stream-ordered allocation so that calls on different HIP streams never share it.
@@ -322,6 +382,13 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.n_frames = n_frames;
   a.chunk_frames = chunk_frames;
   a.prof = d_prof;
+  a.chain_state = nullptr; a.chain_part = nullptr; a.chain_flag = nullptr; a.chain_epoch = 0;
+  if (c->chain_on && chunk_frames == 1 && n_frames > 1 && !d_stages && !d_prof) {
+    // one frame per chunk: the waves hand their closing states on instead of decoding a halo each (run_chunk_chained)
+    if (ChainBuf* b = chain_get(c, s, n_frames)) {
+      a.chain_state = b->state; a.chain_part = b->part; a.chain_flag = b->flag; a.chain_epoch = b->epoch;
+    }
+  }
   GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64};
   if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
   else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3((nchunks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, s, a, T, nchunks);
