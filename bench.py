@@ -291,7 +291,10 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "k_decode<false, false>", "avg_launch_ms": round(kern_ms, 5),
+            # (launches of up to one round of waves at one frame per chunk are "chained": 8 waves per workgroup, states
+            #  handed from wave to wave instead of a halo per wave -- decode_core.h run_chunk_chained)
+            "kernel": "k_decode<false, false, 8>" if (n <= 2048 and not args.chunk and os.environ.get("PDMP3_HIP_CHAIN", "1") != "0")
+                      else "k_decode<false, false, 1>", "avg_launch_ms": round(kern_ms, 5),
             "algorithmic_bytes_per_launch": launch_bytes,
         },
     }
@@ -347,7 +350,7 @@ def main():
         achf = nb * 14336 / (msf * 1e-3) / 1e9
         out["roofline_float_pcm"] = {"frames": nb, "avg_launch_ms": round(msf, 4), "frames_per_s": round(nb / (msf * 1e-3), 1),
                                      "algorithmic_bytes_per_frame": 14336, "achieved": round(achf, 2), "peak": HBM_PEAK_GBS,
-                                     "unit": "GB/s", "frac": round(achf / HBM_PEAK_GBS, 5), "kernel": "k_decode<false, true>"}
+                                     "unit": "GB/s", "frac": round(achf / HBM_PEAK_GBS, 5), "kernel": "k_decode<false, true, 1>"}
         del sp2, sd2, pcm2, pcmf
 
     if world == 1 and not args.no_e2e:

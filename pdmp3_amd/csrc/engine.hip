@@ -29,12 +29,11 @@ using namespace pdmp3;
 
 __constant__ ConstBank c_bank;
 
-// A workgroup is PDMP3_WAVES_PER_WG independent wavefronts (one chunk each, no barrier between them): fewer,
-// larger workgroups only make the dispatch ramp of a launch shorter.
-#ifndef PDMP3_WAVES_PER_WG
-#define PDMP3_WAVES_PER_WG 1
-#endif
-constexpr int kWavesPerWg = PDMP3_WAVES_PER_WG;
+// A workgroup is WPW independent wavefronts (one chunk each, no barrier between them): fewer, larger workgroups only make
+// the dispatch ramp of a launch shorter.  Measured: for the chained one-frame-per-chunk launches (a wave's work is short
+// there) 8 waves per workgroup are 8 % faster than 1 (C2: 31.7 against 34.9 us on the same box); the large launches
+// lose 4 % with 8 and 2 % with 4 -- so the launch picks.
+constexpr int kWavesPerWgChained = 8;
 
 // Workgroup b is observed to run on XCD b % 8, each XCD with its own L2.  A chunk's halo is the tail of the chunk
 // before it, so neighbouring chunks should share an L2: XCD x gets the x-th contiguous eighth of the chunks
@@ -45,12 +44,12 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 }
 
 // F32: float PCM (the sums of P:2028 unscaled, DecodeArgs::pcm_f32) instead of int16
-template <bool DUMP, bool F32 = false>
-__global__ __launch_bounds__(64 * kWavesPerWg, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a, GlobalTables T, int n_chunks) {
-  __shared__ WaveLds L[kWavesPerWg];
+template <bool DUMP, bool F32 = false, int WPW = 1>
+__global__ __launch_bounds__(64 * WPW, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a, GlobalTables T, int n_chunks) {
+  __shared__ WaveLds L[WPW];
   const int w = threadIdx.x >> 6;
-  const int n_wgs = (n_chunks + kWavesPerWg - 1) / kWavesPerWg;
-  const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * kWavesPerWg + w;
+  const int n_wgs = (n_chunks + WPW - 1) / WPW;
+  const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * WPW + w;
   if (chunk >= n_chunks) return;
   if (!DUMP && a.chain_epoch) run_frame<F32>(a, T, (BankPtr)&c_bank, chunk, L[w]);   // one frame per chunk, no halo (decode_core.h)
   else run_chunk<DUMP, false, F32>(a, T, (BankPtr)&c_bank, chunk, L[w]);
@@ -391,9 +390,13 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   }
   GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64};
   if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
-  else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3((nchunks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, s, a, T, nchunks);
-  else if (d_pcm_f32) hipLaunchKernelGGL((k_decode<false, true>), dim3((nchunks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, s, a, T, nchunks);
-  else hipLaunchKernelGGL(k_decode<false>, dim3((nchunks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, s, a, T, nchunks);
+  else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
+  else if (a.chain_epoch) {
+    constexpr int W = kWavesPerWgChained;
+    if (d_pcm_f32) hipLaunchKernelGGL((k_decode<false, true, W>), dim3((nchunks + W - 1) / W), dim3(64 * W), 0, s, a, T, nchunks);
+    else hipLaunchKernelGGL((k_decode<false, false, W>), dim3((nchunks + W - 1) / W), dim3(64 * W), 0, s, a, T, nchunks);
+  } else if (d_pcm_f32) hipLaunchKernelGGL((k_decode<false, true>), dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
+  else hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
   hipError_t e = hipGetLastError();
   const char* what = "launch k_decode";
   if (e == hipSuccess && d_state) {
