@@ -70,6 +70,7 @@
 #define PD_LOAD_DEVICE(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define PD_VMEM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define PD_SLEEP() __builtin_amdgcn_s_sleep(4)
+#define PD_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
 namespace pdmp3 {
 namespace emu {   // provided by tests/host_emul/wave_emul.h: one wave = 64 fibers
@@ -100,6 +101,7 @@ void permlane32_swap(int* a, int* b);         // v_permlane32_swap_b32 vdst = a,
 #define PD_LOAD_DEVICE(p) (*(p))
 #define PD_VMEM_DRAIN() ::pdmp3::emu::wave_sync()
 #define PD_SLEEP() __builtin_trap()        /* the host build runs the waves in frame order: nothing is ever waited for */
+#define PD_SETPRIO(x) ((void)0)
 #endif
 
 namespace pdmp3 {
@@ -268,28 +270,6 @@ PD_FN void state_load(int lane, LaneRegs& R, const float* st) {
   }
 }
 
-// chained chunks: the state a frame leaves, for the wave of the next frame (see PD_STORE_DEVICE above);
-// *flag == epoch once it is all there.  (Tried instead: every value with the epoch in one 8-byte access, no flag and no
-// drain -- the readers' retries of 24 KB each made the launch 30 % slower.)
-PD_FN void chain_publish(int lane, const LaneRegs& R, float* st, unsigned* flag, unsigned epoch) {
-  for (int m = 0; m < kOvlRegs; m++) PD_STORE_DEVICE(&st[m * 64 + lane], R.ovl[m]);
-  for (int s = 0; s < kHistSlots; s++) {
-    PD_STORE_DEVICE(&st[(kOvlRegs + s) * 64 + lane], R.he[s]);
-    PD_STORE_DEVICE(&st[(kOvlRegs + kHistSlots + s) * 64 + lane], R.ho[s]);
-  }
-  PD_VMEM_DRAIN();
-  if (lane == 0) PD_STORE_DEVICE(flag, epoch);
-}
-PD_FN void chain_take(int lane, LaneRegs& R, const float* st, const unsigned* flag, unsigned epoch) {
-  while ((unsigned)PD_UNIFORM(PD_LOAD_DEVICE(flag)) != epoch) PD_SLEEP();
-  asm volatile("" ::: "memory");
-  for (int m = 0; m < kOvlRegs; m++) R.ovl[m] = PD_LOAD_DEVICE(&st[m * 64 + lane]);
-  for (int s = 0; s < kHistSlots; s++) {
-    R.he[s] = PD_LOAD_DEVICE(&st[(kOvlRegs + s) * 64 + lane]);
-    R.ho[s] = PD_LOAD_DEVICE(&st[(kOvlRegs + kHistSlots + s) * 64 + lane]);
-  }
-}
-
 // channel 1's part of the carried state only: its overlap tails (ovl[8..15] in every lane, ovl[16..17] in the
 // (ch 1, sb) lanes) and its polyphase history; what a run of mono frames leaves untouched (P:1777, P:2126 are
 // indexed by channel)
@@ -312,6 +292,51 @@ PD_FN void state_store(int lane, const LaneRegs& R, float* st) {
     st[(kOvlRegs + kHistSlots + s) * 64 + lane] = R.ho[s];
   }
 }
+
+// chained chunks: the state a frame leaves, for the wave of the next frame (see PD_STORE_DEVICE above).
+// A workgroup is WPW waves with consecutive frames on ONE CU.  Inside it the state goes through ordinary stores and
+// loads (one L1, one L2) and a flag in LDS; only the workgroup's last wave publishes for the device (sc1 accesses, a flag
+// in global memory), read by wave 0 of the next workgroup.  That last wave also runs at raised priority until it has
+// published: it gets there in half the time, its SIMD partner catches up while it waits for its own predecessor, and the
+// slow hand-over across workgroups (8 us through the fabric) has that long to arrive before it is wanted.
+// (Tried instead of flags: every value with the epoch in one 8-byte access -- the readers' retries of 24 KB each made the
+// launch 30 % slower.)
+struct ChainPos {
+  unsigned* wg_flag;     // LDS, one per wave of the workgroup: == epoch once that wave's state can be read on this CU
+  int w;                 // this wave's place in its workgroup
+  bool last_in_wg;       // its successor, if any, runs in another workgroup
+};
+PD_FN void chain_publish(int lane, const LaneRegs& R, float* st, unsigned* gflag, unsigned epoch, const ChainPos& cp) {
+  if (cp.last_in_wg) {
+    for (int m = 0; m < kOvlRegs; m++) PD_STORE_DEVICE(&st[m * 64 + lane], R.ovl[m]);
+    for (int s = 0; s < kHistSlots; s++) {
+      PD_STORE_DEVICE(&st[(kOvlRegs + s) * 64 + lane], R.he[s]);
+      PD_STORE_DEVICE(&st[(kOvlRegs + kHistSlots + s) * 64 + lane], R.ho[s]);
+    }
+    PD_VMEM_DRAIN();
+    if (lane == 0) PD_STORE_DEVICE(gflag, epoch);
+  } else {
+    state_store(lane, R, st);
+    PD_VMEM_DRAIN();
+    if (lane == 0) *reinterpret_cast<volatile unsigned*>(&cp.wg_flag[cp.w]) = epoch;
+  }
+}
+PD_FN void chain_take(int lane, LaneRegs& R, const float* st, const unsigned* gflag, unsigned epoch, const ChainPos& cp) {
+  if (cp.w > 0) {
+    while ((unsigned)PD_UNIFORM(*reinterpret_cast<volatile unsigned*>(&cp.wg_flag[cp.w - 1])) != epoch) PD_SLEEP();
+    asm volatile("" ::: "memory");
+    state_load(lane, R, st);
+  } else {
+    while ((unsigned)PD_UNIFORM(PD_LOAD_DEVICE(gflag)) != epoch) PD_SLEEP();
+    asm volatile("" ::: "memory");
+    for (int m = 0; m < kOvlRegs; m++) R.ovl[m] = PD_LOAD_DEVICE(&st[m * 64 + lane]);
+    for (int s = 0; s < kHistSlots; s++) {
+      R.he[s] = PD_LOAD_DEVICE(&st[(kOvlRegs + s) * 64 + lane]);
+      R.ho[s] = PD_LOAD_DEVICE(&st[(kOvlRegs + kHistSlots + s) * 64 + lane]);
+    }
+  }
+}
+
 
 // ---------------------------------------------------------------------------
 // ph_prefetch / ph_commit: 2304 B spectra + 256 B side of one granule,
@@ -970,7 +995,7 @@ constexpr int kProfSlots = 12;
   PD_WAVE_SYNC();
 
 template <bool DUMP, bool PROF = false, bool F32 = false>
-PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveLds& L) {
+PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveLds& L, const ChainPos* cp = nullptr) {
   LaneRegs R;
   const int lane = PD_LANE();
   const unsigned long long t_wave_start = PROF ? PD_CLOCK() : 0ull;
@@ -1129,7 +1154,8 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     // may be waiting for the state it leaves (stereo frames publish theirs, mono frames are skipped by their successors)
     const uint8_t fbl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f1 - 1) * 4)[7];
     if (((fbl & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3) {
-      PD_PHASE(chain_publish(lane, R, a.chain_state + (size_t)(f1 - 1) * kStateFloats, a.chain_flag + (f1 - 1), a.chain_epoch))
+      const ChainPos alone{nullptr, 0, true};
+      PD_PHASE(chain_publish(lane, R, a.chain_state + (size_t)(f1 - 1) * kStateFloats, a.chain_flag + (f1 - 1), a.chain_epoch, cp ? *cp : alone))
     }
   }
 }
@@ -1152,9 +1178,11 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
 // before it (mono frames, and stereo frames after mono ones, take run_chunk and publish at its end).
 // ---------------------------------------------------------------------------
 template <bool F32>
-PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int f, WaveLds& L, bool have_prev, bool h5) {
+PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int f, WaveLds& L, bool have_prev, bool h5,
+                           const ChainPos& cp) {
   LaneRegs R;
   const int lane = PD_LANE();
+  if (cp.last_in_wg) PD_SETPRIO(3);              // (until its state is out: see ChainPos)
   const int g0 = 2 * f, g1 = 2 * f + 1;
   const bool pre = h5 && have_prev;              // wave-uniform: the peek-only pass on granule g0 - 1
   const int g_first = pre ? g0 - 1 : g0;
@@ -1208,13 +1236,14 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
   PD_PHASE(ph_window<F32>(lane, L, R, false, nullptr, nullptr))
   PD_PHASE(
     if (f == a.n_frames - 1 && a.state_out) state_store(lane, R, a.state_out);
-    chain_publish(lane, R, a.chain_state + (size_t)f * kStateFloats, a.chain_flag + f, a.chain_epoch);
+    chain_publish(lane, R, a.chain_state + (size_t)f * kStateFloats, a.chain_flag + f, a.chain_epoch, cp);
   )
+  if (cp.last_in_wg) PD_SETPRIO(0);
   PD_PHASE(ph_window_first(lane, L, R, part))      // (after the hand-over: useful work while the state travels, and its
                                                    //  stores are not waited for by the publisher: 39 -> 33 us)
   // ---- C
   if (have_prev) {
-    PD_PHASE(chain_take(lane, R, a.chain_state + (size_t)(f - 1) * kStateFloats, a.chain_flag + (f - 1), a.chain_epoch))
+    PD_PHASE(chain_take(lane, R, a.chain_state + (size_t)(f - 1) * kStateFloats, a.chain_flag + (f - 1), a.chain_epoch, cp))
   } else if (f == 0 && a.state_in && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET)) {
     PD_PHASE(state_load(lane, R, a.state_in))
   } else {
@@ -1229,7 +1258,7 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
 
 // one frame per chunk: which of the two ways this frame goes (wave-uniform facts from the side records)
 template <bool F32>
-PD_FN void run_frame(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int f, WaveLds& L) {
+PD_FN void run_frame(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int f, WaveLds& L, const ChainPos& cp) {
   if (a.chain_epoch) {
     const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)f * 4)[7];
     const bool stereo = ((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
@@ -1242,11 +1271,11 @@ PD_FN void run_frame(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     if (stereo && (fresh || prev_stereo)) {
       const uint8_t fl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(2 * f + 1) * 2 + 1)[3];
       const bool h5 = (fl & PDMP3_GC_WIN_SWITCH) && ((fl & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
-      run_chunk_chained<F32>(a, T, cb, f, L, !fresh, h5);
+      run_chunk_chained<F32>(a, T, cb, f, L, !fresh, h5, cp);
       return;
     }
   }
-  run_chunk<false, false, F32>(a, T, cb, f, L);
+  run_chunk<false, false, F32>(a, T, cb, f, L, &cp);
 }
 
 }  // namespace pdmp3

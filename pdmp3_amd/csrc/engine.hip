@@ -47,12 +47,20 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 template <bool DUMP, bool F32 = false, int WPW = 1>
 __global__ __launch_bounds__(64 * WPW, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a, GlobalTables T, int n_chunks) {
   __shared__ WaveLds L[WPW];
+  __shared__ unsigned wg_flag[WPW];
   const int w = threadIdx.x >> 6;
   const int n_wgs = (n_chunks + WPW - 1) / WPW;
   const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * WPW + w;
+  if (!DUMP && a.chain_epoch) {            // one frame per chunk, no halo (decode_core.h run_chunk_chained)
+    if (threadIdx.x < WPW) wg_flag[threadIdx.x] = 0;
+    __syncthreads();
+    if (chunk >= n_chunks) return;
+    const ChainPos cp{wg_flag, w, w == WPW - 1};
+    run_frame<F32>(a, T, (BankPtr)&c_bank, chunk, L[w], cp);
+    return;
+  }
   if (chunk >= n_chunks) return;
-  if (!DUMP && a.chain_epoch) run_frame<F32>(a, T, (BankPtr)&c_bank, chunk, L[w]);   // one frame per chunk, no halo (decode_core.h)
-  else run_chunk<DUMP, false, F32>(a, T, (BankPtr)&c_bank, chunk, L[w]);
+  run_chunk<DUMP, false, F32>(a, T, (BankPtr)&c_bank, chunk, L[w]);
 }
 
 // same kernel with shader-clock stamps after every phase (tools/phase_profile.py)

@@ -70,10 +70,15 @@ extern "C" int emul_decode_frames_chained(const int16_t* spectra, const pdmp3_gc
   DecodeArgs a{spectra, side, pcm, pcm_f32, state, state ? state_next.data() : nullptr, nullptr, n_frames, 1, nullptr,
                cstate.data(), cpart.data(), cflag.data(), 7u};
   auto L = std::make_unique<WaveLds>();
+  constexpr int WPW = 8;                       // as the engine launches it: 8 consecutive frames per workgroup
+  unsigned wg_flag[WPW];
   for (int f = 0; f < n_frames; ++f) {
     WaveLds& Lr = *L;
-    if (pcm_f32) emu::run_wave([&] { run_frame<true>(a, T, &H.cb, f, Lr); });
-    else emu::run_wave([&] { run_frame<false>(a, T, &H.cb, f, Lr); });
+    const int w = f % WPW;
+    if (w == 0) for (unsigned& x : wg_flag) x = 0;
+    const ChainPos cp{wg_flag, w, w == WPW - 1};
+    if (pcm_f32) emu::run_wave([&] { run_frame<true>(a, T, &H.cb, f, Lr, cp); });
+    else emu::run_wave([&] { run_frame<false>(a, T, &H.cb, f, Lr, cp); });
   }
   if (state) std::copy(state_next.begin(), state_next.end(), state);
   return 0;
