@@ -296,15 +296,15 @@ PD_FN void state_store(int lane, const LaneRegs& R, float* st) {
 // chained chunks: the state a frame leaves, for the wave of the next frame (see PD_STORE_DEVICE above).
 // A workgroup is WPW waves with consecutive frames on ONE CU.  Inside it the state goes through ordinary stores and
 // loads (one L1, one L2) and a flag in LDS; only the workgroup's last wave publishes for the device (sc1 accesses, a flag
-// in global memory), read by wave 0 of the next workgroup.  That last wave also runs at raised priority until it has
-// published: it gets there in half the time, its SIMD partner catches up while it waits for its own predecessor, and the
-// slow hand-over across workgroups (8 us through the fabric) has that long to arrive before it is wanted.
+// in global memory), read by the first wave of the next workgroup.  Which wave takes which frame, and at which priority,
+// is arranged so that a wave waiting for a state always has a SIMD partner with work to do (k_decode in engine.hip).
 // (Tried instead of flags: every value with the epoch in one 8-byte access -- the readers' retries of 24 KB each made the
 // launch 30 % slower.)
 struct ChainPos {
-  unsigned* wg_flag;     // LDS, one per wave of the workgroup: == epoch once that wave's state can be read on this CU
-  int w;                 // this wave's place in its workgroup
+  unsigned* wg_flag;     // LDS, one per frame of the workgroup: == epoch once that frame's state can be read on this CU
+  int w;                 // this wave's frame within its workgroup (its place in the chain)
   bool last_in_wg;       // its successor, if any, runs in another workgroup
+  bool hi;               // runs at raised priority until it has taken its predecessor's state (see k_decode)
 };
 PD_FN void chain_publish(int lane, const LaneRegs& R, float* st, unsigned* gflag, unsigned epoch, const ChainPos& cp) {
   if (cp.last_in_wg) {
@@ -1154,7 +1154,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     // may be waiting for the state it leaves (stereo frames publish theirs, mono frames are skipped by their successors)
     const uint8_t fbl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f1 - 1) * 4)[7];
     if (((fbl & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3) {
-      const ChainPos alone{nullptr, 0, true};
+      const ChainPos alone{nullptr, 0, true, false};
       PD_PHASE(chain_publish(lane, R, a.chain_state + (size_t)(f1 - 1) * kStateFloats, a.chain_flag + (f1 - 1), a.chain_epoch, cp ? *cp : alone))
     }
   }
@@ -1182,7 +1182,7 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
                            const ChainPos& cp) {
   LaneRegs R;
   const int lane = PD_LANE();
-  if (cp.last_in_wg) PD_SETPRIO(3);              // (until its state is out: see ChainPos)
+  if (cp.hi) PD_SETPRIO(3);
   const int g0 = 2 * f, g1 = 2 * f + 1;
   const bool pre = h5 && have_prev;              // wave-uniform: the peek-only pass on granule g0 - 1
   const int g_first = pre ? g0 - 1 : g0;
@@ -1238,7 +1238,6 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
     if (f == a.n_frames - 1 && a.state_out) state_store(lane, R, a.state_out);
     chain_publish(lane, R, a.chain_state + (size_t)f * kStateFloats, a.chain_flag + f, a.chain_epoch, cp);
   )
-  if (cp.last_in_wg) PD_SETPRIO(0);
   PD_PHASE(ph_window_first(lane, L, R, part))      // (after the hand-over: useful work while the state travels, and its
                                                    //  stores are not waited for by the publisher: 39 -> 33 us)
   // ---- C
@@ -1249,6 +1248,7 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
   } else {
     PD_PHASE(state_zero(lane, R))
   }
+  if (cp.hi) PD_SETPRIO(0);
   // ---- D
   PD_PHASE(ph_mfma<false, kFromPark>(lane, L, R, cb, T, nullptr, nullptr, true, &L.park[0][0]))
   PD_PHASE(ph_window<F32>(lane, L, R, true, a.pcm + (size_t)f * 2304, F32 ? a.pcm_f32 + (size_t)f * 2304 : nullptr))

@@ -50,15 +50,26 @@ __global__ __launch_bounds__(64 * WPW, PDMP3_WAVES_PER_EU) void k_decode(DecodeA
   __shared__ unsigned wg_flag[WPW];
   const int w = threadIdx.x >> 6;
   const int n_wgs = (n_chunks + WPW - 1) / WPW;
-  const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * WPW + w;
   if (!DUMP && a.chain_epoch) {            // one frame per chunk, no halo (decode_core.h run_chunk_chained)
+    // Waves w and w + WPW/2 share a SIMD.  If every wave took frame w, all of them would reach the point where they
+    // need their predecessor's state together, and every SIMD would idle for the hand-over's latency.  So the frames
+    // go alternately to the two waves of a SIMD -- p = 0, 1 on SIMD 0, p = 2, 3 on SIMD 1, ... -- and the first of each
+    // pair runs at raised priority: it publishes early, its partner takes that state late (no wait), and while it waits
+    // for the partner-wave of the SIMD before, its own partner has the SIMD.  In the last pair the roles are swapped, so
+    // that the state for the next workgroup -- the slow hand-over, through the fabric -- is the early one.
+    static_assert(WPW == 1 || (WPW % 2 == 0), "pairs of waves per SIMD");
+    const int half = WPW / 2;
+    const int p = WPW == 1 ? 0 : (((w % half) << 1) | (w / half));
+    const bool hi = WPW > 1 && (p < WPW - 2 ? (p & 1) == 0 : p == WPW - 1);
+    const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * WPW + p;
     if (threadIdx.x < WPW) wg_flag[threadIdx.x] = 0;
     __syncthreads();
     if (chunk >= n_chunks) return;
-    const ChainPos cp{wg_flag, w, w == WPW - 1};
+    const ChainPos cp{wg_flag, p, p == WPW - 1, hi};
     run_frame<F32>(a, T, (BankPtr)&c_bank, chunk, L[w], cp);
     return;
   }
+  const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * WPW + w;
   if (chunk >= n_chunks) return;
   run_chunk<DUMP, false, F32>(a, T, (BankPtr)&c_bank, chunk, L[w]);
 }

@@ -76,7 +76,7 @@ extern "C" int emul_decode_frames_chained(const int16_t* spectra, const pdmp3_gc
     WaveLds& Lr = *L;
     const int w = f % WPW;
     if (w == 0) for (unsigned& x : wg_flag) x = 0;
-    const ChainPos cp{wg_flag, w, w == WPW - 1};
+    const ChainPos cp{wg_flag, w, w == WPW - 1, false};
     if (pcm_f32) emu::run_wave([&] { run_frame<true>(a, T, &H.cb, f, Lr, cp); });
     else emu::run_wave([&] { run_frame<false>(a, T, &H.cb, f, Lr, cp); });
   }
