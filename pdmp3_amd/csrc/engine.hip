@@ -210,10 +210,11 @@ __global__ __launch_bounds__(64) void k_merge(const GcRaw* raw, const pdmp3_fram
   if (lane == 0) state_out[t] = (uint16_t)carry;
 }
 
-// Scratch of a chained launch (DecodeArgs::chain_*): launches on one HIP stream are ordered and share a buffer,
-// launches on different streams never do.
+// Scratch of a chained launch (DecodeArgs::chain_*): launches that are ordered one after the other share a buffer --
+// those of one pdmp3_hip_stream (its slots' kernels are chained by the state event), or those of bare calls on one HIP
+// stream; launches that may overlap never do.
 struct ChainBuf {
-  hipStream_t stream;
+  const void* key;          // whose launches share it: a pdmp3_hip_stream's state scratch, or the HIP stream of bare calls
   bool used;
   int cap;                  // frames
   unsigned epoch;           // of the last launch that used it; flags of older launches are smaller, never equal
@@ -332,11 +333,11 @@ static int auto_chunk(int n_frames, int slots) {
 }
 
 // The scratch of a chained launch of n_frames frames on stream s, or null (then the chunks stay independent).
-static ChainBuf* chain_get(pdmp3_hip_ctx* c, hipStream_t s, int n_frames) {
+static ChainBuf* chain_get(pdmp3_hip_ctx* c, const void* key, hipStream_t s, int n_frames) {
   std::lock_guard<std::mutex> lock(c->chain_mu);
   ChainBuf* b = nullptr;
-  for (ChainBuf& x : c->chain) if (x.used && x.stream == s) { b = &x; break; }
-  if (!b) for (ChainBuf& x : c->chain) if (!x.used) { b = &x; b->used = true; b->stream = s; b->cap = 0; b->epoch = 0; break; }
+  for (ChainBuf& x : c->chain) if (x.used && x.key == key) { b = &x; break; }
+  if (!b) for (ChainBuf& x : c->chain) if (!x.used) { b = &x; b->used = true; b->key = key; b->cap = 0; b->epoch = 0; break; }
   if (!b) return nullptr;
   if (b->cap < n_frames) {                                 // (stream-ordered: earlier launches on s are done with the old one)
     if (b->state) (void)hipFreeAsync(b->state, s);
@@ -366,6 +367,15 @@ static ChainBuf* chain_get(pdmp3_hip_ctx* c, hipStream_t s, int n_frames) {
   return b;
 }
 
+static void chain_release(pdmp3_hip_ctx* c, const void* key) {     // (its launches are complete)
+  std::lock_guard<std::mutex> lock(c->chain_mu);
+  for (ChainBuf& x : c->chain)
+    if (x.used && x.key == key) {
+      (void)hipFree(x.state); (void)hipFree(x.part); (void)hipFree(x.flag);
+      x = ChainBuf{};
+    }
+}
+
 // d_state_tmp: where the kernel leaves the new state before it is copied over d_state (chunk 0 and the channel-1
 // pre-halo read the OLD state while the last chunk writes the new one).  Streams own one; a bare
 // pdmp3_hip_decode_frames call takes a stream-ordered allocation so that calls on different HIP streams never share it.
@@ -390,6 +400,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.pcm = d_pcm;
   a.pcm_f32 = d_pcm_f32;
   a.state_in = (const float*)d_state;
+  const void* chain_key = d_state_tmp ? (const void*)d_state_tmp : (const void*)s;   // (a stream object's scratch, or the bare call's stream)
   bool own_tmp = false;
   if (d_state && !d_state_tmp) {
     HIP_TRY(hipMallocAsync((void**)&d_state_tmp, pdmp3_hip_state_bytes(), s), "hipMallocAsync state");
@@ -403,7 +414,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.chain_state = nullptr; a.chain_part = nullptr; a.chain_flag = nullptr; a.chain_epoch = 0;
   if (c->chain_on && chunk_frames == 1 && n_frames > 1 && !d_stages && !d_prof) {
     // one frame per chunk: the waves hand their closing states on instead of decoding a halo each (run_chunk_chained)
-    if (ChainBuf* b = chain_get(c, s, n_frames)) {
+    if (ChainBuf* b = chain_get(c, chain_key, s, n_frames)) {
       a.chain_state = b->state; a.chain_part = b->part; a.chain_flag = b->flag; a.chain_epoch = b->epoch;
     }
   }
@@ -496,6 +507,7 @@ extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
   (void)hipFree(hs->d_sfstate);
   if (hs->ev_state) (void)hipEventDestroy(hs->ev_state);
   (void)hipFree(hs->d_state);
+  if (hs->d_state_tmp) chain_release(hs->ctx, hs->d_state_tmp);
   (void)hipFree(hs->d_state_tmp);
   (void)hipFree(hs->d_state_prev);
   free(hs);
