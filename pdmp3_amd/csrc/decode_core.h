@@ -889,9 +889,16 @@ PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int16_t* pcm_
 
 // Chained chunks (run_chunk_chained): the window sums of a stereo granule whose history is not there yet.  Every sum is
 // ONE chain of 16 FMAs from the newest slot to the oldest; the terms that read this granule's own slots come first --
-// that part is done now (partial sums to part[18][64], global scratch), the rest (ph_window_rest) when the granule
+// that part is done now (partial sums to part[18][64], LDS), the rest (ph_window_rest) when the granule
 // before it has been transformed: same operations in the same order, bit for bit what ph_window computes.
-PD_FN void ph_window_first(int lane, const WaveLds& L, const LaneRegs& R, float* part) {
+// part[t][64 lanes] lives in LDS that is dead by then (a chained wave has requantised its last granule): the staged
+// spectra + the mono PCM staging hold t = 0..12, the line tables t = 13..17
+PD_FN float* part_row(WaveLds& L, int t) {
+  static_assert(offsetof(WaveLds, pcm) == offsetof(WaveLds, spec) + sizeof(L.spec), "spec and pcm are one block");
+  static_assert(sizeof(L.spec) + sizeof(L.pcm) >= 13 * 64 * sizeof(float) && sizeof(L.ltab) >= 5 * 64 * sizeof(float), "room for part[18][64]");
+  return t < 13 ? reinterpret_cast<float*>(&L.spec[0][0]) + t * 64 : reinterpret_cast<float*>(&L.ltab[0][0]) + (t - 13) * 64;
+}
+PD_FN void ph_window_first(int lane, WaveLds& L, const LaneRegs& R) {
   const int ch = lane >> 5;
   float E[18], O[18];
   PD_UNROLL for (int t = 0; t < 18; t++) { E[t] = L.hyb[ch][t][R.idx_e]; O[t] = L.hyb[ch][t][R.idx_o]; }
@@ -901,15 +908,15 @@ PD_FN void ph_window_first(int lane, const WaveLds& L, const LaneRegs& R, float*
       if (t - 2 * k >= 0) acc = PD_FMA(R.we[k], E[t - 2 * k], acc);
       if (t - 2 * k - 1 >= 0) acc = PD_FMA(R.wo[k], O[t - 2 * k - 1], acc);
     }
-    part[t * 64 + lane] = acc;
+    part_row(L, t)[lane] = acc;
   }
 }
 // R.he / R.ho = slots 3..17 of the granule before (what ph_window left); stereo granules only
 template <bool F32>
-PD_FN void ph_window_rest(int lane, WaveLds& L, const LaneRegs& R, const float* part, int16_t* pcm_g, float* pcmf_g) {
+PD_FN void ph_window_rest(int lane, WaveLds& L, const LaneRegs& R, int16_t* pcm_g, float* pcmf_g) {
   float sum[18];
   PD_UNROLL for (int t = 0; t < 18; t++) {
-    float acc = part[t * 64 + lane];
+    float acc = part_row(L, t)[lane];
     PD_UNROLL for (int k = 0; k < 8; k++) {
       if (t - 2 * k < 0) acc = PD_FMA(R.we[k], R.he[kHistSlots + t - 2 * k], acc);
       if (t - 2 * k - 1 < 0) acc = PD_FMA(R.wo[k], R.ho[kHistSlots + t - 2 * k - 1], acc);
@@ -977,9 +984,8 @@ struct DecodeArgs {
   int chunk_frames;
   unsigned long long* prof;      // PROF builds: [n_chunks][kProfSlots] shader-clock ticks per phase
   // chained chunks (chunk_frames == 1, run_chunk_chained): [n_frames][kStateFloats] states after every frame,
-  // [n_frames][18][64] partial window sums, one flag per frame (== chain_epoch once the frame's state is there)
+  // one flag per frame (== chain_epoch once the frame's state is there)
   float* chain_state;
-  float* chain_part;
   unsigned* chain_flag;
   unsigned chain_epoch;          // 0: chunks are independent (halo), as described above
 };
@@ -1232,13 +1238,12 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
   PD_PHASE(ph_requant<false>(lane, L, cb, T, nullptr, nullptr))
   PD_PHASE(ph_antialias(lane, L, cb))
   PD_PHASE(ph_mfma<false, 0>(lane, L, R, cb, T, nullptr, nullptr, true))
-  float* part = a.chain_part + (size_t)f * (18 * 64);
   PD_PHASE(ph_window<F32>(lane, L, R, false, nullptr, nullptr))
   PD_PHASE(
     if (f == a.n_frames - 1 && a.state_out) state_store(lane, R, a.state_out);
     chain_publish(lane, R, a.chain_state + (size_t)f * kStateFloats, a.chain_flag + f, a.chain_epoch, cp);
   )
-  PD_PHASE(ph_window_first(lane, L, R, part))      // (after the hand-over: useful work while the state travels, and its
+  PD_PHASE(ph_window_first(lane, L, R))      // (after the hand-over: useful work while the state travels, and its
                                                    //  stores are not waited for by the publisher: 39 -> 33 us)
   // ---- C
   if (have_prev) {
@@ -1253,7 +1258,7 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
   PD_PHASE(ph_mfma<false, kFromPark>(lane, L, R, cb, T, nullptr, nullptr, true, &L.park[0][0]))
   PD_PHASE(ph_window<F32>(lane, L, R, true, a.pcm + (size_t)f * 2304, F32 ? a.pcm_f32 + (size_t)f * 2304 : nullptr))
   // ---- E
-  PD_PHASE(ph_window_rest<F32>(lane, L, R, part, a.pcm + (size_t)f * 2304 + 1152, F32 ? a.pcm_f32 + (size_t)f * 2304 + 1152 : nullptr))
+  PD_PHASE(ph_window_rest<F32>(lane, L, R, a.pcm + (size_t)f * 2304 + 1152, F32 ? a.pcm_f32 + (size_t)f * 2304 + 1152 : nullptr))
 }
 
 // one frame per chunk: which of the two ways this frame goes (wave-uniform facts from the side records)

@@ -219,7 +219,6 @@ struct ChainBuf {
   int cap;                  // frames
   unsigned epoch;           // of the last launch that used it; flags of older launches are smaller, never equal
   float* state;
-  float* part;
   unsigned* flag;
 };
 constexpr int kChainBufs = 32;
@@ -262,7 +261,7 @@ extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   (void)hipFree(c->d_win);
   (void)hipFree(c->d_frag);
   (void)hipFree(c->d_unpack);
-  for (ChainBuf& b : c->chain) { (void)hipFree(b.state); (void)hipFree(b.part); (void)hipFree(b.flag); }
+  for (ChainBuf& b : c->chain) { (void)hipFree(b.state); (void)hipFree(b.flag); }
   delete c;
 }
 
@@ -341,19 +340,16 @@ static ChainBuf* chain_get(pdmp3_hip_ctx* c, const void* key, hipStream_t s, int
   if (!b) return nullptr;
   if (b->cap < n_frames) {                                 // (stream-ordered: earlier launches on s are done with the old one)
     if (b->state) (void)hipFreeAsync(b->state, s);
-    if (b->part) (void)hipFreeAsync(b->part, s);
     if (b->flag) (void)hipFreeAsync(b->flag, s);
-    b->state = b->part = nullptr; b->flag = nullptr; b->cap = 0;
+    b->state = nullptr; b->flag = nullptr; b->cap = 0;
     const int cap = n_frames < 256 ? 256 : n_frames;
     if (hipMallocAsync((void**)&b->state, (size_t)cap * kStateFloats * sizeof(float), s) != hipSuccess ||
-        hipMallocAsync((void**)&b->part, (size_t)cap * 18 * 64 * sizeof(float), s) != hipSuccess ||
         hipMallocAsync((void**)&b->flag, (size_t)cap * sizeof(unsigned), s) != hipSuccess ||
         hipMemsetAsync(b->flag, 0, (size_t)cap * sizeof(unsigned), s) != hipSuccess) {
       (void)hipGetLastError();
       if (b->state) (void)hipFreeAsync(b->state, s);
-      if (b->part) (void)hipFreeAsync(b->part, s);
-      if (b->flag) (void)hipFreeAsync(b->flag, s);
-      b->state = b->part = nullptr; b->flag = nullptr;
+        if (b->flag) (void)hipFreeAsync(b->flag, s);
+      b->state = nullptr; b->flag = nullptr;
       return nullptr;
     }
     b->cap = cap;
@@ -371,7 +367,7 @@ static void chain_release(pdmp3_hip_ctx* c, const void* key) {     // (its launc
   std::lock_guard<std::mutex> lock(c->chain_mu);
   for (ChainBuf& x : c->chain)
     if (x.used && x.key == key) {
-      (void)hipFree(x.state); (void)hipFree(x.part); (void)hipFree(x.flag);
+      (void)hipFree(x.state); (void)hipFree(x.flag);
       x = ChainBuf{};
     }
 }
@@ -411,11 +407,11 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.n_frames = n_frames;
   a.chunk_frames = chunk_frames;
   a.prof = d_prof;
-  a.chain_state = nullptr; a.chain_part = nullptr; a.chain_flag = nullptr; a.chain_epoch = 0;
+  a.chain_state = nullptr; a.chain_flag = nullptr; a.chain_epoch = 0;
   if (c->chain_on && chunk_frames == 1 && n_frames > 1 && !d_stages && !d_prof) {
     // one frame per chunk: the waves hand their closing states on instead of decoding a halo each (run_chunk_chained)
     if (ChainBuf* b = chain_get(c, chain_key, s, n_frames)) {
-      a.chain_state = b->state; a.chain_part = b->part; a.chain_flag = b->flag; a.chain_epoch = b->epoch;
+      a.chain_state = b->state; a.chain_flag = b->flag; a.chain_epoch = b->epoch;
     }
   }
   GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64};

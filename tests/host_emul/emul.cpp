@@ -24,7 +24,7 @@ extern "C" int emul_decode_frames(const int16_t* spectra, const pdmp3_gc_side* s
   if (stages) chunk_frames = n_frames;
   // like engine.hip: the kernel writes the new state to scratch (any chunk may read the old one), then it is copied
   std::vector<float> state_next(kStateFloats);
-  DecodeArgs a{spectra, side, pcm, nullptr, state, state ? state_next.data() : nullptr, stages, n_frames, chunk_frames, nullptr, nullptr, nullptr, nullptr, 0u};
+  DecodeArgs a{spectra, side, pcm, nullptr, state, state ? state_next.data() : nullptr, stages, n_frames, chunk_frames, nullptr, nullptr, nullptr, 0u};
   const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
   auto L = std::make_unique<WaveLds>();
   for (int c = 0; c < nchunks; ++c) {
@@ -45,7 +45,7 @@ extern "C" int emul_decode_frames_f32(const int16_t* spectra, const pdmp3_gc_sid
   GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data()};
   if (chunk_frames <= 0) chunk_frames = n_frames;
   std::vector<float> state_next(kStateFloats);
-  DecodeArgs a{spectra, side, nullptr, pcm, state, state ? state_next.data() : nullptr, nullptr, n_frames, chunk_frames, nullptr, nullptr, nullptr, nullptr, 0u};
+  DecodeArgs a{spectra, side, nullptr, pcm, state, state ? state_next.data() : nullptr, nullptr, n_frames, chunk_frames, nullptr, nullptr, nullptr, 0u};
   const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
   auto L = std::make_unique<WaveLds>();
   for (int c = 0; c < nchunks; ++c) {
@@ -65,10 +65,10 @@ extern "C" int emul_decode_frames_chained(const int16_t* spectra, const pdmp3_gc
   if (!ready) { build_host_tables(H); ready = true; }
   GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data()};
   std::vector<float> state_next(kStateFloats);
-  std::vector<float> cstate((size_t)n_frames * kStateFloats), cpart((size_t)n_frames * 18 * 64);
+  std::vector<float> cstate((size_t)n_frames * kStateFloats);
   std::vector<unsigned> cflag((size_t)n_frames, 0u);
   DecodeArgs a{spectra, side, pcm, pcm_f32, state, state ? state_next.data() : nullptr, nullptr, n_frames, 1, nullptr,
-               cstate.data(), cpart.data(), cflag.data(), 7u};
+               cstate.data(), cflag.data(), 7u};
   auto L = std::make_unique<WaveLds>();
   constexpr int WPW = 8;                       // as the engine launches it: 8 consecutive frames per workgroup
   unsigned wg_flag[WPW];
