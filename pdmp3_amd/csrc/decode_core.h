@@ -1185,15 +1185,14 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
 // ---------------------------------------------------------------------------
 template <bool F32>
 PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int f, WaveLds& L, bool have_prev, bool h5,
-                           const ChainPos& cp) {
+                           const ChainPos& cp, int first_sfreq) {   // first_sfreq: of the first granule the wave decodes
   LaneRegs R;
   const int lane = PD_LANE();
   if (cp.hi) PD_SETPRIO(3);
   const int g0 = 2 * f, g1 = 2 * f + 1;
   const bool pre = h5 && have_prev;              // wave-uniform: the peek-only pass on granule g0 - 1
   const int g_first = pre ? g0 - 1 : g0;
-  int cur_sfreq = reinterpret_cast<const uint8_t*>(a.side + (size_t)g_first * 2)[7] & PDMP3_FR_SFREQ_MASK;
-  if (cur_sfreq > 2) cur_sfreq = 2;
+  int cur_sfreq = first_sfreq > 2 ? 2 : first_sfreq;
   PD_PHASE(
     ph_prefetch(lane, R, a.spectra + (size_t)g_first * 1152, a.side + (size_t)g_first * 2);
     load_linetab(lane, L, T, cur_sfreq);
@@ -1265,18 +1264,17 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
 template <bool F32>
 PD_FN void run_frame(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int f, WaveLds& L, const ChainPos& cp) {
   if (a.chain_epoch) {
+    // the three bytes the decision needs, asked for together (one memory round trip before the wave can start, not three)
     const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)f * 4)[7];
+    const uint8_t pb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f > 0 ? f - 1 : 0) * 4)[7];
+    const uint8_t fl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(2 * f + 1) * 2 + 1)[3];
     const bool stereo = ((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
     const bool fresh = f == 0 || (fb & PDMP3_FR_RESET);       // its input state is the caller's / zero
-    bool prev_stereo = false;
-    if (!fresh) {
-      const uint8_t pb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f - 1) * 4)[7];
-      prev_stereo = ((pb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
-    }
+    const bool prev_stereo = ((pb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
     if (stereo && (fresh || prev_stereo)) {
-      const uint8_t fl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(2 * f + 1) * 2 + 1)[3];
       const bool h5 = (fl & PDMP3_GC_WIN_SWITCH) && ((fl & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
-      run_chunk_chained<F32>(a, T, cb, f, L, !fresh, h5, cp);
+      const bool pre = h5 && !fresh;                          // the peek-only pass on the granule before the frame comes first
+      run_chunk_chained<F32>(a, T, cb, f, L, !fresh, h5, cp, (pre ? pb : fb) & PDMP3_FR_SFREQ_MASK);
       return;
     }
   }

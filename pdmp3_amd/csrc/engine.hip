@@ -408,7 +408,9 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.chunk_frames = chunk_frames;
   a.prof = d_prof;
   a.chain_state = nullptr; a.chain_flag = nullptr; a.chain_epoch = 0;
-  if (c->chain_on && chunk_frames == 1 && n_frames > 1 && !d_stages && !d_prof) {
+  if (c->chain_on && chunk_frames == 1 && n_frames > 1 && n_frames <= c->wave_slots && !d_stages && !d_prof) {
+    // (one round of waves: all resident together.  More frames than that at one per chunk -- only on request -- would
+    //  still be correct, workgroups being dispatched in order, but every XCD would wait for the one before it.)
     // one frame per chunk: the waves hand their closing states on instead of decoding a halo each (run_chunk_chained)
     if (ChainBuf* b = chain_get(c, chain_key, s, n_frames)) {
       a.chain_state = b->state; a.chain_flag = b->flag; a.chain_epoch = b->epoch;
