@@ -377,7 +377,10 @@ static void chain_release(pdmp3_hip_ctx* c, const void* key) {     // (its launc
 // pdmp3_hip_decode_frames call takes a stream-ordered allocation so that calls on different HIP streams never share it.
 static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3_gc_side* d_side, int n_frames,
                          void* d_state, int16_t* d_pcm, float* d_stages, int chunk_frames, void* stream,
-                         unsigned long long* d_prof = nullptr, float* d_state_tmp = nullptr, float* d_pcm_f32 = nullptr) {
+                         unsigned long long* d_prof = nullptr, float* d_state_tmp = nullptr, float* d_pcm_f32 = nullptr,
+                         const void* owner = nullptr, bool leave_state_in_tmp = false) {
+  // owner: the stream object whose launches these are (they are ordered: one chain scratch for all of them);
+  // leave_state_in_tmp: the caller swaps its two state buffers instead of having the new state copied back
   if (!c || n_frames < 0) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: bad argument", hipSuccess);
   if (n_frames == 0) return PDMP3_HIP_OK;
   if (!d_spectra || !d_side || !(d_pcm || d_pcm_f32))
@@ -396,7 +399,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.pcm = d_pcm;
   a.pcm_f32 = d_pcm_f32;
   a.state_in = (const float*)d_state;
-  const void* chain_key = d_state_tmp ? (const void*)d_state_tmp : (const void*)s;   // (a stream object's scratch, or the bare call's stream)
+  const void* chain_key = owner ? owner : (const void*)s;   // (a stream object, or the bare call's HIP stream)
   bool own_tmp = false;
   if (d_state && !d_state_tmp) {
     HIP_TRY(hipMallocAsync((void**)&d_state_tmp, pdmp3_hip_state_bytes(), s), "hipMallocAsync state");
@@ -427,7 +430,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   else hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
   hipError_t e = hipGetLastError();
   const char* what = "launch k_decode";
-  if (e == hipSuccess && d_state) {
+  if (e == hipSuccess && d_state && !leave_state_in_tmp) {
     what = "state copy";
     e = hipMemcpyAsync(d_state, d_state_tmp, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, s);
   }
@@ -473,6 +476,7 @@ struct StreamSlot {
   pdmp3_frame_bits* h_bits; uint8_t* h_res;                       // pinned
   pdmp3_frame_bits* d_bits; uint8_t* d_res; GcRaw* d_raw;
   pdmp3_row_desc* h_desc; pdmp3_row_desc* d_desc; uint8_t* d_pool;   // compact bits input: pinned descriptors; the pool is h_res
+  uint8_t* h_in; uint8_t* d_in;   // the blocks h_desc | h_bits | h_res and d_desc | d_bits | d_pool point into
   int busy;
 };
 struct pdmp3_hip_stream {
@@ -499,13 +503,13 @@ extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
     if (t.done) (void)hipEventDestroy(t.done);
     (void)hipHostFree(t.h_spectra); (void)hipHostFree(t.h_side); (void)hipHostFree(t.h_pcm);
     (void)hipFree(t.d_spectra); (void)hipFree(t.d_side); (void)hipFree(t.d_pcm);
-    (void)hipHostFree(t.h_bits); (void)hipHostFree(t.h_res); (void)hipHostFree(t.h_desc);
-    (void)hipFree(t.d_bits); (void)hipFree(t.d_res); (void)hipFree(t.d_raw); (void)hipFree(t.d_desc); (void)hipFree(t.d_pool);
+    (void)hipHostFree(t.h_in);
+    (void)hipFree(t.d_in); (void)hipFree(t.d_res); (void)hipFree(t.d_raw);
   }
   (void)hipFree(hs->d_sfstate);
   if (hs->ev_state) (void)hipEventDestroy(hs->ev_state);
   (void)hipFree(hs->d_state);
-  if (hs->d_state_tmp) chain_release(hs->ctx, hs->d_state_tmp);
+  chain_release(hs->ctx, hs);
   (void)hipFree(hs->d_state_tmp);
   (void)hipFree(hs->d_state_prev);
   free(hs);
@@ -666,8 +670,8 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
   HIP_TRY(hipMemcpyAsync(hs->d_state_prev, hs->d_state, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, t.stream), "keep the state");
   if (hs->f32 && host_dst) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_to: not with float PCM", hipSuccess);
   int rc = hs->f32
-      ? launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm)
-      : launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp);
+      ? launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs)
+      : launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs);
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
   hs->have_state_ev = 1;
@@ -702,8 +706,8 @@ extern "C" int pdmp3_hip_stream_rewind(pdmp3_hip_stream* hs, int slot, int keep_
   HIP_TRY(hipMemcpyAsync(hs->d_state, hs->d_state_prev, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, t.stream), "restore the state");
   if (keep_frames) {
     const int rc = hs->f32
-        ? launch_decode(hs->ctx, t.d_spectra, t.d_side, keep_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm)
-        : launch_decode(hs->ctx, t.d_spectra, t.d_side, keep_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp);
+        ? launch_decode(hs->ctx, t.d_spectra, t.d_side, keep_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs)
+        : launch_decode(hs->ctx, t.d_spectra, t.d_side, keep_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs);
     if (rc != PDMP3_HIP_OK) return rc;
   }
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
@@ -719,14 +723,20 @@ static int ensure_bits(pdmp3_hip_stream* hs) {
   const size_t n = (size_t)hs->max_frames;
   for (int i = 0; i < hs->n_slots; ++i) {
     StreamSlot& t = hs->s[i];
-    HIP_TRY(hipHostMalloc((void**)&t.h_bits, n * sizeof(pdmp3_frame_bits), hipHostMallocDefault), "hipHostMalloc bits");
-    HIP_TRY(hipHostMalloc((void**)&t.h_res, n * PDMP3_RESERVOIR_BYTES + PDMP3_POOL_SLACK_BYTES + 16, hipHostMallocDefault), "hipHostMalloc reservoir");
-    HIP_TRY(hipMalloc((void**)&t.d_bits, n * sizeof(pdmp3_frame_bits)), "hipMalloc bits");
+    // descriptors | side info | rows or pool: ONE pinned block and one device block with the same layout, so that the
+    // compact input of a window goes up in one copy (a hipMemcpyAsync call costs the submitting thread 20-40 us here)
+    const size_t desc_bytes = n * sizeof(pdmp3_row_desc), bits_bytes = n * sizeof(pdmp3_frame_bits);
+    const size_t pool_cap = n * PDMP3_RESERVOIR_BYTES + PDMP3_POOL_SLACK_BYTES + 16;
+    HIP_TRY(hipHostMalloc((void**)&t.h_in, desc_bytes + bits_bytes + pool_cap, hipHostMallocDefault), "hipHostMalloc window input");
+    HIP_TRY(hipMalloc((void**)&t.d_in, desc_bytes + bits_bytes + pool_cap), "hipMalloc window input");
+    t.h_desc = reinterpret_cast<pdmp3_row_desc*>(t.h_in);
+    t.h_bits = reinterpret_cast<pdmp3_frame_bits*>(t.h_in + desc_bytes);
+    t.h_res = t.h_in + desc_bytes + bits_bytes;
+    t.d_desc = reinterpret_cast<pdmp3_row_desc*>(t.d_in);
+    t.d_bits = reinterpret_cast<pdmp3_frame_bits*>(t.d_in + desc_bytes);
+    t.d_pool = t.d_in + desc_bytes + bits_bytes;
     HIP_TRY(hipMalloc((void**)&t.d_res, n * PDMP3_RESERVOIR_BYTES + 16), "hipMalloc reservoir");
     HIP_TRY(hipMalloc((void**)&t.d_raw, n * 4 * sizeof(GcRaw)), "hipMalloc raw");
-    HIP_TRY(hipHostMalloc((void**)&t.h_desc, n * sizeof(pdmp3_row_desc), hipHostMallocDefault), "hipHostMalloc row descriptors");
-    HIP_TRY(hipMalloc((void**)&t.d_desc, n * sizeof(pdmp3_row_desc)), "hipMalloc row descriptors");
-    HIP_TRY(hipMalloc((void**)&t.d_pool, n * PDMP3_RESERVOIR_BYTES + PDMP3_POOL_SLACK_BYTES + 16), "hipMalloc pool");
   }
   HIP_TRY(hipMalloc((void**)&hs->d_sfstate, 2 * 256 * sizeof(uint16_t)), "hipMalloc sfstate");
   HIP_TRY(hipMemset(hs->d_sfstate, 0, 2 * 256 * sizeof(uint16_t)), "memset sfstate");
@@ -776,14 +786,17 @@ static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
   const size_t n = (size_t)n_frames;
-  HIP_TRY(hipMemcpyAsync(t.d_bits, t.h_bits, n * sizeof(pdmp3_frame_bits), hipMemcpyHostToDevice, t.stream), "H2D bits");
-  if (pool_bytes) {           // compact input: pool + descriptors up, rows rebuilt on the device
-    HIP_TRY(hipMemcpyAsync(t.d_pool, t.h_res, pool_bytes, hipMemcpyHostToDevice, t.stream), "H2D pool");
-    HIP_TRY(hipMemcpyAsync(t.d_desc, t.h_desc, n * sizeof(pdmp3_row_desc), hipMemcpyHostToDevice, t.stream), "H2D row descriptors");
+  if (pool_bytes) {           // compact input: descriptors, side info and pool up in one copy, rows rebuilt on the device
+    // (Tried: k_rows reading descriptors, side info and pool straight from the pinned host block, no copy at all -- the
+    //  kernel then runs at PCIe speed and the pipeline, which is bound by the kernels of a window, lost 20 %.)
+    const size_t head = (size_t)hs->max_frames * (sizeof(pdmp3_row_desc) + sizeof(pdmp3_frame_bits));
+    HIP_TRY(hipMemcpyAsync(t.d_in, t.h_in, head + pool_bytes, hipMemcpyHostToDevice, t.stream), "H2D window input");
     hipLaunchKernelGGL(k_rows, dim3((unsigned)n_frames), dim3(128), 0, t.stream, t.d_desc, t.d_pool, t.d_res);
     HIP_TRY(hipGetLastError(), "launch k_rows");
-  } else
-  HIP_TRY(hipMemcpyAsync(t.d_res, t.h_res, n * PDMP3_RESERVOIR_BYTES, hipMemcpyHostToDevice, t.stream), "H2D reservoir");
+  } else {
+    HIP_TRY(hipMemcpyAsync(t.d_bits, t.h_bits, n * sizeof(pdmp3_frame_bits), hipMemcpyHostToDevice, t.stream), "H2D bits");
+    HIP_TRY(hipMemcpyAsync(t.d_res, t.h_res, n * PDMP3_RESERVOIR_BYTES, hipMemcpyHostToDevice, t.stream), "H2D reservoir");
+  }
   {
     int blocks = (n_frames + kUnpackRows - 1) / kUnpackRows;
     if (blocks > 2048) blocks = 2048;
@@ -797,8 +810,9 @@ static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_
                      hs->d_sfstate + 256 * hs->sf_cur, hs->d_sfstate + 256 * (hs->sf_cur ^ 1), t.d_side);
   HIP_TRY(hipGetLastError(), "launch k_merge");
   hs->sf_cur ^= 1;
-  rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp);
+  rc = launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, true);
   if (rc != PDMP3_HIP_OK) return rc;
+  { float* x = hs->d_state; hs->d_state = hs->d_state_tmp; hs->d_state_tmp = x; }   // (the new state is where the kernel left it)
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
   hs->have_state_ev = 1;
   rc = download_pcm(t, n, host_dst, row);
