@@ -8,6 +8,7 @@ absolute relative to the stage amplitude (stages 0-2 are expected bit-exact:
 they only use separately rounded mul/add like the reference).
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -243,3 +244,29 @@ def test_gpu_float_pcm_c2(engine, oracle):
     q = np.clip(np.trunc(f * 32767.0), -32767, 32767)
     q[f > 65538.0] = -32767
     assert np.array_equal(q.astype(np.int16), pcm.cpu().numpy())
+
+
+def test_gpu_chained_launches_equal_independent_chunks(engine):
+    """one frame per wave with the closing states handed from wave to wave (run_chunk_chained; what every launch of up to
+    one round of waves uses) against independent 2-frame chunks with halos: PCM and carried state bit-identical, over many
+    synthetic batches, sizes that leave the last workgroup partly filled, and host threads launching on their own streams"""
+    import threading
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from soak_chain import one
+    for r in range(48):
+        n = 2048 if r % 4 else [1, 2, 7, 8, 9, 63, 65, 1000, 2047][(r // 4) % 9]
+        assert one(engine, 0x5EED000000 + r, n), (r, n)
+    out = {}
+
+    def worker(k):
+        s = torch.cuda.Stream()
+        ok = True
+        with torch.cuda.stream(s):
+            for r in range(12):
+                ok = one(engine, 0xABC000 + 1000 * k + r, 2048) and ok
+        out[k] = ok
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert all(out.get(k) for k in range(4)), out
