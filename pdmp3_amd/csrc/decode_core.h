@@ -851,10 +851,10 @@ PD_FN void pcm_emit(int lane, WaveLds& L, int nch, bool act, const float* sum, i
 
 // full = false (wave-uniform): the last halo granule -- only its slots 3..17 are wanted, as the next granule's history
 template <bool F32>
-PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int16_t* pcm_g, float* pcmf_g) {
-  const GranuleInfo g = granule_info(L);
+PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int nch, int16_t* pcm_g, float* pcmf_g) {
+  // (nch is a parameter: by now the side records in LDS are the NEXT granule's, see run_chunk)
   const int ch = lane >> 5;
-  const bool act = ch < g.nch;                 // (mono: lanes 32..63 idle, their history is channel 1's and stays)
+  const bool act = ch < nch;                   // (mono: lanes 32..63 idle, their history is channel 1's and stays)
   if (!full) {
     if (act) {
       PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
@@ -884,7 +884,7 @@ PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int16_t* pcm_
     }
     PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = E[18 + s]; R.ho[s] = O[18 + s]; }
   }
-  pcm_emit<F32>(lane, L, g.nch, act, sum, pcm_g, pcmf_g);
+  pcm_emit<F32>(lane, L, nch, act, sum, pcm_g, pcmf_g);
 }
 
 // Chained chunks (run_chunk_chained): the window sums of a stereo granule whose history is not there yet.  Every sum is
@@ -1124,20 +1124,19 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       PD_TICK(4)
     }
     PD_TICK(5)
-    if (emit || feeds_next) {
-      PD_PHASE(ph_window<F32>(lane, L, R, emit, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g,
-                                F32 ? a.pcm_f32 + (size_t)f * 2304 + gr * 576 * nch_g : nullptr))
-    }
-    PD_TICK(6)
-    // the next granule is committed to LDS BEFORE this granule's PCM stores are issued: its prefetch
-    // loads are older than those stores, so waiting for them never waits for a store
+    // The next granule is committed to LDS BEFORE this granule's PCM stores are issued (ph_window issues them): its
+    // prefetch loads are older than those stores, so waiting for them never waits for a store.  (With the commit after
+    // the window the wave sat through the acknowledgement of its nine stores every granule: 10 % of the loop.)
     if (g_next < g_end) {
       PD_PHASE(ph_commit(lane, L, R))
+      PD_PHASE(ph_scales(lane, L))                   // next granule's (its side info was committed just above)
     }
-    PD_PHASE(
-      if (!F32) ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, emit);
-      if (g_next < g_end) ph_scales(lane, L);        // next granule's (its side info was committed just above)
-    )
+    PD_TICK(6)
+    if (emit || feeds_next) {
+      PD_PHASE(ph_window<F32>(lane, L, R, emit, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g,
+                                F32 ? a.pcm_f32 + (size_t)f * 2304 + gr * 576 * nch_g : nullptr))
+    }
+    PD_PHASE(if (!F32) ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, emit))
     PD_TICK(7)
   }
 #undef PD_TICK
@@ -1237,7 +1236,7 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
   PD_PHASE(ph_requant<false>(lane, L, cb, T, nullptr, nullptr))
   PD_PHASE(ph_antialias(lane, L, cb))
   PD_PHASE(ph_mfma<false, 0>(lane, L, R, cb, T, nullptr, nullptr, true))
-  PD_PHASE(ph_window<F32>(lane, L, R, false, nullptr, nullptr))
+  PD_PHASE(ph_window<F32>(lane, L, R, false, 2, nullptr, nullptr))
   PD_PHASE(
     if (f == a.n_frames - 1 && a.state_out) state_store(lane, R, a.state_out);
     chain_publish(lane, R, a.chain_state + (size_t)f * kStateFloats, a.chain_flag + f, a.chain_epoch, cp);
@@ -1255,7 +1254,7 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
   if (cp.hi) PD_SETPRIO(0);
   // ---- D
   PD_PHASE(ph_mfma<false, kFromPark>(lane, L, R, cb, T, nullptr, nullptr, true, &L.park[0][0]))
-  PD_PHASE(ph_window<F32>(lane, L, R, true, a.pcm + (size_t)f * 2304, F32 ? a.pcm_f32 + (size_t)f * 2304 : nullptr))
+  PD_PHASE(ph_window<F32>(lane, L, R, true, 2, a.pcm + (size_t)f * 2304, F32 ? a.pcm_f32 + (size_t)f * 2304 : nullptr))
   // ---- E
   PD_PHASE(ph_window_rest<F32>(lane, L, R, a.pcm + (size_t)f * 2304 + 1152, F32 ? a.pcm_f32 + (size_t)f * 2304 + 1152 : nullptr))
 }

@@ -7,7 +7,7 @@ mkdir -p $OUT
 for rep in 1 2; do
   for so in pdmp3_amd/variants/*.so; do
     n=$(basename $so .so)
-    PDMP3_HIP_LIB=$PWD/$so timeout 300 python3 bench.py --no-cpu --no-e2e --steps 300 --warmup 30 --big 0 > $OUT/$n.$rep.json 2>/dev/null
+    PDMP3_HIP_LIB=$PWD/$so timeout 300 python3 bench.py --no-cpu --no-e2e --steps 300 --warmup 30 > $OUT/$n.$rep.json 2>/dev/null
     python3 - <<PY
 import json
 try:
