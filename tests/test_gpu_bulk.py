@@ -410,3 +410,42 @@ def test_corrupted_streams_pcm_against_the_oracle(oracle):
     finally:
         dev.close()
     assert streams > 80 and loud > 0
+
+
+def test_async_decode_is_done_with_the_stream_when_it_returns(streams):
+    """pdmp3_amd_bulk_decode_async's contract: `mp3` may be released when the call returns.  The scanning thread only
+    notes where the frames' main data lies in the caller's buffer and the submitter thread copies it later -- so the
+    call must not return before that has happened: overwrite every input right after its call, wait at the end"""
+    from pdmp3_amd import api
+    names = [k for k in streams if len(streams[k]) > 2000]
+    ref = api.BulkDecoder(threads=2, window_frames=64)
+    b = api.BulkDecoder(threads=2, window_frames=32)
+    try:
+        want = {k: ref.decode(streams[k]) for k in names}
+        outs = {k: np.zeros(max(want[k].size, 1), dtype=np.int16) for k in names}
+        for k in names:
+            buf = np.frombuffer(streams[k], dtype=np.uint8).copy()
+            b.decode_into_async(buf, outs[k])
+            buf[:] = 0xA5                                   # the caller's buffer is gone
+        b.wait()
+        for k in names:
+            assert np.array_equal(outs[k][:want[k].size], want[k]), k
+    finally:
+        b.close()
+        ref.close()
+
+
+def test_compact_upload_equals_snapshot_rows(streams, monkeypatch):
+    """the two forms of the device-Huffman input -- main data once in a pool + row descriptors (k_rows rebuilds the
+    reservoir rows), and a 2064-byte snapshot per frame (PDMP3_BULK_SNAPSHOT_ROWS=1) -- give the same PCM"""
+    from pdmp3_amd import api
+    a = api.BulkDecoder(threads=2, window_frames=48)
+    monkeypatch.setenv("PDMP3_BULK_SNAPSHOT_ROWS", "1")
+    s = api.BulkDecoder(threads=2, window_frames=48)
+    monkeypatch.delenv("PDMP3_BULK_SNAPSHOT_ROWS")
+    try:
+        for k, mp3 in streams.items():
+            assert np.array_equal(a.decode(mp3), s.decode(mp3)), k
+    finally:
+        a.close()
+        s.close()
