@@ -30,7 +30,7 @@ b.record()
 torch.cuda.synchronize()
 p = prof.cpu().numpy().astype(np.float64)
 gran = p[:, 8].sum()
-names = ["load", "scales", "requant", "fetch+aa", "imdct", "dct32", "window", "store"]
+names = ["load", "facts", "requant", "fetch+aa", "imdct+dct32", "-", "commit+scales", "window+store"]   # (the phases between run_chunk's PD_TICK marks)
 tot = p[:, :8].sum()
 print("n_frames %d chunk %d chunks %d kernel %.3f ms  (s_memtime ticks)" % (n, chunk, nchunks, a.elapsed_time(b)))
 for k, nm in enumerate(names):
