@@ -111,9 +111,17 @@ size_t pdmp3_hip_state_bytes(void);
  *   d_state    device, pdmp3_hip_state_bytes() bytes, read before the first
  *              frame and written after the last one; NULL = start from the
  *              zero state and discard the final state
- *   chunk_frames  frames per workgroup chunk (the engine re-derives the state
- *              at chunk boundaries from a halo of preceding frames, SURVEY
- *              8e); 0 = choose automatically
+ *   chunk_frames  frames per wavefront ("chunk"); 0 = choose automatically.
+ *              Chunks of several frames are independent: each re-derives the
+ *              state at its start from a halo of preceding frames.
+ *              At ONE frame per chunk and up to one round of wavefronts (2048
+ *              frames on MI355X; what 0 picks for such sizes) the wavefronts
+ *              hand their frames' closing states on instead ("chained" launch;
+ *              scratch is kept per HIP stream -- for up to 32 streams, beyond
+ *              that the halo form is used -- or per pdmp3_hip_stream object);
+ *              PDMP3_HIP_CHAIN=0 in the environment at pdmp3_hip_create() keeps
+ *              the halo form everywhere.  Same PCM and state either way, bit
+ *              for bit.
  *
  * Asynchronous on `stream`.
  */
