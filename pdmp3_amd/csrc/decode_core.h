@@ -306,34 +306,50 @@ struct ChainPos {
   bool last_in_wg;       // its successor, if any, runs in another workgroup
   bool hi;               // runs at raised priority until it has taken its predecessor's state (see k_decode)
 };
-PD_FN void chain_publish(int lane, const LaneRegs& R, float* st, unsigned* gflag, unsigned epoch, const ChainPos& cp) {
-  if (cp.last_in_wg) {
-    for (int m = 0; m < kOvlRegs; m++) PD_STORE_DEVICE(&st[m * 64 + lane], R.ovl[m]);
-    for (int s = 0; s < kHistSlots; s++) {
-      PD_STORE_DEVICE(&st[(kOvlRegs + s) * 64 + lane], R.he[s]);
-      PD_STORE_DEVICE(&st[(kOvlRegs + kHistSlots + s) * 64 + lane], R.ho[s]);
-    }
-    PD_VMEM_DRAIN();
-    if (lane == 0) PD_STORE_DEVICE(gflag, epoch);
-  } else {
-    state_store(lane, R, st);
-    PD_VMEM_DRAIN();
-    if (lane == 0) *reinterpret_cast<volatile unsigned*>(&cp.wg_flag[cp.w]) = epoch;
+// What travels is kChainFloats per frame: the 18 overlap tails of every lane, and slots 3..17 of the last granule's
+// matrixing output ONCE -- rows [slot][ch][32 coefficients]; the two coefficients of a slot that a lane keeps as
+// he / ho (idx_e, idx_o) are each kept by another lane as well, so the he / ho form is twice the bytes (and the states of
+// a launch then no longer fit the L2 they pass through).
+constexpr int kChainFloats = 64 * (kOvlRegs + kHistSlots);
+#define PD_CHAIN_STORE(p, v) { if (cp.last_in_wg) PD_STORE_DEVICE((p), (v)); else *(p) = (v); }
+PD_FN void chain_signal(int lane, unsigned* gflag, unsigned epoch, const ChainPos& cp) {
+  PD_VMEM_DRAIN();
+  if (lane == 0) {
+    if (cp.last_in_wg) PD_STORE_DEVICE(gflag, epoch);
+    else *reinterpret_cast<volatile unsigned*>(&cp.wg_flag[cp.w]) = epoch;
   }
 }
+// from a wave that has the matrixing output of its last granule in LDS (run_chunk_chained)
+PD_FN void chain_publish_rows(int lane, const WaveLds& L, const LaneRegs& R, float* st, unsigned* gflag, unsigned epoch, const ChainPos& cp) {
+  const int ch = lane >> 5, i = lane & 31;
+  for (int m = 0; m < kOvlRegs; m++) PD_CHAIN_STORE(&st[m * 64 + lane], R.ovl[m])
+  for (int s = 0; s < kHistSlots; s++) PD_CHAIN_STORE(&st[(kOvlRegs + s) * 64 + lane], L.hyb[ch][3 + s][i])
+  chain_signal(lane, gflag, epoch, cp);
+}
+// from a wave that only has he / ho (run_chunk at the end of its frame): coefficient 16 + i is he of lane i < 16,
+// coefficient 16 - i is ho of lane i <= 16 -- together all 32 of a row
+PD_FN void chain_publish_regs(int lane, const LaneRegs& R, float* st, unsigned* gflag, unsigned epoch, const ChainPos& cp) {
+  const int ch = lane >> 5, i = lane & 31;
+  for (int m = 0; m < kOvlRegs; m++) PD_CHAIN_STORE(&st[m * 64 + lane], R.ovl[m])
+  for (int s = 0; s < kHistSlots; s++) {
+    if (i < 16) PD_CHAIN_STORE(&st[(kOvlRegs + s) * 64 + ch * 32 + 16 + i], R.he[s])
+    if (i <= 16) PD_CHAIN_STORE(&st[(kOvlRegs + s) * 64 + ch * 32 + 16 - i], R.ho[s])
+  }
+  chain_signal(lane, gflag, epoch, cp);
+}
 PD_FN void chain_take(int lane, LaneRegs& R, const float* st, const unsigned* gflag, unsigned epoch, const ChainPos& cp) {
+  const int ch = lane >> 5;
+  const float* rows = st + kOvlRegs * 64 + ch * 32;
   if (cp.w > 0) {
     while ((unsigned)PD_UNIFORM(*reinterpret_cast<volatile unsigned*>(&cp.wg_flag[cp.w - 1])) != epoch) PD_SLEEP();
     asm volatile("" ::: "memory");
-    state_load(lane, R, st);
+    for (int m = 0; m < kOvlRegs; m++) R.ovl[m] = st[m * 64 + lane];
+    for (int s = 0; s < kHistSlots; s++) { R.he[s] = rows[s * 64 + R.idx_e]; R.ho[s] = rows[s * 64 + R.idx_o]; }
   } else {
     while ((unsigned)PD_UNIFORM(PD_LOAD_DEVICE(gflag)) != epoch) PD_SLEEP();
     asm volatile("" ::: "memory");
     for (int m = 0; m < kOvlRegs; m++) R.ovl[m] = PD_LOAD_DEVICE(&st[m * 64 + lane]);
-    for (int s = 0; s < kHistSlots; s++) {
-      R.he[s] = PD_LOAD_DEVICE(&st[(kOvlRegs + s) * 64 + lane]);
-      R.ho[s] = PD_LOAD_DEVICE(&st[(kOvlRegs + kHistSlots + s) * 64 + lane]);
-    }
+    for (int s = 0; s < kHistSlots; s++) { R.he[s] = PD_LOAD_DEVICE(&rows[s * 64 + R.idx_e]); R.ho[s] = PD_LOAD_DEVICE(&rows[s * 64 + R.idx_o]); }
   }
 }
 
@@ -983,7 +999,7 @@ struct DecodeArgs {
   int n_frames;
   int chunk_frames;
   unsigned long long* prof;      // PROF builds: [n_chunks][kProfSlots] shader-clock ticks per phase
-  // chained chunks (chunk_frames == 1, run_chunk_chained): [n_frames][kStateFloats] states after every frame,
+  // chained chunks (chunk_frames == 1, run_chunk_chained): [n_frames][kChainFloats] states after every frame,
   // one flag per frame (== chain_epoch once the frame's state is there)
   float* chain_state;
   unsigned* chain_flag;
@@ -1160,7 +1176,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     const uint8_t fbl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f1 - 1) * 4)[7];
     if (((fbl & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3) {
       const ChainPos alone{nullptr, 0, true, false};
-      PD_PHASE(chain_publish(lane, R, a.chain_state + (size_t)(f1 - 1) * kStateFloats, a.chain_flag + (f1 - 1), a.chain_epoch, cp ? *cp : alone))
+      PD_PHASE(chain_publish_regs(lane, R, a.chain_state + (size_t)(f1 - 1) * kChainFloats, a.chain_flag + (f1 - 1), a.chain_epoch, cp ? *cp : alone))
     }
   }
 }
@@ -1236,16 +1252,18 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
   PD_PHASE(ph_requant<false>(lane, L, cb, T, nullptr, nullptr))
   PD_PHASE(ph_antialias(lane, L, cb))
   PD_PHASE(ph_mfma<false, 0>(lane, L, R, cb, T, nullptr, nullptr, true))
-  PD_PHASE(ph_window<F32>(lane, L, R, false, 2, nullptr, nullptr))
   PD_PHASE(
-    if (f == a.n_frames - 1 && a.state_out) state_store(lane, R, a.state_out);
-    chain_publish(lane, R, a.chain_state + (size_t)f * kStateFloats, a.chain_flag + f, a.chain_epoch, cp);
+    if (f == a.n_frames - 1 && a.state_out) {       // (wave-uniform) the launch's closing state, in the caller's form
+      ph_window<F32>(lane, L, R, false, 2, nullptr, nullptr);
+      state_store(lane, R, a.state_out);
+    }
+    chain_publish_rows(lane, L, R, a.chain_state + (size_t)f * kChainFloats, a.chain_flag + f, a.chain_epoch, cp);
   )
   PD_PHASE(ph_window_first(lane, L, R))      // (after the hand-over: useful work while the state travels, and its
                                                    //  stores are not waited for by the publisher: 39 -> 33 us)
   // ---- C
   if (have_prev) {
-    PD_PHASE(chain_take(lane, R, a.chain_state + (size_t)(f - 1) * kStateFloats, a.chain_flag + (f - 1), a.chain_epoch, cp))
+    PD_PHASE(chain_take(lane, R, a.chain_state + (size_t)(f - 1) * kChainFloats, a.chain_flag + (f - 1), a.chain_epoch, cp))
   } else if (f == 0 && a.state_in && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET)) {
     PD_PHASE(state_load(lane, R, a.state_in))
   } else {

@@ -343,7 +343,7 @@ static ChainBuf* chain_get(pdmp3_hip_ctx* c, const void* key, hipStream_t s, int
     if (b->flag) (void)hipFreeAsync(b->flag, s);
     b->state = nullptr; b->flag = nullptr; b->cap = 0;
     const int cap = n_frames < 256 ? 256 : n_frames;
-    if (hipMallocAsync((void**)&b->state, (size_t)cap * kStateFloats * sizeof(float), s) != hipSuccess ||
+    if (hipMallocAsync((void**)&b->state, (size_t)cap * kChainFloats * sizeof(float), s) != hipSuccess ||
         hipMallocAsync((void**)&b->flag, (size_t)cap * sizeof(unsigned), s) != hipSuccess ||
         hipMemsetAsync(b->flag, 0, (size_t)cap * sizeof(unsigned), s) != hipSuccess) {
       (void)hipGetLastError();

@@ -65,7 +65,7 @@ extern "C" int emul_decode_frames_chained(const int16_t* spectra, const pdmp3_gc
   if (!ready) { build_host_tables(H); ready = true; }
   GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data()};
   std::vector<float> state_next(kStateFloats);
-  std::vector<float> cstate((size_t)n_frames * kStateFloats);
+  std::vector<float> cstate((size_t)n_frames * kChainFloats);
   std::vector<unsigned> cflag((size_t)n_frames, 0u);
   DecodeArgs a{spectra, side, pcm, pcm_f32, state, state ? state_next.data() : nullptr, nullptr, n_frames, 1, nullptr,
                cstate.data(), cflag.data(), 7u};
