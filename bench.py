@@ -292,8 +292,8 @@ def main():
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             # (chained launch: 19.9 MB of spectra / side / PCM + the frames' closing states handed from wave to wave,
-            #  12.3 KB written and read once per frame -- DESIGN.md 3)
-            "traffic_note": "includes 2 x 25 MB of state hand-over between the waves of a chained launch",
+            #  8.25 KB written and read once per frame -- DESIGN.md 3)
+            "traffic_note": "includes 2 x 17 MB of state hand-over between the waves of a chained launch",
             # (launches of up to one round of waves at one frame per chunk are "chained": 8 waves per workgroup, states
             #  handed from wave to wave instead of a halo per wave -- decode_core.h run_chunk_chained)
             "kernel": "k_decode<false, false, 8>" if (n <= 2048 and not args.chunk and os.environ.get("PDMP3_HIP_CHAIN", "1") != "0")
