@@ -104,6 +104,11 @@ void permlane32_swap(int* a, int* b);         // v_permlane32_swap_b32 vdst = a,
 #define PD_SETPRIO(x) ((void)0)
 #endif
 
+// development only (tools/ab_pmc.sh): phases switched off for instruction-count / timing experiments -- results are wrong
+#ifndef PD_EXP_SKIP
+#define PD_EXP_SKIP 0
+#endif
+
 namespace pdmp3 {
 
 constexpr int kOvlRegs = 18;          // overlap: [ch][h][r] in MFMA C/D layout for p = 18 + j, plus p = 34, 35 of the lane's own (ch, sb)
@@ -153,23 +158,31 @@ struct GlobalTables {
   const float* frag_mat;    // [2 even/odd][4 k-steps]: 16 x 16 halves of the 32-point DCT-II, rows in register order
 };
 
-// LDS per wave (~16.9 KB).  Buffers whose lifetimes do not overlap share storage:
-//   xr   (ph_requant .. ph_fetch)           | hyb  (ph_imdct .. ph_window)
+// LDS.  WaveData is a wave's own working set; TabLds are the hot tables -- one copy per wave in the chunk kernels
+// (WaveLds), one per WORKGROUP in the granule kernel (run_granule).  Buffers whose lifetimes do not overlap share
+// storage:   xr (ph_requant .. ph_mfma's operand fetch)   |   hyb (ph_mfma .. ph_window)
 // hyb rows are [slot t][33]: the DCT lane that owns slot t transforms its row in place.
-struct WaveLds {
+struct WaveData {
   alignas(16) int16_t spec[2][576];     // committed one granule ahead (before the previous granule's PCM stores)
   alignas(16) int16_t pcm[576];
   alignas(16) uint8_t side[2][128];
   float scale[2][64];
-  union {
+  union alignas(16) {
     float xr[2][576];
     float hyb[2][18][33];
   };
-  alignas(16) float win[4][36];
-  float pow43s[kPow43Small];
-  alignas(16) uint16_t ltab[3][576];
   float peek[4];
   float lo[2][4][16];       // MFMA build: even / odd folded time slots 16, 17: [a|b][2 ch + (t - 16)][k]
+};
+struct TabLds {
+  alignas(16) float win[4][36];
+  float pow43z[2 * kPow43Small];   // [128 + v] = sign(v) |v|^(4/3) for v = -128 .. 127: magnitude lookup and sign in one read
+  alignas(16) uint16_t ltab[3][576];
+  uint8_t bandaddr[5][64];         // long blocks (ph_requant_long): 4 x scale index of the lane's lines, see fast_line()
+  int sfreq;                       // the sampling frequency ltab / bandaddr are for
+};
+struct WaveLds : WaveData {
+  TabLds tab;
   float park[18][64];       // chained chunks: granule 0's hybrid outputs until the frame before has been transformed
 };
 
@@ -202,7 +215,7 @@ struct GranuleInfo {
   PD_MFN int kind(int ch) const { return is_short(ch) ? (is_mixed(ch) ? 2 : 1) : 0; }
 };
 
-PD_FN GranuleInfo granule_info(const WaveLds& L) {
+PD_FN GranuleInfo granule_info(const WaveData& L) {
   GranuleInfo g;
   // (the first dword of each record: count1 u16, global_gain, flags; byte 7: frame flags)
   const uint32_t w0 = (uint32_t)PD_UNIFORM(*reinterpret_cast<const uint32_t*>(&L.side[0][0]));
@@ -223,6 +236,16 @@ PD_FN GranuleInfo granule_info(const WaveLds& L) {
 PD_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 PD_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
+// two binary32 values in a register pair: element-wise + - * on them are the packed VALU forms (v_pk_add_f32,
+// v_pk_mul_f32: one issue slot for two results; each element rounded exactly like the scalar operation)
+#if defined(__HIPCC__)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#else
+typedef float f32x2 __attribute__((vector_size(8)));
+typedef unsigned short u16x2 __attribute__((vector_size(4)));
+#endif
+
 // ---------------------------------------------------------------------------
 // chunk prologue: per-lane constants, LDS copies of hot tables
 // ---------------------------------------------------------------------------
@@ -232,7 +255,8 @@ PD_FN void state_zero(int lane, LaneRegs& R) {
   for (int s = 0; s < kHistSlots; s++) { R.he[s] = 0.0f; R.ho[s] = 0.0f; }
 }
 
-PD_FN void lane_init(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTables& T) {
+// the per-lane constants of a wave
+PD_FN void lane_init(int lane, WaveData& L, LaneRegs& R, BankPtr cb, const GlobalTables& T) {
   const int i = lane & 31;
   // v[i] = C[16+i] (i<16), 0 (i==16), -C[48-i] (i>16);  v[32+i] = -C[16-i] (i<=16), -C[i-16] (i>16)
   // where C = 32-point DCT-II of the slot (derivation: DESIGN.md "polyphase").
@@ -244,20 +268,37 @@ PD_FN void lane_init(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const Global
     R.wo[k] = -cb->dwin[64 * k + 32 + i];
   }
   state_zero(lane, R);
-  L.pow43s[lane] = T.pow43[lane];
-  L.pow43s[lane + 64] = T.pow43[lane + 64];
-  for (int k = lane; k < 144; k += 64) (&L.win[0][0])[k] = T.win[k];
   if (lane < 4) L.peek[lane] = 1.0f;
   for (int k = 0; k < 10; k++) R.bi[k] = T.frag_long[k * 64 + lane];
   for (int k = 0; k < 8; k++) R.bm[k] = T.frag_mat[k * 64 + lane];
 }
 
-// the line tables of one sampling frequency (3 kinds x 576 u16 = 216 x 16 B)
-PD_FN void load_linetab(int lane, WaveLds& L, const GlobalTables& T, int sfreq) {
-  const Chunk16* src = reinterpret_cast<const Chunk16*>(T.linetab + (size_t)sfreq * 3 * 576);
-  Chunk16* dst = reinterpret_cast<Chunk16*>(&L.ltab[0][0]);
-  for (int k = lane; k < 216; k += 64) dst[k] = src[k];
+// Lines of a lane in the long-block fast path (ph_requant_long): the PAIRS (2 l + 128 i, 2 l + 1 + 128 i), i = 0..3 --
+// one LDS dword of int16 spectra each, and always inside one scalefactor band (every long band boundary of P:879-892
+// is even) -- and the single line 512 + l (i = 4).
+PD_HD int fast_line(int lane, int i) { return i < 4 ? 2 * lane + 128 * i : 512 + lane; }
+PD_FN unsigned band_addr_of(const GlobalTables& T, int sfreq, int line) {      // 4 x long-block band of a line
+  return (unsigned)((T.linetab[(size_t)sfreq * 3 * 576 + line] >> 10) << 2);
 }
+
+// The tables, brought in by `nthr` threads (tid = 0 .. nthr - 1): the sampling-frequency independent ones ...
+PD_FN void tab_load_fixed(int tid, int nthr, TabLds& S, const GlobalTables& T) {
+  for (int k = tid; k < 2 * kPow43Small; k += nthr) {
+    const int v = k - kPow43Small;
+    const float p = T.pow43[v < 0 ? -v : v];
+    S.pow43z[k] = v < 0 ? -p : p;
+  }
+  for (int k = tid; k < 144; k += nthr) (&S.win[0][0])[k] = T.win[k];
+}
+// ... and the line tables of one sampling frequency (3 kinds x 576 u16 = 216 x 16 B)
+PD_FN void tab_load_sfreq(int tid, int nthr, TabLds& S, const GlobalTables& T, int sfreq) {
+  const Chunk16* src = reinterpret_cast<const Chunk16*>(T.linetab + (size_t)sfreq * 3 * 576);
+  Chunk16* dst = reinterpret_cast<Chunk16*>(&S.ltab[0][0]);
+  for (int k = tid; k < 216; k += nthr) dst[k] = src[k];
+  for (int k = tid; k < 5 * 64; k += nthr) S.bandaddr[k >> 6][k & 63] = (uint8_t)band_addr_of(T, sfreq, fast_line(k & 63, k >> 6));
+  if (tid == 0) S.sfreq = sfreq;
+}
+PD_FN void load_linetab(int lane, TabLds& S, const GlobalTables& T, int sfreq) { tab_load_sfreq(lane, 64, S, T, sfreq); }
 
 // state layout (opaque to callers): float ovl[kOvlRegs][64 lanes]; float he[15][64]; float ho[15][64]
 constexpr int kStateFloats = 64 * (kOvlRegs + 2 * kHistSlots);
@@ -320,7 +361,7 @@ PD_FN void chain_signal(int lane, unsigned* gflag, unsigned epoch, const ChainPo
   }
 }
 // from a wave that has the matrixing output of its last granule in LDS (run_chunk_chained)
-PD_FN void chain_publish_rows(int lane, const WaveLds& L, const LaneRegs& R, float* st, unsigned* gflag, unsigned epoch, const ChainPos& cp) {
+PD_FN void chain_publish_rows(int lane, const WaveData& L, const LaneRegs& R, float* st, unsigned* gflag, unsigned epoch, const ChainPos& cp) {
   const int ch = lane >> 5, i = lane & 31;
   for (int m = 0; m < kOvlRegs; m++) PD_CHAIN_STORE(&st[m * 64 + lane], R.ovl[m])
   for (int s = 0; s < kHistSlots; s++) PD_CHAIN_STORE(&st[(kOvlRegs + s) * 64 + lane], L.hyb[ch][3 + s][i])
@@ -368,7 +409,7 @@ PD_FN void ph_prefetch(int lane, LaneRegs& R, const int16_t* spectra_g, const pd
   }
 }
 
-PD_FN void ph_commit(int lane, WaveLds& L, const LaneRegs& R) {
+PD_FN void ph_commit(int lane, WaveData& L, const LaneRegs& R) {
   Chunk16* dst = reinterpret_cast<Chunk16*>(&L.spec[0][0]);
   dst[lane] = R.pf0;
   dst[lane + 64] = R.pf1;
@@ -397,7 +438,7 @@ PD_HD float pow2_neg_half(uint32_t n) {  // 2^(-n/2); 0 from n = 300 on (binary3
 }
 
 // straight-line (select-only) so that the LDS reads of both channels are in flight together
-PD_FN void ph_scales(int lane, WaveLds& L) {
+PD_FN void ph_scales(int lane, WaveData& L) {
   const bool is_long = lane < 22;
   const int ll = is_long ? lane : 21;
   const int q = is_long ? 0 : (lane < 61 ? lane - 22 : 38);
@@ -425,21 +466,38 @@ PD_FN void ph_scales(int lane, WaveLds& L) {
 // REORDERED lines l, l + 64, ..., l + 512 of both channels (consecutive lanes
 // touch consecutive LDS words: no bank conflicts on the int16 / u16 tables).
 // ---------------------------------------------------------------------------
+template <bool TG> PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalTables& T, const GranuleInfo& g);   // (below)
+
 // NI = 9: the whole granule.  NI = 1: only the reordered lines 0..63 (the peek-only halo granule, see run_chunk).
-template <bool DUMP, int NI = 9>
-PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, float* dump0, float* dump1) {
+// FAST: granules of long blocks take ph_requant_long.  TG: the tables in S may be for another sampling frequency than
+// the granule's (granule kernel: one table block per workgroup) -- then the line table is read from global memory.
+template <bool DUMP, int NI = 9, bool FAST = false, bool TG = false>
+PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const GlobalTables& T, float* dump0, float* dump1) {
   const GranuleInfo g = granule_info(L);
+  const bool tg = TG && (g.sfreq != S.sfreq);                       // wave-uniform
+  const uint16_t* gtab = T.linetab + (size_t)g.sfreq * 3 * 576;
   const bool joint = (g.nch == 2) && (g.mode == 1) && (g.mode_ext != 0);
   const bool ms = joint && (g.mode_ext & 2);
   const bool is = joint && (g.mode_ext & 1);
   const int cmin = (g.count1_0 > g.count1_1) ? g.count1_1 : g.count1_0;   // P:1920 (H2)
   const int kind0 = g.kind(0), kind1 = g.kind(1);
+  if (FAST && !DUMP && NI == 9) {
+    if (kind0 == 0 && (g.nch == 1 || kind1 == 0) && !is) {     // wave-uniform
+      ph_requant_long<TG>(lane, L, S, T, g);
+      return;
+    }
+  }
   float x0[NI], x1[NI];
 #define PD_LINE(i) (lane + 64 * (i))
   {
     unsigned e0[NI], e1[NI];
-    PD_UNROLL for (int i = 0; i < NI; i++) e0[i] = L.ltab[kind0][PD_LINE(i)];
-    PD_UNROLL for (int i = 0; i < NI; i++) e1[i] = L.ltab[kind1][PD_LINE(i)];
+    if (tg) {
+      PD_UNROLL for (int i = 0; i < NI; i++) e0[i] = gtab[kind0 * 576 + PD_LINE(i)];
+      PD_UNROLL for (int i = 0; i < NI; i++) e1[i] = gtab[kind1 * 576 + PD_LINE(i)];
+    } else {
+      PD_UNROLL for (int i = 0; i < NI; i++) e0[i] = S.ltab[kind0][PD_LINE(i)];
+      PD_UNROLL for (int i = 0; i < NI; i++) e1[i] = S.ltab[kind1][PD_LINE(i)];
+    }
     int v0[NI], v1[NI];
     float s0[NI], s1[NI];
     PD_UNROLL for (int i = 0; i < NI; i++) { v0[i] = L.spec[0][e0[i] & 1023]; s0[i] = L.scale[0][e0[i] >> 10]; }
@@ -459,7 +517,7 @@ PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, f
         pg1[i] = T.pow43[a1[i] >= kPow43Small ? (a1[i] > 8206 ? 8206 : a1[i]) : 0];
       }
     }
-    PD_UNROLL for (int i = 0; i < NI; i++) { ps0[i] = L.pow43s[a0[i] & (kPow43Small - 1)]; ps1[i] = L.pow43s[a1[i] & (kPow43Small - 1)]; }
+    PD_UNROLL for (int i = 0; i < NI; i++) { ps0[i] = S.pow43z[kPow43Small + (a0[i] & (kPow43Small - 1))]; ps1[i] = S.pow43z[kPow43Small + (a1[i] & (kPow43Small - 1))]; }
     PD_UNROLL for (int i = 0; i < NI; i++) {
       const float p = a0[i] >= kPow43Small ? pg0[i] : ps0[i];
       x0[i] = s0[i] * (v0[i] < 0 ? -p : p);                 // (t1*t2)*t3, P:2132
@@ -495,10 +553,10 @@ PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, f
       bool do_long = false, do_short = false;
       int sfb = 0, win = 0;
       if (kind0 == 0) {
-        sfb = L.ltab[0][d] >> 10;
+        sfb = (tg ? gtab[d] : S.ltab[0][d]) >> 10;
         do_long = (sfb < 21);
       } else if (kind0 == 2 && d < 36) {
-        sfb = L.ltab[0][d] >> 10;
+        sfb = (tg ? gtab[d] : S.ltab[0][d]) >> 10;
         do_long = (sfb < 8);
       } else {
         // band of POSITION d in the un-reordered [win][j] layout (P:2203)
@@ -543,6 +601,116 @@ PD_FN void ph_requant(int lane, WaveLds& L, BankPtr cb, const GlobalTables& T, f
 }
 
 // ---------------------------------------------------------------------------
+// ph_requant_long: the same stage for the common granule -- long blocks in every channel, no intensity stereo
+// (wave-uniform).  Reorder is the identity there and the band of a line is a constant of the lane, so nothing goes
+// through the line table: lane l owns the line pairs (2 l + 128 i, 2 l + 1 + 128 i), i = 0..3, and line 512 + l
+// (fast_line): one LDS dword of spectra per pair, the band's scale address from bandaddr[], |is|^(4/3) WITH its sign
+// from pow43z[] in one read, the product and the MS sum / difference as packed operations, 8-byte stores.
+// Same arithmetic per line as ph_requant: (t1 t2) (+-t3), P:2132; MS in binary64 like P:1923-1926.
+// ---------------------------------------------------------------------------
+PD_FN float pow43z_at(const TabLds& S, int v) {
+#if defined(__HIPCC__)
+  // |v| >= 128 reads past the table (somewhere in LDS or beyond it: harmless); such values are replaced by the caller
+  return S.pow43z[kPow43Small + v];
+#else
+  return S.pow43z[kPow43Small + ((unsigned)(v + kPow43Small) < 2u * kPow43Small ? v : 0)];
+#endif
+}
+// the full table for the values outside -128 .. 127 (rare): every lane issues its loads unconditionally (entry 0 when
+// its value is small -- one shared line), so that all of a group's gathers are in flight together
+PD_FN int pow43_big_index(int v) {
+  const int a = v < 0 ? -v : v;
+  return a < kPow43Small ? 0 : (a > 8206 ? 8206 : a);
+}
+PD_FN float pow43_big_pick(int v, float small, float big) {
+  const int a = v < 0 ? -v : v;
+  return a < kPow43Small ? small : (v < 0 ? -big : big);
+}
+PD_FN float ms_scale(float x) { return (float)((double)x * 0.70710678118654752440); }      // P:1923-1926
+
+// |is|^(4/3) with its sign comes from the LDS table for -128 .. 127.  Values outside it are a few per granule at most,
+// so each of the 18 value positions of the lanes is tested on its own (wave-uniform) and only a position that holds
+// one anywhere in the wave goes to the full table -- issue: the load (all of a granule's before anything waits for
+// one); pick: its result in place of the LDS value.
+#define PD_BIG_ISSUE(flag, v, g_) { g_ = 0.0f; if (flag) g_ = T.pow43[pow43_big_index(v)]; }
+#define PD_BIG_PICK(flag, v, p, g_) if (flag) p = pow43_big_pick(v, p, g_);
+
+template <bool TG>
+PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalTables& T, const GranuleInfo& g) {
+  const bool tg = TG && (g.sfreq != S.sfreq);                       // wave-uniform
+  const bool two = g.nch == 2;
+  const bool ms = two && (g.mode == 1) && (g.mode_ext & 2);
+  const int cmin = (g.count1_0 > g.count1_1) ? g.count1_1 : g.count1_0;   // P:1920 (H2)
+  const uint32_t* sp0 = reinterpret_cast<const uint32_t*>(&L.spec[0][0]);
+  const uint32_t* sp1 = reinterpret_cast<const uint32_t*>(&L.spec[1][0]);
+  const char* sc0 = reinterpret_cast<const char*>(&L.scale[0][0]);
+  const char* sc1 = reinterpret_cast<const char*>(&L.scale[1][0]);
+  uint32_t w0[4], w1[4];
+  unsigned ba[5];
+  PD_UNROLL for (int i = 0; i < 4; i++) { w0[i] = sp0[lane + 64 * i]; w1[i] = two ? sp1[lane + 64 * i] : 0u; }
+  const int v0s = L.spec[0][512 + lane], v1s = two ? L.spec[1][512 + lane] : 0;
+  if (tg) { PD_UNROLL for (int i = 0; i < 5; i++) ba[i] = band_addr_of(T, g.sfreq, fast_line(lane, i)); }
+  else { PD_UNROLL for (int i = 0; i < 5; i++) ba[i] = S.bandaddr[i][lane]; }
+  // a 16-bit value is inside -128 .. 127 <=> its bits 15..7 are all alike <=> bits 15..8 of v ^ (v << 1) are zero
+  bool fa0[4], fb0[4], fa1[4], fb1[4];
+  float ga0[4], gb0[4], ga1[4], gb1[4], gs0, gs1;
+  PD_UNROLL for (int i = 0; i < 4; i++) {
+    const uint32_t m0 = w0[i] ^ (w0[i] << 1), m1 = w1[i] ^ (w1[i] << 1);
+    fa0[i] = PD_ANY((m0 & 0x0000ff00u) != 0u); fb0[i] = PD_ANY((m0 & 0xff000000u) != 0u);
+    fa1[i] = PD_ANY((m1 & 0x0000ff00u) != 0u); fb1[i] = PD_ANY((m1 & 0xff000000u) != 0u);
+    PD_BIG_ISSUE(fa0[i], (int)(int16_t)(w0[i] & 0xffffu), ga0[i]) PD_BIG_ISSUE(fb0[i], (int)w0[i] >> 16, gb0[i])
+    PD_BIG_ISSUE(fa1[i], (int)(int16_t)(w1[i] & 0xffffu), ga1[i]) PD_BIG_ISSUE(fb1[i], (int)w1[i] >> 16, gb1[i])
+  }
+  const bool fs0 = PD_ANY((unsigned)(v0s + kPow43Small) >= 2u * kPow43Small);
+  const bool fs1 = PD_ANY((unsigned)(v1s + kPow43Small) >= 2u * kPow43Small);
+  PD_BIG_ISSUE(fs0, v0s, gs0) PD_BIG_ISSUE(fs1, v1s, gs1)
+  float s0[5], s1[5];
+  PD_UNROLL for (int i = 0; i < 5; i++) {
+    s0[i] = *reinterpret_cast<const float*>(sc0 + ba[i]);
+    s1[i] = *reinterpret_cast<const float*>(sc1 + ba[i]);
+  }
+  PD_UNROLL for (int i = 0; i < 5; i++) {
+    f32x2 x0, x1;
+    if (i < 4) {
+      const int a0 = (int)(int16_t)(w0[i] & 0xffffu), b0 = (int)w0[i] >> 16;
+      const int a1 = (int)(int16_t)(w1[i] & 0xffffu), b1 = (int)w1[i] >> 16;
+      float pa0 = pow43z_at(S, a0), pb0 = pow43z_at(S, b0), pa1 = pow43z_at(S, a1), pb1 = pow43z_at(S, b1);
+      PD_BIG_PICK(fa0[i], a0, pa0, ga0[i]) PD_BIG_PICK(fb0[i], b0, pb0, gb0[i])
+      PD_BIG_PICK(fa1[i], a1, pa1, ga1[i]) PD_BIG_PICK(fb1[i], b1, pb1, gb1[i])
+      const f32x2 p0 = {pa0, pb0}, p1 = {pa1, pb1};
+      const f32x2 t0 = {s0[i], s0[i]}, t1 = {s1[i], s1[i]};
+      x0 = t0 * p0;
+      x1 = t1 * p1;
+    } else {
+      float q0 = pow43z_at(S, v0s), q1 = pow43z_at(S, v1s);
+      PD_BIG_PICK(fs0, v0s, q0, gs0) PD_BIG_PICK(fs1, v1s, q1, gs1)
+      x0 = (f32x2){s0[4] * q0, 0.0f};
+      x1 = (f32x2){s1[4] * q1, 0.0f};
+    }
+    if (ms) {   // P:1921-1928: lines below the smaller count1 only
+      const f32x2 sum = x0 + x1, dif = x0 - x1;
+      f32x2 l, r;
+      l[0] = ms_scale(sum[0]); r[0] = ms_scale(dif[0]);
+      if (i < 4) { l[1] = ms_scale(sum[1]); r[1] = ms_scale(dif[1]); } else { l[1] = 0.0f; r[1] = 0.0f; }
+      const int end = i < 4 ? 128 * i + 128 : 576;                 // the group's last line + 1
+      const bool in_a = (end <= cmin) || fast_line(lane, i) < cmin;        // (wave-uniform || per lane)
+      const bool in_b = (end <= cmin) || fast_line(lane, i) + 1 < cmin;
+      x0[0] = in_a ? l[0] : x0[0]; x0[1] = in_b ? l[1] : x0[1];
+      x1[0] = in_a ? r[0] : x1[0]; x1[1] = in_b ? r[1] : x1[1];
+    }
+    if (i < 4) {
+      *reinterpret_cast<f32x2*>(&L.xr[0][2 * lane + 128 * i]) = x0;
+      if (two) *reinterpret_cast<f32x2*>(&L.xr[1][2 * lane + 128 * i]) = x1;
+    } else {
+      L.xr[0][512 + lane] = x0[0];
+      if (two) L.xr[1][512 + lane] = x1[0];
+    }
+  }
+}
+#undef PD_BIG_ISSUE
+#undef PD_BIG_PICK
+
+// ---------------------------------------------------------------------------
 // MFMA formulation of IMDCT + matrixing (device build)
 //
 // v_mfma_f32_16x16x4_f32: lane l = (j = l & 15, kq = l >> 4) holds A[row j][k = kq], B[k = kq][col j] and
@@ -572,7 +740,7 @@ PD_FN f32x4 mfma16(float a, float b, f32x4 c) {
 #endif
 
 // alias reduction in place (P:1706-1732): lane (ch, sb) owns the boundary below subband sb
-PD_FN void ph_antialias(int lane, WaveLds& L, BankPtr cb, bool only_first = false) {   // only_first: boundary sb 0 | 1 alone
+PD_FN void ph_antialias(int lane, WaveData& L, BankPtr cb, bool only_first = false) {   // only_first: boundary sb 0 | 1 alone
   const GranuleInfo g = granule_info(L);
   const int ch = lane >> 5, sb = lane & 31;
   if (ch >= g.nch || sb == 0) return;
@@ -593,7 +761,7 @@ PD_FN void ph_antialias(int lane, WaveLds& L, BankPtr cb, bool only_first = fals
 // H5 scalefactor peek of the granule after that reads.  Lanes 0..2 = j: an 18-term dot product against column 18 + j of
 // the same matrices the MFMA path uses (fragment layout: element (k, n) of column tile nt sits at [(k / 4) * 2 + nt][(k % 4) * 16 + n]),
 // windowed like the epilogue of ph_mfma, left in the lane's overlap register of (ch 0, h 0, r 0).
-PD_FN void ph_peek_tail(int lane, const WaveLds& L, LaneRegs& R, const GlobalTables& T) {
+PD_FN void ph_peek_tail(int lane, const WaveData& L, const TabLds& S, LaneRegs& R, const GlobalTables& T) {
   if (lane >= 3) return;
   const GranuleInfo g = granule_info(L);
   const bool shrt = g.is_short(0);
@@ -601,8 +769,23 @@ PD_FN void ph_peek_tail(int lane, const WaveLds& L, LaneRegs& R, const GlobalTab
   const float* frag = (shrt && !lowrow) ? T.frag_short : T.frag_long;
   float y = 0.0f;
   PD_UNROLL for (int m = 0; m < 18; m++) y = PD_FMA(L.xr[0][m], frag[((m >> 2) * 2 + 1) * 64 + (m & 3) * 16 + lane], y);
-  if (!(shrt && !lowrow)) y = y * L.win[lowrow ? 0 : g.block_type(0)][18 + lane];
+  if (!(shrt && !lowrow)) y = y * S.win[lowrow ? 0 : g.block_type(0)][18 + lane];
   R.ovl[0] = y;
+}
+
+// The same for the granule kernel's H5 waves: lanes 0..2 = j get the IMDCT output p = j of (channel 0, subband 0) --
+// windowed, WITHOUT the overlap (the caller adds the tail of the granule before) -- i.e. what ph_imdct leaves in
+// y1[0] of lanes 0..2: the same fmaf chain over the same fragment values.
+PD_FN float ph_peek_head(int lane, const WaveData& L, const TabLds& S, const GlobalTables& T) {
+  const GranuleInfo g = granule_info(L);
+  const bool shrt = g.is_short(0);
+  const bool lowrow = (g.flags(0) & PDMP3_GC_WIN_SWITCH) && g.is_mixed(0);     // subbands 0, 1 of a mixed block: long transform, window 0
+  const float* frag = (shrt && !lowrow) ? T.frag_short : T.frag_long;
+  const int n = lane < 3 ? lane : 0;
+  float y = 0.0f;
+  PD_UNROLL for (int m = 0; m < 18; m++) y = PD_FMA(L.xr[0][m], frag[((m >> 2) * 2 + 0) * 64 + (m & 3) * 16 + n], y);
+  if (!(shrt && !lowrow)) y = y * S.win[lowrow ? 0 : g.block_type(0)][n];
+  return y;
 }
 
 // MODE (chained chunks, run_chunk_chained): 0 = the whole phase; kPark = the same, and the hybrid outputs -- computed
@@ -611,7 +794,7 @@ PD_FN void ph_peek_tail(int lane, const WaveLds& L, LaneRegs& R, const GlobalTab
 // the matrixing as usual; R.ovl is left alone.
 constexpr int kPark = 1, kFromPark = 2;
 template <bool DUMP, int MODE = 0>
-PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTables& T, float* dump2, float* dump3,
+PD_FN void ph_mfma(int lane, WaveData& L, const TabLds& S, LaneRegs& R, BankPtr cb, const GlobalTables& T, float* dump2, float* dump3,
                    bool do_matrix, float* park = nullptr) {   // do_matrix (wave-uniform) = false: a halo granule whose polyphase input nobody reads
   const GranuleInfo g = granule_info(L);
   const int j = lane & 15, kq = lane >> 4;
@@ -642,7 +825,7 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTa
     float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     PD_UNROLL for (int m = 0; m < 18; m++)
       PD_UNROLL for (int q = 0; q < 4; q++) y[q] = PD_FMA(in[m], cb->c36x[q][m], y[q]);
-    const float* w = L.win[llow ? 0 : g.block_type(cl)];
+    const float* w = S.win[llow ? 0 : g.block_type(cl)];
     y[0] = y[0] * w[16]; y[1] = y[1] * w[17]; y[2] = y[2] * w[34]; y[3] = y[3] * w[35];
     if (any_short) {                      // wave-uniform
       float ys[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -711,8 +894,8 @@ PD_FN void ph_mfma(int lane, WaveLds& L, LaneRegs& R, BankPtr cb, const GlobalTa
           PD_UNROLL for (int nt = 0; nt < 2; nt++) accl[nt] = mfma16(afr[0][kk], R.bi[kk * 2 + nt], accl[nt]);
       }
       // window factors of this lane's columns: t = j and p = 18 + j
-      const float* wb = L.win[bt];
-      const float* w0 = L.win[0];
+      const float* wb = S.win[bt];
+      const float* w0 = S.win[0];
       const float wb1 = wb[j], wb2 = wb[18 + j];
       const float w01 = w0[j], w02 = w0[18 + j];
       PD_UNROLL for (int h = 0; h < 2; h++)
@@ -823,7 +1006,7 @@ PD_FN void permlane32_swap(int& a, int& b) {
 
 // the 18 sums of a lane (P:2028) -> PCM of the granule: conversion, channel pairing, stores
 template <bool F32>
-PD_FN void pcm_emit(int lane, WaveLds& L, int nch, bool act, const float* sum, int16_t* pcm_g, float* pcmf_g) {
+PD_FN void pcm_emit(int lane, WaveData& L, int nch, bool act, const float* sum, int16_t* pcm_g, float* pcmf_g) {
   const int i = lane & 31;
   int out[18];
   if (act) {
@@ -867,7 +1050,7 @@ PD_FN void pcm_emit(int lane, WaveLds& L, int nch, bool act, const float* sum, i
 
 // full = false (wave-uniform): the last halo granule -- only its slots 3..17 are wanted, as the next granule's history
 template <bool F32>
-PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int nch, int16_t* pcm_g, float* pcmf_g) {
+PD_FN void ph_window(int lane, WaveData& L, LaneRegs& R, bool full, int nch, int16_t* pcm_g, float* pcmf_g) {
   // (nch is a parameter: by now the side records in LDS are the NEXT granule's, see run_chunk)
   const int ch = lane >> 5;
   const bool act = ch < nch;                   // (mono: lanes 32..63 idle, their history is channel 1's and stays)
@@ -910,9 +1093,9 @@ PD_FN void ph_window(int lane, WaveLds& L, LaneRegs& R, bool full, int nch, int1
 // part[t][64 lanes] lives in LDS that is dead by then (a chained wave has requantised its last granule): the staged
 // spectra + the mono PCM staging hold t = 0..12, the line tables t = 13..17
 PD_FN float* part_row(WaveLds& L, int t) {
-  static_assert(offsetof(WaveLds, pcm) == offsetof(WaveLds, spec) + sizeof(L.spec), "spec and pcm are one block");
-  static_assert(sizeof(L.spec) + sizeof(L.pcm) >= 13 * 64 * sizeof(float) && sizeof(L.ltab) >= 5 * 64 * sizeof(float), "room for part[18][64]");
-  return t < 13 ? reinterpret_cast<float*>(&L.spec[0][0]) + t * 64 : reinterpret_cast<float*>(&L.ltab[0][0]) + (t - 13) * 64;
+  static_assert(offsetof(WaveData, pcm) == offsetof(WaveData, spec) + sizeof(L.spec), "spec and pcm are one block");
+  static_assert(sizeof(L.spec) + sizeof(L.pcm) >= 13 * 64 * sizeof(float) && sizeof(L.tab.ltab) >= 5 * 64 * sizeof(float), "room for part[18][64]");
+  return t < 13 ? reinterpret_cast<float*>(&L.spec[0][0]) + t * 64 : reinterpret_cast<float*>(&L.tab.ltab[0][0]) + (t - 13) * 64;
 }
 PD_FN void ph_window_first(int lane, WaveLds& L, const LaneRegs& R) {
   const int ch = lane >> 5;
@@ -944,7 +1127,7 @@ PD_FN void ph_window_rest(int lane, WaveLds& L, const LaneRegs& R, int16_t* pcm_
 
 // PCM of a mono granule (576 samples = 1152 bytes) from the LDS staging buffer; stereo granules were stored by
 // ph_window straight from registers.
-PD_FN void ph_store(int lane, WaveLds& L, int nch, int16_t* pcm_g, bool emit) {
+PD_FN void ph_store(int lane, WaveData& L, int nch, int16_t* pcm_g, bool emit) {
   if (!emit) return;
   if (nch != 2) {
     const Chunk16* src = reinterpret_cast<const Chunk16*>(L.pcm);
@@ -1004,7 +1187,10 @@ struct DecodeArgs {
   float* chain_state;
   unsigned* chain_flag;
   unsigned chain_epoch;          // 0: chunks are independent (halo), as described above
+  // granule kernel (run_granule): chain_state = [2 n_frames][kGranFloats], chain_flag = two flags per granule
+  unsigned debug_flags;          // tests: PD_DEBUG_FAR_TIMEOUT = every wait for another workgroup gives up at once
 };
+constexpr unsigned PD_DEBUG_FAR_TIMEOUT = 1u;
 
 constexpr int kProfSlots = 12;
 
@@ -1016,8 +1202,15 @@ constexpr int kProfSlots = 12;
   }                                                     \
   PD_WAVE_SYNC();
 
-template <bool DUMP, bool PROF = false, bool F32 = false>
-PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveLds& L, const ChainPos* cp = nullptr) {
+struct GranPos;
+PD_FN void gran_publish_regs(int lane, const LaneRegs& R, const DecodeArgs& a, int g, const GranPos& gp);   // (below)
+
+// OWN_TABS: S is this wave's own table block -- filled here, and refilled when the stream changes its sampling
+// frequency; otherwise (granule kernel: S belongs to the workgroup and is there already) granules of another sampling
+// frequency read the global line table (ph_requant's TG).  gp: granule kernel only -- where the closing state goes.
+template <bool DUMP, bool PROF = false, bool F32 = false, bool OWN_TABS = true>
+PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveData& L, TabLds& S, const ChainPos* cp = nullptr,
+                     const GranPos* gp = nullptr) {
   LaneRegs R;
   const int lane = PD_LANE();
   const unsigned long long t_wave_start = PROF ? PD_CLOCK() : 0ull;
@@ -1076,7 +1269,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
 
   PD_PHASE(
     ph_prefetch(lane, R, a.spectra + (size_t)g_first * 1152, a.side + (size_t)g_first * 2);
-    load_linetab(lane, L, T, cur_sfreq);
+    if (OWN_TABS) { load_linetab(lane, S, T, cur_sfreq); tab_load_fixed(lane, 64, S, T); }
     lane_init(lane, L, R, cb, T);
     if (a.state_in) {
       if (from_stream_start) state_load(lane, R, a.state_in);
@@ -1105,8 +1298,8 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     {
       int sf = L.side[0][7] & PDMP3_FR_SFREQ_MASK;
       if (sf > 2) sf = 2;
-      if (sf != cur_sfreq) {          // wave-uniform: first granule, or the stream changed sampling rate
-        PD_PHASE(load_linetab(lane, L, T, sf))
+      if (OWN_TABS && sf != cur_sfreq) {          // wave-uniform: first granule, or the stream changed sampling rate
+        PD_PHASE(load_linetab(lane, S, T, sf))
         cur_sfreq = sf;
       }
     }
@@ -1118,25 +1311,25 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     PD_TICK(1)
     float* dmp = DUMP ? a.stages + ((size_t)f * 16 + gr * 8) * 576 : nullptr;
     if (g == g_peek) {                     // wave-uniform: lines 0..63, boundary sb 0 | 1, three IMDCT outputs
-      PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<false, 1>(lane, L, cb, T, nullptr, nullptr))
+      PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<false, 1, false, !OWN_TABS>(lane, L, S, cb, T, nullptr, nullptr))
       PD_TICK(2)
       PD_PHASE(
         if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
         ph_antialias(lane, L, cb, true);
       )
       PD_TICK(3)
-      PD_PHASE(ph_peek_tail(lane, L, R, T))
+      PD_PHASE(ph_peek_tail(lane, L, S, R, T))
       PD_TICK(4)
     } else {
-      PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<DUMP>(lane, L, cb, T, dmp, dmp + 576))
+      PD_PHASE(if (reset_here) state_zero(lane, R); if (!(PD_EXP_SKIP & 1)) ph_requant<DUMP, 9, false, !OWN_TABS>(lane, L, S, cb, T, dmp, dmp + 576))
       PD_TICK(2)
       PD_PHASE(
         // the next granule's HBM reads fly during this granule's transforms
         if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
-        ph_antialias(lane, L, cb);
+        if (!(PD_EXP_SKIP & 2)) ph_antialias(lane, L, cb);
       )
       PD_TICK(3)
-      PD_PHASE(ph_mfma<DUMP>(lane, L, R, cb, T, dmp + 2 * 576, dmp + 3 * 576, emit || feeds_next))
+      PD_PHASE(if (!(PD_EXP_SKIP & 4)) ph_mfma<DUMP>(lane, L, S, R, cb, T, dmp + 2 * 576, dmp + 3 * 576, emit || feeds_next))
       PD_TICK(4)
     }
     PD_TICK(5)
@@ -1145,10 +1338,10 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     // the window the wave sat through the acknowledgement of its nine stores every granule: 10 % of the loop.)
     if (g_next < g_end) {
       PD_PHASE(ph_commit(lane, L, R))
-      PD_PHASE(ph_scales(lane, L))                   // next granule's (its side info was committed just above)
+      PD_PHASE(if (!(PD_EXP_SKIP & 8)) ph_scales(lane, L))                   // next granule's (its side info was committed just above)
     }
     PD_TICK(6)
-    if (emit || feeds_next) {
+    if ((emit || feeds_next) && !(PD_EXP_SKIP & 16)) {
       PD_PHASE(ph_window<F32>(lane, L, R, emit, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g,
                                 F32 ? a.pcm_f32 + (size_t)f * 2304 + gr * 576 * nch_g : nullptr))
     }
@@ -1175,8 +1368,12 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     // may be waiting for the state it leaves (stereo frames publish theirs, mono frames are skipped by their successors)
     const uint8_t fbl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f1 - 1) * 4)[7];
     if (((fbl & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3) {
-      const ChainPos alone{nullptr, 0, true, false};
-      PD_PHASE(chain_publish_regs(lane, R, a.chain_state + (size_t)(f1 - 1) * kChainFloats, a.chain_flag + (f1 - 1), a.chain_epoch, cp ? *cp : alone))
+      if (gp) {
+        PD_PHASE(gran_publish_regs(lane, R, a, 2 * f1 - 1, *gp))
+      } else {
+        const ChainPos alone{nullptr, 0, true, false};
+        PD_PHASE(chain_publish_regs(lane, R, a.chain_state + (size_t)(f1 - 1) * kChainFloats, a.chain_flag + (f1 - 1), a.chain_epoch, cp ? *cp : alone))
+      }
     }
   }
 }
@@ -1210,19 +1407,20 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
   int cur_sfreq = first_sfreq > 2 ? 2 : first_sfreq;
   PD_PHASE(
     ph_prefetch(lane, R, a.spectra + (size_t)g_first * 1152, a.side + (size_t)g_first * 2);
-    load_linetab(lane, L, T, cur_sfreq);
+    load_linetab(lane, L.tab, T, cur_sfreq);
+    tab_load_fixed(lane, 64, L.tab, T);
     lane_init(lane, L, R, cb, T);
   )
   PD_PHASE(ph_commit(lane, L, R))
   PD_PHASE(ph_scales(lane, L))
   float tail3 = 0.0f;                            // lanes 0..2: IMDCT tail p = 18 + lane of (channel 0, subband 0) of the granule before
   if (pre) {
-      PD_PHASE(ph_requant<false, 1>(lane, L, cb, T, nullptr, nullptr))
+      PD_PHASE(ph_requant<false, 1>(lane, L, L.tab, cb, T, nullptr, nullptr))
     PD_PHASE(
       ph_prefetch(lane, R, a.spectra + (size_t)g0 * 1152, a.side + (size_t)g0 * 2);
       ph_antialias(lane, L, cb, true);
     )
-    PD_PHASE(ph_peek_tail(lane, L, R, T))
+    PD_PHASE(ph_peek_tail(lane, L, L.tab, R, T))
     tail3 = R.ovl[0];
     R.ovl[0] = 0.0f;
     PD_PHASE(ph_commit(lane, L, R))
@@ -1230,7 +1428,7 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
     int sf = L.side[0][7] & PDMP3_FR_SFREQ_MASK;
     if (sf > 2) sf = 2;
     if (sf != cur_sfreq) {
-      PD_PHASE(load_linetab(lane, L, T, sf))
+      PD_PHASE(load_linetab(lane, L.tab, T, sf))
       cur_sfreq = sf;
     }
   } else if (h5 && a.state_in && f == 0 && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET)) {
@@ -1238,20 +1436,20 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
   }
   // ---- A
   PD_LAUNDER(cb);
-  PD_PHASE(ph_requant<false>(lane, L, cb, T, nullptr, nullptr))
+  PD_PHASE(ph_requant<false>(lane, L, L.tab, cb, T, nullptr, nullptr))
   PD_PHASE(
     ph_prefetch(lane, R, a.spectra + (size_t)g1 * 1152, a.side + (size_t)g1 * 2);
     ph_antialias(lane, L, cb);
   )
-  PD_PHASE(ph_mfma<false, kPark>(lane, L, R, cb, T, nullptr, nullptr, false, &L.park[0][0]))
+  PD_PHASE(ph_mfma<false, kPark>(lane, L, L.tab, R, cb, T, nullptr, nullptr, false, &L.park[0][0]))
   PD_PHASE(if (h5 && lane < 3) L.peek[lane] += tail3)
   PD_PHASE(ph_commit(lane, L, R))
   PD_PHASE(ph_scales(lane, L))
   // ---- B
   PD_LAUNDER(cb);
-  PD_PHASE(ph_requant<false>(lane, L, cb, T, nullptr, nullptr))
+  PD_PHASE(ph_requant<false>(lane, L, L.tab, cb, T, nullptr, nullptr))
   PD_PHASE(ph_antialias(lane, L, cb))
-  PD_PHASE(ph_mfma<false, 0>(lane, L, R, cb, T, nullptr, nullptr, true))
+  PD_PHASE(ph_mfma<false, 0>(lane, L, L.tab, R, cb, T, nullptr, nullptr, true))
   PD_PHASE(
     if (f == a.n_frames - 1 && a.state_out) {       // (wave-uniform) the launch's closing state, in the caller's form
       ph_window<F32>(lane, L, R, false, 2, nullptr, nullptr);
@@ -1271,7 +1469,7 @@ PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr
   }
   if (cp.hi) PD_SETPRIO(0);
   // ---- D
-  PD_PHASE(ph_mfma<false, kFromPark>(lane, L, R, cb, T, nullptr, nullptr, true, &L.park[0][0]))
+  PD_PHASE(ph_mfma<false, kFromPark>(lane, L, L.tab, R, cb, T, nullptr, nullptr, true, &L.park[0][0]))
   PD_PHASE(ph_window<F32>(lane, L, R, true, 2, a.pcm + (size_t)f * 2304, F32 ? a.pcm_f32 + (size_t)f * 2304 : nullptr))
   // ---- E
   PD_PHASE(ph_window_rest<F32>(lane, L, R, a.pcm + (size_t)f * 2304 + 1152, F32 ? a.pcm_f32 + (size_t)f * 2304 + 1152 : nullptr))
@@ -1295,7 +1493,406 @@ PD_FN void run_frame(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       return;
     }
   }
-  run_chunk<false, false, F32>(a, T, cb, f, L, &cp);
+  run_chunk<false, false, F32>(a, T, cb, f, L, L.tab, &cp);
+}
+
+// ---------------------------------------------------------------------------
+// Granule kernel: ONE GRANULE PER WAVE, no loop, no halo (run_granule).
+//
+// What granule g needs from granule g - 1 is (i) its IMDCT tails -- a function of g - 1's own spectra -- and (ii) slots
+// 3..17 of its matrixing output -- a function of its spectra and of the tails of g - 2.  Neither hangs on a chain:
+//   a  spectra -> requantise -> alias reduction -> IMDCT, windowed: y1 (first halves), y2 (tails)      [own data only]
+//   b  tails y2 -> chain_state[g], flag A
+//   c  wait for flag A of g - 1 (published at ITS step b), overlap-add, frequency inversion, matrixing  -> hyb in LDS
+//   d  matrixing rows 3..17 (+ the three hybrid outputs an H5 granule after it peeks at) -> chain_state[g], flag B
+//   e  the window sums as far as they read this granule's own slots (registers)
+//   f  wait for flag B of g - 1, the rest of the sums, PCM
+// A wave is straight-line code whose state arrives late and leaves early: no loop-carried registers, no prefetch
+// registers, no spills -- 128 VGPRs, four waves per SIMD, and a launch of N frames is 2 N waves that are ALL in flight
+// up to 2048 frames (MI355X), every SIMD with four instruction streams to pick from instead of two.
+// Same operations in the same order as run_chunk: PCM and carried state bit-identical (tests compare).
+// Workgroup = WPW waves = WPW consecutive granules; its tables (TabLds) are shared.  Inside a workgroup the flags are
+// in LDS and the state goes through ordinary stores / loads (one CU: one L1, one L2); the workgroup's last wave
+// publishes with device scope for the first wave of the next one.  Only that first wave ever waits for ANOTHER
+// workgroup, and that wait is BOUNDED: if the state does not come (the workgroup before it is not resident -- a
+// partitioned or shared device, a dispatcher that does not go in order), the wave gives up, decodes its frame the
+// independent way (run_chunk: halo) and publishes from there.  A launch therefore finishes whatever the residency and
+// the dispatch order; waiting costs time, never progress.  (A ticket counter handing out the places in start order
+// gave the same guarantee but serialised the launch's 512 workgroups on one atomic: +4 us on the C2 batch.)
+// Mono frames, and stereo frames right after mono ones (channel 1's state is further back, run_chunk's pre-halo finds
+// it): the wave of granule 0 runs run_chunk on the frame and publishes at its end, the wave of granule 1 leaves.
+// ---------------------------------------------------------------------------
+constexpr int kGranFloats = 64 * (kOvlRegs + kHistSlots);          // tails [18][64] | rows [15][64]
+struct GranPos {
+  unsigned* wg_flag;     // LDS: [2 w + k] == epoch once wave w's tails (k = 0) / rows (k = 1) can be read on this CU;
+                         // [2 wpw] != 0: wave 0 has given up waiting and decodes its frame the independent way
+  int w;                 // place of the granule within its workgroup
+  int wpw;
+};
+PD_FN bool gran_last_in_wg(const GranPos& gp) { return gp.w == gp.wpw - 1; }
+#define PD_GRAN_STORE(p, v) { if (last_) PD_STORE_DEVICE((p), (v)); else *(p) = (v); }
+PD_FN void gran_signal(int lane, const DecodeArgs& a, int g, int k, const GranPos& gp) {
+  PD_VMEM_DRAIN();
+  if (lane == 0) {
+    if (gran_last_in_wg(gp)) PD_STORE_DEVICE(a.chain_flag + 2 * (size_t)g + k, a.chain_epoch);
+    else *reinterpret_cast<volatile unsigned*>(&gp.wg_flag[2 * gp.w + k]) = a.chain_epoch;
+  }
+}
+PD_FN void gran_publish_tails(int lane, const float* y2, const DecodeArgs& a, int g, const GranPos& gp) {
+  float* st = a.chain_state + (size_t)g * kGranFloats;
+  const bool last_ = gran_last_in_wg(gp);
+  for (int m = 0; m < kOvlRegs; m++) PD_GRAN_STORE(&st[m * 64 + lane], y2[m])
+  gran_signal(lane, a, g, 0, gp);
+}
+PD_FN void gran_publish_rows(int lane, const WaveData& L, const DecodeArgs& a, int g, const GranPos& gp) {
+  float* st = a.chain_state + (size_t)g * kGranFloats + kOvlRegs * 64;
+  const bool last_ = gran_last_in_wg(gp);
+  const int ch = lane >> 5, i = lane & 31;
+  for (int s = 0; s < kHistSlots; s++) PD_GRAN_STORE(&st[s * 64 + lane], L.hyb[ch][3 + s][i])
+  gran_signal(lane, a, g, 1, gp);
+}
+// from a wave that has the state in registers (run_chunk at the end of a frame), for granule g = the frame's second:
+// coefficient 16 + i is he of lane i < 16, coefficient 16 - i is ho of lane i <= 16 -- together all 32 of a row
+PD_FN void gran_publish_regs(int lane, const LaneRegs& R, const DecodeArgs& a, int g, const GranPos& gp) {
+  float* st = a.chain_state + (size_t)g * kGranFloats;
+  const bool last_ = gran_last_in_wg(gp);
+  const int ch = lane >> 5, i = lane & 31;
+  for (int m = 0; m < kOvlRegs; m++) PD_GRAN_STORE(&st[m * 64 + lane], R.ovl[m])
+  for (int s = 0; s < kHistSlots; s++) {
+    if (i < 16) PD_GRAN_STORE(&st[(kOvlRegs + s) * 64 + ch * 32 + 16 + i], R.he[s])
+    if (i <= 16) PD_GRAN_STORE(&st[(kOvlRegs + s) * 64 + ch * 32 + 16 - i], R.ho[s])
+  }
+  PD_VMEM_DRAIN();
+  if (lane == 0) {
+    PD_UNROLL for (int k = 0; k < 2; k++) {
+      if (last_) PD_STORE_DEVICE(a.chain_flag + 2 * (size_t)g + k, a.chain_epoch);
+      else *reinterpret_cast<volatile unsigned*>(&gp.wg_flag[2 * gp.w + k]) = a.chain_epoch;
+    }
+  }
+}
+#undef PD_GRAN_STORE
+// Wait for part k of granule g - 1 (gp: the WAITING granule's place).  0: there, same workgroup; 1: there, another
+// workgroup (device-scope reads); -1: given up -- the bounded wait for another workgroup ran out (wave 0), or the wave
+// before this one in the workgroup has taken its frame over (wave 1 sees wave 0's abort word, wg_flag[2 wpw])
+constexpr int kGranFarPolls = 1 << 13;      // x (a device-scope load + s_sleep): some milliseconds
+PD_FN int gran_wait(const DecodeArgs& a, int g, int k, const GranPos& gp) {
+  if (gp.w > 0) {
+    for (;;) {
+      if ((unsigned)PD_UNIFORM(*reinterpret_cast<volatile unsigned*>(&gp.wg_flag[2 * (gp.w - 1) + k])) == a.chain_epoch) break;
+      if (gp.w == 1 && PD_UNIFORM(*reinterpret_cast<volatile unsigned*>(&gp.wg_flag[2 * gp.wpw])) != 0) return -1;
+      PD_SLEEP();
+    }
+    asm volatile("" ::: "memory");
+    return 0;
+  }
+  if (a.debug_flags & PD_DEBUG_FAR_TIMEOUT) return -1;
+  for (int n = 0; (unsigned)PD_UNIFORM(PD_LOAD_DEVICE(a.chain_flag + 2 * (size_t)(g - 1) + k)) != a.chain_epoch; ++n) {
+    if (n >= kGranFarPolls) return -1;
+    PD_SLEEP();
+  }
+  asm volatile("" ::: "memory");
+  return 1;
+}
+PD_FN bool gran_take_tails(int lane, float* ovl, const DecodeArgs& a, int g, const GranPos& gp) {
+  const float* st = a.chain_state + (size_t)(g - 1) * kGranFloats;
+  const int how = gran_wait(a, g, 0, gp);
+  if (how < 0) return false;
+  if (how) { for (int m = 0; m < kOvlRegs; m++) ovl[m] = PD_LOAD_DEVICE(&st[m * 64 + lane]); }
+  else { for (int m = 0; m < kOvlRegs; m++) ovl[m] = st[m * 64 + lane]; }
+  return true;
+}
+PD_FN bool gran_take_rows(int lane, LaneRegs& R, const DecodeArgs& a, int g, const GranPos& gp) {
+  const float* rows = a.chain_state + (size_t)(g - 1) * kGranFloats + kOvlRegs * 64 + (lane >> 5) * 32;
+  const int how = gran_wait(a, g, 1, gp);
+  if (how < 0) return false;
+  if (how) {
+    for (int s = 0; s < kHistSlots; s++) { R.he[s] = PD_LOAD_DEVICE(&rows[s * 64 + R.idx_e]); R.ho[s] = PD_LOAD_DEVICE(&rows[s * 64 + R.idx_o]); }
+  } else {
+    for (int s = 0; s < kHistSlots; s++) { R.he[s] = rows[s * 64 + R.idx_e]; R.ho[s] = rows[s * 64 + R.idx_o]; }
+  }
+  return true;
+}
+
+// ---- ph_mfma in two stages (stereo granules).  ph_imdct: everything up to the windowed IMDCT outputs, indexed like
+// R.ovl: y1 = first halves (what the overlap is added to), y2 = tails (the next granule's overlap).  xr is dead after it.
+PD_FN void ph_imdct(int lane, const WaveData& L, const TabLds& S, const LaneRegs& R, BankPtr cb, const GlobalTables& T, float* y1, float* y2) {
+  const GranuleInfo g = granule_info(L);
+  const int j = lane & 15, kq = lane >> 4;
+  const bool any_short = g.is_short(0) || g.is_short(1);
+  {   // IMDCT outputs p = 16, 17, 34, 35 on the VALU: lane = (cl, sb), scalar-broadcast coefficients
+    const int cl = lane >> 5, sb = lane & 31;
+    const bool lwsf = (g.flags(cl) & PDMP3_GC_WIN_SWITCH) != 0;
+    const bool llow = lwsf && g.is_mixed(cl) && sb < 2;
+    const bool lshort = g.is_short(cl) && !llow;
+    const float* x = &L.xr[cl][18 * sb];
+    float in[18];
+    PD_UNROLL for (int m = 0; m < 18; m++) in[m] = x[m];
+    float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    PD_UNROLL for (int m = 0; m < 18; m++)
+      PD_UNROLL for (int q = 0; q < 4; q++) y[q] = PD_FMA(in[m], cb->c36x[q][m], y[q]);
+    const float* w = S.win[llow ? 0 : g.block_type(cl)];
+    y[0] = y[0] * w[16]; y[1] = y[1] * w[17]; y[2] = y[2] * w[34]; y[3] = y[3] * w[35];
+    if (any_short) {                      // wave-uniform
+      float ys[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      PD_UNROLL for (int m = 0; m < 18; m++)
+        PD_UNROLL for (int q = 0; q < 4; q++) ys[q] = PD_FMA(in[m], cb->s36x[q][m], ys[q]);
+      PD_UNROLL for (int q = 0; q < 4; q++) y[q] = lshort ? ys[q] : y[q];
+    }
+    y1[16] = y[0]; y1[17] = y[1]; y2[16] = y[2]; y2[17] = y[3];
+  }
+  PD_UNROLL for (int cc = 0; cc < 2; cc++) {
+    const int ch = 1 - cc;
+    const bool shrt = g.is_short(ch);
+    const bool wsf = (g.flags(ch) & PDMP3_GC_WIN_SWITCH) != 0;
+    const bool mixrows = wsf && g.is_mixed(ch);        // subbands 0, 1 use window/transform 0 (P:1769-1771)
+    const int bt = g.block_type(ch);
+    float bfr[10];
+    if (shrt) { PD_UNROLL for (int k = 0; k < 10; k++) bfr[k] = T.frag_short[k * 64 + lane]; }
+    else { PD_UNROLL for (int k = 0; k < 10; k++) bfr[k] = R.bi[k]; }
+    f32x4 acc[2][2];
+    float afr[2][5];
+    PD_UNROLL for (int h = 0; h < 2; h++)
+      PD_UNROLL for (int kk = 0; kk < 5; kk++) {
+        const int k = 4 * kk + kq;
+        afr[h][kk] = L.xr[ch][18 * (h ? 31 - j : j) + (k < 18 ? k : 0)];   // second row tile: subbands reversed
+        if (k >= 18) afr[h][kk] = 0.0f;
+      }
+    PD_UNROLL for (int h = 0; h < 2; h++)
+      PD_UNROLL for (int nt = 0; nt < 2; nt++) acc[h][nt] = mfma16(afr[h][0], bfr[nt], (f32x4){0, 0, 0, 0});
+    PD_UNROLL for (int kk = 1; kk < 5; kk++)
+      PD_UNROLL for (int h = 0; h < 2; h++)
+        PD_UNROLL for (int nt = 0; nt < 2; nt++) acc[h][nt] = mfma16(afr[h][kk], bfr[kk * 2 + nt], acc[h][nt]);
+    f32x4 accl[2];
+    PD_UNROLL for (int nt = 0; nt < 2; nt++) accl[nt] = acc[0][nt];
+    if (shrt && mixrows) {             // wave-uniform: rows sb 0, 1 of the first tile take the long transform
+      PD_UNROLL for (int nt = 0; nt < 2; nt++) accl[nt] = mfma16(afr[0][0], R.bi[nt], (f32x4){0, 0, 0, 0});
+      PD_UNROLL for (int kk = 1; kk < 5; kk++)
+        PD_UNROLL for (int nt = 0; nt < 2; nt++) accl[nt] = mfma16(afr[0][kk], R.bi[kk * 2 + nt], accl[nt]);
+    }
+    const float* wb = S.win[bt];
+    const float* w0 = S.win[0];
+    const float wb1 = wb[j], wb2 = wb[18 + j];
+    const float w01 = w0[j], w02 = w0[18 + j];
+    PD_UNROLL for (int h = 0; h < 2; h++)
+      PD_UNROLL for (int r = 0; r < 4; r++) {
+        const bool lowrow = mixrows && h == 0 && kq == 0 && r < 2;      // subbands 0, 1 (first tile, rows 0, 1)
+        float a1 = acc[h][0][r], a2 = acc[h][1][r];
+        if (h == 0 && lowrow) { a1 = accl[0][r]; a2 = accl[1][r]; }
+        const bool win_folded = shrt && !lowrow;                        // short transform: window is in the matrix
+        const float f1 = lowrow ? w01 : wb1, f2 = lowrow ? w02 : wb2;
+        if (!win_folded) { a1 = a1 * f1; a2 = a2 * f2; }
+        y1[ch * 8 + h * 4 + r] = a1;
+        y2[ch * 8 + h * 4 + r] = a2;
+      }
+  }
+}
+// ph_overlap_matrix: the rest -- overlap-add against the tails `ovl` of the granule before (P:1775), frequency
+// inversion (P:1738-1746), the H5 peek values, matrixing -> hyb
+PD_FN void ph_overlap_matrix(int lane, WaveData& L, const LaneRegs& R, const float* y1, const float* ovl) {
+  const int j = lane & 15, kq = lane >> 4;
+  {
+    const int cl = lane >> 5, sb = lane & 31;
+    const float o16 = y1[16] + ovl[16];
+    float o17 = y1[17] + ovl[17];
+    if (sb & 1) o17 = -o17;
+    const float p16 = PD_SHFL_XOR(o16, 31), p17 = PD_SHFL_XOR(o17, 31);
+    if (sb < 16) {
+      L.lo[0][2 * cl + 0][sb] = o16 + p16; L.lo[1][2 * cl + 0][sb] = o16 - p16;
+      L.lo[0][2 * cl + 1][sb] = o17 + p17; L.lo[1][2 * cl + 1][sb] = o17 - p17;
+    }
+  }
+  PD_UNROLL for (int cc = 0; cc < 2; cc++) {
+    const int ch = 1 - cc;
+    float outa[8];
+    PD_UNROLL for (int h = 0; h < 2; h++)
+      PD_UNROLL for (int r = 0; r < 4; r++) {
+        const int oi = ch * 8 + h * 4 + r;
+        float o = y1[oi] + ovl[oi];
+        const int sb = h ? 31 - (4 * kq + r) : 4 * kq + r;
+        if ((sb & 1) && (j & 1)) o = -o;
+        outa[h * 4 + r] = o;
+        if (ch == 0 && h == 0 && r == 0 && kq == 0 && j < 3) L.peek[j] = o;
+      }
+    f32x4 me = (f32x4){0, 0, 0, 0}, mo = (f32x4){0, 0, 0, 0};
+    PD_UNROLL for (int r = 0; r < 4; r++) {
+      const float a = outa[r] + outa[4 + r], b = outa[r] - outa[4 + r];
+      me = mfma16(a, R.bm[r], me);
+      mo = mfma16(b, R.bm[4 + r], mo);
+    }
+    PD_UNROLL for (int r = 0; r < 4; r++) {
+      L.hyb[ch][4 * kq + r][2 * j] = me[r];
+      L.hyb[ch][4 * kq + r][2 * j + 1] = mo[r];
+    }
+  }
+  PD_WAVE_SYNC();                          // lo[] was written by other lanes
+  {
+    f32x4 me = (f32x4){0, 0, 0, 0}, mo = (f32x4){0, 0, 0, 0};
+    PD_UNROLL for (int r = 0; r < 4; r++) {
+      const float a = (j < 4) ? L.lo[0][j & 3][4 * kq + r] : 0.0f;
+      const float b = (j < 4) ? L.lo[1][j & 3][4 * kq + r] : 0.0f;
+      me = mfma16(a, R.bm[r], me);
+      mo = mfma16(b, R.bm[4 + r], mo);
+    }
+    if (kq == 0) {
+      PD_UNROLL for (int r = 0; r < 4; r++) {
+        const int ch = r >> 1, t = 16 + (r & 1);
+        L.hyb[ch][t][2 * j] = me[r]; L.hyb[ch][t][2 * j + 1] = mo[r];
+      }
+    }
+  }
+}
+// the window sums of a stereo granule in two parts (same chain of 16 FMAs per sum as ph_window, newest slot first):
+// the terms that read the granule's own slots ...
+PD_FN void ph_window_own(int lane, const WaveData& L, const LaneRegs& R, float* acc) {
+  const int ch = lane >> 5;
+  float E[18], O[18];
+  PD_UNROLL for (int t = 0; t < 18; t++) { E[t] = L.hyb[ch][t][R.idx_e]; O[t] = L.hyb[ch][t][R.idx_o]; }
+  PD_UNROLL for (int t = 0; t < 18; t++) {
+    float s = 0.0f;
+    PD_UNROLL for (int k = 0; k < 8; k++) {
+      if (t - 2 * k >= 0) s = PD_FMA(R.we[k], E[t - 2 * k], s);
+      if (t - 2 * k - 1 >= 0) s = PD_FMA(R.wo[k], O[t - 2 * k - 1], s);
+    }
+    acc[t] = s;
+  }
+}
+// ... and the ones that read the history R.he / R.ho (slots 3..17 of the granule before); PCM
+template <bool F32>
+PD_FN void ph_window_hist(int lane, WaveData& L, const LaneRegs& R, const float* acc, int16_t* pcm_g, float* pcmf_g) {
+  float sum[18];
+  PD_UNROLL for (int t = 0; t < 18; t++) {
+    float s = acc[t];
+    PD_UNROLL for (int k = 0; k < 8; k++) {
+      if (t - 2 * k < 0) s = PD_FMA(R.we[k], R.he[kHistSlots + t - 2 * k], s);
+      if (t - 2 * k - 1 < 0) s = PD_FMA(R.wo[k], R.ho[kHistSlots + t - 2 * k - 1], s);
+    }
+    sum[t] = s;
+  }
+  pcm_emit<F32>(lane, L, 2, true, sum, pcm_g, pcmf_g);
+}
+
+// one granule of a stereo frame whose predecessor's state comes through the chain (or is the caller's / zero: `fresh`).
+// pf: the granule's spectra / side records, in flight since the kernel's entry.  false: a wait was given up (gran_wait),
+// nothing of the granule's PCM has been written.
+template <bool F32>
+PD_FN bool run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int g, WaveData& L, const TabLds& S, const GranPos& gp,
+                       bool fresh, bool h5, const LaneRegs& pf) {
+  LaneRegs R;
+  const int lane = PD_LANE();
+  const int f = g >> 1, gr = g & 1;
+  const bool from_caller = fresh && gr == 0 && f == 0 && a.state_in && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET);
+  const bool from_zero = fresh && gr == 0 && !from_caller;
+  // (development: shader-clock stamps per wave when a.prof is set -- tools/phase_profile.py)
+#define PD_GT(k) if (a.prof) { const unsigned long long t_ = PD_CLOCK(); if (lane == 0) a.prof[(size_t)g * kProfSlots + (k)] = t_; }
+  PD_GT(1)
+  R.pf0 = pf.pf0; R.pf1 = pf.pf1; R.pf2 = pf.pf2; R.pf3 = pf.pf3;
+  PD_PHASE(lane_init(lane, L, R, cb, T))
+  if (gr == 1 && h5) {
+    // (wave-uniform) granule 1 / channel 1 is a short block: its scales read three hybrid outputs of granule 0.
+    // Waiting for other waves to get there would put this wave most of a granule behind all others -- and a launch
+    // ends with its last wave -- so it derives the three numbers itself, from data only: lines 0..63 of the granule
+    // before the frame requantised, one alias boundary, three IMDCT tails (ph_peek_tail, as in run_chunk); the same of
+    // granule 0 with the three first-half outputs (what ph_imdct computes for them); their sum is what
+    // ph_overlap_matrix of granule 0's wave leaves in peek[].
+    LaneRegs R0, R1;
+    R1.ovl[0] = 0.0f;
+    float tail = 0.0f;
+    PD_PHASE(
+      ph_prefetch(lane, R0, a.spectra + (size_t)(g - 1) * 1152, a.side + (size_t)(g - 1) * 2);
+      if (!fresh) ph_prefetch(lane, R1, a.spectra + (size_t)(g - 2) * 1152, a.side + (size_t)(g - 2) * 2);
+    )
+    if (fresh) {
+      if (f == 0 && a.state_in && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET) && lane < 3) tail = a.state_in[lane];
+    } else {
+      PD_PHASE(ph_commit(lane, L, R1))
+      PD_PHASE(ph_scales(lane, L))
+      PD_PHASE((ph_requant<false, 1, false, true>(lane, L, S, cb, T, nullptr, nullptr)))
+      PD_PHASE(ph_antialias(lane, L, cb, true))
+      PD_PHASE(ph_peek_tail(lane, L, S, R1, T))
+      tail = lane < 3 ? R1.ovl[0] : 0.0f;
+    }
+    PD_PHASE(ph_commit(lane, L, R0))
+    PD_PHASE(ph_scales(lane, L))
+    PD_PHASE((ph_requant<false, 1, false, true>(lane, L, S, cb, T, nullptr, nullptr)))
+    PD_PHASE(ph_antialias(lane, L, cb, true))
+    const float pk = ph_peek_head(lane, L, S, T) + tail;
+    PD_WAVE_SYNC();
+    PD_PHASE(ph_commit(lane, L, R))
+    PD_PHASE(if (lane < 3) L.peek[lane] = pk)
+  } else {
+    PD_PHASE(ph_commit(lane, L, R))
+  }
+  PD_PHASE(ph_scales(lane, L))
+  PD_GT(2)
+  PD_LAUNDER(cb);
+  PD_PHASE((ph_requant<false, 9, true, true>(lane, L, S, cb, T, nullptr, nullptr)))
+  PD_GT(3)
+  PD_PHASE(ph_antialias(lane, L, cb))
+  float y1[kOvlRegs], y2[kOvlRegs];
+  PD_PHASE(ph_imdct(lane, L, S, R, cb, T, y1, y2))
+  PD_GT(4)
+  PD_PHASE(gran_publish_tails(lane, y2, a, g, gp))
+  PD_GT(5)
+  float ovl[kOvlRegs];
+  if (from_caller) { PD_UNROLL for (int m = 0; m < kOvlRegs; m++) ovl[m] = a.state_in[m * 64 + lane]; }
+  else if (from_zero) { PD_UNROLL for (int m = 0; m < kOvlRegs; m++) ovl[m] = 0.0f; }
+  else if (!gran_take_tails(lane, ovl, a, g, gp)) return false;
+  PD_GT(6)
+  PD_PHASE(ph_overlap_matrix(lane, L, R, y1, ovl))
+  PD_GT(7)
+  PD_PHASE(
+    if (g == 2 * a.n_frames - 1 && a.state_out) {       // (wave-uniform) the launch's closing state, in the caller's form
+      float* so = a.state_out;
+      const int ch = lane >> 5;
+      PD_UNROLL for (int m = 0; m < kOvlRegs; m++) so[m * 64 + lane] = y2[m];
+      PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
+        so[(kOvlRegs + s) * 64 + lane] = L.hyb[ch][3 + s][R.idx_e];
+        so[(kOvlRegs + kHistSlots + s) * 64 + lane] = L.hyb[ch][3 + s][R.idx_o];
+      }
+    }
+    gran_publish_rows(lane, L, a, g, gp);
+  )
+  PD_GT(8)
+  float acc[18];
+  PD_PHASE(ph_window_own(lane, L, R, acc))
+  PD_GT(9)
+  if (from_caller) {
+    PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
+      R.he[s] = a.state_in[(kOvlRegs + s) * 64 + lane];
+      R.ho[s] = a.state_in[(kOvlRegs + kHistSlots + s) * 64 + lane];
+    }
+  } else if (from_zero) { PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = 0.0f; R.ho[s] = 0.0f; } }
+  else if (!gran_take_rows(lane, R, a, g, gp)) return false;
+  PD_GT(10)
+  PD_PHASE(ph_window_hist<F32>(lane, L, R, acc, a.pcm + (size_t)f * 2304 + gr * 1152, F32 ? a.pcm_f32 + (size_t)f * 2304 + gr * 1152 : nullptr))
+  PD_GT(11)
+#undef PD_GT
+  return true;
+}
+
+// The wave of granule g: which way its frame goes (wave-uniform facts from the side records; both waves of a frame
+// decide alike).  gp = this granule's place; pf = its input, prefetched.
+template <bool F32>
+PD_FN void run_granule_wave(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int g, WaveData& L, TabLds& S, const GranPos& gp,
+                            const LaneRegs& pf) {
+  const int f = g >> 1, gr = g & 1;
+  const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)f * 4)[7];
+  const uint8_t pb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f > 0 ? f - 1 : 0) * 4)[7];
+  const uint8_t fl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(2 * f + 1) * 2 + 1)[3];
+  const bool stereo = ((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
+  const bool fresh = f == 0 || (fb & PDMP3_FR_RESET);       // its input state is the caller's / zero
+  const bool prev_stereo = ((pb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
+  if (stereo && (fresh || prev_stereo)) {
+    const bool h5 = (fl & PDMP3_GC_WIN_SWITCH) && ((fl & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
+    if (run_granule<F32>(a, T, cb, g, L, S, gp, fresh, h5, pf)) return;
+    // a wait was given up.  Wave 1: wave 0 has taken the frame over.  Wave 0 (the only one that waits for another
+    // workgroup, and its granule is a frame's first): says so to wave 1 and decodes the frame below.
+    if (gp.w != 0) return;
+    if (PD_LANE() == 0) *reinterpret_cast<volatile unsigned*>(&gp.wg_flag[2 * gp.wpw]) = 1u;
+  } else if (gr == 1) return;                                // the frame is decoded by the wave of its first granule
+  PD_WAVE_SYNC();
+  const GranPos second{gp.wg_flag, gp.w + 1, gp.wpw};       // (a frame's two granules are in one workgroup: WPW is even)
+  run_chunk<false, false, F32, false>(a, T, cb, f, L, S, nullptr, &second);
 }
 
 }  // namespace pdmp3

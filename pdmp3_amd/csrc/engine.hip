@@ -71,13 +71,46 @@ __global__ __launch_bounds__(64 * WPW, PDMP3_WAVES_PER_EU) void k_decode(DecodeA
   }
   const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * WPW + w;
   if (chunk >= n_chunks) return;
-  run_chunk<DUMP, false, F32>(a, T, (BankPtr)&c_bank, chunk, L[w]);
+  run_chunk<DUMP, false, F32>(a, T, (BankPtr)&c_bank, chunk, L[w], L[w].tab);
+}
+
+// One granule per wave (decode_core.h run_granule): WPW consecutive granules per workgroup, the workgroup's place in the
+// chain from a ticket.  128 VGPRs and 9.3 KB of LDS per wave + one table block per workgroup: two workgroups = 16 waves
+// per CU, four per SIMD.
+constexpr int kWavesPerWgGran = 8;
+template <bool F32>
+__global__ __launch_bounds__(64 * kWavesPerWgGran) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_decode_g(DecodeArgs a, GlobalTables T) {
+  constexpr int W = kWavesPerWgGran;
+  __shared__ WaveData L[W];
+  __shared__ TabLds S;
+  __shared__ unsigned wg_flag[2 * W + 1];
+  static_assert(sizeof(WaveData) * W + sizeof(TabLds) + sizeof(unsigned) * (2 * W + 1) <= 80 * 1024, "two workgroups per CU");
+  const int tid = (int)threadIdx.x;
+  const unsigned long long t_entry = a.prof ? PD_CLOCK() : 0ull;
+  const int w = tid >> 6;
+  const int g = (int)blockIdx.x * W + w;
+  const bool valid = g < 2 * a.n_frames;
+  // the wave's own input first: its round trip passes under the workgroup's table loads
+  LaneRegs pf;
+  if (valid) ph_prefetch(tid & 63, pf, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2);
+  if (tid < 2 * W + 1) wg_flag[tid] = 0;
+  // the workgroup's tables: for the sampling frequency of the launch's first frame (granules of another one read the
+  // global line table)
+  int sf0 = reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_SFREQ_MASK;
+  if (sf0 > 2) sf0 = 2;
+  tab_load_fixed(tid, 64 * W, S, T);
+  tab_load_sfreq(tid, 64 * W, S, T, sf0);
+  __syncthreads();
+  if (!valid) return;
+  if (a.prof && (tid & 63) == 0) a.prof[(size_t)g * kProfSlots] = t_entry;
+  const GranPos gp{wg_flag, w, W};
+  run_granule_wave<F32>(a, T, (BankPtr)&c_bank, g, L[w], S, gp, pf);
 }
 
 // same kernel with shader-clock stamps after every phase (tools/phase_profile.py)
 __global__ __launch_bounds__(64, PDMP3_WAVES_PER_EU) void k_decode_prof(DecodeArgs a, GlobalTables T) {
   __shared__ WaveLds L;
-  run_chunk<false, true>(a, T, (BankPtr)&c_bank, (int)blockIdx.x, L);
+  run_chunk<false, true>(a, T, (BankPtr)&c_bank, (int)blockIdx.x, L, L.tab);
 }
 
 __global__ __launch_bounds__(64) void k_generate(uint64_t seed, int64_t first, int16_t* spectra, pdmp3_gc_side* side) {
@@ -218,9 +251,11 @@ struct ChainBuf {
   bool used;
   int cap;                  // frames
   unsigned epoch;           // of the last launch that used it; flags of older launches are smaller, never equal
-  float* state;
-  unsigned* flag;
+  float* state;             // cap x max(kChainFloats, 2 kGranFloats) floats
+  unsigned* flag;           // cap x 4 flags, then the ticket counter of the granule kernel
 };
+// what a launch gets of it (a copy made under the lock: another thread's launch may replace the buffers right after)
+struct ChainUse { float* state; unsigned* flag; unsigned epoch; };
 constexpr int kChainBufs = 32;
 
 struct pdmp3_hip_ctx {
@@ -231,7 +266,11 @@ struct pdmp3_hip_ctx {
   uint16_t* d_linetab;
   float* d_win;
   float* d_frag;            // frag_long [10][64] | frag_short [10][64] | frag_mat [8][64]
-  bool chain_on;            // PDMP3_HIP_CHAIN=0 switches the chained form of one-frame-per-chunk launches off
+  int chain_mode;           // PDMP3_HIP_CHAIN: 0 = independent chunks with halos everywhere, 1 = one frame per wave, chained
+                            // (round 2), 2 (default) = one granule per wave (k_decode_g)
+  int gran_max_frames;      // launches up to this many frames take the granule kernel (PDMP3_HIP_GRAN_MAX)
+  int wave_slots_gran;      // waves of k_decode_g the device holds at once (CUs x 4 SIMDs x 4)
+  unsigned debug_flags;     // PDMP3_HIP_DEBUG_FAR_TIMEOUT=1: every wait for another workgroup gives up at once (tests)
   std::mutex chain_mu;
   ChainBuf chain[kChainBufs];
 };
@@ -278,12 +317,17 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
   c->device = device;
   {
     const char* e = getenv("PDMP3_HIP_CHAIN");
-    c->chain_on = !(e && *e == '0');
+    c->chain_mode = (e && *e >= '0' && *e <= '2') ? *e - '0' : 2;
   }
   {
     hipDeviceProp_t prop;
-    c->wave_slots = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-                        ? prop.multiProcessorCount * 4 * PDMP3_WAVES_PER_EU : 2048;
+    const int cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    c->wave_slots = cus * 4 * PDMP3_WAVES_PER_EU;
+    c->wave_slots_gran = cus * 4 * 4;
+    const char* d = getenv("PDMP3_HIP_DEBUG_FAR_TIMEOUT");
+    c->debug_flags = (d && *d == '1') ? PD_DEBUG_FAR_TIMEOUT : 0u;
+    const char* e = getenv("PDMP3_HIP_GRAN_MAX");
+    c->gran_max_frames = e && atoi(e) > 0 ? atoi(e) : c->wave_slots_gran / 4;     // (measured: faster than one frame per wave up to here)
   }
   // every failure from here on releases what was allocated so far (pdmp3_hip_destroy takes a partly built context)
   UnpackTables* U = new UnpackTables;
@@ -331,36 +375,41 @@ static int auto_chunk(int n_frames, int slots) {
   return (int)(L < 1 ? 1 : L);
 }
 
-// The scratch of a chained launch of n_frames frames on stream s, or null (then the chunks stay independent).
-static ChainBuf* chain_get(pdmp3_hip_ctx* c, const void* key, hipStream_t s, int n_frames) {
+// The scratch of a chained launch of n_frames frames on stream s; false: none to be had, the chunks stay independent.
+static bool chain_get(pdmp3_hip_ctx* c, const void* key, hipStream_t s, int n_frames, ChainUse* use) {
   std::lock_guard<std::mutex> lock(c->chain_mu);
   ChainBuf* b = nullptr;
   for (ChainBuf& x : c->chain) if (x.used && x.key == key) { b = &x; break; }
-  if (!b) for (ChainBuf& x : c->chain) if (!x.used) { b = &x; b->used = true; b->key = key; b->cap = 0; b->epoch = 0; break; }
-  if (!b) return nullptr;
+  if (!b) for (ChainBuf& x : c->chain) if (!x.used) { b = &x; *b = ChainBuf{}; b->used = true; b->key = key; break; }
+  if (!b) return false;
+  constexpr size_t kFloatsPerFrame = (size_t)(2 * kGranFloats > kChainFloats ? 2 * kGranFloats : kChainFloats);
   if (b->cap < n_frames) {                                 // (stream-ordered: earlier launches on s are done with the old one)
     if (b->state) (void)hipFreeAsync(b->state, s);
     if (b->flag) (void)hipFreeAsync(b->flag, s);
     b->state = nullptr; b->flag = nullptr; b->cap = 0;
     const int cap = n_frames < 256 ? 256 : n_frames;
-    if (hipMallocAsync((void**)&b->state, (size_t)cap * kChainFloats * sizeof(float), s) != hipSuccess ||
-        hipMallocAsync((void**)&b->flag, (size_t)cap * sizeof(unsigned), s) != hipSuccess ||
-        hipMemsetAsync(b->flag, 0, (size_t)cap * sizeof(unsigned), s) != hipSuccess) {
+    const size_t flag_bytes = (size_t)cap * 4 * sizeof(unsigned);
+    if (hipMallocAsync((void**)&b->state, (size_t)cap * kFloatsPerFrame * sizeof(float), s) != hipSuccess ||
+        hipMallocAsync((void**)&b->flag, flag_bytes, s) != hipSuccess ||
+        hipMemsetAsync(b->flag, 0, flag_bytes, s) != hipSuccess) {
       (void)hipGetLastError();
       if (b->state) (void)hipFreeAsync(b->state, s);
-        if (b->flag) (void)hipFreeAsync(b->flag, s);
+      if (b->flag) (void)hipFreeAsync(b->flag, s);
       b->state = nullptr; b->flag = nullptr;
-      return nullptr;
+      return false;
     }
     b->cap = cap;
     b->epoch = 0;
   }
   if (b->epoch == 0xffffffffu) {                           // (never in practice: flags start over)
-    if (hipMemsetAsync(b->flag, 0, (size_t)b->cap * sizeof(unsigned), s) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(b->flag, 0, (size_t)b->cap * 4 * sizeof(unsigned), s) != hipSuccess) return false;
     b->epoch = 0;
   }
   b->epoch++;
-  return b;
+  use->state = b->state;
+  use->flag = b->flag;
+  use->epoch = b->epoch;
+  return true;
 }
 
 static void chain_release(pdmp3_hip_ctx* c, const void* key) {     // (its launches are complete)
@@ -390,9 +439,9 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   if (n_frames == 0) return PDMP3_HIP_OK;
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(c->device), "hipSetDevice");     // (a bare call may come from a thread whose current device is another one)
+  const int chunk_frames_arg = chunk_frames;             // (0 = the engine's choice)
   if (chunk_frames <= 0) chunk_frames = auto_chunk(n_frames, c->wave_slots);
   if (d_stages || chunk_frames > n_frames) chunk_frames = n_frames;
-  const int nchunks = (n_frames + chunk_frames - 1) / chunk_frames;
   DecodeArgs a;
   a.spectra = d_spectra;
   a.side = d_side;
@@ -410,17 +459,34 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.n_frames = n_frames;
   a.chunk_frames = chunk_frames;
   a.prof = d_prof;
-  a.chain_state = nullptr; a.chain_flag = nullptr; a.chain_epoch = 0;
-  if (c->chain_on && chunk_frames == 1 && n_frames > 1 && n_frames <= c->wave_slots && !d_stages && !d_prof) {
-    // (one round of waves: all resident together.  More frames than that at one per chunk -- only on request -- would
-    //  still be correct, workgroups being dispatched in order, but every XCD would wait for the one before it.)
-    // one frame per chunk: the waves hand their closing states on instead of decoding a halo each (run_chunk_chained)
-    if (ChainBuf* b = chain_get(c, chain_key, s, n_frames)) {
-      a.chain_state = b->state; a.chain_flag = b->flag; a.chain_epoch = b->epoch;
+  a.chain_state = nullptr; a.chain_flag = nullptr; a.chain_epoch = 0; a.debug_flags = c->debug_flags;
+  bool gran = false;
+  const bool plain = !d_stages && !d_prof;
+  const bool gran_prof = d_prof && chunk_frames_arg == -2;          // (development: the granule kernel with per-wave stamps)
+  if ((plain || gran_prof) && c->chain_mode == 2 && chunk_frames_arg <= 1 && n_frames <= c->gran_max_frames) {
+    // one granule per wave (run_granule): tails and matrixing rows are handed from wave to wave, no halo.  Waits for
+    // another workgroup are bounded (then: halo), so the launch finishes whatever part of it is resident; up to
+    // gran_max_frames all of it is
+    ChainUse u;
+    if (chain_get(c, chain_key, s, n_frames, &u)) {
+      a.chain_state = u.state; a.chain_flag = u.flag; a.chain_epoch = u.epoch;
+      a.chunk_frames = 1;
+      gran = true;
     }
   }
+  if (!gran && plain && c->chain_mode >= 1 && chunk_frames == 1 && n_frames > 1 && n_frames <= c->wave_slots) {
+    // one frame per wave, chained (run_chunk_chained): one round of waves, all resident together
+    ChainUse u;
+    if (chain_get(c, chain_key, s, n_frames, &u)) { a.chain_state = u.state; a.chain_flag = u.flag; a.chain_epoch = u.epoch; }
+  }
   GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64};
-  if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
+  const int nchunks = (n_frames + a.chunk_frames - 1) / a.chunk_frames;
+  if (gran) {
+    const int n_wgs = (2 * n_frames + kWavesPerWgGran - 1) / kWavesPerWgGran;
+    if (d_pcm_f32) hipLaunchKernelGGL(k_decode_g<true>, dim3(n_wgs), dim3(64 * kWavesPerWgGran), 0, s, a, T);
+    else hipLaunchKernelGGL(k_decode_g<false>, dim3(n_wgs), dim3(64 * kWavesPerWgGran), 0, s, a, T);
+  }
+  else if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
   else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
   else if (a.chain_epoch) {
     constexpr int W = kWavesPerWgChained;

@@ -10,6 +10,7 @@
 #include "../../pdmp3_amd/csrc/gen_core.h"
 
 #include <memory>
+#include <type_traits>
 #include <vector>
 
 using namespace pdmp3;
@@ -29,8 +30,8 @@ extern "C" int emul_decode_frames(const int16_t* spectra, const pdmp3_gc_side* s
   auto L = std::make_unique<WaveLds>();
   for (int c = 0; c < nchunks; ++c) {
     WaveLds& Lr = *L;
-    if (stages) emu::run_wave([&] { run_chunk<true>(a, T, &H.cb, c, Lr); });
-    else emu::run_wave([&] { run_chunk<false>(a, T, &H.cb, c, Lr); });
+    if (stages) emu::run_wave([&] { run_chunk<true>(a, T, &H.cb, c, Lr, Lr.tab); });
+    else emu::run_wave([&] { run_chunk<false>(a, T, &H.cb, c, Lr, Lr.tab); });
   }
   if (state) std::copy(state_next.begin(), state_next.end(), state);
   return 0;
@@ -50,7 +51,7 @@ extern "C" int emul_decode_frames_f32(const int16_t* spectra, const pdmp3_gc_sid
   auto L = std::make_unique<WaveLds>();
   for (int c = 0; c < nchunks; ++c) {
     WaveLds& Lr = *L;
-    emu::run_wave([&] { run_chunk<false, false, true>(a, T, &H.cb, c, Lr); });
+    emu::run_wave([&] { run_chunk<false, false, true>(a, T, &H.cb, c, Lr, Lr.tab); });
   }
   if (state) std::copy(state_next.begin(), state_next.end(), state);
   return 0;
@@ -79,6 +80,44 @@ extern "C" int emul_decode_frames_chained(const int16_t* spectra, const pdmp3_gc
     const ChainPos cp{wg_flag, w, w == WPW - 1, false};
     if (pcm_f32) emu::run_wave([&] { run_frame<true>(a, T, &H.cb, f, Lr, cp); });
     else emu::run_wave([&] { run_frame<false>(a, T, &H.cb, f, Lr, cp); });
+  }
+  if (state) std::copy(state_next.begin(), state_next.end(), state);
+  return 0;
+}
+
+// one granule per wave (run_granule_wave), as the engine's granule kernel launches it: 8 consecutive granules per workgroup
+// sharing one table block; the waves run in granule order here, so every flag is set before it is waited for
+extern "C" int emul_decode_frames_granules(const int16_t* spectra, const pdmp3_gc_side* side, int n_frames,
+                                           float* state, int16_t* pcm, float* pcm_f32, unsigned debug_flags) {
+  static HostTables H;
+  static bool ready = false;
+  if (!ready) { build_host_tables(H); ready = true; }
+  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data()};
+  std::vector<float> state_next(kStateFloats);
+  std::vector<float> cstate((size_t)n_frames * 2 * kGranFloats);
+  std::vector<unsigned> cflag((size_t)n_frames * 4, 0u);
+  DecodeArgs a{spectra, side, pcm, pcm_f32, state, state ? state_next.data() : nullptr, nullptr, n_frames, 1, nullptr,
+               cstate.data(), cflag.data(), 7u, debug_flags};
+  auto L = std::make_unique<WaveData>();
+  auto S = std::make_unique<TabLds>();
+  int sf0 = reinterpret_cast<const uint8_t*>(side)[7] & PDMP3_FR_SFREQ_MASK;
+  if (sf0 > 2) sf0 = 2;
+  emu::run_wave([&] { tab_load_fixed(emu::lane(), 64, *S, T); tab_load_sfreq(emu::lane(), 64, *S, T, sf0); });
+  constexpr int WPW = 8;
+  unsigned wg_flag[2 * WPW + 1];
+  for (int g = 0; g < 2 * n_frames; ++g) {
+    const int w = g % WPW;
+    if (w == 0) for (unsigned& x : wg_flag) x = 0;
+    const GranPos gp{wg_flag, w, WPW};
+    WaveData& Lr = *L;
+    TabLds& Sr = *S;
+    auto body = [&](auto f32) {
+      LaneRegs pf;
+      ph_prefetch(emu::lane(), pf, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2);
+      run_granule_wave<decltype(f32)::value>(a, T, &H.cb, g, Lr, Sr, gp, pf);
+    };
+    if (pcm_f32) emu::run_wave([&] { body(std::true_type{}); });
+    else emu::run_wave([&] { body(std::false_type{}); });
   }
   if (state) std::copy(state_next.begin(), state_next.end(), state);
   return 0;

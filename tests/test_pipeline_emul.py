@@ -38,6 +38,9 @@ def test_emul_vs_oracle(oracle, emul, name):
     err = float(np.abs(ws[:, :, :nch, 3] - gs[:, :, :nch, 3]).max())
     assert err <= 1e-5 * amp, "hybrid output differs by %g (amplitude %g)" % (err, amp)
     assert_pcm_close(got, want, pcm_tolerance(ws[:, :, :, 3]), name)
+    # the stage dumps come from the general formulation of every phase; without them the wave takes the fast paths
+    # (ph_requant_long for granules of long blocks): the same arithmetic per line, so the same PCM bit for bit
+    assert np.array_equal(emul_decode(emul, sp, sd), got), "fast paths differ from the general formulation"
 
 
 @pytest.mark.parametrize("chunk", [1, 2, 3, 5, 16])
@@ -197,3 +200,64 @@ def test_emul_float_pcm(oracle, emul, name):
     got2 = np.zeros((n, 2304), np.float32)
     emul.emul_decode_frames_f32(_p(sp), _p(sd), n, None, _p(got2), 3)
     assert np.array_equal(got, got2)
+
+
+def emul_decode_granules(emul, sp, sd, state=None, f32=False, debug=0):
+    n = sp.shape[0]
+    pcm = np.zeros((n, 2304), np.float32 if f32 else np.int16)
+    emul.emul_decode_frames_granules(_p(sp), _p(sd), n, _p(state), None if f32 else _p(pcm), _p(pcm) if f32 else None, debug)
+    return pcm
+
+
+@pytest.mark.parametrize("name", list(corpus.CASES))
+def test_emul_granule_waves_equal_independent_chunks(emul, name):
+    """run_granule (one granule per wave, tails and matrixing rows handed on) is the same arithmetic in the same order as
+    run_chunk: PCM bit-identical for every block-type mix (incl. the H5 corner, whose peek values travel with the rows),
+    mono corpora (run_chunk inside the granule kernel) and the long-block fast path of the requantisation"""
+    sp, sd = corpus.case(name, n=13)
+    want = emul_decode(emul, sp, sd, 0)
+    assert np.array_equal(emul_decode_granules(emul, sp, sd), want)
+
+
+def test_emul_granule_waves_states_resets_mode_and_rate_switches(emul, oracle):
+    sp, sd = _mode_switch_records()
+    whole = emul_decode(emul, sp, sd, 0)
+    assert np.array_equal(emul_decode_granules(emul, sp, sd), whole)
+    # the carried state in and out, batch after batch (granule 0 of a batch takes the caller's state; H5 at frame 0)
+    sp, sd = oracle.generate(C2_SEED, 0, 64)
+    whole = emul_decode(emul, sp, sd, 0)
+    st = np.zeros(emul.emul_state_floats(), np.float32)
+    st_ref = np.zeros(emul.emul_state_floats(), np.float32)
+    cuts = [0, 1, 2, 9, 10, 31, 47, 48, 64]
+    out = [emul_decode_granules(emul, sp[a:b], sd[a:b], st) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(out), whole)
+    emul_decode(emul, sp, sd, 0, st_ref)
+    assert np.array_equal(st.view(np.uint32), st_ref.view(np.uint32))
+    # a RESET frame in the middle: its input state is zero, no wait
+    sd2 = sd.copy()
+    sd2["frame"][20] |= 0x40
+    assert np.array_equal(emul_decode_granules(emul, sp, sd2), emul_decode(emul, sp, sd2, 0))
+    # float PCM
+    got = emul_decode_granules(emul, sp[:24], sd[:24], f32=True)
+    want = np.zeros((24, 2304), np.float32)
+    emul.emul_decode_frames_f32(_p(sp[:24]), _p(sd[:24]), 24, None, _p(want), 0)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # every frame a short block in granule 1 / channel 1 (H5: the peek values come with the rows of granule 0)
+    sp3, sd3 = corpus.case("ms_short_heavy_480", n=16)
+    assert np.array_equal(emul_decode_granules(emul, sp3, sd3), emul_decode(emul, sp3, sd3, 0))
+    # the sampling frequency changes inside the batch: the workgroup's tables are for frame 0's, the other frames read
+    # the global line table (ph_requant's TG)
+    a, sa = corpus.case("ms_long_441", n=6)
+    b, sb = corpus.case("ms_short_heavy_480", n=6)
+    sp4 = np.concatenate([a, b, a]); sd4 = np.concatenate([sa, sb, sa])
+    assert np.array_equal(emul_decode_granules(emul, sp4, sd4), emul_decode(emul, sp4, sd4, 0))
+
+
+@pytest.mark.parametrize("name", ["ms_long_441", "ms_short_heavy_480", "mono_441"])
+def test_emul_granule_waves_give_up_waiting_for_other_workgroups(emul, name):
+    """the bounded wait (gran_wait): with every wait for another workgroup giving up at once, the first wave of each
+    workgroup decodes its frame with a halo (run_chunk), tells the wave of the frame's second granule to leave and
+    publishes from there -- same PCM"""
+    sp, sd = corpus.case(name, n=21)
+    want = emul_decode(emul, sp, sd, 0)
+    assert np.array_equal(emul_decode_granules(emul, sp, sd, debug=1), want)
