@@ -33,6 +33,7 @@
 
 #if defined(__HIPCC__)
 #define PD_FN __device__ __forceinline__
+#define PD_SLOW_FN __device__ __attribute__((noinline))      /* a real call: its registers and spills are its own */
 #define PD_MFN __device__ __forceinline__
 #define PD_HD __host__ __device__ __forceinline__
 // Built with -ffp-contract=off: a*b+c stays two roundings (as in the reference's
@@ -76,6 +77,7 @@ namespace pdmp3 {
 namespace emu {   // provided by tests/host_emul/wave_emul.h: one wave = 64 fibers
 int lane();                                   // the calling fiber's lane
 void wave_sync();                             // returns when all 64 lanes have arrived
+void wave_yield();                            // all 64 lanes arrive, the other live waves run
 float shfl_xor(float v, int mask);
 bool any(bool c);
 void mfma16(float a, float b, float* cd);     // v_mfma_f32_16x16x4_f32: cd[4] in and out
@@ -83,6 +85,7 @@ void permlane32_swap(int* a, int* b);         // v_permlane32_swap_b32 vdst = a,
 }  // namespace emu
 }  // namespace pdmp3
 #define PD_FN static inline
+#define PD_SLOW_FN static
 #define PD_MFN inline
 #define PD_HD static inline
 #define PD_FMA(a, b, c) __builtin_fmaf((a), (b), (c))   /* a true fused multiply-add, as on the device */
@@ -100,7 +103,7 @@ void permlane32_swap(int* a, int* b);         // v_permlane32_swap_b32 vdst = a,
 #define PD_STORE_DEVICE(p, v) (*(p) = (v))
 #define PD_LOAD_DEVICE(p) (*(p))
 #define PD_VMEM_DRAIN() ::pdmp3::emu::wave_sync()
-#define PD_SLEEP() __builtin_trap()        /* the host build runs the waves in frame order: nothing is ever waited for */
+#define PD_SLEEP() ::pdmp3::emu::wave_yield()    /* the other live waves of the workgroup run (a lone wave comes straight back) */
 #define PD_SETPRIO(x) ((void)0)
 #endif
 
@@ -178,8 +181,8 @@ struct TabLds {
   alignas(16) float win[4][36];
   float pow43z[2 * kPow43Small];   // [128 + v] = sign(v) |v|^(4/3) for v = -128 .. 127: magnitude lookup and sign in one read
   alignas(16) uint16_t ltab[3][576];
-  uint8_t bandaddr[5][64];         // long blocks (ph_requant_long): 4 x scale index of the lane's lines, see fast_line()
-  int sfreq;                       // the sampling frequency ltab / bandaddr are for
+  uint8_t bandaddr[3][5][64];      // long blocks (ph_requant_long): [sfreq] 4 x scale index of the lane's lines, see fast_line()
+  int sfreq;                       // the sampling frequency ltab is for
 };
 struct WaveLds : WaveData {
   TabLds tab;
@@ -289,13 +292,16 @@ PD_FN void tab_load_fixed(int tid, int nthr, TabLds& S, const GlobalTables& T) {
     S.pow43z[k] = v < 0 ? -p : p;
   }
   for (int k = tid; k < 144; k += nthr) (&S.win[0][0])[k] = T.win[k];
+  for (int k = tid; k < 3 * 5 * 64; k += nthr) {
+    const int sf = k / 320, r = k - 320 * sf;
+    S.bandaddr[sf][r >> 6][r & 63] = (uint8_t)band_addr_of(T, sf, fast_line(r & 63, r >> 6));
+  }
 }
 // ... and the line tables of one sampling frequency (3 kinds x 576 u16 = 216 x 16 B)
 PD_FN void tab_load_sfreq(int tid, int nthr, TabLds& S, const GlobalTables& T, int sfreq) {
   const Chunk16* src = reinterpret_cast<const Chunk16*>(T.linetab + (size_t)sfreq * 3 * 576);
   Chunk16* dst = reinterpret_cast<Chunk16*>(&S.ltab[0][0]);
   for (int k = tid; k < 216; k += nthr) dst[k] = src[k];
-  for (int k = tid; k < 5 * 64; k += nthr) S.bandaddr[k >> 6][k & 63] = (uint8_t)band_addr_of(T, sfreq, fast_line(k & 63, k >> 6));
   if (tid == 0) S.sfreq = sfreq;
 }
 PD_FN void load_linetab(int lane, TabLds& S, const GlobalTables& T, int sfreq) { tab_load_sfreq(lane, 64, S, T, sfreq); }
@@ -637,7 +643,6 @@ PD_FN float ms_scale(float x) { return (float)((double)x * 0.7071067811865475244
 
 template <bool TG>
 PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalTables& T, const GranuleInfo& g) {
-  const bool tg = TG && (g.sfreq != S.sfreq);                       // wave-uniform
   const bool two = g.nch == 2;
   const bool ms = two && (g.mode == 1) && (g.mode_ext & 2);
   const int cmin = (g.count1_0 > g.count1_1) ? g.count1_1 : g.count1_0;   // P:1920 (H2)
@@ -649,8 +654,7 @@ PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalT
   unsigned ba[5];
   PD_UNROLL for (int i = 0; i < 4; i++) { w0[i] = sp0[lane + 64 * i]; w1[i] = two ? sp1[lane + 64 * i] : 0u; }
   const int v0s = L.spec[0][512 + lane], v1s = two ? L.spec[1][512 + lane] : 0;
-  if (tg) { PD_UNROLL for (int i = 0; i < 5; i++) ba[i] = band_addr_of(T, g.sfreq, fast_line(lane, i)); }
-  else { PD_UNROLL for (int i = 0; i < 5; i++) ba[i] = S.bandaddr[i][lane]; }
+  PD_UNROLL for (int i = 0; i < 5; i++) ba[i] = S.bandaddr[g.sfreq][i][lane];
   // a 16-bit value is inside -128 .. 127 <=> its bits 15..7 are all alike <=> bits 15..8 of v ^ (v << 1) are zero
   bool fa0[4], fb0[4], fa1[4], fb1[4];
   float ga0[4], gb0[4], ga1[4], gb1[4], gs0, gs1;
@@ -1189,6 +1193,7 @@ struct DecodeArgs {
   unsigned chain_epoch;          // 0: chunks are independent (halo), as described above
   // granule kernel (run_granule): chain_state = [2 n_frames][kGranFloats], chain_flag = two flags per granule
   unsigned debug_flags;          // tests: PD_DEBUG_FAR_TIMEOUT = every wait for another workgroup gives up at once
+  int sf_hint;                   // the sampling frequency the workgroups' line tables are loaded for
 };
 constexpr unsigned PD_DEBUG_FAR_TIMEOUT = 1u;
 
@@ -1208,14 +1213,15 @@ PD_FN void gran_publish_regs(int lane, const LaneRegs& R, const DecodeArgs& a, i
 // OWN_TABS: S is this wave's own table block -- filled here, and refilled when the stream changes its sampling
 // frequency; otherwise (granule kernel: S belongs to the workgroup and is there already) granules of another sampling
 // frequency read the global line table (ph_requant's TG).  gp: granule kernel only -- where the closing state goes.
+// state_only: decode nothing -- only derive the state at the START of the chunk (its halo), into *state_only.
 template <bool DUMP, bool PROF = false, bool F32 = false, bool OWN_TABS = true>
 PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveData& L, TabLds& S, const ChainPos* cp = nullptr,
-                     const GranPos* gp = nullptr) {
+                     const GranPos* gp = nullptr, LaneRegs* state_only = nullptr) {
   LaneRegs R;
   const int lane = PD_LANE();
   const unsigned long long t_wave_start = PROF ? PD_CLOCK() : 0ull;
   const int f0 = chunk * a.chunk_frames;
-  int f1 = f0 + a.chunk_frames;
+  int f1 = state_only ? f0 : f0 + a.chunk_frames;
   if (f1 > a.n_frames) f1 = a.n_frames;
   const int g_begin = 2 * f0, g_end = 2 * f1;
   int g_start = 0;
@@ -1231,7 +1237,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     if (shrt && g_start > 0) g_peek = g_start;
     if (g_start < 0) g_start = 0;
   }
-  const bool last = (f1 == a.n_frames);
+  const bool last = (f1 == a.n_frames) && !state_only;
   // Channel 1 across mono frames.  The halo re-derives a channel's state from the last two granules in which
   // the channel was decoded; mono frames leave channel 1's overlap and polyphase history as the last stereo
   // frame left them (the reference's store[ch] / v_vec[ch], P:1777, P:2126), however long ago that was.  So
@@ -1246,7 +1252,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   if (g_start > 0) {
     const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f0 - 1) * 4)[7];
     const bool prev_mono = ((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 && !(fb & PDMP3_FR_RESET);
-    if (prev_mono && ((last && a.state_out) || last_stereo_or_reset(a.side, f0, f1) >= 0)) {
+    if (prev_mono && ((last && a.state_out) || state_only || last_stereo_or_reset(a.side, f0, f1) >= 0)) {
       const int fs = last_stereo_or_reset(a.side, 0, f0 - 1);
       if (fs < 0) ch1_from_state = true;
       else {
@@ -1362,6 +1368,11 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   }
   if (last && a.state_out) {
     PD_PHASE(state_store(lane, R, a.state_out))
+  }
+  if (state_only) {
+    PD_UNROLL for (int m = 0; m < kOvlRegs; m++) state_only->ovl[m] = R.ovl[m];
+    PD_UNROLL for (int k = 0; k < kHistSlots; k++) { state_only->he[k] = R.he[k]; state_only->ho[k] = R.ho[k]; }
+    return;
   }
   if (!DUMP && !PROF && a.chain_epoch) {
     // a chained launch (one frame per chunk) in which this frame took the independent path: the wave of the next frame
@@ -1523,93 +1534,110 @@ PD_FN void run_frame(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
 // it): the wave of granule 0 runs run_chunk on the frame and publishes at its end, the wave of granule 1 leaves.
 // ---------------------------------------------------------------------------
 constexpr int kGranFloats = 64 * (kOvlRegs + kHistSlots);          // tails [18][64] | rows [15][64]
+// Hand-over INSIDE a workgroup goes through LDS, into the receiver's own block ("mailboxes"), at no cost in space:
+//   tails [18][64]  -> the receiver's xr, dead from the end of its ph_imdct until its ph_overlap_matrix writes hyb there
+//   rows  [15][64]  -> the receiver's spec | pcm | side | scale (4224 B in a row), dead from the end of its ph_imdct on
+// The receiver says when the space is free (GranMb::free, after its ph_imdct), the sender then writes and says so
+// (tails_full / rows_full).  A sender waits for `free` without bound: it depends on the receiver's own progress only
+// (its transforms up to the IMDCT need nothing from anybody).  LDS operations of a wave execute in order, so the
+// flag follows the data.  Only the workgroup's last wave publishes through memory -- chain_state[g], device scope,
+// flags in chain_flag -- and only its first wave reads that.
+struct GranMb { unsigned free, tails_full, rows_full, pad; };       // LDS, one per wave of the workgroup, zero at entry
 struct GranPos {
-  unsigned* wg_flag;     // LDS: [2 w + k] == epoch once wave w's tails (k = 0) / rows (k = 1) can be read on this CU;
-                         // [2 wpw] != 0: wave 0 has given up waiting and decodes its frame the independent way
+  WaveData* wl;          // the workgroup's per-wave LDS blocks
+  GranMb* mb;            // [wpw]
   int w;                 // place of the granule within its workgroup
   int wpw;
 };
-PD_FN bool gran_last_in_wg(const GranPos& gp) { return gp.w == gp.wpw - 1; }
-#define PD_GRAN_STORE(p, v) { if (last_) PD_STORE_DEVICE((p), (v)); else *(p) = (v); }
-PD_FN void gran_signal(int lane, const DecodeArgs& a, int g, int k, const GranPos& gp) {
+static_assert(sizeof(WaveData::xr) >= kOvlRegs * 64 * sizeof(float), "tails mailbox");
+static_assert(offsetof(WaveData, scale) + sizeof(WaveData::scale) - offsetof(WaveData, spec) >= kHistSlots * 64 * sizeof(float) &&
+              offsetof(WaveData, xr) >= offsetof(WaveData, scale) + sizeof(WaveData::scale), "rows mailbox");
+PD_FN float* gran_tails_box(WaveData& L) { return &L.xr[0][0]; }
+PD_FN float* gran_rows_box(WaveData& L) { return reinterpret_cast<float*>(&L.spec[0][0]); }
+PD_FN void gran_lds_flag(int lane, volatile unsigned* p) { if (lane == 0) *p = 1u; }
+PD_FN void gran_lds_wait(const volatile unsigned* p) {
+  while (PD_UNIFORM(*p) == 0) PD_SLEEP();
+  asm volatile("" ::: "memory");
+}
+PD_FN void gran_far_signal(int lane, const DecodeArgs& a, int g, int k) {
   PD_VMEM_DRAIN();
-  if (lane == 0) {
-    if (gran_last_in_wg(gp)) PD_STORE_DEVICE(a.chain_flag + 2 * (size_t)g + k, a.chain_epoch);
-    else *reinterpret_cast<volatile unsigned*>(&gp.wg_flag[2 * gp.w + k]) = a.chain_epoch;
+  if (lane == 0) PD_STORE_DEVICE(a.chain_flag + 2 * (size_t)g + k, a.chain_epoch);
+}
+// the tails of granule g (place gp) to whoever decodes granule g + 1
+PD_FN void gran_send_tails(int lane, const float* y2, const DecodeArgs& a, int g, const GranPos& gp) {
+  if (gp.w == gp.wpw - 1) {
+    float* st = a.chain_state + (size_t)g * kGranFloats;
+    for (int m = 0; m < kOvlRegs; m++) PD_STORE_DEVICE(&st[m * 64 + lane], y2[m]);
+    gran_far_signal(lane, a, g, 0);
+  } else {
+    GranMb& mb = gp.mb[gp.w + 1];
+    gran_lds_wait(&mb.free);
+    float* box = gran_tails_box(gp.wl[gp.w + 1]);
+    for (int m = 0; m < kOvlRegs; m++) box[m * 64 + lane] = y2[m];
+    PD_WAVE_SYNC();
+    gran_lds_flag(lane, &mb.tails_full);
   }
 }
-PD_FN void gran_publish_tails(int lane, const float* y2, const DecodeArgs& a, int g, const GranPos& gp) {
-  float* st = a.chain_state + (size_t)g * kGranFloats;
-  const bool last_ = gran_last_in_wg(gp);
-  for (int m = 0; m < kOvlRegs; m++) PD_GRAN_STORE(&st[m * 64 + lane], y2[m])
-  gran_signal(lane, a, g, 0, gp);
-}
-PD_FN void gran_publish_rows(int lane, const WaveData& L, const DecodeArgs& a, int g, const GranPos& gp) {
-  float* st = a.chain_state + (size_t)g * kGranFloats + kOvlRegs * 64;
-  const bool last_ = gran_last_in_wg(gp);
+// slots 3..17 of granule g's matrixing output, from the wave that has them in LDS
+PD_FN void gran_send_rows(int lane, const WaveData& L, const DecodeArgs& a, int g, const GranPos& gp) {
   const int ch = lane >> 5, i = lane & 31;
-  for (int s = 0; s < kHistSlots; s++) PD_GRAN_STORE(&st[s * 64 + lane], L.hyb[ch][3 + s][i])
-  gran_signal(lane, a, g, 1, gp);
+  if (gp.w == gp.wpw - 1) {
+    float* st = a.chain_state + (size_t)g * kGranFloats + kOvlRegs * 64;
+    for (int s = 0; s < kHistSlots; s++) PD_STORE_DEVICE(&st[s * 64 + lane], L.hyb[ch][3 + s][i]);
+    gran_far_signal(lane, a, g, 1);
+  } else {
+    GranMb& mb = gp.mb[gp.w + 1];
+    gran_lds_wait(&mb.free);
+    float* box = gran_rows_box(gp.wl[gp.w + 1]);
+    for (int s = 0; s < kHistSlots; s++) box[s * 64 + lane] = L.hyb[ch][3 + s][i];
+    PD_WAVE_SYNC();
+    gran_lds_flag(lane, &mb.rows_full);
+  }
 }
-// from a wave that has the state in registers (run_chunk at the end of a frame), for granule g = the frame's second:
-// coefficient 16 + i is he of lane i < 16, coefficient 16 - i is ho of lane i <= 16 -- together all 32 of a row
+// both parts from a wave that has the state in registers (run_chunk at the end of a frame), for granule g = the frame's
+// second (gp = ITS place): coefficient 16 + i is he of lane i < 16, coefficient 16 - i is ho of lane i <= 16 -- together
+// all 32 of a row
 PD_FN void gran_publish_regs(int lane, const LaneRegs& R, const DecodeArgs& a, int g, const GranPos& gp) {
-  float* st = a.chain_state + (size_t)g * kGranFloats;
-  const bool last_ = gran_last_in_wg(gp);
+  // (does the frame after it take the state from the chain at all?  -- same facts as run_granule_wave)
+  const int fn = (g >> 1) + 1;
+  if (fn >= a.n_frames) return;
+  const uint8_t nb = reinterpret_cast<const uint8_t*>(a.side + (size_t)fn * 4)[7];
+  if (((nb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 || (nb & PDMP3_FR_RESET)) return;
   const int ch = lane >> 5, i = lane & 31;
-  for (int m = 0; m < kOvlRegs; m++) PD_GRAN_STORE(&st[m * 64 + lane], R.ovl[m])
-  for (int s = 0; s < kHistSlots; s++) {
-    if (i < 16) PD_GRAN_STORE(&st[(kOvlRegs + s) * 64 + ch * 32 + 16 + i], R.he[s])
-    if (i <= 16) PD_GRAN_STORE(&st[(kOvlRegs + s) * 64 + ch * 32 + 16 - i], R.ho[s])
-  }
-  PD_VMEM_DRAIN();
-  if (lane == 0) {
-    PD_UNROLL for (int k = 0; k < 2; k++) {
-      if (last_) PD_STORE_DEVICE(a.chain_flag + 2 * (size_t)g + k, a.chain_epoch);
-      else *reinterpret_cast<volatile unsigned*>(&gp.wg_flag[2 * gp.w + k]) = a.chain_epoch;
+  const bool far = gp.w == gp.wpw - 1;
+  float* tails = far ? a.chain_state + (size_t)g * kGranFloats : nullptr;
+  if (far) {
+    for (int m = 0; m < kOvlRegs; m++) PD_STORE_DEVICE(&tails[m * 64 + lane], R.ovl[m]);
+    float* rows = tails + kOvlRegs * 64;
+    for (int s = 0; s < kHistSlots; s++) {
+      if (i < 16) PD_STORE_DEVICE(&rows[s * 64 + ch * 32 + 16 + i], R.he[s]);
+      if (i <= 16) PD_STORE_DEVICE(&rows[s * 64 + ch * 32 + 16 - i], R.ho[s]);
     }
+    PD_VMEM_DRAIN();
+    if (lane == 0) { PD_STORE_DEVICE(a.chain_flag + 2 * (size_t)g, a.chain_epoch); PD_STORE_DEVICE(a.chain_flag + 2 * (size_t)g + 1, a.chain_epoch); }
+  } else {
+    GranMb& mb = gp.mb[gp.w + 1];
+    gran_lds_wait(&mb.free);
+    float* tb = gran_tails_box(gp.wl[gp.w + 1]);
+    float* rb = gran_rows_box(gp.wl[gp.w + 1]);
+    for (int m = 0; m < kOvlRegs; m++) tb[m * 64 + lane] = R.ovl[m];
+    for (int s = 0; s < kHistSlots; s++) {
+      if (i < 16) rb[s * 64 + ch * 32 + 16 + i] = R.he[s];
+      if (i <= 16) rb[s * 64 + ch * 32 + 16 - i] = R.ho[s];
+    }
+    PD_WAVE_SYNC();
+    if (lane == 0) { mb.tails_full = 1u; mb.rows_full = 1u; }
   }
 }
-#undef PD_GRAN_STORE
-// Wait for part k of granule g - 1 (gp: the WAITING granule's place).  0: there, same workgroup; 1: there, another
-// workgroup (device-scope reads); -1: given up -- the bounded wait for another workgroup ran out (wave 0), or the wave
-// before this one in the workgroup has taken its frame over (wave 1 sees wave 0's abort word, wg_flag[2 wpw])
+// Wave 0 of a workgroup: part k of granule g - 1 from the workgroup before.  The wait is BOUNDED (false: given up)
 constexpr int kGranFarPolls = 1 << 13;      // x (a device-scope load + s_sleep): some milliseconds
-PD_FN int gran_wait(const DecodeArgs& a, int g, int k, const GranPos& gp) {
-  if (gp.w > 0) {
-    for (;;) {
-      if ((unsigned)PD_UNIFORM(*reinterpret_cast<volatile unsigned*>(&gp.wg_flag[2 * (gp.w - 1) + k])) == a.chain_epoch) break;
-      if (gp.w == 1 && PD_UNIFORM(*reinterpret_cast<volatile unsigned*>(&gp.wg_flag[2 * gp.wpw])) != 0) return -1;
-      PD_SLEEP();
-    }
-    asm volatile("" ::: "memory");
-    return 0;
-  }
-  if (a.debug_flags & PD_DEBUG_FAR_TIMEOUT) return -1;
+PD_FN bool gran_far_wait(const DecodeArgs& a, int g, int k, bool bounded) {
+  if (bounded && (a.debug_flags & PD_DEBUG_FAR_TIMEOUT)) return false;
   for (int n = 0; (unsigned)PD_UNIFORM(PD_LOAD_DEVICE(a.chain_flag + 2 * (size_t)(g - 1) + k)) != a.chain_epoch; ++n) {
-    if (n >= kGranFarPolls) return -1;
+    if (bounded && n >= kGranFarPolls) return false;
     PD_SLEEP();
   }
   asm volatile("" ::: "memory");
-  return 1;
-}
-PD_FN bool gran_take_tails(int lane, float* ovl, const DecodeArgs& a, int g, const GranPos& gp) {
-  const float* st = a.chain_state + (size_t)(g - 1) * kGranFloats;
-  const int how = gran_wait(a, g, 0, gp);
-  if (how < 0) return false;
-  if (how) { for (int m = 0; m < kOvlRegs; m++) ovl[m] = PD_LOAD_DEVICE(&st[m * 64 + lane]); }
-  else { for (int m = 0; m < kOvlRegs; m++) ovl[m] = st[m * 64 + lane]; }
-  return true;
-}
-PD_FN bool gran_take_rows(int lane, LaneRegs& R, const DecodeArgs& a, int g, const GranPos& gp) {
-  const float* rows = a.chain_state + (size_t)(g - 1) * kGranFloats + kOvlRegs * 64 + (lane >> 5) * 32;
-  const int how = gran_wait(a, g, 1, gp);
-  if (how < 0) return false;
-  if (how) {
-    for (int s = 0; s < kHistSlots; s++) { R.he[s] = PD_LOAD_DEVICE(&rows[s * 64 + R.idx_e]); R.ho[s] = PD_LOAD_DEVICE(&rows[s * 64 + R.idx_o]); }
-  } else {
-    for (int s = 0; s < kHistSlots; s++) { R.he[s] = rows[s * 64 + R.idx_e]; R.ho[s] = rows[s * 64 + R.idx_o]; }
-  }
   return true;
 }
 
@@ -1771,23 +1799,41 @@ PD_FN void ph_window_hist(int lane, WaveData& L, const LaneRegs& R, const float*
   pcm_emit<F32>(lane, L, 2, true, sum, pcm_g, pcmf_g);
 }
 
-// one granule of a stereo frame whose predecessor's state comes through the chain (or is the caller's / zero: `fresh`).
-// pf: the granule's spectra / side records, in flight since the kernel's entry.  false: a wait was given up (gran_wait),
-// nothing of the granule's PCM has been written.
+// run_chunk as a CALLED function, for the granule kernel's rare paths (frames that do not go the granule way; the state
+// at the start of a frame when the bounded wait for another workgroup has run out).  Not inlined on purpose: inlined,
+// its register demand and its spills shape the allocation of the whole kernel -- the hot path went from no spills to
+// hundreds.  Arguments by value / as plain pointers (the LDS blocks become generic pointers: slower accesses, here only).
 template <bool F32>
-PD_FN bool run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int g, WaveData& L, const TabLds& S, const GranPos& gp,
-                       bool fresh, bool h5, const LaneRegs& pf) {
+PD_SLOW_FN void gran_slow_chunk(DecodeArgs a, GlobalTables T, BankPtr cb, int f, WaveData* L, TabLds* S, GranPos second, bool publish,
+                                LaneRegs* state_only) {
+#if defined(__HIPCC__)
+  // (arguments of a called function arrive in vector registers; the constant bank's address has to be scalar again)
+  const unsigned long long u = (unsigned long long)cb;
+  cb = (BankPtr)(((unsigned long long)(unsigned)PD_UNIFORM((int)(u >> 32)) << 32) | (unsigned)PD_UNIFORM((int)u));
+  f = PD_UNIFORM(f);
+#endif
+  run_chunk<false, false, F32, false>(a, T, cb, f, *L, *S, nullptr, publish ? &second : nullptr, state_only);
+}
+
+// One granule of a stereo frame whose predecessor's state comes through the chain (or is the caller's / zero: `fresh`).
+// pf: the granule's spectra / side records, in flight since the kernel's entry; next_takes: the wave of granule g + 1
+// will take this one's state from the chain.
+template <bool F32>
+PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int g, WaveData& L, TabLds& S, const GranPos& gp,
+                       bool fresh, bool h5, bool next_takes, const LaneRegs& pf) {
   LaneRegs R;
   const int lane = PD_LANE();
   const int f = g >> 1, gr = g & 1;
   const bool from_caller = fresh && gr == 0 && f == 0 && a.state_in && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET);
   const bool from_zero = fresh && gr == 0 && !from_caller;
-  // (development: shader-clock stamps per wave when a.prof is set -- tools/phase_profile.py)
+  const bool from_chain = !from_caller && !from_zero;
+  // (development: shader-clock stamps per wave when a.prof is set -- tools/gran_profile.py)
 #define PD_GT(k) if (a.prof) { const unsigned long long t_ = PD_CLOCK(); if (lane == 0) a.prof[(size_t)g * kProfSlots + (k)] = t_; }
   PD_GT(1)
   R.pf0 = pf.pf0; R.pf1 = pf.pf1; R.pf2 = pf.pf2; R.pf3 = pf.pf3;
   PD_PHASE(lane_init(lane, L, R, cb, T))
   if (gr == 1 && h5) {
+    PD_SETPRIO(3);     // (this wave has a fifth more to do than the other three of its SIMD, and a launch ends with its last wave)
     // (wave-uniform) granule 1 / channel 1 is a short block: its scales read three hybrid outputs of granule 0.
     // Waiting for other waves to get there would put this wave most of a granule behind all others -- and a launch
     // ends with its last wave -- so it derives the three numbers itself, from data only: lines 0..63 of the granule
@@ -1831,43 +1877,72 @@ PD_FN bool run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   float y1[kOvlRegs], y2[kOvlRegs];
   PD_PHASE(ph_imdct(lane, L, S, R, cb, T, y1, y2))
   PD_GT(4)
-  PD_PHASE(gran_publish_tails(lane, y2, a, g, gp))
+  // from here on the wave reads nothing of spec / side / scale / xr any more: its mailboxes are free
+  if (gp.w > 0) gran_lds_flag(lane, &gp.mb[gp.w].free);
+  if (next_takes) { PD_PHASE(gran_send_tails(lane, y2, a, g, gp)) }
   PD_GT(5)
   float ovl[kOvlRegs];
+  bool have_halo = false;
+  LaneRegs H;                  // (memory, and touched only if the wait below is given up)
   if (from_caller) { PD_UNROLL for (int m = 0; m < kOvlRegs; m++) ovl[m] = a.state_in[m * 64 + lane]; }
   else if (from_zero) { PD_UNROLL for (int m = 0; m < kOvlRegs; m++) ovl[m] = 0.0f; }
-  else if (!gran_take_tails(lane, ovl, a, g, gp)) return false;
+  else if (gp.w > 0) {
+    gran_lds_wait(&gp.mb[gp.w].tails_full);
+    const float* box = gran_tails_box(L);
+    PD_UNROLL for (int m = 0; m < kOvlRegs; m++) ovl[m] = box[m * 64 + lane];
+    PD_WAVE_SYNC();
+  } else if (gran_far_wait(a, g, 0, true)) {
+    const float* st = a.chain_state + (size_t)(g - 1) * kGranFloats;
+    PD_UNROLL for (int m = 0; m < kOvlRegs; m++) ovl[m] = PD_LOAD_DEVICE(&st[m * 64 + lane]);
+  } else {
+    // The workgroup before this one has not delivered within the bound (it is not resident: a partitioned or shared
+    // device, a dispatcher that does not go in order).  Do not depend on it: derive the state at the start of the
+    // frame the independent way, from the granules before it (run_chunk's halo) -- waiting costs time, never progress.
+    PD_WAVE_SYNC();
+    gran_slow_chunk<F32>(a, T, cb, f, &L, &S, gp, false, &H);
+    PD_WAVE_SYNC();
+    PD_UNROLL for (int m = 0; m < kOvlRegs; m++) ovl[m] = H.ovl[m];
+    have_halo = true;
+  }
   PD_GT(6)
   PD_PHASE(ph_overlap_matrix(lane, L, R, y1, ovl))
   PD_GT(7)
-  PD_PHASE(
-    if (g == 2 * a.n_frames - 1 && a.state_out) {       // (wave-uniform) the launch's closing state, in the caller's form
-      float* so = a.state_out;
-      const int ch = lane >> 5;
-      PD_UNROLL for (int m = 0; m < kOvlRegs; m++) so[m * 64 + lane] = y2[m];
-      PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
-        so[(kOvlRegs + s) * 64 + lane] = L.hyb[ch][3 + s][R.idx_e];
-        so[(kOvlRegs + kHistSlots + s) * 64 + lane] = L.hyb[ch][3 + s][R.idx_o];
-      }
+  if (g == 2 * a.n_frames - 1 && a.state_out) {       // (wave-uniform) the launch's closing state, in the caller's form
+    float* so = a.state_out;
+    const int ch = lane >> 5;
+    PD_UNROLL for (int m = 0; m < kOvlRegs; m++) so[m * 64 + lane] = y2[m];
+    PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
+      so[(kOvlRegs + s) * 64 + lane] = L.hyb[ch][3 + s][R.idx_e];
+      so[(kOvlRegs + kHistSlots + s) * 64 + lane] = L.hyb[ch][3 + s][R.idx_o];
     }
-    gran_publish_rows(lane, L, a, g, gp);
-  )
+  }
+  if (next_takes) { PD_PHASE(gran_send_rows(lane, L, a, g, gp)) }
   PD_GT(8)
   float acc[18];
   PD_PHASE(ph_window_own(lane, L, R, acc))
   PD_GT(9)
-  if (from_caller) {
+  if (have_halo) { PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = H.he[s]; R.ho[s] = H.ho[s]; } }
+  else if (from_caller) {
     PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
       R.he[s] = a.state_in[(kOvlRegs + s) * 64 + lane];
       R.ho[s] = a.state_in[(kOvlRegs + kHistSlots + s) * 64 + lane];
     }
   } else if (from_zero) { PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = 0.0f; R.ho[s] = 0.0f; } }
-  else if (!gran_take_rows(lane, R, a, g, gp)) return false;
+  else if (gp.w > 0) {
+    gran_lds_wait(&gp.mb[gp.w].rows_full);
+    const float* rows = gran_rows_box(L) + (lane >> 5) * 32;
+    PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = rows[s * 64 + R.idx_e]; R.ho[s] = rows[s * 64 + R.idx_o]; }
+  } else {
+    // (the tails came, so the workgroup before this one is running: its rows will come -- no bound needed)
+    gran_far_wait(a, g, 1, false);
+    const float* rows = a.chain_state + (size_t)(g - 1) * kGranFloats + kOvlRegs * 64 + (lane >> 5) * 32;
+    PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = PD_LOAD_DEVICE(&rows[s * 64 + R.idx_e]); R.ho[s] = PD_LOAD_DEVICE(&rows[s * 64 + R.idx_o]); }
+  }
+  (void)from_chain;
   PD_GT(10)
   PD_PHASE(ph_window_hist<F32>(lane, L, R, acc, a.pcm + (size_t)f * 2304 + gr * 1152, F32 ? a.pcm_f32 + (size_t)f * 2304 + gr * 1152 : nullptr))
   PD_GT(11)
 #undef PD_GT
-  return true;
 }
 
 // The wave of granule g: which way its frame goes (wave-uniform facts from the side records; both waves of a frame
@@ -1878,21 +1953,24 @@ PD_FN void run_granule_wave(const DecodeArgs& a, const GlobalTables& T, BankPtr 
   const int f = g >> 1, gr = g & 1;
   const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)f * 4)[7];
   const uint8_t pb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f > 0 ? f - 1 : 0) * 4)[7];
+  const uint8_t nb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f + 1 < a.n_frames ? f + 1 : f) * 4)[7];
   const uint8_t fl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(2 * f + 1) * 2 + 1)[3];
   const bool stereo = ((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
   const bool fresh = f == 0 || (fb & PDMP3_FR_RESET);       // its input state is the caller's / zero
   const bool prev_stereo = ((pb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
-  if (stereo && (fresh || prev_stereo)) {
-    const bool h5 = (fl & PDMP3_GC_WIN_SWITCH) && ((fl & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
-    if (run_granule<F32>(a, T, cb, g, L, S, gp, fresh, h5, pf)) return;
-    // a wait was given up.  Wave 1: wave 0 has taken the frame over.  Wave 0 (the only one that waits for another
-    // workgroup, and its granule is a frame's first): says so to wave 1 and decodes the frame below.
-    if (gp.w != 0) return;
-    if (PD_LANE() == 0) *reinterpret_cast<volatile unsigned*>(&gp.wg_flag[2 * gp.wpw]) = 1u;
-  } else if (gr == 1) return;                                // the frame is decoded by the wave of its first granule
-  PD_WAVE_SYNC();
-  const GranPos second{gp.wg_flag, gp.w + 1, gp.wpw};       // (a frame's two granules are in one workgroup: WPW is even)
-  run_chunk<false, false, F32, false>(a, T, cb, f, L, S, nullptr, &second);
+  const bool chained = stereo && (fresh || prev_stereo);
+  const bool h5 = (fl & PDMP3_GC_WIN_SWITCH) && ((fl & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
+  bool next_takes = false;
+  if (chained) {
+    // who takes this granule's state from the chain: granule 1 of the same frame; or the next frame, if it is a stereo
+    // frame that does not start from zero (this frame being stereo, it then goes this way too)
+    next_takes = gr == 0 || (f + 1 < a.n_frames && ((nb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 && !(nb & PDMP3_FR_RESET));
+    run_granule<F32>(a, T, cb, g, L, S, gp, fresh, h5, next_takes, pf);
+    return;
+  }
+  if (gr == 1) return;                                       // the frame is decoded by the wave of its first granule
+  const GranPos second{gp.wl, gp.mb, gp.w + 1, gp.wpw};     // (a frame's two granules are in one workgroup: WPW is even)
+  gran_slow_chunk<F32>(a, T, cb, f, &L, &S, second, true, nullptr);
 }
 
 }  // namespace pdmp3

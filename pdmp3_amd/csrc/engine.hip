@@ -77,14 +77,14 @@ __global__ __launch_bounds__(64 * WPW, PDMP3_WAVES_PER_EU) void k_decode(DecodeA
 // One granule per wave (decode_core.h run_granule): WPW consecutive granules per workgroup, the workgroup's place in the
 // chain from a ticket.  128 VGPRs and 9.3 KB of LDS per wave + one table block per workgroup: two workgroups = 16 waves
 // per CU, four per SIMD.
-constexpr int kWavesPerWgGran = 8;
-template <bool F32>
-__global__ __launch_bounds__(64 * kWavesPerWgGran) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_decode_g(DecodeArgs a, GlobalTables T) {
-  constexpr int W = kWavesPerWgGran;
+// W = 16: one workgroup per CU holds the CU's sixteen waves (a launch of 2048 frames is one workgroup on every CU of
+// an MI355X); W = 8 for the smaller launches: twice as many CUs share the work, two waves per SIMD.
+template <bool F32, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_decode_g(DecodeArgs a, GlobalTables T) {
   __shared__ WaveData L[W];
   __shared__ TabLds S;
-  __shared__ unsigned wg_flag[2 * W + 1];
-  static_assert(sizeof(WaveData) * W + sizeof(TabLds) + sizeof(unsigned) * (2 * W + 1) <= 80 * 1024, "two workgroups per CU");
+  __shared__ GranMb mb[W];
+  static_assert(sizeof(WaveData) * W + sizeof(TabLds) + sizeof(GranMb) * W <= 160 * 1024, "one workgroup of 16 waves per CU");
   const int tid = (int)threadIdx.x;
   const unsigned long long t_entry = a.prof ? PD_CLOCK() : 0ull;
   const int w = tid >> 6;
@@ -93,17 +93,15 @@ __global__ __launch_bounds__(64 * kWavesPerWgGran) __attribute__((amdgpu_waves_p
   // the wave's own input first: its round trip passes under the workgroup's table loads
   LaneRegs pf;
   if (valid) ph_prefetch(tid & 63, pf, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2);
-  if (tid < 2 * W + 1) wg_flag[tid] = 0;
-  // the workgroup's tables: for the sampling frequency of the launch's first frame (granules of another one read the
-  // global line table)
-  int sf0 = reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_SFREQ_MASK;
-  if (sf0 > 2) sf0 = 2;
+  if (tid < W * 4) reinterpret_cast<unsigned*>(mb)[tid] = 0u;
+  // the workgroup's tables; the line tables are for the sampling frequency the caller expects (granules of another
+  // one read the global line table) -- nothing here waits for the launch's own data
   tab_load_fixed(tid, 64 * W, S, T);
-  tab_load_sfreq(tid, 64 * W, S, T, sf0);
+  tab_load_sfreq(tid, 64 * W, S, T, a.sf_hint);
   __syncthreads();
   if (!valid) return;
   if (a.prof && (tid & 63) == 0) a.prof[(size_t)g * kProfSlots] = t_entry;
-  const GranPos gp{wg_flag, w, W};
+  const GranPos gp{L, mb, w, W};
   run_granule_wave<F32>(a, T, (BankPtr)&c_bank, g, L[w], S, gp, pf);
 }
 
@@ -271,6 +269,7 @@ struct pdmp3_hip_ctx {
   int gran_max_frames;      // launches up to this many frames take the granule kernel (PDMP3_HIP_GRAN_MAX)
   int wave_slots_gran;      // waves of k_decode_g the device holds at once (CUs x 4 SIMDs x 4)
   unsigned debug_flags;     // PDMP3_HIP_DEBUG_FAR_TIMEOUT=1: every wait for another workgroup gives up at once (tests)
+  int sf_hint;              // sampling-frequency index the granule kernel's line tables are loaded for (PDMP3_HIP_SF_HINT; 0 = 44.1 kHz)
   std::mutex chain_mu;
   ChainBuf chain[kChainBufs];
 };
@@ -324,10 +323,12 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     const int cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     c->wave_slots = cus * 4 * PDMP3_WAVES_PER_EU;
     c->wave_slots_gran = cus * 4 * 4;
+    const char* h = getenv("PDMP3_HIP_SF_HINT");
+    c->sf_hint = (h && *h >= '0' && *h <= '2') ? *h - '0' : 0;
     const char* d = getenv("PDMP3_HIP_DEBUG_FAR_TIMEOUT");
     c->debug_flags = (d && *d == '1') ? PD_DEBUG_FAR_TIMEOUT : 0u;
     const char* e = getenv("PDMP3_HIP_GRAN_MAX");
-    c->gran_max_frames = e && atoi(e) > 0 ? atoi(e) : c->wave_slots_gran / 4;     // (measured: faster than one frame per wave up to here)
+    c->gran_max_frames = e && atoi(e) > 0 ? atoi(e) : c->wave_slots_gran * 2;     // (measured on MI355X: faster than chunks with halos up to about 8192 frames)
   }
   // every failure from here on releases what was allocated so far (pdmp3_hip_destroy takes a partly built context)
   UnpackTables* U = new UnpackTables;
@@ -459,7 +460,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.n_frames = n_frames;
   a.chunk_frames = chunk_frames;
   a.prof = d_prof;
-  a.chain_state = nullptr; a.chain_flag = nullptr; a.chain_epoch = 0; a.debug_flags = c->debug_flags;
+  a.chain_state = nullptr; a.chain_flag = nullptr; a.chain_epoch = 0; a.debug_flags = c->debug_flags; a.sf_hint = c->sf_hint;
   bool gran = false;
   const bool plain = !d_stages && !d_prof;
   const bool gran_prof = d_prof && chunk_frames_arg == -2;          // (development: the granule kernel with per-wave stamps)
@@ -482,9 +483,17 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64};
   const int nchunks = (n_frames + a.chunk_frames - 1) / a.chunk_frames;
   if (gran) {
-    const int n_wgs = (2 * n_frames + kWavesPerWgGran - 1) / kWavesPerWgGran;
-    if (d_pcm_f32) hipLaunchKernelGGL(k_decode_g<true>, dim3(n_wgs), dim3(64 * kWavesPerWgGran), 0, s, a, T);
-    else hipLaunchKernelGGL(k_decode_g<false>, dim3(n_wgs), dim3(64 * kWavesPerWgGran), 0, s, a, T);
+    // (workgroups of 8 waves while that gives every CU at most one of them)
+    const bool small = 2 * n_frames <= c->wave_slots_gran / 2;
+    const int W = small ? 8 : 16;
+    const int n_wgs = (2 * n_frames + W - 1) / W;
+    if (small) {
+      if (d_pcm_f32) hipLaunchKernelGGL((k_decode_g<true, 8>), dim3(n_wgs), dim3(64 * W), 0, s, a, T);
+      else hipLaunchKernelGGL((k_decode_g<false, 8>), dim3(n_wgs), dim3(64 * W), 0, s, a, T);
+    } else {
+      if (d_pcm_f32) hipLaunchKernelGGL((k_decode_g<true, 16>), dim3(n_wgs), dim3(64 * W), 0, s, a, T);
+      else hipLaunchKernelGGL((k_decode_g<false, 16>), dim3(n_wgs), dim3(64 * W), 0, s, a, T);
+    }
   }
   else if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
   else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);

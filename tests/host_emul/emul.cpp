@@ -85,10 +85,11 @@ extern "C" int emul_decode_frames_chained(const int16_t* spectra, const pdmp3_gc
   return 0;
 }
 
-// one granule per wave (run_granule_wave), as the engine's granule kernel launches it: 8 consecutive granules per workgroup
-// sharing one table block; the waves run in granule order here, so every flag is set before it is waited for
+// one granule per wave (run_granule_wave), as the engine's granule kernel launches it: workgroups of 16 consecutive granules
+// sharing one table block; the waves of a workgroup are live together (they hand their states on through each other's
+// LDS), the workgroups run one after the other
 extern "C" int emul_decode_frames_granules(const int16_t* spectra, const pdmp3_gc_side* side, int n_frames,
-                                           float* state, int16_t* pcm, float* pcm_f32, unsigned debug_flags) {
+                                           float* state, int16_t* pcm, float* pcm_f32, unsigned debug_flags, int sf_hint) {
   static HostTables H;
   static bool ready = false;
   if (!ready) { build_host_tables(H); ready = true; }
@@ -97,27 +98,27 @@ extern "C" int emul_decode_frames_granules(const int16_t* spectra, const pdmp3_g
   std::vector<float> cstate((size_t)n_frames * 2 * kGranFloats);
   std::vector<unsigned> cflag((size_t)n_frames * 4, 0u);
   DecodeArgs a{spectra, side, pcm, pcm_f32, state, state ? state_next.data() : nullptr, nullptr, n_frames, 1, nullptr,
-               cstate.data(), cflag.data(), 7u, debug_flags};
-  auto L = std::make_unique<WaveData>();
+               cstate.data(), cflag.data(), 7u, debug_flags, sf_hint};
+  constexpr int WPW = 16;
+  auto L = std::make_unique<WaveData[]>(WPW);
   auto S = std::make_unique<TabLds>();
-  int sf0 = reinterpret_cast<const uint8_t*>(side)[7] & PDMP3_FR_SFREQ_MASK;
-  if (sf0 > 2) sf0 = 2;
-  emu::run_wave([&] { tab_load_fixed(emu::lane(), 64, *S, T); tab_load_sfreq(emu::lane(), 64, *S, T, sf0); });
-  constexpr int WPW = 8;
-  unsigned wg_flag[2 * WPW + 1];
-  for (int g = 0; g < 2 * n_frames; ++g) {
-    const int w = g % WPW;
-    if (w == 0) for (unsigned& x : wg_flag) x = 0;
-    const GranPos gp{wg_flag, w, WPW};
-    WaveData& Lr = *L;
-    TabLds& Sr = *S;
-    auto body = [&](auto f32) {
-      LaneRegs pf;
-      ph_prefetch(emu::lane(), pf, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2);
-      run_granule_wave<decltype(f32)::value>(a, T, &H.cb, g, Lr, Sr, gp, pf);
-    };
-    if (pcm_f32) emu::run_wave([&] { body(std::true_type{}); });
-    else emu::run_wave([&] { body(std::false_type{}); });
+  emu::run_wave([&] { tab_load_fixed(emu::lane(), 64, *S, T); tab_load_sfreq(emu::lane(), 64, *S, T, sf_hint); });
+  GranMb mb[WPW];
+  for (int g0 = 0; g0 < 2 * n_frames; g0 += WPW) {
+    const int nw = 2 * n_frames - g0 < WPW ? 2 * n_frames - g0 : WPW;
+    memset(mb, 0, sizeof mb);
+    std::function<void()> bodies[WPW];
+    for (int w = 0; w < nw; ++w) {
+      bodies[w] = [&, w] {
+        const int g = g0 + w;
+        const GranPos gp{L.get(), mb, w, WPW};
+        LaneRegs pf;
+        ph_prefetch(emu::lane(), pf, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2);
+        if (pcm_f32) run_granule_wave<true>(a, T, &H.cb, g, L[w], *S, gp, pf);
+        else run_granule_wave<false>(a, T, &H.cb, g, L[w], *S, gp, pf);
+      };
+    }
+    emu::run_waves(bodies, nw);
   }
   if (state) std::copy(state_next.begin(), state_next.end(), state);
   return 0;

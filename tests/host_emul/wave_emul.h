@@ -47,7 +47,7 @@ namespace pdmp3 {
 namespace emu {
 
 constexpr int kLanes = 64;
-constexpr size_t kStackBytes = 512 * 1024;
+constexpr size_t kStackBytes = 256 * 1024;
 
 struct Wave {
   void* sp[kLanes];
@@ -60,18 +60,47 @@ struct Wave {
   bool flag[kLanes];
 };
 
-static thread_local Wave g_wave;
+// Several waves (a workgroup) can be live at once: they are run one at a time, a wave hands the processor to the next
+// live one where the device code sleeps in a wait loop (wave_yield) and when it ends.
+constexpr int kMaxWaves = 16;
+struct Group {
+  Wave wave[kMaxWaves];
+  bool live[kMaxWaves];
+  int n, cur;
+  void* main_sp;
+};
+static thread_local Group g_group;
+static thread_local Wave* g_cur = &g_group.wave[0];
+#define g_wave (*g_cur)
 
 inline int lane() { return g_wave.cur; }
+inline int wave_index() { return g_group.cur; }
+
+// lane 0 of the running wave (all its lanes parked in a rendezvous): run the next live wave; returns when it is this wave's turn again
+inline void switch_wave(bool ended) {
+  Group& G = g_group;
+  const int me = G.cur;
+  if (ended) G.live[me] = false;
+  int nx = -1;
+  for (int k = 1; k <= G.n; k++) { const int c = (me + k) % G.n; if (G.live[c]) { nx = c; break; } }
+  void* dummy;
+  if (nx < 0) { pd_ctx_switch(&dummy, G.main_sp); abort(); }          // the last wave has ended
+  if (nx == me) return;
+  G.cur = nx;
+  g_cur = &G.wave[nx];
+  Wave& a = G.wave[me];
+  Wave& b = G.wave[nx];
+  pd_ctx_switch(ended ? &dummy : &a.sp[a.cur], b.sp[b.cur]);
+}
 
 static void fiber_main() {
   Wave& w = g_wave;
   (*w.body)();
-  // lanes finish in order: hand over to the next one, the last one returns to the caller
+  // lanes finish in order: hand over to the next one; the last one passes the processor to the next live wave (or back to the caller)
   const int me = w.cur;
   void* dummy;
   if (me + 1 < kLanes) { w.cur = me + 1; pd_ctx_switch(&dummy, w.sp[me + 1]); }
-  else pd_ctx_switch(&dummy, w.main_sp);
+  else switch_wave(true);
   abort();   // never resumed
 }
 
@@ -82,11 +111,16 @@ inline void wave_sync() {
   pd_ctx_switch(&w.sp[me], w.sp[nx]);
 }
 
-// run `body` once per lane as one wave
-inline void run_wave(std::function<void()> body) {
-  Wave& w = g_wave;
+// device code sleeping in a wave-uniform wait loop: let the other waves of the workgroup run
+inline void wave_yield() {
+  wave_sync();
+  if (lane() == 0) switch_wave(false);
+  wave_sync();
+}
+
+static void prepare_wave(Wave& w, std::function<void()>* body) {
   if (!w.stacks) w.stacks = (char*)aligned_alloc(64, kStackBytes * kLanes);
-  w.body = &body;
+  w.body = body;
   for (int l = 0; l < kLanes; l++) {
     uintptr_t top = (uintptr_t)(w.stacks + kStackBytes * (l + 1));
     top &= ~(uintptr_t)15;
@@ -97,8 +131,22 @@ inline void run_wave(std::function<void()> body) {
     w.sp[l] = (void*)s;
   }
   w.cur = 0;
-  pd_ctx_switch(&w.main_sp, w.sp[0]);
 }
+
+// run bodies[i] once per lane as wave i, all of them live together (a workgroup)
+inline void run_waves(std::function<void()>* bodies, int n) {
+  Group& G = g_group;
+  if (n > kMaxWaves) abort();
+  G.n = n;
+  for (int i = 0; i < n; i++) { prepare_wave(G.wave[i], &bodies[i]); G.live[i] = true; }
+  G.cur = 0;
+  g_cur = &G.wave[0];
+  pd_ctx_switch(&G.main_sp, G.wave[0].sp[0]);
+  G.cur = 0;
+  g_cur = &G.wave[0];
+}
+// run `body` once per lane as one wave
+inline void run_wave(std::function<void()> body) { run_waves(&body, 1); }
 
 inline float shfl_xor(float v, int mask) {
   Wave& w = g_wave;

@@ -202,10 +202,10 @@ def test_emul_float_pcm(oracle, emul, name):
     assert np.array_equal(got, got2)
 
 
-def emul_decode_granules(emul, sp, sd, state=None, f32=False, debug=0):
+def emul_decode_granules(emul, sp, sd, state=None, f32=False, debug=0, sf_hint=0):
     n = sp.shape[0]
     pcm = np.zeros((n, 2304), np.float32 if f32 else np.int16)
-    emul.emul_decode_frames_granules(_p(sp), _p(sd), n, _p(state), None if f32 else _p(pcm), _p(pcm) if f32 else None, debug)
+    emul.emul_decode_frames_granules(_p(sp), _p(sd), n, _p(state), None if f32 else _p(pcm), _p(pcm) if f32 else None, debug, sf_hint)
     return pcm
 
 
@@ -245,12 +245,13 @@ def test_emul_granule_waves_states_resets_mode_and_rate_switches(emul, oracle):
     # every frame a short block in granule 1 / channel 1 (H5: the peek values come with the rows of granule 0)
     sp3, sd3 = corpus.case("ms_short_heavy_480", n=16)
     assert np.array_equal(emul_decode_granules(emul, sp3, sd3), emul_decode(emul, sp3, sd3, 0))
-    # the sampling frequency changes inside the batch: the workgroup's tables are for frame 0's, the other frames read
-    # the global line table (ph_requant's TG)
+    # the sampling frequency changes inside the batch, and the workgroups' line tables are for another one altogether:
+    # such granules read the global line table (ph_requant's TG)
     a, sa = corpus.case("ms_long_441", n=6)
     b, sb = corpus.case("ms_short_heavy_480", n=6)
     sp4 = np.concatenate([a, b, a]); sd4 = np.concatenate([sa, sb, sa])
-    assert np.array_equal(emul_decode_granules(emul, sp4, sd4), emul_decode(emul, sp4, sd4, 0))
+    for hint in (0, 1, 2):
+        assert np.array_equal(emul_decode_granules(emul, sp4, sd4, sf_hint=hint), emul_decode(emul, sp4, sd4, 0)), hint
 
 
 @pytest.mark.parametrize("name", ["ms_long_441", "ms_short_heavy_480", "mono_441"])
