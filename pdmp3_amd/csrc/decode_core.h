@@ -72,6 +72,9 @@
 #define PD_VMEM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define PD_SLEEP() __builtin_amdgcn_s_sleep(4)
 #define PD_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+// a flag word that is KNOWN to be in LDS, read / written as such (through a struct handed to a called function the
+// compiler loses the address space and falls back to flat accesses, which wait for every counter)
+#define PD_LDS_FLAG(p) (*(volatile __attribute__((address_space(3))) unsigned*)(p))
 #else
 namespace pdmp3 {
 namespace emu {   // provided by tests/host_emul/wave_emul.h: one wave = 64 fibers
@@ -105,6 +108,7 @@ void permlane32_swap(int* a, int* b);         // v_permlane32_swap_b32 vdst = a,
 #define PD_VMEM_DRAIN() ::pdmp3::emu::wave_sync()
 #define PD_SLEEP() ::pdmp3::emu::wave_yield()    /* the other live waves of the workgroup run (a lone wave comes straight back) */
 #define PD_SETPRIO(x) ((void)0)
+#define PD_LDS_FLAG(p) (*(volatile unsigned*)(p))
 #endif
 
 // development only (tools/ab_pmc.sh): phases switched off for instruction-count / timing experiments -- results are wrong
@@ -183,6 +187,7 @@ struct TabLds {
   alignas(16) uint16_t ltab[3][576];
   uint8_t bandaddr[3][5][64];      // long blocks (ph_requant_long): [sfreq] 4 x scale index of the lane's lines, see fast_line()
   int sfreq;                       // the sampling frequency ltab is for
+  unsigned ready;                  // granule kernel: waves of the workgroup that have stored their part of the tables
 };
 struct WaveLds : WaveData {
   TabLds tab;
@@ -472,12 +477,15 @@ PD_FN void ph_scales(int lane, WaveData& L) {
 // REORDERED lines l, l + 64, ..., l + 512 of both channels (consecutive lanes
 // touch consecutive LDS words: no bank conflicts on the int16 / u16 tables).
 // ---------------------------------------------------------------------------
-template <bool TG> PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalTables& T, const GranuleInfo& g);   // (below)
+template <bool TG, bool SCALES> PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalTables& T, const GranuleInfo& g);   // (below)
+PD_FN void ph_scales(int lane, WaveData& L);
 
 // NI = 9: the whole granule.  NI = 1: only the reordered lines 0..63 (the peek-only halo granule, see run_chunk).
 // FAST: granules of long blocks take ph_requant_long.  TG: the tables in S may be for another sampling frequency than
 // the granule's (granule kernel: one table block per workgroup) -- then the line table is read from global memory.
-template <bool DUMP, int NI = 9, bool FAST = false, bool TG = false>
+// SCALES: the band scales (ph_scales) are computed in here -- in the fast path while the loads from the full |is|^(4/3)
+// table are in flight (straight-line callers, which have nothing else to put there).
+template <bool DUMP, int NI = 9, bool FAST = false, bool TG = false, bool SCALES = false>
 PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const GlobalTables& T, float* dump0, float* dump1) {
   const GranuleInfo g = granule_info(L);
   const bool tg = TG && (g.sfreq != S.sfreq);                       // wave-uniform
@@ -489,20 +497,22 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
   const int kind0 = g.kind(0), kind1 = g.kind(1);
   if (FAST && !DUMP && NI == 9) {
     if (kind0 == 0 && (g.nch == 1 || kind1 == 0) && !is) {     // wave-uniform
-      ph_requant_long<TG>(lane, L, S, T, g);
+      ph_requant_long<TG, SCALES>(lane, L, S, T, g);
       return;
     }
   }
+  if (SCALES) { ph_scales(lane, L); PD_WAVE_SYNC(); }
   float x0[NI], x1[NI];
 #define PD_LINE(i) (lane + 64 * (i))
   {
     unsigned e0[NI], e1[NI];
+    // (the values are pinned inside each branch: merged, the two would become one FLAT load of a selected address)
     if (tg) {
-      PD_UNROLL for (int i = 0; i < NI; i++) e0[i] = gtab[kind0 * 576 + PD_LINE(i)];
-      PD_UNROLL for (int i = 0; i < NI; i++) e1[i] = gtab[kind1 * 576 + PD_LINE(i)];
+      PD_UNROLL for (int i = 0; i < NI; i++) { e0[i] = gtab[kind0 * 576 + PD_LINE(i)]; PD_PIN(e0[i]); }
+      PD_UNROLL for (int i = 0; i < NI; i++) { e1[i] = gtab[kind1 * 576 + PD_LINE(i)]; PD_PIN(e1[i]); }
     } else {
-      PD_UNROLL for (int i = 0; i < NI; i++) e0[i] = S.ltab[kind0][PD_LINE(i)];
-      PD_UNROLL for (int i = 0; i < NI; i++) e1[i] = S.ltab[kind1][PD_LINE(i)];
+      PD_UNROLL for (int i = 0; i < NI; i++) { e0[i] = S.ltab[kind0][PD_LINE(i)]; PD_PIN(e0[i]); }
+      PD_UNROLL for (int i = 0; i < NI; i++) { e1[i] = S.ltab[kind1][PD_LINE(i)]; PD_PIN(e1[i]); }
     }
     int v0[NI], v1[NI];
     float s0[NI], s1[NI];
@@ -634,14 +644,11 @@ PD_FN float pow43_big_pick(int v, float small, float big) {
 }
 PD_FN float ms_scale(float x) { return (float)((double)x * 0.70710678118654752440); }      // P:1923-1926
 
-// |is|^(4/3) with its sign comes from the LDS table for -128 .. 127.  Values outside it are a few per granule at most,
-// so each of the 18 value positions of the lanes is tested on its own (wave-uniform) and only a position that holds
-// one anywhere in the wave goes to the full table -- issue: the load (all of a granule's before anything waits for
-// one); pick: its result in place of the LDS value.
-#define PD_BIG_ISSUE(flag, v, g_) { g_ = 0.0f; if (flag) g_ = T.pow43[pow43_big_index(v)]; }
-#define PD_BIG_PICK(flag, v, p, g_) if (flag) p = pow43_big_pick(v, p, g_);
-
-template <bool TG>
+// |is|^(4/3) with its sign comes from the LDS table for -128 .. 127.  Values outside it are a few per granule at most:
+// the lanes that hold one fetch theirs from the full table under their own execution mask (a skipped block for
+// everybody else: one compare and a scalar branch per pair of lines) -- all of a granule's loads are issued before
+// anything waits for one, the scales are computed under them, the results are picked up afterwards.
+template <bool TG, bool SCALES>
 PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalTables& T, const GranuleInfo& g) {
   const bool two = g.nch == 2;
   const bool ms = two && (g.mode == 1) && (g.mode_ext & 2);
@@ -656,40 +663,51 @@ PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalT
   const int v0s = L.spec[0][512 + lane], v1s = two ? L.spec[1][512 + lane] : 0;
   PD_UNROLL for (int i = 0; i < 5; i++) ba[i] = S.bandaddr[g.sfreq][i][lane];
   // a 16-bit value is inside -128 .. 127 <=> its bits 15..7 are all alike <=> bits 15..8 of v ^ (v << 1) are zero
-  bool fa0[4], fb0[4], fa1[4], fb1[4];
-  float ga0[4], gb0[4], ga1[4], gb1[4], gs0, gs1;
+  bool big0[4], big1[4];
+  float ga0[4], gb0[4], ga1[4], gb1[4], gs0 = 0.0f, gs1 = 0.0f;
   PD_UNROLL for (int i = 0; i < 4; i++) {
-    const uint32_t m0 = w0[i] ^ (w0[i] << 1), m1 = w1[i] ^ (w1[i] << 1);
-    fa0[i] = PD_ANY((m0 & 0x0000ff00u) != 0u); fb0[i] = PD_ANY((m0 & 0xff000000u) != 0u);
-    fa1[i] = PD_ANY((m1 & 0x0000ff00u) != 0u); fb1[i] = PD_ANY((m1 & 0xff000000u) != 0u);
-    PD_BIG_ISSUE(fa0[i], (int)(int16_t)(w0[i] & 0xffffu), ga0[i]) PD_BIG_ISSUE(fb0[i], (int)w0[i] >> 16, gb0[i])
-    PD_BIG_ISSUE(fa1[i], (int)(int16_t)(w1[i] & 0xffffu), ga1[i]) PD_BIG_ISSUE(fb1[i], (int)w1[i] >> 16, gb1[i])
+    big0[i] = ((w0[i] ^ (w0[i] << 1)) & 0xff00ff00u) != 0u;
+    big1[i] = ((w1[i] ^ (w1[i] << 1)) & 0xff00ff00u) != 0u;
+    ga0[i] = gb0[i] = ga1[i] = gb1[i] = 0.0f;
+    // (PD_PIN keeps the blocks conditional: left alone, the compiler speculates the loads -- entry 0 is always safe --
+    //  and every lane computes 18 indices and issues 18 gathers per granule for the handful that are wanted)
+    if (big0[i]) {
+      int ia = pow43_big_index((int)(int16_t)(w0[i] & 0xffffu)), ib = pow43_big_index((int)w0[i] >> 16);
+      PD_PIN(ia); PD_PIN(ib);
+      ga0[i] = T.pow43[ia];
+      gb0[i] = T.pow43[ib];
+    }
+    if (big1[i]) {
+      int ia = pow43_big_index((int)(int16_t)(w1[i] & 0xffffu)), ib = pow43_big_index((int)w1[i] >> 16);
+      PD_PIN(ia); PD_PIN(ib);
+      ga1[i] = T.pow43[ia];
+      gb1[i] = T.pow43[ib];
+    }
   }
-  const bool fs0 = PD_ANY((unsigned)(v0s + kPow43Small) >= 2u * kPow43Small);
-  const bool fs1 = PD_ANY((unsigned)(v1s + kPow43Small) >= 2u * kPow43Small);
-  PD_BIG_ISSUE(fs0, v0s, gs0) PD_BIG_ISSUE(fs1, v1s, gs1)
-  float s0[5], s1[5];
+  const bool bigs0 = (unsigned)(v0s + kPow43Small) >= 2u * kPow43Small, bigs1 = (unsigned)(v1s + kPow43Small) >= 2u * kPow43Small;
+  if (bigs0) { int ia = pow43_big_index(v0s); PD_PIN(ia); gs0 = T.pow43[ia]; }
+  if (bigs1) { int ia = pow43_big_index(v1s); PD_PIN(ia); gs1 = T.pow43[ia]; }
+  if (SCALES) { ph_scales(lane, L); PD_WAVE_SYNC(); }       // (the loads above are in flight)
   PD_UNROLL for (int i = 0; i < 5; i++) {
-    s0[i] = *reinterpret_cast<const float*>(sc0 + ba[i]);
-    s1[i] = *reinterpret_cast<const float*>(sc1 + ba[i]);
-  }
-  PD_UNROLL for (int i = 0; i < 5; i++) {
+    const float s0 = *reinterpret_cast<const float*>(sc0 + ba[i]);
+    const float s1 = *reinterpret_cast<const float*>(sc1 + ba[i]);
     f32x2 x0, x1;
     if (i < 4) {
       const int a0 = (int)(int16_t)(w0[i] & 0xffffu), b0 = (int)w0[i] >> 16;
       const int a1 = (int)(int16_t)(w1[i] & 0xffffu), b1 = (int)w1[i] >> 16;
       float pa0 = pow43z_at(S, a0), pb0 = pow43z_at(S, b0), pa1 = pow43z_at(S, a1), pb1 = pow43z_at(S, b1);
-      PD_BIG_PICK(fa0[i], a0, pa0, ga0[i]) PD_BIG_PICK(fb0[i], b0, pb0, gb0[i])
-      PD_BIG_PICK(fa1[i], a1, pa1, ga1[i]) PD_BIG_PICK(fb1[i], b1, pb1, gb1[i])
+      if (big0[i]) { pa0 = pow43_big_pick(a0, pa0, ga0[i]); pb0 = pow43_big_pick(b0, pb0, gb0[i]); PD_PIN(pa0); PD_PIN(pb0); }
+      if (big1[i]) { pa1 = pow43_big_pick(a1, pa1, ga1[i]); pb1 = pow43_big_pick(b1, pb1, gb1[i]); PD_PIN(pa1); PD_PIN(pb1); }
       const f32x2 p0 = {pa0, pb0}, p1 = {pa1, pb1};
-      const f32x2 t0 = {s0[i], s0[i]}, t1 = {s1[i], s1[i]};
+      const f32x2 t0 = {s0, s0}, t1 = {s1, s1};
       x0 = t0 * p0;
       x1 = t1 * p1;
     } else {
       float q0 = pow43z_at(S, v0s), q1 = pow43z_at(S, v1s);
-      PD_BIG_PICK(fs0, v0s, q0, gs0) PD_BIG_PICK(fs1, v1s, q1, gs1)
-      x0 = (f32x2){s0[4] * q0, 0.0f};
-      x1 = (f32x2){s1[4] * q1, 0.0f};
+      if (bigs0) { q0 = pow43_big_pick(v0s, q0, gs0); PD_PIN(q0); }
+      if (bigs1) { q1 = pow43_big_pick(v1s, q1, gs1); PD_PIN(q1); }
+      x0 = (f32x2){s0 * q0, 0.0f};
+      x1 = (f32x2){s1 * q1, 0.0f};
     }
     if (ms) {   // P:1921-1928: lines below the smaller count1 only
       const f32x2 sum = x0 + x1, dif = x0 - x1;
@@ -711,8 +729,6 @@ PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalT
     }
   }
 }
-#undef PD_BIG_ISSUE
-#undef PD_BIG_PICK
 
 // ---------------------------------------------------------------------------
 // MFMA formulation of IMDCT + matrixing (device build)
@@ -1554,9 +1570,15 @@ static_assert(offsetof(WaveData, scale) + sizeof(WaveData::scale) - offsetof(Wav
               offsetof(WaveData, xr) >= offsetof(WaveData, scale) + sizeof(WaveData::scale), "rows mailbox");
 PD_FN float* gran_tails_box(WaveData& L) { return &L.xr[0][0]; }
 PD_FN float* gran_rows_box(WaveData& L) { return reinterpret_cast<float*>(&L.spec[0][0]); }
-PD_FN void gran_lds_flag(int lane, volatile unsigned* p) { if (lane == 0) *p = 1u; }
-PD_FN void gran_lds_wait(const volatile unsigned* p) {
-  while (PD_UNIFORM(*p) == 0) PD_SLEEP();
+PD_FN void gran_lds_flag(int lane, unsigned* p) { if (lane == 0) PD_LDS_FLAG(p) = 1u; }
+// the workgroup's tables are complete once all its waves have stored their part (TabLds::ready, counted up by each wave
+// after its stores -- the kernel has no barrier behind the table loads: they pass under the waves' first phases)
+PD_FN void gran_tabs_wait(const TabLds& S, int wpw) {
+  while ((int)PD_UNIFORM(PD_LDS_FLAG(const_cast<unsigned*>(&S.ready))) < wpw) PD_SLEEP();
+  asm volatile("" ::: "memory");
+}
+PD_FN void gran_lds_wait(unsigned* p) {
+  while (PD_UNIFORM(PD_LDS_FLAG(p)) == 0) PD_SLEEP();
   asm volatile("" ::: "memory");
 }
 PD_FN void gran_far_signal(int lane, const DecodeArgs& a, int g, int k) {
@@ -1626,7 +1648,7 @@ PD_FN void gran_publish_regs(int lane, const LaneRegs& R, const DecodeArgs& a, i
       if (i <= 16) rb[s * 64 + ch * 32 + 16 - i] = R.ho[s];
     }
     PD_WAVE_SYNC();
-    if (lane == 0) { mb.tails_full = 1u; mb.rows_full = 1u; }
+    if (lane == 0) { PD_LDS_FLAG(&mb.tails_full) = 1u; PD_LDS_FLAG(&mb.rows_full) = 1u; }
   }
 }
 // Wave 0 of a workgroup: part k of granule g - 1 from the workgroup before.  The wait is BOUNDED (false: given up)
@@ -1812,6 +1834,7 @@ PD_SLOW_FN void gran_slow_chunk(DecodeArgs a, GlobalTables T, BankPtr cb, int f,
   cb = (BankPtr)(((unsigned long long)(unsigned)PD_UNIFORM((int)(u >> 32)) << 32) | (unsigned)PD_UNIFORM((int)u));
   f = PD_UNIFORM(f);
 #endif
+  gran_tabs_wait(*S, second.wpw);
   run_chunk<false, false, F32, false>(a, T, cb, f, *L, *S, nullptr, publish ? &second : nullptr, state_only);
 }
 
@@ -1843,6 +1866,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
     LaneRegs R0, R1;
     R1.ovl[0] = 0.0f;
     float tail = 0.0f;
+    gran_tabs_wait(S, gp.wpw);
     PD_PHASE(
       ph_prefetch(lane, R0, a.spectra + (size_t)(g - 1) * 1152, a.side + (size_t)(g - 1) * 2);
       if (!fresh) ph_prefetch(lane, R1, a.spectra + (size_t)(g - 2) * 1152, a.side + (size_t)(g - 2) * 2);
@@ -1868,14 +1892,15 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   } else {
     PD_PHASE(ph_commit(lane, L, R))
   }
-  PD_PHASE(ph_scales(lane, L))
   PD_GT(2)
+  gran_tabs_wait(S, gp.wpw);
   PD_LAUNDER(cb);
-  PD_PHASE((ph_requant<false, 9, true, true>(lane, L, S, cb, T, nullptr, nullptr)))
+  if (!(PD_EXP_SKIP & 1)) { PD_PHASE((ph_requant<false, 9, true, true, true>(lane, L, S, cb, T, nullptr, nullptr))) }
   PD_GT(3)
-  PD_PHASE(ph_antialias(lane, L, cb))
+  if (!(PD_EXP_SKIP & 2)) { PD_PHASE(ph_antialias(lane, L, cb)) }
   float y1[kOvlRegs], y2[kOvlRegs];
-  PD_PHASE(ph_imdct(lane, L, S, R, cb, T, y1, y2))
+  if (PD_EXP_SKIP & 4) { PD_UNROLL for (int m = 0; m < kOvlRegs; m++) { y1[m] = L.xr[0][m * 64 + lane]; y2[m] = L.xr[1][m * 64 + lane]; } }
+  else { PD_PHASE(ph_imdct(lane, L, S, R, cb, T, y1, y2)) }
   PD_GT(4)
   // from here on the wave reads nothing of spec / side / scale / xr any more: its mailboxes are free
   if (gp.w > 0) gran_lds_flag(lane, &gp.mb[gp.w].free);
@@ -1905,7 +1930,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
     have_halo = true;
   }
   PD_GT(6)
-  PD_PHASE(ph_overlap_matrix(lane, L, R, y1, ovl))
+  if (PD_EXP_SKIP & 8) { L.hyb[0][lane & 15][lane >> 2] = y1[0] + ovl[1]; } else { PD_PHASE(ph_overlap_matrix(lane, L, R, y1, ovl)) }
   PD_GT(7)
   if (g == 2 * a.n_frames - 1 && a.state_out) {       // (wave-uniform) the launch's closing state, in the caller's form
     float* so = a.state_out;
@@ -1919,7 +1944,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   if (next_takes) { PD_PHASE(gran_send_rows(lane, L, a, g, gp)) }
   PD_GT(8)
   float acc[18];
-  PD_PHASE(ph_window_own(lane, L, R, acc))
+  if (PD_EXP_SKIP & 16) { PD_UNROLL for (int t = 0; t < 18; t++) acc[t] = L.hyb[0][t][lane & 31]; } else { PD_PHASE(ph_window_own(lane, L, R, acc)) }
   PD_GT(9)
   if (have_halo) { PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = H.he[s]; R.ho[s] = H.ho[s]; } }
   else if (from_caller) {
@@ -1940,7 +1965,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   }
   (void)from_chain;
   PD_GT(10)
-  PD_PHASE(ph_window_hist<F32>(lane, L, R, acc, a.pcm + (size_t)f * 2304 + gr * 1152, F32 ? a.pcm_f32 + (size_t)f * 2304 + gr * 1152 : nullptr))
+  if (PD_EXP_SKIP & 32) { a.pcm[(size_t)f * 2304 + gr * 1152 + lane] = (int16_t)(acc[0] + acc[17] + R.he[0] + R.ho[14]); } else { PD_PHASE(ph_window_hist<F32>(lane, L, R, acc, a.pcm + (size_t)f * 2304 + gr * 1152, F32 ? a.pcm_f32 + (size_t)f * 2304 + gr * 1152 : nullptr)) }
   PD_GT(11)
 #undef PD_GT
 }

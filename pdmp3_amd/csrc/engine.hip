@@ -94,11 +94,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   LaneRegs pf;
   if (valid) ph_prefetch(tid & 63, pf, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2);
   if (tid < W * 4) reinterpret_cast<unsigned*>(mb)[tid] = 0u;
+  if (tid == 0) S.ready = 0u;
+  __syncthreads();                       // (nothing to wait for in front of it: the waves arrive together)
   // the workgroup's tables; the line tables are for the sampling frequency the caller expects (granules of another
-  // one read the global line table) -- nothing here waits for the launch's own data
+  // one read the global line table).  No barrier behind the loads: each wave counts itself in when its part is
+  // stored (TabLds::ready) and whoever needs the tables waits for the count -- by then it is long there
   tab_load_fixed(tid, 64 * W, S, T);
   tab_load_sfreq(tid, 64 * W, S, T, a.sf_hint);
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if ((tid & 63) == 0) atomicAdd(&S.ready, 1u);
   if (!valid) return;
   if (a.prof && (tid & 63) == 0) a.prof[(size_t)g * kProfSlots] = t_entry;
   const GranPos gp{L, mb, w, W};

@@ -103,6 +103,7 @@ extern "C" int emul_decode_frames_granules(const int16_t* spectra, const pdmp3_g
   auto L = std::make_unique<WaveData[]>(WPW);
   auto S = std::make_unique<TabLds>();
   emu::run_wave([&] { tab_load_fixed(emu::lane(), 64, *S, T); tab_load_sfreq(emu::lane(), 64, *S, T, sf_hint); });
+  S->ready = WPW;
   GranMb mb[WPW];
   for (int g0 = 0; g0 < 2 * n_frames; g0 += WPW) {
     const int nw = 2 * n_frames - g0 < WPW ? 2 * n_frames - g0 : WPW;
