@@ -230,6 +230,7 @@ def main():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
+    kernel_name = eng.last_launch_kernel()
 
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
@@ -291,13 +292,9 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-            # (chained launch: 19.9 MB of spectra / side / PCM + the frames' closing states handed from wave to wave,
-            #  8.25 KB written and read once per frame -- DESIGN.md 3)
-            "traffic_note": "includes 2 x 17 MB of state hand-over between the waves of a chained launch",
-            # (launches of up to one round of waves at one frame per chunk are "chained": 8 waves per workgroup, states
-            #  handed from wave to wave instead of a halo per wave -- decode_core.h run_chunk_chained)
-            "kernel": "k_decode<false, false, 8>" if (n <= 2048 and not args.chunk and os.environ.get("PDMP3_HIP_CHAIN", "1") != "0")
-                      else "k_decode<false, false, 1>", "avg_launch_ms": round(kern_ms, 5),
+            # (which kernel that was is the engine's decision -- granule kernel up to 8192 frames, else independent
+            #  chunks -- and is read back from it: pdmp3_hip_last_launch_kind)
+            "kernel": kernel_name, "avg_launch_ms": round(kern_ms, 5),
             "algorithmic_bytes_per_launch": launch_bytes,
         },
     }

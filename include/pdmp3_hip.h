@@ -114,14 +114,16 @@ size_t pdmp3_hip_state_bytes(void);
  *   chunk_frames  frames per wavefront ("chunk"); 0 = choose automatically.
  *              Chunks of several frames are independent: each re-derives the
  *              state at its start from a halo of preceding frames.
- *              At ONE frame per chunk and up to one round of wavefronts (2048
- *              frames on MI355X; what 0 picks for such sizes) the wavefronts
- *              hand their frames' closing states on instead ("chained" launch;
- *              scratch is kept per HIP stream -- for up to 32 streams, beyond
- *              that the halo form is used -- or per pdmp3_hip_stream object);
- *              PDMP3_HIP_CHAIN=0 in the environment at pdmp3_hip_create() keeps
- *              the halo form everywhere.  Same PCM and state either way, bit
- *              for bit.
+ *              At 0 or 1, launches of up to 8192 frames (MI355X; PDMP3_HIP_GRAN_MAX)
+ *              are decoded ONE GRANULE PER WAVEFRONT instead: the wavefronts hand
+ *              IMDCT tails and polyphase rows on, no halo (scratch is kept per HIP
+ *              stream -- for up to 32 streams, beyond that the halo form is used --
+ *              or per pdmp3_hip_stream object).  A wavefront never depends on
+ *              another workgroup for progress: that wait is bounded and ends in a
+ *              halo decode.  PDMP3_HIP_CHAIN=0 in the environment at
+ *              pdmp3_hip_create() keeps the halo form everywhere.  Same PCM and
+ *              state either way, bit for bit.  pdmp3_hip_last_launch_kind() tells
+ *              which form the engine's latest launch took.
  *
  * Asynchronous on `stream`.
  */
@@ -133,6 +135,16 @@ int pdmp3_hip_decode_frames(pdmp3_hip_ctx* ctx,
                             int16_t* d_pcm,
                             int chunk_frames,
                             void* stream);
+
+/* How the latest decode launch of this engine (any thread) was laid out:
+ * PDMP3_HIP_LAUNCH_CHUNKS = independent chunks with halos (k_decode), otherwise
+ * the granule kernel (k_decode_g) with 8 / 16 wavefronts per workgroup.
+ * For reports (bench.py names the kernel it timed from this), not for control. */
+#define PDMP3_HIP_LAUNCH_NONE      0
+#define PDMP3_HIP_LAUNCH_CHUNKS    1
+#define PDMP3_HIP_LAUNCH_GRANULES8  8
+#define PDMP3_HIP_LAUNCH_GRANULES16 16
+int pdmp3_hip_last_launch_kind(const pdmp3_hip_ctx* ctx);
 
 /* Float PCM (not in the reference, whose only output is int16): the same decode, but what is stored is
  * the binary32 synthesis sum that P:2028-2031 scale by 32767, truncate and clip -- full scale is +-1.0, nothing is

@@ -61,12 +61,11 @@
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
   __builtin_amdgcn_wave_barrier();                          \
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
-// chained chunks: a wave hands its frame's closing state to the wave of the next frame through global memory.  The two
-// waves may sit on different XCDs, whose L2s are not coherent for ordinary accesses.  Device-scope release / acquire
-// FENCES write back / invalidate a whole L2 here (tried: the C2 launch went from 37 to 98 us), so the state travels in
-// device-scope relaxed ATOMIC accesses (sc1: written through, read past the reader's L1), ordered against the flag by
-// the wave's own vector-memory counter; nothing else is flushed.  (A second path through the shared L2 for waves of
-// the same XCD -- ordinary stores, an earlier flag -- was no faster.)  The waiting wave sleeps between polls.
+// granule kernel: the last wave of a workgroup hands its granule's state to the first wave of the next workgroup through
+// global memory.  The two may sit on different XCDs, whose L2s are not coherent for ordinary accesses.  Device-scope
+// release / acquire FENCES write back / invalidate a whole L2 here (tried in round 2: a 37 us launch went to 98 us), so
+// the state travels in device-scope relaxed ATOMIC accesses (sc1: written through, read past the reader's L1), ordered
+// against the flag by the wave's own vector-memory counter; nothing else is flushed.  The waiting wave sleeps between polls.
 #define PD_STORE_DEVICE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define PD_LOAD_DEVICE(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define PD_VMEM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -191,7 +190,6 @@ struct TabLds {
 };
 struct WaveLds : WaveData {
   TabLds tab;
-  float park[18][64];       // chained chunks: granule 0's hybrid outputs until the frame before has been transformed
 };
 
 typedef uint32_t Chunk16 __attribute__((vector_size(16)));   // one 16-byte global/LDS access
@@ -344,67 +342,6 @@ PD_FN void state_store(int lane, const LaneRegs& R, float* st) {
     st[(kOvlRegs + kHistSlots + s) * 64 + lane] = R.ho[s];
   }
 }
-
-// chained chunks: the state a frame leaves, for the wave of the next frame (see PD_STORE_DEVICE above).
-// A workgroup is WPW waves with consecutive frames on ONE CU.  Inside it the state goes through ordinary stores and
-// loads (one L1, one L2) and a flag in LDS; only the workgroup's last wave publishes for the device (sc1 accesses, a flag
-// in global memory), read by the first wave of the next workgroup.  Which wave takes which frame, and at which priority,
-// is arranged so that a wave waiting for a state always has a SIMD partner with work to do (k_decode in engine.hip).
-// (Tried instead of flags: every value with the epoch in one 8-byte access -- the readers' retries of 24 KB each made the
-// launch 30 % slower.)
-struct ChainPos {
-  unsigned* wg_flag;     // LDS, one per frame of the workgroup: == epoch once that frame's state can be read on this CU
-  int w;                 // this wave's frame within its workgroup (its place in the chain)
-  bool last_in_wg;       // its successor, if any, runs in another workgroup
-  bool hi;               // runs at raised priority until it has taken its predecessor's state (see k_decode)
-};
-// What travels is kChainFloats per frame: the 18 overlap tails of every lane, and slots 3..17 of the last granule's
-// matrixing output ONCE -- rows [slot][ch][32 coefficients]; the two coefficients of a slot that a lane keeps as
-// he / ho (idx_e, idx_o) are each kept by another lane as well, so the he / ho form is twice the bytes (and the states of
-// a launch then no longer fit the L2 they pass through).
-constexpr int kChainFloats = 64 * (kOvlRegs + kHistSlots);
-#define PD_CHAIN_STORE(p, v) { if (cp.last_in_wg) PD_STORE_DEVICE((p), (v)); else *(p) = (v); }
-PD_FN void chain_signal(int lane, unsigned* gflag, unsigned epoch, const ChainPos& cp) {
-  PD_VMEM_DRAIN();
-  if (lane == 0) {
-    if (cp.last_in_wg) PD_STORE_DEVICE(gflag, epoch);
-    else *reinterpret_cast<volatile unsigned*>(&cp.wg_flag[cp.w]) = epoch;
-  }
-}
-// from a wave that has the matrixing output of its last granule in LDS (run_chunk_chained)
-PD_FN void chain_publish_rows(int lane, const WaveData& L, const LaneRegs& R, float* st, unsigned* gflag, unsigned epoch, const ChainPos& cp) {
-  const int ch = lane >> 5, i = lane & 31;
-  for (int m = 0; m < kOvlRegs; m++) PD_CHAIN_STORE(&st[m * 64 + lane], R.ovl[m])
-  for (int s = 0; s < kHistSlots; s++) PD_CHAIN_STORE(&st[(kOvlRegs + s) * 64 + lane], L.hyb[ch][3 + s][i])
-  chain_signal(lane, gflag, epoch, cp);
-}
-// from a wave that only has he / ho (run_chunk at the end of its frame): coefficient 16 + i is he of lane i < 16,
-// coefficient 16 - i is ho of lane i <= 16 -- together all 32 of a row
-PD_FN void chain_publish_regs(int lane, const LaneRegs& R, float* st, unsigned* gflag, unsigned epoch, const ChainPos& cp) {
-  const int ch = lane >> 5, i = lane & 31;
-  for (int m = 0; m < kOvlRegs; m++) PD_CHAIN_STORE(&st[m * 64 + lane], R.ovl[m])
-  for (int s = 0; s < kHistSlots; s++) {
-    if (i < 16) PD_CHAIN_STORE(&st[(kOvlRegs + s) * 64 + ch * 32 + 16 + i], R.he[s])
-    if (i <= 16) PD_CHAIN_STORE(&st[(kOvlRegs + s) * 64 + ch * 32 + 16 - i], R.ho[s])
-  }
-  chain_signal(lane, gflag, epoch, cp);
-}
-PD_FN void chain_take(int lane, LaneRegs& R, const float* st, const unsigned* gflag, unsigned epoch, const ChainPos& cp) {
-  const int ch = lane >> 5;
-  const float* rows = st + kOvlRegs * 64 + ch * 32;
-  if (cp.w > 0) {
-    while ((unsigned)PD_UNIFORM(*reinterpret_cast<volatile unsigned*>(&cp.wg_flag[cp.w - 1])) != epoch) PD_SLEEP();
-    asm volatile("" ::: "memory");
-    for (int m = 0; m < kOvlRegs; m++) R.ovl[m] = st[m * 64 + lane];
-    for (int s = 0; s < kHistSlots; s++) { R.he[s] = rows[s * 64 + R.idx_e]; R.ho[s] = rows[s * 64 + R.idx_o]; }
-  } else {
-    while ((unsigned)PD_UNIFORM(PD_LOAD_DEVICE(gflag)) != epoch) PD_SLEEP();
-    asm volatile("" ::: "memory");
-    for (int m = 0; m < kOvlRegs; m++) R.ovl[m] = PD_LOAD_DEVICE(&st[m * 64 + lane]);
-    for (int s = 0; s < kHistSlots; s++) { R.he[s] = PD_LOAD_DEVICE(&rows[s * 64 + R.idx_e]); R.ho[s] = PD_LOAD_DEVICE(&rows[s * 64 + R.idx_o]); }
-  }
-}
-
 
 // ---------------------------------------------------------------------------
 // ph_prefetch / ph_commit: 2304 B spectra + 256 B side of one granule,
@@ -808,14 +745,9 @@ PD_FN float ph_peek_head(int lane, const WaveData& L, const TabLds& S, const Glo
   return y;
 }
 
-// MODE (chained chunks, run_chunk_chained): 0 = the whole phase; kPark = the same, and the hybrid outputs -- computed
-// against whatever R.ovl holds (zero there) -- are also left in park[18][64] (indexed like R.ovl); kFromPark = no IMDCT:
-// the outputs are park[] plus the overlap tails R.ovl now holds (sign as below: -(a + b) == (-a) + (-b) exactly), then
-// the matrixing as usual; R.ovl is left alone.
-constexpr int kPark = 1, kFromPark = 2;
-template <bool DUMP, int MODE = 0>
+template <bool DUMP>
 PD_FN void ph_mfma(int lane, WaveData& L, const TabLds& S, LaneRegs& R, BankPtr cb, const GlobalTables& T, float* dump2, float* dump3,
-                   bool do_matrix, float* park = nullptr) {   // do_matrix (wave-uniform) = false: a halo granule whose polyphase input nobody reads
+                   bool do_matrix) {   // do_matrix (wave-uniform) = false: a halo granule whose polyphase input nobody reads
   const GranuleInfo g = granule_info(L);
   const int j = lane & 15, kq = lane >> 4;
   if (DUMP) {   // stage 2 = lines after alias reduction
@@ -832,10 +764,6 @@ PD_FN void ph_mfma(int lane, WaveData& L, const TabLds& S, LaneRegs& R, BankPtr 
     const int cl = lane >> 5, sb = lane & 31;
     const bool act = cl < g.nch;
     float o16, o17;
-    if (MODE == kFromPark) {
-      o16 = park[16 * 64 + lane] + R.ovl[16];
-      o17 = park[17 * 64 + lane] + ((sb & 1) ? -R.ovl[17] : R.ovl[17]);
-    } else {
     const bool lwsf = (g.flags(cl) & PDMP3_GC_WIN_SWITCH) != 0;
     const bool llow = lwsf && g.is_mixed(cl) && sb < 2;
     const bool lshort = g.is_short(cl) && !llow;
@@ -857,8 +785,6 @@ PD_FN void ph_mfma(int lane, WaveData& L, const TabLds& S, LaneRegs& R, BankPtr 
     R.ovl[16] = act ? y[2] : R.ovl[16];                                   // P:1776
     R.ovl[17] = act ? y[3] : R.ovl[17];
     if (sb & 1) o17 = -o17;                                               // P:1738-1746
-    if (MODE == kPark) { park[16 * 64 + lane] = o16; park[17 * 64 + lane] = o17; }
-    }
     if (DUMP) { if (act) { dump3[cl * 4 * 576 + 18 * sb + 16] = o16; dump3[cl * 4 * 576 + 18 * sb + 17] = o17; } }
     // matrixing fold: x[k] +- x[31 - k]; subband 31 - sb of the same channel is lane ^ 31
     if (do_matrix) {
@@ -875,17 +801,6 @@ PD_FN void ph_mfma(int lane, WaveData& L, const TabLds& S, LaneRegs& R, BankPtr 
     const int ch = 1 - cc;
     if (ch < g.nch) {                    // wave-uniform
       float outa[8];
-      if (MODE == kFromPark) {
-        PD_UNROLL for (int h = 0; h < 2; h++)
-          PD_UNROLL for (int r = 0; r < 4; r++) {
-            const int oi = ch * 8 + h * 4 + r;
-            const int sb = h ? 31 - (4 * kq + r) : 4 * kq + r;
-            const bool flip = (sb & 1) && (j & 1);
-            const float o = park[oi * 64 + lane] + (flip ? -R.ovl[oi] : R.ovl[oi]);
-            outa[h * 4 + r] = o;
-            if (ch == 0 && h == 0 && r == 0 && kq == 0 && j < 3) L.peek[j] = o;
-          }
-      } else {
       const bool shrt = g.is_short(ch);
       const bool wsf = (g.flags(ch) & PDMP3_GC_WIN_SWITCH) != 0;
       const bool mixrows = wsf && g.is_mixed(ch);        // subbands 0, 1 use window/transform 0 (P:1769-1771)
@@ -932,11 +847,9 @@ PD_FN void ph_mfma(int lane, WaveData& L, const TabLds& S, LaneRegs& R, BankPtr 
           const int sb = h ? 31 - (4 * kq + r) : 4 * kq + r;              // subband of this row (tile 1 is reversed)
           if ((sb & 1) && (j & 1)) o = -o;                                // P:1738-1746: odd subband, odd sample
           outa[h * 4 + r] = o;
-          if (MODE == kPark) park[oi * 64 + lane] = o;
           if (DUMP) dump3[ch * 4 * 576 + 18 * sb + j] = o;
           if (ch == 0 && h == 0 && r == 0 && kq == 0 && j < 3) L.peek[j] = o;   // H5 source: (ch 0, sb 0, t 0..2)
         }
-      }
       // matrixing of time slots t = j (rows) of this channel: butterflies, then even / odd 16 x 16 products
       if (do_matrix) {
         f32x4 me = (f32x4){0, 0, 0, 0}, mo = (f32x4){0, 0, 0, 0};
@@ -1106,45 +1019,6 @@ PD_FN void ph_window(int lane, WaveData& L, LaneRegs& R, bool full, int nch, int
   pcm_emit<F32>(lane, L, nch, act, sum, pcm_g, pcmf_g);
 }
 
-// Chained chunks (run_chunk_chained): the window sums of a stereo granule whose history is not there yet.  Every sum is
-// ONE chain of 16 FMAs from the newest slot to the oldest; the terms that read this granule's own slots come first --
-// that part is done now (partial sums to part[18][64], LDS), the rest (ph_window_rest) when the granule
-// before it has been transformed: same operations in the same order, bit for bit what ph_window computes.
-// part[t][64 lanes] lives in LDS that is dead by then (a chained wave has requantised its last granule): the staged
-// spectra + the mono PCM staging hold t = 0..12, the line tables t = 13..17
-PD_FN float* part_row(WaveLds& L, int t) {
-  static_assert(offsetof(WaveData, pcm) == offsetof(WaveData, spec) + sizeof(L.spec), "spec and pcm are one block");
-  static_assert(sizeof(L.spec) + sizeof(L.pcm) >= 13 * 64 * sizeof(float) && sizeof(L.tab.ltab) >= 5 * 64 * sizeof(float), "room for part[18][64]");
-  return t < 13 ? reinterpret_cast<float*>(&L.spec[0][0]) + t * 64 : reinterpret_cast<float*>(&L.tab.ltab[0][0]) + (t - 13) * 64;
-}
-PD_FN void ph_window_first(int lane, WaveLds& L, const LaneRegs& R) {
-  const int ch = lane >> 5;
-  float E[18], O[18];
-  PD_UNROLL for (int t = 0; t < 18; t++) { E[t] = L.hyb[ch][t][R.idx_e]; O[t] = L.hyb[ch][t][R.idx_o]; }
-  PD_UNROLL for (int t = 0; t < 18; t++) {
-    float acc = 0.0f;
-    PD_UNROLL for (int k = 0; k < 8; k++) {
-      if (t - 2 * k >= 0) acc = PD_FMA(R.we[k], E[t - 2 * k], acc);
-      if (t - 2 * k - 1 >= 0) acc = PD_FMA(R.wo[k], O[t - 2 * k - 1], acc);
-    }
-    part_row(L, t)[lane] = acc;
-  }
-}
-// R.he / R.ho = slots 3..17 of the granule before (what ph_window left); stereo granules only
-template <bool F32>
-PD_FN void ph_window_rest(int lane, WaveLds& L, const LaneRegs& R, int16_t* pcm_g, float* pcmf_g) {
-  float sum[18];
-  PD_UNROLL for (int t = 0; t < 18; t++) {
-    float acc = part_row(L, t)[lane];
-    PD_UNROLL for (int k = 0; k < 8; k++) {
-      if (t - 2 * k < 0) acc = PD_FMA(R.we[k], R.he[kHistSlots + t - 2 * k], acc);
-      if (t - 2 * k - 1 < 0) acc = PD_FMA(R.wo[k], R.ho[kHistSlots + t - 2 * k - 1], acc);
-    }
-    sum[t] = acc;
-  }
-  pcm_emit<F32>(lane, L, 2, true, sum, pcm_g, pcmf_g);
-}
-
 // PCM of a mono granule (576 samples = 1152 bytes) from the LDS staging buffer; stereo granules were stored by
 // ph_window straight from registers.
 PD_FN void ph_store(int lane, WaveData& L, int nch, int16_t* pcm_g, bool emit) {
@@ -1202,12 +1076,11 @@ struct DecodeArgs {
   int n_frames;
   int chunk_frames;
   unsigned long long* prof;      // PROF builds: [n_chunks][kProfSlots] shader-clock ticks per phase
-  // chained chunks (chunk_frames == 1, run_chunk_chained): [n_frames][kChainFloats] states after every frame,
-  // one flag per frame (== chain_epoch once the frame's state is there)
+  // granule kernel (run_granule): chain_state = [2 n_frames][kGranFloats], chain_flag = two flags per granule
+  // (== chain_epoch once that part of the granule's state is there)
   float* chain_state;
   unsigned* chain_flag;
-  unsigned chain_epoch;          // 0: chunks are independent (halo), as described above
-  // granule kernel (run_granule): chain_state = [2 n_frames][kGranFloats], chain_flag = two flags per granule
+  unsigned chain_epoch;          // 0: independent chunks (halo), as described above
   unsigned debug_flags;          // tests: PD_DEBUG_FAR_TIMEOUT = every wait for another workgroup gives up at once
   int sf_hint;                   // the sampling frequency the workgroups' line tables are loaded for
 };
@@ -1231,7 +1104,7 @@ PD_FN void gran_publish_regs(int lane, const LaneRegs& R, const DecodeArgs& a, i
 // frequency read the global line table (ph_requant's TG).  gp: granule kernel only -- where the closing state goes.
 // state_only: decode nothing -- only derive the state at the START of the chunk (its halo), into *state_only.
 template <bool DUMP, bool PROF = false, bool F32 = false, bool OWN_TABS = true>
-PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveData& L, TabLds& S, const ChainPos* cp = nullptr,
+PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveData& L, TabLds& S,
                      const GranPos* gp = nullptr, LaneRegs* state_only = nullptr) {
   LaneRegs R;
   const int lane = PD_LANE();
@@ -1390,137 +1263,14 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     PD_UNROLL for (int k = 0; k < kHistSlots; k++) { state_only->he[k] = R.he[k]; state_only->ho[k] = R.ho[k]; }
     return;
   }
-  if (!DUMP && !PROF && a.chain_epoch) {
-    // a chained launch (one frame per chunk) in which this frame took the independent path: the wave of the next frame
-    // may be waiting for the state it leaves (stereo frames publish theirs, mono frames are skipped by their successors)
+  if (!DUMP && !PROF && gp) {
+    // granule kernel, a frame that took this path: the wave of the next frame may be waiting for the state it leaves
+    // (stereo frames publish theirs; after a mono frame nobody takes anything from the chain)
     const uint8_t fbl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f1 - 1) * 4)[7];
     if (((fbl & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3) {
-      if (gp) {
-        PD_PHASE(gran_publish_regs(lane, R, a, 2 * f1 - 1, *gp))
-      } else {
-        const ChainPos alone{nullptr, 0, true, false};
-        PD_PHASE(chain_publish_regs(lane, R, a.chain_state + (size_t)(f1 - 1) * kChainFloats, a.chain_flag + (f1 - 1), a.chain_epoch, cp ? *cp : alone))
-      }
+      PD_PHASE(gran_publish_regs(lane, R, a, 2 * f1 - 1, *gp))
     }
   }
-}
-
-// ---------------------------------------------------------------------------
-// Chained chunks: one frame per wave WITHOUT a halo (launches of up to one round of waves, where the halo is half of
-// every wave's work).  What frame f needs from frame f - 1 -- the IMDCT tails of its second granule and slots 3..17 of
-// that granule's matrixing output -- depends on frame f - 1's own spectra only (that is why a two-granule halo can
-// re-derive it), so no wave waits for a chain: every wave first does all the work that does not need its
-// predecessor, publishes its own closing state, and only then takes its predecessor's:
-//   A  granule 0: requantise .. IMDCT; its hybrid outputs are parked in LDS (computed against zero tails)
-//   B  granule 1 completely (its overlap partner is granule 0, in registers) up to the matrixing; its window sums as
-//      the frame's closing state -> chain_state[f], flag[f]; its window sums as far as they read its own slots
-//   C  wait for flag[f - 1]; R.ovl / R.he / R.ho = chain_state[f - 1]   (frame 0 / a RESET frame: the caller's / zero)
-//   D  granule 0: parked outputs + tails, matrixing, window, PCM     E  granule 1: the rest of its window sums, PCM
-// Same operations in the same order as run_chunk on the same frames: bit-identical PCM (tests compare).
-// The H5 corner -- granule 1 / channel 1 is a short block, its requantisation reads three hybrid outputs of granule
-// 0, which need the tails -- is served by the peek-only pass of run_chunk on the granule before the frame.
-// Taken by stereo frames whose predecessor's state is available that way: frame 0, a RESET frame, or a stereo frame
-// before it (mono frames, and stereo frames after mono ones, take run_chunk and publish at its end).
-// ---------------------------------------------------------------------------
-template <bool F32>
-PD_FN void run_chunk_chained(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int f, WaveLds& L, bool have_prev, bool h5,
-                           const ChainPos& cp, int first_sfreq) {   // first_sfreq: of the first granule the wave decodes
-  LaneRegs R;
-  const int lane = PD_LANE();
-  if (cp.hi) PD_SETPRIO(3);
-  const int g0 = 2 * f, g1 = 2 * f + 1;
-  const bool pre = h5 && have_prev;              // wave-uniform: the peek-only pass on granule g0 - 1
-  const int g_first = pre ? g0 - 1 : g0;
-  int cur_sfreq = first_sfreq > 2 ? 2 : first_sfreq;
-  PD_PHASE(
-    ph_prefetch(lane, R, a.spectra + (size_t)g_first * 1152, a.side + (size_t)g_first * 2);
-    load_linetab(lane, L.tab, T, cur_sfreq);
-    tab_load_fixed(lane, 64, L.tab, T);
-    lane_init(lane, L, R, cb, T);
-  )
-  PD_PHASE(ph_commit(lane, L, R))
-  PD_PHASE(ph_scales(lane, L))
-  float tail3 = 0.0f;                            // lanes 0..2: IMDCT tail p = 18 + lane of (channel 0, subband 0) of the granule before
-  if (pre) {
-      PD_PHASE(ph_requant<false, 1>(lane, L, L.tab, cb, T, nullptr, nullptr))
-    PD_PHASE(
-      ph_prefetch(lane, R, a.spectra + (size_t)g0 * 1152, a.side + (size_t)g0 * 2);
-      ph_antialias(lane, L, cb, true);
-    )
-    PD_PHASE(ph_peek_tail(lane, L, L.tab, R, T))
-    tail3 = R.ovl[0];
-    R.ovl[0] = 0.0f;
-    PD_PHASE(ph_commit(lane, L, R))
-    PD_PHASE(ph_scales(lane, L))
-    int sf = L.side[0][7] & PDMP3_FR_SFREQ_MASK;
-    if (sf > 2) sf = 2;
-    if (sf != cur_sfreq) {
-      PD_PHASE(load_linetab(lane, L.tab, T, sf))
-      cur_sfreq = sf;
-    }
-  } else if (h5 && a.state_in && f == 0 && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET)) {
-    tail3 = a.state_in[lane];                    // ovl[0] of the caller's state (lanes 0..2 are the ones that use it)
-  }
-  // ---- A
-  PD_LAUNDER(cb);
-  PD_PHASE(ph_requant<false>(lane, L, L.tab, cb, T, nullptr, nullptr))
-  PD_PHASE(
-    ph_prefetch(lane, R, a.spectra + (size_t)g1 * 1152, a.side + (size_t)g1 * 2);
-    ph_antialias(lane, L, cb);
-  )
-  PD_PHASE(ph_mfma<false, kPark>(lane, L, L.tab, R, cb, T, nullptr, nullptr, false, &L.park[0][0]))
-  PD_PHASE(if (h5 && lane < 3) L.peek[lane] += tail3)
-  PD_PHASE(ph_commit(lane, L, R))
-  PD_PHASE(ph_scales(lane, L))
-  // ---- B
-  PD_LAUNDER(cb);
-  PD_PHASE(ph_requant<false>(lane, L, L.tab, cb, T, nullptr, nullptr))
-  PD_PHASE(ph_antialias(lane, L, cb))
-  PD_PHASE(ph_mfma<false, 0>(lane, L, L.tab, R, cb, T, nullptr, nullptr, true))
-  PD_PHASE(
-    if (f == a.n_frames - 1 && a.state_out) {       // (wave-uniform) the launch's closing state, in the caller's form
-      ph_window<F32>(lane, L, R, false, 2, nullptr, nullptr);
-      state_store(lane, R, a.state_out);
-    }
-    chain_publish_rows(lane, L, R, a.chain_state + (size_t)f * kChainFloats, a.chain_flag + f, a.chain_epoch, cp);
-  )
-  PD_PHASE(ph_window_first(lane, L, R))      // (after the hand-over: useful work while the state travels, and its
-                                                   //  stores are not waited for by the publisher: 39 -> 33 us)
-  // ---- C
-  if (have_prev) {
-    PD_PHASE(chain_take(lane, R, a.chain_state + (size_t)(f - 1) * kChainFloats, a.chain_flag + (f - 1), a.chain_epoch, cp))
-  } else if (f == 0 && a.state_in && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET)) {
-    PD_PHASE(state_load(lane, R, a.state_in))
-  } else {
-    PD_PHASE(state_zero(lane, R))
-  }
-  if (cp.hi) PD_SETPRIO(0);
-  // ---- D
-  PD_PHASE(ph_mfma<false, kFromPark>(lane, L, L.tab, R, cb, T, nullptr, nullptr, true, &L.park[0][0]))
-  PD_PHASE(ph_window<F32>(lane, L, R, true, 2, a.pcm + (size_t)f * 2304, F32 ? a.pcm_f32 + (size_t)f * 2304 : nullptr))
-  // ---- E
-  PD_PHASE(ph_window_rest<F32>(lane, L, R, a.pcm + (size_t)f * 2304 + 1152, F32 ? a.pcm_f32 + (size_t)f * 2304 + 1152 : nullptr))
-}
-
-// one frame per chunk: which of the two ways this frame goes (wave-uniform facts from the side records)
-template <bool F32>
-PD_FN void run_frame(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int f, WaveLds& L, const ChainPos& cp) {
-  if (a.chain_epoch) {
-    // the three bytes the decision needs, asked for together (one memory round trip before the wave can start, not three)
-    const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)f * 4)[7];
-    const uint8_t pb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f > 0 ? f - 1 : 0) * 4)[7];
-    const uint8_t fl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(2 * f + 1) * 2 + 1)[3];
-    const bool stereo = ((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
-    const bool fresh = f == 0 || (fb & PDMP3_FR_RESET);       // its input state is the caller's / zero
-    const bool prev_stereo = ((pb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
-    if (stereo && (fresh || prev_stereo)) {
-      const bool h5 = (fl & PDMP3_GC_WIN_SWITCH) && ((fl & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
-      const bool pre = h5 && !fresh;                          // the peek-only pass on the granule before the frame comes first
-      run_chunk_chained<F32>(a, T, cb, f, L, !fresh, h5, cp, (pre ? pb : fb) & PDMP3_FR_SFREQ_MASK);
-      return;
-    }
-  }
-  run_chunk<false, false, F32>(a, T, cb, f, L, L.tab, &cp);
 }
 
 // ---------------------------------------------------------------------------
@@ -1835,7 +1585,7 @@ PD_SLOW_FN void gran_slow_chunk(DecodeArgs a, GlobalTables T, BankPtr cb, int f,
   f = PD_UNIFORM(f);
 #endif
   gran_tabs_wait(*S, second.wpw);
-  run_chunk<false, false, F32, false>(a, T, cb, f, *L, *S, nullptr, publish ? &second : nullptr, state_only);
+  run_chunk<false, false, F32, false>(a, T, cb, f, *L, *S, publish ? &second : nullptr, state_only);
 }
 
 // One granule of a stereo frame whose predecessor's state comes through the chain (or is the caller's / zero: `fresh`).

@@ -29,12 +29,6 @@ using namespace pdmp3;
 
 __constant__ ConstBank c_bank;
 
-// A workgroup is WPW independent wavefronts (one chunk each, no barrier between them): fewer, larger workgroups only make
-// the dispatch ramp of a launch shorter.  Measured: for the chained one-frame-per-chunk launches (a wave's work is short
-// there) 8 waves per workgroup are 8 % faster than 1 (C2: 31.7 against 34.9 us on the same box); the large launches
-// lose 4 % with 8 and 2 % with 4 -- so the launch picks.
-constexpr int kWavesPerWgChained = 8;
-
 // Workgroup b is observed to run on XCD b % 8, each XCD with its own L2.  A chunk's halo is the tail of the chunk
 // before it, so neighbouring chunks should share an L2: XCD x gets the x-th contiguous eighth of the chunks
 // (bijective for any count).  Purely a placement choice -- nothing is communicated between workgroups.
@@ -43,32 +37,16 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+// Independent chunks: one wavefront (= one workgroup) per chunk of frames, a halo in front of each.
 // F32: float PCM (the sums of P:2028 unscaled, DecodeArgs::pcm_f32) instead of int16
+// (The wave's LDS block is addressed through its wave number although a workgroup is one wave: with the block at a
+//  constant address the same source compiles to a kernel that issues 40 more vector loads per granule and takes 1.45 ms
+//  instead of 1.05 ms for 131072 frames -- measured on MI355X, ROCm 7.2; profiles/r03_kernel_experiments.txt.)
 template <bool DUMP, bool F32 = false, int WPW = 1>
 __global__ __launch_bounds__(64 * WPW, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a, GlobalTables T, int n_chunks) {
   __shared__ WaveLds L[WPW];
-  __shared__ unsigned wg_flag[WPW];
   const int w = threadIdx.x >> 6;
   const int n_wgs = (n_chunks + WPW - 1) / WPW;
-  if (!DUMP && a.chain_epoch) {            // one frame per chunk, no halo (decode_core.h run_chunk_chained)
-    // Waves w and w + WPW/2 share a SIMD.  If every wave took frame w, all of them would reach the point where they
-    // need their predecessor's state together, and every SIMD would idle for the hand-over's latency.  So the frames
-    // go alternately to the two waves of a SIMD -- p = 0, 1 on SIMD 0, p = 2, 3 on SIMD 1, ... -- and the first of each
-    // pair runs at raised priority: it publishes early, its partner takes that state late (no wait), and while it waits
-    // for the partner-wave of the SIMD before, its own partner has the SIMD.  In the last pair the roles are swapped, so
-    // that the state for the next workgroup -- the slow hand-over, through the fabric -- is the early one.
-    static_assert(WPW == 1 || (WPW % 2 == 0), "pairs of waves per SIMD");
-    const int half = WPW / 2;
-    const int p = WPW == 1 ? 0 : (((w % half) << 1) | (w / half));
-    const bool hi = WPW > 1 && (p < WPW - 2 ? (p & 1) == 0 : p == WPW - 1);
-    const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * WPW + p;
-    if (threadIdx.x < WPW) wg_flag[threadIdx.x] = 0;
-    __syncthreads();
-    if (chunk >= n_chunks) return;
-    const ChainPos cp{wg_flag, p, p == WPW - 1, hi};
-    run_frame<F32>(a, T, (BankPtr)&c_bank, chunk, L[w], cp);
-    return;
-  }
   const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * WPW + w;
   if (chunk >= n_chunks) return;
   run_chunk<DUMP, false, F32>(a, T, (BankPtr)&c_bank, chunk, L[w], L[w].tab);
@@ -112,8 +90,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 
 // same kernel with shader-clock stamps after every phase (tools/phase_profile.py)
 __global__ __launch_bounds__(64, PDMP3_WAVES_PER_EU) void k_decode_prof(DecodeArgs a, GlobalTables T) {
-  __shared__ WaveLds L;
-  run_chunk<false, true>(a, T, (BankPtr)&c_bank, (int)blockIdx.x, L, L.tab);
+  __shared__ WaveLds L[1];
+  const int w = threadIdx.x >> 6;
+  run_chunk<false, true>(a, T, (BankPtr)&c_bank, (int)blockIdx.x, L[w], L[w].tab);
 }
 
 __global__ __launch_bounds__(64) void k_generate(uint64_t seed, int64_t first, int16_t* spectra, pdmp3_gc_side* side) {
@@ -254,8 +233,9 @@ struct ChainBuf {
   bool used;
   int cap;                  // frames
   unsigned epoch;           // of the last launch that used it; flags of older launches are smaller, never equal
-  float* state;             // cap x max(kChainFloats, 2 kGranFloats) floats
-  unsigned* flag;           // cap x 4 flags, then the ticket counter of the granule kernel
+  float* state;             // cap x 2 kGranFloats floats
+  unsigned* flag;           // cap x 4 flags
+  unsigned long long last_use;   // launch counter value of its latest use (the least recently used one is evicted)
 };
 // what a launch gets of it (a copy made under the lock: another thread's launch may replace the buffers right after)
 struct ChainUse { float* state; unsigned* flag; unsigned epoch; };
@@ -269,13 +249,15 @@ struct pdmp3_hip_ctx {
   uint16_t* d_linetab;
   float* d_win;
   float* d_frag;            // frag_long [10][64] | frag_short [10][64] | frag_mat [8][64]
-  int chain_mode;           // PDMP3_HIP_CHAIN: 0 = independent chunks with halos everywhere, 1 = one frame per wave, chained
-                            // (round 2), 2 (default) = one granule per wave (k_decode_g)
+  int chain_mode;           // PDMP3_HIP_CHAIN=0: independent chunks with halos everywhere; otherwise launches up to
+                            // gran_max_frames take the granule kernel (k_decode_g)
   int gran_max_frames;      // launches up to this many frames take the granule kernel (PDMP3_HIP_GRAN_MAX)
   int wave_slots_gran;      // waves of k_decode_g the device holds at once (CUs x 4 SIMDs x 4)
   unsigned debug_flags;     // PDMP3_HIP_DEBUG_FAR_TIMEOUT=1: every wait for another workgroup gives up at once (tests)
+  int last_kind;            // PDMP3_HIP_LAUNCH_* of the latest decode launch (reports only)
   int sf_hint;              // sampling-frequency index the granule kernel's line tables are loaded for (PDMP3_HIP_SF_HINT; 0 = 44.1 kHz)
   std::mutex chain_mu;
+  unsigned long long chain_clock;
   ChainBuf chain[kChainBufs];
 };
 
@@ -295,6 +277,7 @@ static int fail(int code, const char* what, hipError_t e) {
 extern "C" const char* pdmp3_hip_last_error(void) { return g_err; }
 
 extern "C" size_t pdmp3_hip_state_bytes(void) { return (size_t)kStateFloats * sizeof(float); }
+extern "C" int pdmp3_hip_last_launch_kind(const pdmp3_hip_ctx* c) { return c ? c->last_kind : PDMP3_HIP_LAUNCH_NONE; }
 
 extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   if (!c) return;
@@ -321,7 +304,7 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
   c->device = device;
   {
     const char* e = getenv("PDMP3_HIP_CHAIN");
-    c->chain_mode = (e && *e >= '0' && *e <= '2') ? *e - '0' : 2;
+    c->chain_mode = (e && *e == '0') ? 0 : 1;
   }
   {
     hipDeviceProp_t prop;
@@ -387,8 +370,19 @@ static bool chain_get(pdmp3_hip_ctx* c, const void* key, hipStream_t s, int n_fr
   ChainBuf* b = nullptr;
   for (ChainBuf& x : c->chain) if (x.used && x.key == key) { b = &x; break; }
   if (!b) for (ChainBuf& x : c->chain) if (!x.used) { b = &x; *b = ChainBuf{}; b->used = true; b->key = key; break; }
-  if (!b) return false;
-  constexpr size_t kFloatsPerFrame = (size_t)(2 * kGranFloats > kChainFloats ? 2 * kGranFloats : kChainFloats);
+  if (!b) {
+    // every slot is taken: the least recently used one goes (a HIP stream that bare calls once ran on may be long gone,
+    // and its scratch -- 17 KB per frame -- would otherwise stay until the engine is destroyed).  hipFree waits for
+    // whatever still uses it.
+    ChainBuf* lru = &c->chain[0];
+    for (ChainBuf& x : c->chain) if (x.last_use < lru->last_use) lru = &x;
+    (void)hipFree(lru->state); (void)hipFree(lru->flag);
+    *lru = ChainBuf{};
+    lru->used = true; lru->key = key;
+    b = lru;
+  }
+  b->last_use = ++c->chain_clock;
+  constexpr size_t kFloatsPerFrame = (size_t)2 * kGranFloats;
   if (b->cap < n_frames) {                                 // (stream-ordered: earlier launches on s are done with the old one)
     if (b->state) (void)hipFreeAsync(b->state, s);
     if (b->flag) (void)hipFreeAsync(b->flag, s);
@@ -469,7 +463,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   bool gran = false;
   const bool plain = !d_stages && !d_prof;
   const bool gran_prof = d_prof && chunk_frames_arg == -2;          // (development: the granule kernel with per-wave stamps)
-  if ((plain || gran_prof) && c->chain_mode == 2 && chunk_frames_arg <= 1 && n_frames <= c->gran_max_frames) {
+  if ((plain || gran_prof) && c->chain_mode != 0 && chunk_frames_arg <= 1 && n_frames <= c->gran_max_frames) {
     // one granule per wave (run_granule): tails and matrixing rows are handed from wave to wave, no halo.  Waits for
     // another workgroup are bounded (then: halo), so the launch finishes whatever part of it is resident; up to
     // gran_max_frames all of it is
@@ -480,17 +474,13 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
       gran = true;
     }
   }
-  if (!gran && plain && c->chain_mode >= 1 && chunk_frames == 1 && n_frames > 1 && n_frames <= c->wave_slots) {
-    // one frame per wave, chained (run_chunk_chained): one round of waves, all resident together
-    ChainUse u;
-    if (chain_get(c, chain_key, s, n_frames, &u)) { a.chain_state = u.state; a.chain_flag = u.flag; a.chain_epoch = u.epoch; }
-  }
   GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64};
   const int nchunks = (n_frames + a.chunk_frames - 1) / a.chunk_frames;
   if (gran) {
     // (workgroups of 8 waves while that gives every CU at most one of them)
     const bool small = 2 * n_frames <= c->wave_slots_gran / 2;
     const int W = small ? 8 : 16;
+    c->last_kind = W;
     const int n_wgs = (2 * n_frames + W - 1) / W;
     if (small) {
       if (d_pcm_f32) hipLaunchKernelGGL((k_decode_g<true, 8>), dim3(n_wgs), dim3(64 * W), 0, s, a, T);
@@ -499,15 +489,13 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
       if (d_pcm_f32) hipLaunchKernelGGL((k_decode_g<true, 16>), dim3(n_wgs), dim3(64 * W), 0, s, a, T);
       else hipLaunchKernelGGL((k_decode_g<false, 16>), dim3(n_wgs), dim3(64 * W), 0, s, a, T);
     }
+  } else {
+    c->last_kind = PDMP3_HIP_LAUNCH_CHUNKS;
+    if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
+    else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
+    else if (d_pcm_f32) hipLaunchKernelGGL((k_decode<false, true>), dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
+    else hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
   }
-  else if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
-  else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
-  else if (a.chain_epoch) {
-    constexpr int W = kWavesPerWgChained;
-    if (d_pcm_f32) hipLaunchKernelGGL((k_decode<false, true, W>), dim3((nchunks + W - 1) / W), dim3(64 * W), 0, s, a, T, nchunks);
-    else hipLaunchKernelGGL((k_decode<false, false, W>), dim3((nchunks + W - 1) / W), dim3(64 * W), 0, s, a, T, nchunks);
-  } else if (d_pcm_f32) hipLaunchKernelGGL((k_decode<false, true>), dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
-  else hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
   hipError_t e = hipGetLastError();
   const char* what = "launch k_decode";
   if (e == hipSuccess && d_state && !leave_state_in_tmp) {

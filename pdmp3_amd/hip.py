@@ -24,7 +24,7 @@ FRAME_PCM_INT16 = 2304
 FRAME_SIDE_BYTES = 512
 
 EXPORTS = [
-    "pdmp3_hip_create", "pdmp3_hip_destroy", "pdmp3_hip_last_error", "pdmp3_hip_state_bytes",
+    "pdmp3_hip_create", "pdmp3_hip_destroy", "pdmp3_hip_last_error", "pdmp3_hip_state_bytes", "pdmp3_hip_last_launch_kind",
     "pdmp3_hip_decode_frames", "pdmp3_hip_decode_frames_f32", "pdmp3_hip_decode_frames_stages", "pdmp3_hip_generate_frames",
     "pdmp3_host_generate_frames",
     "pdmp3_hip_stream_create", "pdmp3_hip_stream_destroy", "pdmp3_hip_stream_reset", "pdmp3_hip_stream_spectra",
@@ -64,6 +64,8 @@ def load_library():
     lib.pdmp3_hip_destroy.argtypes = [vp]
     lib.pdmp3_hip_last_error.restype = C.c_char_p
     lib.pdmp3_hip_state_bytes.restype = C.c_size_t
+    if hasattr(lib, "pdmp3_hip_last_launch_kind"):
+        lib.pdmp3_hip_last_launch_kind.argtypes = [vp]
     lib.pdmp3_hip_decode_frames.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp]
     lib.pdmp3_hip_decode_frames_f32.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp]
     lib.pdmp3_hip_decode_frames_stages.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
@@ -117,6 +119,12 @@ class Engine:
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.tdev).cuda_stream)
+
+    def last_launch_kernel(self):
+        """name of the kernel the latest decode launch ran (pdmp3_hip_last_launch_kind)"""
+        k = self.lib.pdmp3_hip_last_launch_kind(self.h)
+        return {1: "k_decode (independent chunks, halo)", 8: "k_decode_g<.., 8> (one granule per wave, 8 waves per workgroup)",
+                16: "k_decode_g<.., 16> (one granule per wave, 16 waves per workgroup)"}.get(k, "none")
 
     # -- device buffers ----------------------------------------------------
     def alloc_frames(self, n_frames):

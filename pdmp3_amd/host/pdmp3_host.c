@@ -2027,7 +2027,7 @@ int pdmp3_amd_write_wav(const char* path, const void* pcm, size_t bytes, long ra
  * the FIRST file name only, O_CREAT without O_TRUNC, "-" = stdout.  PDMP3_CLI_WAV=1: the same samples as
  * "<first name>.wav" (truncated, 44-byte header with the first stream's rate and channel count, sizes filled in when
  * the driver is done; to stdout with unknown-length sizes). */
-static int g_out_fd = -2, g_out_wav = 0;
+static int g_out_fd = -2, g_out_wav = 0, g_out_hdr = 0;
 static uint64_t g_out_bytes = 0;
 static long g_out_rate = 44100;
 static int g_out_ch = 2;
@@ -2051,18 +2051,29 @@ static void write_raw(const char* filename, const unsigned char* data, size_t nb
       g_out_fd = open(name, O_WRONLY | O_CREAT | (g_out_wav ? O_TRUNC : 0), 0666);  /* raw: no O_TRUNC, like the reference */
       if (g_out_fd == -1) { perror(name); exit(-1); }
     } else g_out_fd = 1;
-    if (g_out_wav) {
-      unsigned char h[44];
-      g_out_rate = rate > 0 ? rate : 44100; g_out_ch = channels == 1 ? 1 : 2;
-      wav_header(h, g_out_rate, g_out_ch, 0, 0xffffffffu);
-      write_all(g_out_fd, h, 44);
-    }
+  }
+  /* the sink is opened by the FIRST call, data or not -- the reference calls its writer after every pdmp3_read, the
+   * first NEED_MORE with nothing decoded included (P:2565-2566, P:2239-2251), so the output is named after the first
+   * file even if that one yields no PCM; only the WAV header waits for the first data (rate and channels) */
+  if (g_out_wav && !g_out_hdr && nbytes) {
+    unsigned char h[44];
+    g_out_rate = rate > 0 ? rate : 44100; g_out_ch = channels == 1 ? 1 : 2;
+    wav_header(h, g_out_rate, g_out_ch, 0, 0xffffffffu);
+    write_all(g_out_fd, h, 44);
+    g_out_hdr = 1;
   }
   write_all(g_out_fd, data, nbytes);
   g_out_bytes += nbytes;
 }
 
 static void finish_output(void) {
+  if (g_out_fd >= 0 && g_out_wav && !g_out_hdr) {            /* no data at all: an empty WAV file */
+    unsigned char h[44];
+    wav_header(h, g_out_rate, g_out_ch, 0, 0);
+    write_all(g_out_fd, h, 44);
+    g_out_hdr = 1;
+    return;
+  }
   if (g_out_fd >= 0 && g_out_wav && g_out_fd != 1 && g_out_bytes <= 0xfffffff0u && lseek(g_out_fd, 0, SEEK_SET) == 0) {
     unsigned char h[44];
     wav_header(h, g_out_rate, g_out_ch, 0, (uint32_t)g_out_bytes);
@@ -2077,7 +2088,7 @@ static void cli_stream_file(pdmp3_handle* id, const char* filename, FILE* fp) {
   size_t done;
   int res;
   while ((res = pdmp3_read(id, out, INBUF_SIZE, &done)) != PDMP3_ERR) {
-    if (done) write_raw(filename, out, done, (long)kSampleRates[id->l_hdr.sfreq], id->l_hdr.mode == 3 ? 1 : 2);
+    write_raw(filename, out, done, done ? (long)kSampleRates[id->l_hdr.sfreq] : 0, id->l_hdr.mode == 3 ? 1 : 2);
     if (res == PDMP3_NEED_MORE) {
       unsigned char in[4096];
       const size_t n = fread(in, 1, sizeof in, fp);
@@ -2170,7 +2181,7 @@ void pdmp3(char* const* mp3s) {
       long rate = 0; int ch = 0;
       const long long got = pdmp3_amd_bulk_decode(b, data, (size_t)size, pcm, (size_t)total, &rate, &ch);
       if (got != total) { fputs("pdmp3: engine failure\n", stderr); exit(-1); }
-      if (total) write_raw(filename, pcm, (size_t)total, rate, ch);
+      write_raw(filename, pcm, (size_t)total, rate, ch);
       free(pcm);
       bulk_used = 1;
     } else {

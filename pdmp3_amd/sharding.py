@@ -57,6 +57,22 @@ def shard_with_halo(n_frames, rank, world, halo=HALO_FRAMES, frame_flags=None):
     return first, hi - first, lo - first
 
 
+def frame_flags_of(side):
+    """The per-frame flag bytes (pdmp3_gc_side.frame) of a batch of records -- what the host stage hands out with them
+    (pdmp3_amd.api.parse_like_cli / the bulk decoder's record form): numpy structured array [n, 2, 2] or uint8 [n, 4, 128]."""
+    import numpy as np
+    a = np.asarray(side)
+    if a.dtype.names:
+        return np.ascontiguousarray(a["frame"].reshape(a.shape[0], -1)[:, 0])
+    return np.ascontiguousarray(a.reshape(a.shape[0], -1, 128)[:, 0, 7])
+
+
+def shard_records(side, rank, world, halo=HALO_FRAMES):
+    """shard_with_halo for a stream that is at hand as records: the cut is moved back past mono runs as far as channel 1's
+    state reaches (halo_start), read off the records' own flag bytes."""
+    return shard_with_halo(len(side), rank, world, halo, frame_flags_of(side))
+
+
 def assign_files(sizes, world):
     """Largest-first greedy: returns a list (per rank) of file indices."""
     load = [0] * world

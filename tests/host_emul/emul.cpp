@@ -57,34 +57,6 @@ extern "C" int emul_decode_frames_f32(const int16_t* spectra, const pdmp3_gc_sid
   return 0;
 }
 
-// one frame per chunk, chained (run_frame / run_chunk_chained): the waves run in frame order here, so every flag is set
-// before it is waited for; pcm (int16) or pcm_f32, the other one null
-extern "C" int emul_decode_frames_chained(const int16_t* spectra, const pdmp3_gc_side* side, int n_frames,
-                                          float* state, int16_t* pcm, float* pcm_f32) {
-  static HostTables H;
-  static bool ready = false;
-  if (!ready) { build_host_tables(H); ready = true; }
-  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data()};
-  std::vector<float> state_next(kStateFloats);
-  std::vector<float> cstate((size_t)n_frames * kChainFloats);
-  std::vector<unsigned> cflag((size_t)n_frames, 0u);
-  DecodeArgs a{spectra, side, pcm, pcm_f32, state, state ? state_next.data() : nullptr, nullptr, n_frames, 1, nullptr,
-               cstate.data(), cflag.data(), 7u};
-  auto L = std::make_unique<WaveLds>();
-  constexpr int WPW = 8;                       // as the engine launches it: 8 consecutive frames per workgroup
-  unsigned wg_flag[WPW];
-  for (int f = 0; f < n_frames; ++f) {
-    WaveLds& Lr = *L;
-    const int w = f % WPW;
-    if (w == 0) for (unsigned& x : wg_flag) x = 0;
-    const ChainPos cp{wg_flag, w, w == WPW - 1, false};
-    if (pcm_f32) emu::run_wave([&] { run_frame<true>(a, T, &H.cb, f, Lr, cp); });
-    else emu::run_wave([&] { run_frame<false>(a, T, &H.cb, f, Lr, cp); });
-  }
-  if (state) std::copy(state_next.begin(), state_next.end(), state);
-  return 0;
-}
-
 // one granule per wave (run_granule_wave), as the engine's granule kernel launches it: workgroups of 16 consecutive granules
 // sharing one table block; the waves of a workgroup are live together (they hand their states on through each other's
 // LDS), the workgroups run one after the other

@@ -188,6 +188,41 @@ def test_cli_writes_wav(oracle, tmp_path, streaming):
     assert raw[20:22] == b"\x03\x00" and raw[34:36] == b"\x20\x00" and raw[44:] == f32.tobytes()
 
 
+@pytest.mark.parametrize("streaming", ["0", "1"])
+def test_cli_names_its_output_after_the_first_file_even_if_that_one_is_empty(oracle, tmp_path, streaming):
+    """the reference's driver calls its writer after EVERY pdmp3_read, the first NEED_MORE with nothing decoded included
+    (pdmp3.c:2565-2566, 2239-2251): the .raw is named after the FIRST file even if that file yields no PCM, and a file
+    without a decodable frame still leaves an (empty) .raw"""
+    good = packer.generate(n_frames=40, seed=0xE1, sfreq=0, mode=1, mode_ext=2, bitrate_index=9)
+    bad = tmp_path / "bad.mp3"
+    bad.write_bytes(good[:700])                       # less than one buffered frame's worth: nothing is decoded (H10)
+    ok = tmp_path / "good.mp3"
+    ok.write_bytes(good)
+    cli = os.path.join(ROOT, "pdmp3_amd", "pdmp3_cli")
+    env = dict(os.environ, PDMP3_CLI_STREAMING=streaming)
+    subprocess.check_call([cli, str(bad), str(ok)], timeout=120, env=env)
+    assert not (tmp_path / "good.mp3.raw").exists()
+    got = (tmp_path / "bad.mp3.raw").read_bytes()
+    from oracle.oracle import OracleStream
+    o = OracleStream(oracle)
+    want = o.decode_like_cli(good[:700]) + o.decode_like_cli(good)
+    o.close()
+    assert len(got) == len(want)
+    assert_pcm_close(_as16(got), _as16(want), 1, "bad + good")
+    (tmp_path / "bad.mp3.raw").unlink()
+    subprocess.check_call([cli, str(bad)], timeout=120, env=env)
+    assert (tmp_path / "bad.mp3.raw").read_bytes() == o_empty(oracle, good[:700])
+
+
+def o_empty(oracle, data):
+    from oracle.oracle import OracleStream
+    o = OracleStream(oracle)
+    try:
+        return o.decode_like_cli(data)
+    finally:
+        o.close()
+
+
 def test_cli_several_files_one_handle(oracle, tmp_path):
     """pdmp3() decodes all its files with ONE handle into "<first name>.raw": parse state left by a file shows in
     the next (SURVEY H4-H6, H20).  The whole-stream path the CLI takes for regular files carries it the same way;

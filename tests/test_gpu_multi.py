@@ -65,3 +65,31 @@ def test_corpus_dealt_over_devices(oracle):
     for i, f in enumerate(files):
         want = np.frombuffer(oracle.decode_buffer_like_cli(f), dtype=np.int16)
         assert outs[i].shape == want.shape and np.abs(outs[i].astype(np.int32) - want).max() <= 1, i
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_record_shards_of_a_mode_switching_stream(engine, world):
+    """frame-range shards of a stream with stereo / mono / stereo runs: each rank's first frame comes from the records'
+    own flag bytes (sharding.shard_records -> halo_start: a cut after mono frames starts in front of the last stereo
+    frame, where channel 1's state is from); shards decoded one by one on the GPU, halo discarded, == the whole decode"""
+    import torch
+    from pdmp3_amd import api
+    from pdmp3_amd.sharding import shard_records
+    parts = [dict(n_frames=19, seed=41, bitrate_index=9), dict(n_frames=23, seed=42, mode=3, bitrate_index=7),
+             dict(n_frames=3, seed=43, mode=1, mode_ext=2, bitrate_index=11, block_pct=(10, 10, 70, 10)),
+             dict(n_frames=17, seed=44, mode=3, bitrate_index=7),
+             dict(n_frames=21, seed=45, mode=1, mode_ext=2, bitrate_index=11, block_pct=(10, 10, 70, 10))]
+    mp3 = b"".join(packer.generate(**p) for p in parts)
+    sp, sd = api.parse_like_cli(mp3, 64)
+    n = sp.shape[0]
+    dsp, dsd = engine.upload(sp, sd)
+    whole = torch.zeros((n, 2304), dtype=torch.int16, device=engine.tdev)
+    engine.decode(dsp, dsd, whole)
+    out = []
+    for rank in range(world):
+        first, count, discard = shard_records(sd, rank, world)
+        pcm = torch.zeros((count, 2304), dtype=torch.int16, device=engine.tdev)
+        engine.decode(dsp[first:first + count].contiguous(), dsd[first:first + count].contiguous(), pcm)
+        out.append(pcm[discard:])
+    torch.cuda.synchronize()
+    assert np.array_equal(torch.cat(out).cpu().numpy(), whole.cpu().numpy())

@@ -246,16 +246,16 @@ def test_gpu_float_pcm_c2(engine, oracle):
     assert np.array_equal(q.astype(np.int16), pcm.cpu().numpy())
 
 
-def test_gpu_chained_launches_equal_independent_chunks(engine):
-    """one frame per wave with the closing states handed from wave to wave (run_chunk_chained; what every launch of up to
-    one round of waves uses) against independent 2-frame chunks with halos: PCM and carried state bit-identical, over many
-    synthetic batches, sizes that leave the last workgroup partly filled, and host threads launching on their own streams"""
+def test_gpu_granule_launches_equal_independent_chunks(engine):
+    """one granule per wave with tails and rows handed from wave to wave (run_granule; what every launch of up to 8192
+    frames uses) against independent 2-frame chunks with halos: PCM and carried state bit-identical, over many synthetic
+    batches, sizes that leave the last workgroup partly filled, and host threads launching on their own streams"""
     import threading
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from soak_chain import one
     for r in range(48):
-        n = 2048 if r % 4 else [1, 2, 7, 8, 9, 63, 65, 1000, 2047][(r // 4) % 9]
+        n = 2048 if r % 4 else [1, 2, 7, 8, 9, 63, 65, 1000, 2047, 4099][(r // 4) % 10]
         assert one(engine, 0x5EED000000 + r, n), (r, n)
     out = {}
 

@@ -106,53 +106,6 @@ def test_emul_channel1_state_across_batches(oracle, emul):
             assert np.array_equal(np.concatenate(out), whole), (chunk, cuts)
 
 
-def emul_decode_chained(emul, sp, sd, state=None, f32=False):
-    n = sp.shape[0]
-    pcm = np.zeros((n, 2304), np.float32 if f32 else np.int16)
-    emul.emul_decode_frames_chained(_p(sp), _p(sd), n, _p(state), None if f32 else _p(pcm), _p(pcm) if f32 else None)
-    return pcm
-
-
-@pytest.mark.parametrize("name", list(corpus.CASES))
-def test_emul_chained_frames_equal_independent_chunks(emul, name):
-    """run_chunk_chained (one frame per wave, states handed on instead of halos) is the same arithmetic in the same
-    order: PCM bit-identical to the independent-chunk form, for every block-type mix (incl. the H5 corner: short
-    granule 1 / channel 1), mono corpora (which take the independent path inside a chained launch) and float PCM"""
-    sp, sd = corpus.case(name, n=12)
-    want = emul_decode(emul, sp, sd, 0)
-    assert np.array_equal(emul_decode_chained(emul, sp, sd), want)
-    assert np.array_equal(emul_decode(emul, sp, sd, 1), want)
-
-
-def test_emul_chained_frames_states_resets_and_mode_switches(emul, oracle):
-    # stereo / mono / stereo runs: mono frames and the stereo frames after them take run_chunk and publish at its end
-    sp, sd = _mode_switch_records()
-    whole = emul_decode(emul, sp, sd, 0)
-    assert np.array_equal(emul_decode_chained(emul, sp, sd), whole)
-    # the carried state in and out, batch after batch (frame 0 of a batch takes the caller's state; H5 at frame 0)
-    sp, sd = oracle.generate(C2_SEED, 0, 64)
-    whole = emul_decode(emul, sp, sd, 0)
-    st = np.zeros(emul.emul_state_floats(), np.float32)
-    st_ref = np.zeros(emul.emul_state_floats(), np.float32)
-    cuts = [0, 1, 2, 9, 10, 31, 47, 48, 64]
-    out = [emul_decode_chained(emul, sp[a:b], sd[a:b], st) for a, b in zip(cuts[:-1], cuts[1:])]
-    assert np.array_equal(np.concatenate(out), whole)
-    emul_decode(emul, sp, sd, 0, st_ref)
-    assert np.array_equal(st.view(np.uint32), st_ref.view(np.uint32))
-    # a RESET frame in the middle: its input state is zero, no wait
-    sd2 = sd.copy()
-    sd2["frame"][20] |= 0x40
-    assert np.array_equal(emul_decode_chained(emul, sp, sd2), emul_decode(emul, sp, sd2, 0))
-    # float PCM
-    got = emul_decode_chained(emul, sp[:24], sd[:24], f32=True)
-    want = np.zeros((24, 2304), np.float32)
-    emul.emul_decode_frames_f32(_p(sp[:24]), _p(sd[:24]), 24, None, _p(want), 0)
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-    # every frame a short block in granule 1 / channel 1 (H5 pre-pass in every wave)
-    sp3, sd3 = corpus.case("ms_short_heavy_480", n=16)
-    assert np.array_equal(emul_decode_chained(emul, sp3, sd3), emul_decode(emul, sp3, sd3, 0))
-
-
 def test_shard_cut_after_mono_frames_reaches_back_to_the_last_stereo_frame(emul):
     """pdmp3_amd.sharding.halo_start: a shard whose cut follows mono frames starts in front of the last stereo frame,
     so that channel 1 is what that frame left (the kernel's pre-halo finds it inside the shard); with the fixed

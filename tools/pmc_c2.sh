@@ -4,7 +4,7 @@ TAG=${1:-pmcc2}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-for m in 1 2; do
+for m in 0 1; do
   export PDMP3_HIP_CHAIN=$m
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/m$m.sq1 -o p -- python3 tools/pmc_target.py 2048 0 > $OUT/m$m.sq1.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/m$m.sq3 -o p -- python3 tools/pmc_target.py 2048 0 > $OUT/m$m.sq3.log 2>&1

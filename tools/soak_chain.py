@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Soak test of the chained launches (decode_core.h run_chunk_chained) on the GPU: many synthetic 2048-frame batches, each
-decoded one frame per wave (chained hand-over between waves) and with independent 2-frame chunks (halo): PCM and carried
-state must be bit-identical.  Also sizes that leave the last workgroup partly filled, and several host threads launching
-on their own HIP streams at once.
+"""Soak test of the granule kernel (decode_core.h run_granule) on the GPU: many synthetic 2048-frame batches, each
+decoded one granule per wave (tails and rows handed from wave to wave) and with independent 2-frame chunks (halo): PCM
+and carried state must be bit-identical.  Also sizes that leave the last workgroup partly filled, and several host
+threads launching on their own HIP streams at once.
 
   python tools/soak_chain.py [rounds]
 """
@@ -20,7 +20,7 @@ def one(eng, seed, n, stream=None):
     eng.generate(seed, 0, n, spectra, side)
     st1, st2 = eng.new_state(), eng.new_state()
     pcm2 = torch.empty_like(pcm)
-    eng.decode(spectra, side, pcm, chunk_frames=1, state=st1)      # chained
+    eng.decode(spectra, side, pcm, chunk_frames=1, state=st1)      # one granule per wave
     eng.decode(spectra, side, pcm2, chunk_frames=2, state=st2)     # independent chunks
     torch.cuda.synchronize()
     return bool(torch.equal(pcm, pcm2)) and bool(torch.equal(st1, st2))
