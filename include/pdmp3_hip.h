@@ -114,7 +114,7 @@ size_t pdmp3_hip_state_bytes(void);
  *   chunk_frames  frames per wavefront ("chunk"); 0 = choose automatically.
  *              Chunks of several frames are independent: each re-derives the
  *              state at its start from a halo of preceding frames.
- *              At 0 or 1, launches of up to 8192 frames (MI355X; PDMP3_HIP_GRAN_MAX)
+ *              At 0 or 1, launches of up to 12288 frames (MI355X; PDMP3_HIP_GRAN_MAX)
  *              are decoded ONE GRANULE PER WAVEFRONT instead: the wavefronts hand
  *              IMDCT tails and polyphase rows on, no halo (scratch is kept per HIP
  *              stream -- for up to 32 streams, beyond that the halo form is used --

@@ -316,7 +316,7 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     const char* d = getenv("PDMP3_HIP_DEBUG_FAR_TIMEOUT");
     c->debug_flags = (d && *d == '1') ? PD_DEBUG_FAR_TIMEOUT : 0u;
     const char* e = getenv("PDMP3_HIP_GRAN_MAX");
-    c->gran_max_frames = e && atoi(e) > 0 ? atoi(e) : c->wave_slots_gran * 2;     // (measured on MI355X: faster than chunks with halos up to about 8192 frames)
+    c->gran_max_frames = e && atoi(e) > 0 ? atoi(e) : c->wave_slots_gran * 3;     // (measured on MI355X: faster than chunks with halos up to about 14000 frames)
   }
   // every failure from here on releases what was allocated so far (pdmp3_hip_destroy takes a partly built context)
   UnpackTables* U = new UnpackTables;
