@@ -1604,6 +1604,12 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
 #define PD_GT(k) if (a.prof) { const unsigned long long t_ = PD_CLOCK(); if (lane == 0) a.prof[(size_t)g * kProfSlots + (k)] = t_; }
   PD_GT(1)
   R.pf0 = pf.pf0; R.pf1 = pf.pf1; R.pf2 = pf.pf2; R.pf3 = pf.pf3;
+  // A launch ends with its slowest wave, and those are the two of every workgroup whose hand-over goes through memory
+  // (the last one publishes with stores it has to see acknowledged, the first one reads past its caches): the last wave
+  // runs ahead of the other three of its SIMD until it has published, the first one catches up after it has taken
+  const bool far_sender = gp.w == gp.wpw - 1 && next_takes;
+  const bool far_taker = gp.w == 0 && from_chain;
+  if (far_sender) PD_SETPRIO(2);
   PD_PHASE(lane_init(lane, L, R, cb, T))
   if (gr == 1 && h5) {
     PD_SETPRIO(3);     // (this wave has a fifth more to do than the other three of its SIMD, and a launch ends with its last wave)
@@ -1692,6 +1698,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
     }
   }
   if (next_takes) { PD_PHASE(gran_send_rows(lane, L, a, g, gp)) }
+  if (far_sender && !(gr == 1 && h5)) PD_SETPRIO(0);
   PD_GT(8)
   float acc[18];
   if (PD_EXP_SKIP & 16) { PD_UNROLL for (int t = 0; t < 18; t++) acc[t] = L.hyb[0][t][lane & 31]; } else { PD_PHASE(ph_window_own(lane, L, R, acc)) }

@@ -36,3 +36,26 @@ tot = p[ok, 11] - p[ok, 0]
 print("  %-24s median %8.0f  p10 %8.0f  p90 %8.0f  max %8.0f ticks" % ("wave lifetime", np.median(tot), np.percentile(tot, 10), np.percentile(tot, 90), tot.max()))
 # per-XCD clocks are not synchronised; but within the launch the spread of entry times on one counter is informative
 print("  entry spread (max - min over all waves, unsynchronised counters): %.0f ticks" % (p[ok, 0].max() - p[ok, 0].min()))
+
+# who are the slow waves?
+sdh = sd.cpu().numpy()                       # [n, 4, 128] bytes
+flags = sdh[:, :, 3]                         # per (frame, gr*2+ch)
+short = ((flags & 0x04) != 0) & (((flags & 0x18) >> 3) == 2)
+g_idx = np.arange(2 * n)
+f_idx, gr_idx = g_idx >> 1, g_idx & 1
+h5 = short[f_idx, 3] & (gr_idx == 1)
+any_short = short[f_idx, 2 * gr_idx] | short[f_idx, 2 * gr_idx + 1]
+W = 16 if 2 * n > 2048 else 8
+place = g_idx % W
+life = p[:, 11] - p[:, 0]
+order = np.argsort(-life)
+top = order[: max(8, len(order) // 20)]
+print("slowest 5 %% of the waves: lifetime median %.0f; of them H5 %.0f %%, a short block in the granule %.0f %%, place 0 %.0f %%, place %d %.0f %%"
+      % (np.median(life[top]), 100 * h5[top].mean(), 100 * any_short[top].mean(), 100 * (place[top] == 0).mean(), W - 1, 100 * (place[top] == W - 1).mean()))
+print("all waves: H5 %.1f %%, short %.1f %%" % (100 * h5.mean(), 100 * any_short.mean()))
+for nm, m in (("H5", h5), ("short, not H5", any_short & ~h5), ("long", ~any_short), ("place 0", place == 0), ("place last", place == W - 1)):
+    if m.any():
+        print("  %-14s n %5d  lifetime median %7.0f  p90 %7.0f  max %7.0f" % (nm, m.sum(), np.median(life[m]), np.percentile(life[m], 90), life[m].max()))
+# phases of the long-block waves against the short-block ones
+for nm, m in (("long", ~any_short), ("short", any_short & ~h5)):
+    print("  phases (median ticks) %-6s: %s" % (nm, " ".join("%.0f" % np.median(d[m, k]) for k in range(11))))
