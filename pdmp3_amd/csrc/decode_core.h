@@ -162,6 +162,8 @@ struct GlobalTables {
   const float* frag_long;   // [5 kk][2 nt]   cos_N36 columns {p = j | p = 18 + j}
   const float* frag_short;  // [5 kk][2 nt]   3 x 12-point IMDCT with win[2] folded in, same column map
   const float* frag_mat;    // [2 even/odd][4 k-steps]: 16 x 16 halves of the 32-point DCT-II, rows in register order
+  const float* taps;        // [16][64 lanes]: the lane's window coefficients we[0..7], wo[0..7] (g_synth_dtbl, sign folded)
+  const void* tab_image;    // [3 sfreq] images of TabLds (host_tables.h: build_tab_images), copied to LDS as they are
 };
 
 // LDS.  WaveData is a wave's own working set; TabLds are the hot tables -- one copy per wave in the chunk kernels
@@ -180,14 +182,14 @@ struct WaveData {
   float peek[4];
   float lo[2][4][16];       // MFMA build: even / odd folded time slots 16, 17: [a|b][2 ch + (t - 16)][k]
 };
-struct TabLds {
+struct alignas(16) TabLds {
   alignas(16) float win[4][36];
   float pow43z[2 * kPow43Small];   // [128 + v] = sign(v) |v|^(4/3) for v = -128 .. 127: magnitude lookup and sign in one read
   alignas(16) uint16_t ltab[3][576];
   uint8_t bandaddr[3][5][64];      // long blocks (ph_requant_long): [sfreq] 4 x scale index of the lane's lines, see fast_line()
   int sfreq;                       // the sampling frequency ltab is for
-  unsigned ready;                  // granule kernel: waves of the workgroup that have stored their part of the tables
 };
+static_assert(sizeof(TabLds) % 16 == 0, "copied in 16-byte pieces");
 struct WaveLds : WaveData {
   TabLds tab;
 };
@@ -265,13 +267,14 @@ PD_FN void state_zero(int lane, LaneRegs& R) {
 PD_FN void lane_init(int lane, WaveData& L, LaneRegs& R, BankPtr cb, const GlobalTables& T) {
   const int i = lane & 31;
   // v[i] = C[16+i] (i<16), 0 (i==16), -C[48-i] (i>16);  v[32+i] = -C[16-i] (i<=16), -C[i-16] (i>16)
-  // where C = 32-point DCT-II of the slot (derivation: DESIGN.md "polyphase").
-  const float sgn_e = (i < 16) ? 1.0f : ((i == 16) ? 0.0f : -1.0f);
+  // where C = 32-point DCT-II of the slot (derivation: DESIGN.md "polyphase").  The window coefficients that go with
+  // them -- sgn_e * D[64 k + i] and -D[64 k + 32 + i] -- come per lane from T.taps (host_tables.h).
+  (void)cb;
   R.idx_e = (i < 16) ? 16 + i : ((i == 16) ? 0 : 48 - i);
   R.idx_o = (i <= 16) ? 16 - i : i - 16;
   for (int k = 0; k < 8; k++) {
-    R.we[k] = sgn_e * cb->dwin[64 * k + i];
-    R.wo[k] = -cb->dwin[64 * k + 32 + i];
+    R.we[k] = T.taps[k * 64 + lane];
+    R.wo[k] = T.taps[(8 + k) * 64 + lane];
   }
   state_zero(lane, R);
   if (lane < 4) L.peek[lane] = 1.0f;
@@ -287,27 +290,15 @@ PD_FN unsigned band_addr_of(const GlobalTables& T, int sfreq, int line) {      /
   return (unsigned)((T.linetab[(size_t)sfreq * 3 * 576 + line] >> 10) << 2);
 }
 
-// The tables, brought in by `nthr` threads (tid = 0 .. nthr - 1): the sampling-frequency independent ones ...
-PD_FN void tab_load_fixed(int tid, int nthr, TabLds& S, const GlobalTables& T) {
-  for (int k = tid; k < 2 * kPow43Small; k += nthr) {
-    const int v = k - kPow43Small;
-    const float p = T.pow43[v < 0 ? -v : v];
-    S.pow43z[k] = v < 0 ? -p : p;
-  }
-  for (int k = tid; k < 144; k += nthr) (&S.win[0][0])[k] = T.win[k];
-  for (int k = tid; k < 3 * 5 * 64; k += nthr) {
-    const int sf = k / 320, r = k - 320 * sf;
-    S.bandaddr[sf][r >> 6][r & 63] = (uint8_t)band_addr_of(T, sf, fast_line(r & 63, r >> 6));
-  }
+// The tables, brought in by `nthr` threads (tid = 0 .. nthr - 1): the image of TabLds for one sampling frequency, built on
+// the host (host_tables.h: the signed |is|^(4/3) table, the IMDCT windows, the band addresses of all three sampling
+// frequencies, the line tables of this one), copied as it is.
+PD_FN void tab_load_image(int tid, int nthr, TabLds& S, const GlobalTables& T, int sfreq) {
+  const Chunk16* src = reinterpret_cast<const Chunk16*>(reinterpret_cast<const char*>(T.tab_image) + (size_t)sfreq * sizeof(TabLds));
+  Chunk16* dst = reinterpret_cast<Chunk16*>(&S);
+  for (int k = tid; k < (int)(sizeof(TabLds) / 16); k += nthr) dst[k] = src[k];
 }
-// ... and the line tables of one sampling frequency (3 kinds x 576 u16 = 216 x 16 B)
-PD_FN void tab_load_sfreq(int tid, int nthr, TabLds& S, const GlobalTables& T, int sfreq) {
-  const Chunk16* src = reinterpret_cast<const Chunk16*>(T.linetab + (size_t)sfreq * 3 * 576);
-  Chunk16* dst = reinterpret_cast<Chunk16*>(&S.ltab[0][0]);
-  for (int k = tid; k < 216; k += nthr) dst[k] = src[k];
-  if (tid == 0) S.sfreq = sfreq;
-}
-PD_FN void load_linetab(int lane, TabLds& S, const GlobalTables& T, int sfreq) { tab_load_sfreq(lane, 64, S, T, sfreq); }
+PD_FN void load_linetab(int lane, TabLds& S, const GlobalTables& T, int sfreq) { tab_load_image(lane, 64, S, T, sfreq); }
 
 // state layout (opaque to callers): float ovl[kOvlRegs][64 lanes]; float he[15][64]; float ho[15][64]
 constexpr int kStateFloats = 64 * (kOvlRegs + 2 * kHistSlots);
@@ -652,10 +643,12 @@ PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalT
       l[0] = ms_scale(sum[0]); r[0] = ms_scale(dif[0]);
       if (i < 4) { l[1] = ms_scale(sum[1]); r[1] = ms_scale(dif[1]); } else { l[1] = 0.0f; r[1] = 0.0f; }
       const int end = i < 4 ? 128 * i + 128 : 576;                 // the group's last line + 1
-      const bool in_a = (end <= cmin) || fast_line(lane, i) < cmin;        // (wave-uniform || per lane)
-      const bool in_b = (end <= cmin) || fast_line(lane, i) + 1 < cmin;
-      x0[0] = in_a ? l[0] : x0[0]; x0[1] = in_b ? l[1] : x0[1];
-      x1[0] = in_a ? r[0] : x1[0]; x1[1] = in_b ? r[1] : x1[1];
+      if (end <= cmin) { x0 = l; x1 = r; }                         // wave-uniform: the whole group is below the bound
+      else {
+        const bool in_a = fast_line(lane, i) < cmin, in_b = fast_line(lane, i) + 1 < cmin;
+        x0[0] = in_a ? l[0] : x0[0]; x0[1] = in_b ? l[1] : x0[1];
+        x1[0] = in_a ? r[0] : x1[0]; x1[1] = in_b ? r[1] : x1[1];
+      }
     }
     if (i < 4) {
       *reinterpret_cast<f32x2*>(&L.xr[0][2 * lane + 128 * i]) = x0;
@@ -1164,7 +1157,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
 
   PD_PHASE(
     ph_prefetch(lane, R, a.spectra + (size_t)g_first * 1152, a.side + (size_t)g_first * 2);
-    if (OWN_TABS) { load_linetab(lane, S, T, cur_sfreq); tab_load_fixed(lane, 64, S, T); }
+    if (OWN_TABS) load_linetab(lane, S, T, cur_sfreq);
     lane_init(lane, L, R, cb, T);
     if (a.state_in) {
       if (from_stream_start) state_load(lane, R, a.state_in);
@@ -1314,6 +1307,7 @@ struct GranPos {
   GranMb* mb;            // [wpw]
   int w;                 // place of the granule within its workgroup
   int wpw;
+  unsigned* tabs_ready;  // LDS: waves of the workgroup that have stored their part of the tables
 };
 static_assert(sizeof(WaveData::xr) >= kOvlRegs * 64 * sizeof(float), "tails mailbox");
 static_assert(offsetof(WaveData, scale) + sizeof(WaveData::scale) - offsetof(WaveData, spec) >= kHistSlots * 64 * sizeof(float) &&
@@ -1321,10 +1315,10 @@ static_assert(offsetof(WaveData, scale) + sizeof(WaveData::scale) - offsetof(Wav
 PD_FN float* gran_tails_box(WaveData& L) { return &L.xr[0][0]; }
 PD_FN float* gran_rows_box(WaveData& L) { return reinterpret_cast<float*>(&L.spec[0][0]); }
 PD_FN void gran_lds_flag(int lane, unsigned* p) { if (lane == 0) PD_LDS_FLAG(p) = 1u; }
-// the workgroup's tables are complete once all its waves have stored their part (TabLds::ready, counted up by each wave
+// the workgroup's tables are complete once all its waves have stored their part (GranPos::tabs_ready, counted up by each wave
 // after its stores -- the kernel has no barrier behind the table loads: they pass under the waves' first phases)
-PD_FN void gran_tabs_wait(const TabLds& S, int wpw) {
-  while ((int)PD_UNIFORM(PD_LDS_FLAG(const_cast<unsigned*>(&S.ready))) < wpw) PD_SLEEP();
+PD_FN void gran_tabs_wait(const GranPos& gp) {
+  while ((int)PD_UNIFORM(PD_LDS_FLAG(gp.tabs_ready)) < gp.wpw) PD_SLEEP();
   asm volatile("" ::: "memory");
 }
 PD_FN void gran_lds_wait(unsigned* p) {
@@ -1584,7 +1578,7 @@ PD_SLOW_FN void gran_slow_chunk(DecodeArgs a, GlobalTables T, BankPtr cb, int f,
   cb = (BankPtr)(((unsigned long long)(unsigned)PD_UNIFORM((int)(u >> 32)) << 32) | (unsigned)PD_UNIFORM((int)u));
   f = PD_UNIFORM(f);
 #endif
-  gran_tabs_wait(*S, second.wpw);
+  gran_tabs_wait(second);
   run_chunk<false, false, F32, false>(a, T, cb, f, *L, *S, publish ? &second : nullptr, state_only);
 }
 
@@ -1622,7 +1616,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
     LaneRegs R0, R1;
     R1.ovl[0] = 0.0f;
     float tail = 0.0f;
-    gran_tabs_wait(S, gp.wpw);
+    gran_tabs_wait(gp);
     PD_PHASE(
       ph_prefetch(lane, R0, a.spectra + (size_t)(g - 1) * 1152, a.side + (size_t)(g - 1) * 2);
       if (!fresh) ph_prefetch(lane, R1, a.spectra + (size_t)(g - 2) * 1152, a.side + (size_t)(g - 2) * 2);
@@ -1649,7 +1643,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
     PD_PHASE(ph_commit(lane, L, R))
   }
   PD_GT(2)
-  gran_tabs_wait(S, gp.wpw);
+  gran_tabs_wait(gp);
   PD_LAUNDER(cb);
   if (!(PD_EXP_SKIP & 1)) { PD_PHASE((ph_requant<false, 9, true, true, true>(lane, L, S, cb, T, nullptr, nullptr))) }
   PD_GT(3)
@@ -1751,7 +1745,7 @@ PD_FN void run_granule_wave(const DecodeArgs& a, const GlobalTables& T, BankPtr 
     return;
   }
   if (gr == 1) return;                                       // the frame is decoded by the wave of its first granule
-  const GranPos second{gp.wl, gp.mb, gp.w + 1, gp.wpw};     // (a frame's two granules are in one workgroup: WPW is even)
+  const GranPos second{gp.wl, gp.mb, gp.w + 1, gp.wpw, gp.tabs_ready};     // (a frame's two granules are in one workgroup: WPW is even)
   gran_slow_chunk<F32>(a, T, cb, f, &L, &S, second, true, nullptr);
 }
 

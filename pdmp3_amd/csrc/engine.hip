@@ -62,7 +62,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   __shared__ WaveData L[W];
   __shared__ TabLds S;
   __shared__ GranMb mb[W];
-  static_assert(sizeof(WaveData) * W + sizeof(TabLds) + sizeof(GranMb) * W <= 160 * 1024, "one workgroup of 16 waves per CU");
+  __shared__ unsigned tabs_ready;
+  static_assert(sizeof(WaveData) * W + sizeof(TabLds) + sizeof(GranMb) * W + 16 <= 160 * 1024, "one workgroup of 16 waves per CU");
   const int tid = (int)threadIdx.x;
   const unsigned long long t_entry = a.prof ? PD_CLOCK() : 0ull;
   const int w = tid >> 6;
@@ -72,19 +73,18 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   LaneRegs pf;
   if (valid) ph_prefetch(tid & 63, pf, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2);
   if (tid < W * 4) reinterpret_cast<unsigned*>(mb)[tid] = 0u;
-  if (tid == 0) S.ready = 0u;
+  if (tid == 0) tabs_ready = 0u;
   __syncthreads();                       // (nothing to wait for in front of it: the waves arrive together)
   // the workgroup's tables; the line tables are for the sampling frequency the caller expects (granules of another
   // one read the global line table).  No barrier behind the loads: each wave counts itself in when its part is
-  // stored (TabLds::ready) and whoever needs the tables waits for the count -- by then it is long there
-  tab_load_fixed(tid, 64 * W, S, T);
-  tab_load_sfreq(tid, 64 * W, S, T, a.sf_hint);
+  // stored (GranPos::tabs_ready) and whoever needs the tables waits for the count -- by then it is long there
+  tab_load_image(tid, 64 * W, S, T, a.sf_hint);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if ((tid & 63) == 0) atomicAdd(&S.ready, 1u);
+  if ((tid & 63) == 0) atomicAdd(&tabs_ready, 1u);
   if (!valid) return;
   if (a.prof && (tid & 63) == 0) a.prof[(size_t)g * kProfSlots] = t_entry;
-  const GranPos gp{L, mb, w, W};
+  const GranPos gp{L, mb, w, W, &tabs_ready};
   run_granule_wave<F32>(a, T, (BankPtr)&c_bank, g, L[w], S, gp, pf);
 }
 
@@ -248,7 +248,8 @@ struct pdmp3_hip_ctx {
   float* d_pow43;
   uint16_t* d_linetab;
   float* d_win;
-  float* d_frag;            // frag_long [10][64] | frag_short [10][64] | frag_mat [8][64]
+  float* d_frag;            // frag_long [10][64] | frag_short [10][64] | frag_mat [8][64] | taps [16][64]
+  void* d_tab_image;        // [3] TabLds images
   int chain_mode;           // PDMP3_HIP_CHAIN=0: independent chunks with halos everywhere; otherwise launches up to
                             // gran_max_frames take the granule kernel (k_decode_g)
   int gran_max_frames;      // launches up to this many frames take the granule kernel (PDMP3_HIP_GRAN_MAX)
@@ -286,6 +287,7 @@ extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   (void)hipFree(c->d_linetab);
   (void)hipFree(c->d_win);
   (void)hipFree(c->d_frag);
+  (void)hipFree(c->d_tab_image);
   (void)hipFree(c->d_unpack);
   for (ChainBuf& b : c->chain) { (void)hipFree(b.state); (void)hipFree(b.flag); }
   delete c;
@@ -329,7 +331,8 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     CREATE_STEP(hipMalloc(&c->d_pow43, H.pow43.size() * sizeof(float)), "hipMalloc pow43")
     CREATE_STEP(hipMalloc(&c->d_linetab, H.linetab.size() * sizeof(uint16_t)), "hipMalloc linetab")
     CREATE_STEP(hipMalloc(&c->d_win, H.win.size() * sizeof(float)), "hipMalloc win")
-    CREATE_STEP(hipMalloc(&c->d_frag, (10 + 10 + 8) * 64 * sizeof(float)), "hipMalloc frag")
+    CREATE_STEP(hipMalloc(&c->d_frag, (10 + 10 + 8 + 16) * 64 * sizeof(float)), "hipMalloc frag")
+    CREATE_STEP(hipMalloc(&c->d_tab_image, 3 * sizeof(TabLds)), "hipMalloc table images")
     CREATE_STEP(hipMalloc((void**)&c->d_unpack, sizeof(UnpackTables)), "hipMalloc unpack tables")
     CREATE_STEP(hipMemcpy(c->d_pow43, H.pow43.data(), H.pow43.size() * sizeof(float), hipMemcpyHostToDevice), "upload pow43")
     CREATE_STEP(hipMemcpy(c->d_linetab, H.linetab.data(), H.linetab.size() * sizeof(uint16_t), hipMemcpyHostToDevice), "upload linetab")
@@ -337,6 +340,8 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     CREATE_STEP(hipMemcpy(c->d_frag, H.frag_long.data(), 10 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_long")
     CREATE_STEP(hipMemcpy(c->d_frag + 10 * 64, H.frag_short.data(), 10 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_short")
     CREATE_STEP(hipMemcpy(c->d_frag + 20 * 64, H.frag_mat.data(), 8 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_mat")
+    CREATE_STEP(hipMemcpy(c->d_frag + 28 * 64, H.taps.data(), 16 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload taps")
+    CREATE_STEP(hipMemcpy(c->d_tab_image, H.tab_image.data(), 3 * sizeof(TabLds), hipMemcpyHostToDevice), "upload table images")
     CREATE_STEP(hipMemcpy(c->d_unpack, U, sizeof(UnpackTables), hipMemcpyHostToDevice), "upload unpack tables")
     CREATE_STEP(hipDeviceSynchronize(), "sync after uploads")
   } while (0);
@@ -474,7 +479,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
       gran = true;
     }
   }
-  GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64};
+  GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64, c->d_frag + 28 * 64, c->d_tab_image};
   const int nchunks = (n_frames + a.chunk_frames - 1) / a.chunk_frames;
   if (gran) {
     // (workgroups of 8 waves while that gives every CU at most one of them)

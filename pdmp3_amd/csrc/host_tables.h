@@ -31,6 +31,8 @@ struct HostTables {
   std::vector<uint16_t> linetab;   // 3*3*576: source line | scale index << 10, per reordered line
   std::vector<float> win;          // 4*36
   std::vector<float> frag_long, frag_short, frag_mat;   // MFMA B fragments, [fragment][64 lanes]
+  std::vector<float> taps;         // [16][64]: per-lane window coefficients (decode_core.h lane_init)
+  std::vector<TabLds> tab_image;   // [3 sfreq]: what the kernels copy to LDS (decode_core.h tab_load_image)
   // the reference's libm expressions, kept to verify the device's ldexp forms
   // (decode_core.h: pow2_neg_half / pow2_quarter) over their whole index range
   std::vector<float> t1, t2;
@@ -40,6 +42,7 @@ struct HostTables {
 inline const uint16_t* sfb_long_of(int sfreq) { return sfreq == 0 ? kSfbLong0 : (sfreq == 1 ? kSfbLong1 : kSfbLong2); }
 inline const uint16_t* sfb_short_of(int sfreq) { return sfreq == 0 ? kSfbShort0 : (sfreq == 1 ? kSfbShort1 : kSfbShort2); }
 
+inline void build_tab_images(HostTables& H);
 inline void build_host_tables(HostTables& H) {
   ConstBank& cb = H.cb;
   memset(&cb, 0, sizeof cb);
@@ -134,6 +137,38 @@ inline void build_host_tables(HostTables& H) {
         const float nref = (float)cos(((float)(16 + i) * (2 * k + 1)) * (3.14159265358979323846 / 64.0));
         H.frag_mat[(eo * 4 + r) * 64 + l] = n >= 16 ? nref : -nref;
       }
+  build_tab_images(H);
+}
+
+
+// the per-lane polyphase window coefficients and the LDS table images (after build_host_tables)
+inline void build_tab_images(HostTables& H) {
+  H.taps.assign(16 * 64, 0.0f);
+  for (int lane = 0; lane < 64; lane++) {
+    const int i = lane & 31;
+    const float sgn_e = (i < 16) ? 1.0f : ((i == 16) ? 0.0f : -1.0f);
+    for (int k = 0; k < 8; k++) {
+      H.taps[k * 64 + lane] = sgn_e * kSynthD[64 * k + i];
+      H.taps[(8 + k) * 64 + lane] = -kSynthD[64 * k + 32 + i];
+    }
+  }
+  H.tab_image.resize(3);
+  for (int sf = 0; sf < 3; sf++) {
+    TabLds& S = H.tab_image[sf];
+    memset(&S, 0, sizeof S);
+    for (int k = 0; k < 144; k++) (&S.win[0][0])[k] = H.win[k];
+    for (int k = 0; k < 2 * kPow43Small; k++) {
+      const int v = k - kPow43Small;
+      const float p = H.pow43[v < 0 ? -v : v];
+      S.pow43z[k] = v < 0 ? -p : p;
+    }
+    memcpy(&S.ltab[0][0], &H.linetab[(size_t)sf * 3 * 576], 3 * 576 * sizeof(uint16_t));
+    for (int f = 0; f < 3; f++)
+      for (int i = 0; i < 5; i++)
+        for (int lane = 0; lane < 64; lane++)
+          S.bandaddr[f][i][lane] = (uint8_t)((H.linetab[(size_t)f * 3 * 576 + fast_line(lane, i)] >> 10) << 2);
+    S.sfreq = sf;
+  }
 }
 
 // Code books (tables_data.h: kHuffBooks, derived from the reference's tree arrays P:160-520) -> the two-level

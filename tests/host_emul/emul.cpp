@@ -20,7 +20,7 @@ extern "C" int emul_decode_frames(const int16_t* spectra, const pdmp3_gc_side* s
   static HostTables H;
   static bool ready = false;
   if (!ready) { build_host_tables(H); ready = true; }
-  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data()};
+  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data(), H.taps.data(), H.tab_image.data()};
   if (chunk_frames <= 0) chunk_frames = n_frames;
   if (stages) chunk_frames = n_frames;
   // like engine.hip: the kernel writes the new state to scratch (any chunk may read the old one), then it is copied
@@ -43,7 +43,7 @@ extern "C" int emul_decode_frames_f32(const int16_t* spectra, const pdmp3_gc_sid
   static HostTables H;
   static bool ready = false;
   if (!ready) { build_host_tables(H); ready = true; }
-  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data()};
+  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data(), H.taps.data(), H.tab_image.data()};
   if (chunk_frames <= 0) chunk_frames = n_frames;
   std::vector<float> state_next(kStateFloats);
   DecodeArgs a{spectra, side, nullptr, pcm, state, state ? state_next.data() : nullptr, nullptr, n_frames, chunk_frames, nullptr, nullptr, nullptr, 0u};
@@ -65,7 +65,7 @@ extern "C" int emul_decode_frames_granules(const int16_t* spectra, const pdmp3_g
   static HostTables H;
   static bool ready = false;
   if (!ready) { build_host_tables(H); ready = true; }
-  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data()};
+  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data(), H.taps.data(), H.tab_image.data()};
   std::vector<float> state_next(kStateFloats);
   std::vector<float> cstate((size_t)n_frames * 2 * kGranFloats);
   std::vector<unsigned> cflag((size_t)n_frames * 4, 0u);
@@ -74,8 +74,8 @@ extern "C" int emul_decode_frames_granules(const int16_t* spectra, const pdmp3_g
   constexpr int WPW = 16;
   auto L = std::make_unique<WaveData[]>(WPW);
   auto S = std::make_unique<TabLds>();
-  emu::run_wave([&] { tab_load_fixed(emu::lane(), 64, *S, T); tab_load_sfreq(emu::lane(), 64, *S, T, sf_hint); });
-  S->ready = WPW;
+  emu::run_wave([&] { tab_load_image(emu::lane(), 64, *S, T, sf_hint); });
+  unsigned tabs_ready = WPW;
   GranMb mb[WPW];
   for (int g0 = 0; g0 < 2 * n_frames; g0 += WPW) {
     const int nw = 2 * n_frames - g0 < WPW ? 2 * n_frames - g0 : WPW;
@@ -84,7 +84,7 @@ extern "C" int emul_decode_frames_granules(const int16_t* spectra, const pdmp3_g
     for (int w = 0; w < nw; ++w) {
       bodies[w] = [&, w] {
         const int g = g0 + w;
-        const GranPos gp{L.get(), mb, w, WPW};
+        const GranPos gp{L.get(), mb, w, WPW, &tabs_ready};
         LaneRegs pf;
         ph_prefetch(emu::lane(), pf, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2);
         if (pcm_f32) run_granule_wave<true>(a, T, &H.cb, g, L[w], *S, gp, pf);
