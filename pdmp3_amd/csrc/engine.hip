@@ -256,6 +256,7 @@ struct pdmp3_hip_ctx {
   int wave_slots_gran;      // waves of k_decode_g the device holds at once (CUs x 4 SIMDs x 4)
   unsigned debug_flags;     // PDMP3_HIP_DEBUG_FAR_TIMEOUT=1: every wait for another workgroup gives up at once (tests)
   int last_kind;            // PDMP3_HIP_LAUNCH_* of the latest decode launch (reports only)
+  int direct_max_frames;    // record batches of a stream up to this size run on the pinned host buffers directly (PDMP3_HIP_DIRECT_MAX)
   int sf_hint;              // sampling-frequency index the granule kernel's line tables are loaded for (PDMP3_HIP_SF_HINT; 0 = 44.1 kHz)
   std::mutex chain_mu;
   unsigned long long chain_clock;
@@ -313,6 +314,8 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     const int cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     c->wave_slots = cus * 4 * PDMP3_WAVES_PER_EU;
     c->wave_slots_gran = cus * 4 * 4;
+    const char* dm = getenv("PDMP3_HIP_DIRECT_MAX");
+    c->direct_max_frames = dm ? atoi(dm) : 32;
     const char* h = getenv("PDMP3_HIP_SF_HINT");
     c->sf_hint = (h && *h >= '0' && *h <= '2') ? *h - '0' : 0;
     const char* d = getenv("PDMP3_HIP_DEBUG_FAR_TIMEOUT");
@@ -551,6 +554,7 @@ struct StreamSlot {
   pdmp3_row_desc* h_desc; pdmp3_row_desc* d_desc; uint8_t* d_pool;   // compact bits input: pinned descriptors; the pool is h_res
   uint8_t* h_in; uint8_t* d_in;   // the blocks h_desc | h_bits | h_res and d_desc | d_bits | d_pool point into
   int busy;
+  int direct;                     // the latest record submit ran on the pinned host buffers themselves (submit_records)
 };
 struct pdmp3_hip_stream {
   pdmp3_hip_ctx* ctx;
@@ -737,11 +741,35 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
   if (n_frames == 0) return PDMP3_HIP_OK;
   HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
   const size_t n = (size_t)n_frames;
+  if (hs->f32 && host_dst) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_to: not with float PCM", hipSuccess);
+  // Small batches (the streaming API's read-ahead: a handful of frames per call): no copies at all.  The kernel reads the
+  // records from the slot's PINNED host buffers and writes the PCM into pinned host memory itself -- a few KB each way,
+  // one PCIe round trip under the waves' first phase instead of two copy commands in front of the kernel and one behind
+  // it -- and the three state buffers rotate instead of being copied (previous <- current <- next).  Per batch: one
+  // launch, two event records, one wait.  (PDMP3_HIP_DIRECT_MAX: largest such batch in frames, 0 = never.)
+  t.direct = 0;
+  if (n_frames <= hs->ctx->direct_max_frames && (!host_dst || row == PDMP3_FRAME_PCM_BYTES)) {
+    if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
+    void* dst = host_dst ? host_dst : (void*)t.h_pcm;
+    int rc = hs->f32
+        ? launch_decode(hs->ctx, t.h_spectra, t.h_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)dst, hs, true)
+        : launch_decode(hs->ctx, t.h_spectra, t.h_side, n_frames, hs->d_state, (int16_t*)dst, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, true);
+    if (rc != PDMP3_HIP_OK) return rc;
+    float* const was_prev = hs->d_state_prev;
+    hs->d_state_prev = hs->d_state;            // (what pdmp3_hip_stream_rewind goes back to)
+    hs->d_state = hs->d_state_tmp;             // the kernel left the new state here
+    hs->d_state_tmp = was_prev;
+    HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
+    hs->have_state_ev = 1;
+    HIP_TRY(hipEventRecord(t.done, t.stream), "record done event");
+    t.busy = 1;
+    t.direct = 1;
+    return PDMP3_HIP_OK;
+  }
   HIP_TRY(hipMemcpyAsync(t.d_spectra, t.h_spectra, n * PDMP3_FRAME_SPECTRA_BYTES, hipMemcpyHostToDevice, t.stream), "H2D spectra");
   HIP_TRY(hipMemcpyAsync(t.d_side, t.h_side, n * PDMP3_FRAME_SIDE_BYTES, hipMemcpyHostToDevice, t.stream), "H2D side");
   if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
   HIP_TRY(hipMemcpyAsync(hs->d_state_prev, hs->d_state, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, t.stream), "keep the state");
-  if (hs->f32 && host_dst) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_to: not with float PCM", hipSuccess);
   int rc = hs->f32
       ? launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs)
       : launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs);
@@ -778,9 +806,12 @@ extern "C" int pdmp3_hip_stream_rewind(pdmp3_hip_stream* hs, int slot, int keep_
   t.busy = 0;
   HIP_TRY(hipMemcpyAsync(hs->d_state, hs->d_state_prev, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, t.stream), "restore the state");
   if (keep_frames) {
+    // (the records are where the submit took them from: the pinned host buffers if it ran on those)
+    const int16_t* sp = t.direct ? t.h_spectra : t.d_spectra;
+    const pdmp3_gc_side* sd = t.direct ? t.h_side : t.d_side;
     const int rc = hs->f32
-        ? launch_decode(hs->ctx, t.d_spectra, t.d_side, keep_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs)
-        : launch_decode(hs->ctx, t.d_spectra, t.d_side, keep_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs);
+        ? launch_decode(hs->ctx, sp, sd, keep_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs)
+        : launch_decode(hs->ctx, sp, sd, keep_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs);
     if (rc != PDMP3_HIP_OK) return rc;
   }
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
