@@ -96,9 +96,12 @@ CASES = {
     "ms_loud_clip": dict(mode=MODE_JOINT, mode_ext=2, sfreq=0, gain_range=(170, 215), big_prob=0.02),
     "ms_sf15": dict(mode=MODE_JOINT, mode_ext=2, sfreq=0, block_mix=(40, 15, 30, 15), sf_max=16),
     "ms_resets": dict(mode=MODE_JOINT, mode_ext=2, sfreq=0, block_mix=(40, 15, 30, 15), reset_every=3),
-    # intensity stereo, long blocks only and is_pos <= 7 (the part of H3 that is well defined)
+    # intensity stereo with is_pos <= 7 (the part of H3 that is well defined: larger values read past is_ratios[6])
     "is_long_441": dict(mode=MODE_JOINT, mode_ext=1, sfreq=0, block_mix=(100, 0, 0, 0), count1_range=(100, 500), sf_max=8),
     "ms_is_long_480": dict(mode=MODE_JOINT, mode_ext=3, sfreq=1, block_mix=(100, 0, 0, 0), count1_range=(100, 500), sf_max=8),
+    # ... and on short / mixed blocks (Stereo_Process_Intensity_Short, P:2190-2220): the oracle equals oracle/_ref there
+    "is_short_441": dict(mode=MODE_JOINT, mode_ext=1, sfreq=0, block_mix=(30, 10, 50, 10), count1_range=(100, 500), sf_max=8),
+    "ms_is_short_480": dict(mode=MODE_JOINT, mode_ext=3, sfreq=1, block_mix=(20, 10, 60, 10), count1_range=(100, 500), sf_max=8),
 }
 
 

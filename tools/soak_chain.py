@@ -31,7 +31,7 @@ def main():
     eng = Engine()
     bad = 0
     for r in range(rounds):
-        n = 2048 if r % 4 else [1, 2, 7, 8, 9, 63, 65, 1000, 2047][(r // 4) % 9]
+        n = 2048 if r % 4 else [1, 2, 7, 8, 9, 63, 65, 1000, 2047, 4099, 12288][(r // 4) % 11]
         if not one(eng, 0x5EED000000 + r, n):
             bad += 1
             print("MISMATCH seed %d n %d" % (r, n))
