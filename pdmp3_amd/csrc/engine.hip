@@ -114,24 +114,47 @@ constexpr int kRowBytes = PDMP3_RESERVOIR_BYTES;
 constexpr int kRowStrideW = kRowBytes / 4 + 1;          // 517
 constexpr int kFrameBitsW = sizeof(pdmp3_frame_bits) / 4;   // 20
 
-// LDS: the 34 KB table blob, the 16 reservoir rows the wave works on (33 KB) and their side info, brought in with
-// coalesced loads: 68 KB per workgroup, so two workgroups share a CU and four windows' k_unpack (128 workgroups
-// each) can be resident at once -- the kernel is a long dependent chain per lane with the SIMD to itself, what
-// counts is how many streams' windows overlap.  (Staging the output lines in LDS as well, 141 KB, changed nothing
-// for one window and halved that.)  The lines go straight to HBM: the wave zeroes its 16 frames' spectra with
-// coalesced stores first, then each lane stores its pairs / quads (same wave, same addresses: program order holds).
+// LDS: the 34 KB table blob, the 16 reservoir rows the workgroup works on (33 KB) and their side info, brought in with
+// coalesced loads, and the 16 KB ring of symbol records: 85 KB, one workgroup per CU.  The kernel is a long dependent
+// chain per lane -- where does the next code word start -- and a window of 2048 frames has only 8192 of them (128
+// waves on 1024 SIMDs), so what counts is the length of that chain: WAVE 0 of the workgroup walks the 64 bit streams
+// (unpack_core.h unpack_step: two table lookups and an add per symbol, pairs and quads in one loop) and leaves a record
+// per symbol and lane in the ring; WAVES 1-3 take turns with the ring's rows (row i belongs to wave 1 + i % 3), read
+// linbits and signs and store the lines (unpack_value).  Round 2's single loop did all of it in wave 0, a loop per
+// symbol kind: 406 trips of ~700 cycles per window, 140 us; this one: <= 288 trips of the walker's half.
+// The lines go straight to HBM: the workgroup zeroes its 16 frames' spectra with coalesced stores first (a barrier
+// later, so the zeroes are there before any wave stores a line).
+constexpr int kRingRows = 32;                              // trips the walker may be ahead of the value waves
+constexpr int kRingCheck = 8;                              // ... looked at every so many trips
+struct UnpackRing {
+  SymRec rec[kRingRows][kUnpackLanes];                     // tag (trip / kRingRows) & 3 in bits 30-31 of .x: the row is of THIS turn
+  unsigned next[3];                                        // value wave c: the first trip it has not taken yet
+};
+typedef unsigned ring_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ring_u32x2 ring_load(const SymRec* p) {
+  return *(const volatile __attribute__((address_space(3))) ring_u32x2*)(p);
+}
+__device__ __forceinline__ void ring_store(SymRec* p, uint32_t x, uint32_t y) {
+  ring_u32x2 v;
+  v.x = x; v.y = y;
+  *(volatile __attribute__((address_space(3))) ring_u32x2*)(p) = v;
+}
+
 __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* tabs, const pdmp3_frame_bits* bits,
                                                             const uint8_t* res, int n_frames, int16_t* spectra,
                                                             pdmp3_gc_side* side, GcRaw* raw) {
   __shared__ UnpackTables U;
   __shared__ uint32_t rows[kUnpackRows * kRowStrideW + 4];
   __shared__ uint32_t fbits[kUnpackRows * kFrameBitsW];
+  __shared__ UnpackRing ring;
   {
     const uint4* src = reinterpret_cast<const uint4*>(tabs);
     uint4* dst = reinterpret_cast<uint4*>(&U);
     const int n16 = (int)((offsetof(UnpackTables, lut) + (size_t)tabs->n_lut * 4 + 15) / 16);
     for (int i = threadIdx.x; i < n16; i += kUnpackThreads) dst[i] = src[i];
   }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int fl = lane >> 2, g = lane & 3;                  // the granule-channel of this lane, in every wave
   for (int f0 = blockIdx.x * kUnpackRows; f0 < n_frames; f0 += gridDim.x * kUnpackRows) {
     const int nrows = n_frames - f0 < kUnpackRows ? n_frames - f0 : kUnpackRows;
     __syncthreads();                                       // (previous pass done with the buffers; first pass: U complete)
@@ -145,15 +168,75 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
       for (int i = threadIdx.x; i < nrows * kFrameBitsW; i += kUnpackThreads) fbits[i] = fsrc[i];
       uint4* z = reinterpret_cast<uint4*>(spectra + (size_t)f0 * 4 * 576);
       for (int i = threadIdx.x; i < nrows * 4 * 72; i += kUnpackThreads) z[i] = make_uint4(0, 0, 0, 0);
+      for (int i = threadIdx.x; i < kRingRows * kUnpackLanes; i += kUnpackThreads) (&ring.rec[0][0])[i].x = 3u << 30;   // "the turn before trip 0"
+      if (threadIdx.x < 3) ring.next[threadIdx.x] = threadIdx.x;
     }
     __syncthreads();
-    const int fl = threadIdx.x >> 2, g = threadIdx.x & 3;
-    if (threadIdx.x < kUnpackLanes && fl < nrows) {
-      const size_t idx = (size_t)(f0 + fl) * 4 + g;
-      unpack_gc(U, U.lut, reinterpret_cast<const uint8_t*>(rows + fl * kRowStrideW),
-                *reinterpret_cast<const pdmp3_frame_bits*>(fbits + fl * kFrameBitsW), g, spectra + idx * 576, side + idx,
-                raw + idx);
+    const size_t idx = (size_t)(f0 + fl) * 4 + g;
+    const uint8_t* row = reinterpret_cast<const uint8_t*>(rows + fl * kRowStrideW);
+    int16_t* is = spectra + idx * 576;
+    SymPlan P;
+    SymState st;
+    bool live = false;
+    if (wave == 0) {
+      // ---- the walker
+      if (fl < nrows)
+        live = unpack_head(U, row, *reinterpret_cast<const pdmp3_frame_bits*>(fbits + fl * kFrameBitsW), g, side + idx, raw + idx, P, st);
+      Win3 w;
+      if (live) w3_open(w, row, st.pos);
+      // the plan in REGISTERS (as a struct it stays in memory and every trip starts with a load of its table base)
+      int qb0 = P.base0, qb1 = P.base1, qb2 = P.base2;
+      unsigned ql0 = P.lin0, ql1 = P.lin1, ql2 = P.lin2, qq = P.qbase, qe0 = P.e0, qe1 = P.e1, qn = P.nbig, qend = P.end;
+      PD_PIN(qb0); PD_PIN(qb1); PD_PIN(qb2); PD_PIN(ql0); PD_PIN(ql1); PD_PIN(ql2);
+      PD_PIN(qq); PD_PIN(qe0); PD_PIN(qe1); PD_PIN(qn); PD_PIN(qend);
+      unsigned trip = 0;
+      for (;; ++trip) {
+        if ((trip & (kRingCheck - 1)) == 0) {              // room for the next kRingCheck rows?  (rarely not: three waves take them out)
+          for (;;) {
+            const unsigned n0 = PD_LDS_FLAG(&ring.next[0]), n1 = PD_LDS_FLAG(&ring.next[1]), n2 = PD_LDS_FLAG(&ring.next[2]);
+            const unsigned lo = n0 < n1 ? (n0 < n2 ? n0 : n2) : (n1 < n2 ? n1 : n2);
+            if (__builtin_amdgcn_readfirstlane(lo) + kRingRows >= trip + kRingCheck) break;
+            PD_SLEEP();
+          }
+        }
+        const bool act = live && sym_active(qn, qend, st);
+        if (!__any(act)) break;
+        uint32_t rx = kRecNopLine << 16, ry = 0;
+        if (act) {
+          const SymRec r = unpack_step(U.lut, qb0, qb1, qb2, ql0, ql1, ql2, qq, qe0, qe1, qn, st, w);
+          rx = r.x; ry = r.y;
+        }
+        ring_store(&ring.rec[trip % kRingRows][lane], rx | ((trip / kRingRows) & 3u) << 30, ry);
+      }
+      for (int k = 0; k < 3; ++k, ++trip) {                // one end row per value wave (room: kRingCheck > 3 rows were checked for)
+        if ((trip & (kRingCheck - 1)) == 0) {
+          for (;;) {
+            const unsigned n0 = PD_LDS_FLAG(&ring.next[0]), n1 = PD_LDS_FLAG(&ring.next[1]), n2 = PD_LDS_FLAG(&ring.next[2]);
+            const unsigned lo = n0 < n1 ? (n0 < n2 ? n0 : n2) : (n1 < n2 ? n1 : n2);
+            if (__builtin_amdgcn_readfirstlane(lo) + kRingRows >= trip + kRingCheck) break;
+            PD_SLEEP();
+          }
+        }
+        ring_store(&ring.rec[trip % kRingRows][lane], (kRecNopLine << 16) | ((trip / kRingRows) & 3u) << 30, kRecEnd);
+      }
+    } else {
+      // ---- a value wave: rows wave - 1, wave + 2, ...
+      for (unsigned trip = (unsigned)wave - 1;; trip += 3) {
+        const SymRec* slot = &ring.rec[trip % kRingRows][lane];
+        const unsigned tag = (trip / kRingRows) & 3u;
+        ring_u32x2 r;
+        for (;;) {
+          r = ring_load(slot);
+          if (__all((r.x >> 30) == tag)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) PD_LDS_FLAG(&ring.next[wave - 1]) = trip + 3;
+        if (r.y & kRecEnd) break;
+        unpack_value(row, SymRec{r.x, r.y}, is);
+      }
     }
+    __syncthreads();                                       // every line of every record is stored
+    if (wave == 0 && live) unpack_tail(U.lut, row, P, st, is, raw + idx);
   }
 }
 

@@ -205,18 +205,26 @@ inline bool build_unpack_tables(UnpackTables& U) {
         first[p] = 0x80000000u | ((uint32_t)deepest[p] << 24) | n;
         n += 1u << deepest[p];
       }
+    const bool quads = b == kHuffBookOfTable[32] || b == kHuffBookOfTable[33];
     for (int i = 0; i < nc; i++) {
       const int len = codes[i].len;
       const uint32_t val = codes[i].err ? 0 : codes[i].val;
+      uint32_t nsign, nlin = 0;
+      if (quads) nsign = (val & 1) + (val >> 1 & 1) + (val >> 2 & 1) + (val >> 3 & 1);
+      else {
+        nsign = ((val >> 4) != 0) + ((val & 15) != 0);
+        nlin = ((val >> 4) == 15) + ((val & 15) == 15);
+      }
+      const uint32_t tail = ((uint32_t)len << 13) | (nsign << 18) | (nlin << 21) | (((uint32_t)len + nsign) << 23) | val;
       if (len <= HL) {
         const uint32_t base = codes[i].code << (HL - len);
-        for (uint32_t k = 0; k < (1u << (HL - len)); k++) first[base + k] = ((uint32_t)len << 8) | val;
+        for (uint32_t k = 0; k < (1u << (HL - len)); k++) first[base + k] = ((uint32_t)len << 8) | tail;
       } else {
         const uint32_t p = codes[i].code >> (len - HL);
         const int sb = deepest[p], extra = len - HL;
         uint32_t* sub = U.lut + (first[p] & 0xffffffu);
         const uint32_t base = (codes[i].code & ((1u << extra) - 1)) << (sb - extra);
-        for (uint32_t k = 0; k < (1u << (sb - extra)); k++) sub[base + k] = ((uint32_t)extra << 8) | val;
+        for (uint32_t k = 0; k < (1u << (sb - extra)); k++) sub[base + k] = ((uint32_t)extra << 8) | tail;
       }
     }
   }

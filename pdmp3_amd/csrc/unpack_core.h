@@ -44,8 +44,19 @@ constexpr unsigned kResBytes = PDMP3_RESERVOIR_BYTES;
 constexpr unsigned kFastLimit = (kResBytes - 8) * 8u;   // bit positions from which an 8-byte load stays inside the row
 
 // One contiguous blob; every workgroup copies it into LDS.
-// lut entry: leaf  = len << 8 | (x << 4 | y)            (len = bits of this level)
+// lut entry: leaf  = (x << 4 | y) or v w x y             bits 0-7
+//                    | len << 8                          bits 8-12: bits of THIS level
+//                    | clen << 13                        bits 13-17: the whole code word (8 + len in a second level)
+//                    | nsign << 18                       bits 18-20: values != 0, each followed by a sign bit
+//                    | nlin << 21                        bits 21-22: values == 15 of a pair (linbits follow, if the table has any)
+//                    | (clen + nsign) << 23              bits 23-27
 //            link  = 0x80000000 | sub_bits << 24 | offset of the second-level table (entries from lut[0])
+//            0     = no code word ends here (the reference's error path: nothing is consumed, the values are 0)
+constexpr unsigned kLeafLenMask = 31;
+PD_HD unsigned leaf_len(uint32_t e) { return (e >> 8) & kLeafLenMask; }
+PD_HD unsigned leaf_clen(uint32_t e) { return (e >> 13) & 31; }
+PD_HD unsigned leaf_nlin(uint32_t e) { return (e >> 21) & 3; }
+PD_HD unsigned leaf_adv(uint32_t e) { return (e >> 23) & 31; }
 struct UnpackTables {
   uint16_t book_base[20];        // first-level table of book b starts at lut[book_base[b]]
   int8_t book_of_table[36];      // ISO table number (0..33) -> book, -1: no code words (tables 0, 4, 14)
@@ -183,7 +194,7 @@ PD_HD unsigned lut_symbol(const uint32_t* lut, unsigned base, uint64_t w, unsign
     e = lut[(e & 0xffffffu) + (unsigned)((w << kHuffFirstBits) >> (64 - sb))];
     len = kHuffFirstBits;
   }
-  used += len + (e >> 8);
+  used += len + leaf_len(e);
   return e & 0xff;
 }
 PD_HD unsigned lut_symbol_slow(const uint32_t* lut, unsigned base, BitPos& b) {
@@ -208,8 +219,10 @@ PD_HD unsigned part2_bits(const UnpackTables& U, const pdmp3_frame_bits& F, int 
 
 #if defined(__HIPCC__)
 #define PD_COLD __device__ __noinline__
+#define PD_MUL24(a, b) __umul24((a), (b))        /* full-rate multiply of small values */
 #else
 #define PD_COLD static __attribute__((noinline))
+#define PD_MUL24(a, b) ((a) * (b))
 #endif
 
 // store the pair at (even) line pos; big_values > 288 is not checked by the reference (H8): lines >= 576 are dropped
@@ -253,62 +266,6 @@ PD_COLD unsigned unpack_pairs_slow(const uint32_t* lut, BitPos& b, int base0, in
   return pos;
 }
 
-// The big_values pairs [0, nbig) of one granule-channel (cf. decode_pairs in pdmp3_host.c), ONE loop over the three
-// regions: the lanes of a wave sit in different regions with different tables, and three loops in a row would cost
-// the sum of the longest region of each kind instead of the longest granule-channel.  A region whose table has no
-// code words (0, 4, 14) reads no bits and leaves its (pre-zeroed) lines alone.  The loop body is branch-free apart
-// from that: second-level lookup, linbits and sign bits are selects (64 lanes decode 64 different streams -- every
-// data-dependent branch is taken by some lane anyway, and its overhead by all).
-PD_HD unsigned unpack_pairs(const UnpackTables& U, const uint32_t* lut, BitPos& b, RegWin& r, const pdmp3_gc_bits& s,
-                            unsigned e0, unsigned e1, unsigned nbig, int16_t* is) {
-  int base_r[3];
-  unsigned lin_r[3];
-  for (int k = 0; k < 3; k++) {
-    const unsigned tn = s.table_select[k];
-    const int book = U.book_of_table[tn];
-    base_r[k] = book < 0 ? -1 : (int)U.book_base[book];
-    lin_r[k] = U.linbits[tn];
-  }
-  unsigned pos = 0;
-  for (; pos < nbig && b.pos <= kFastLimit; pos += 2) {
-    const int base = pos < e0 ? base_r[0] : pos < e1 ? base_r[1] : base_r[2];
-    const unsigned linbits = pos < e0 ? lin_r[0] : pos < e1 ? lin_r[1] : lin_r[2];
-    if (base < 0) continue;
-    // the code word: <= 19 bits
-    rw_ask(r);
-    const uint32_t w = rw_peek(r, b.pos);
-    const uint32_t e1st = lut[(unsigned)base + (w >> (32 - kHuffFirstBits))];
-    const bool link = (e1st & 0x80000000u) != 0;
-    uint32_t e = e1st;
-    if (link) {                                    // only books deeper than 8 bits; sub_bits is 1..11
-      const unsigned sb = (e1st >> 24) & 0x1f;
-      e = lut[(e1st & 0xffffffu) + ((w << kHuffFirstBits) >> (32 - sb))];
-    }
-    b.pos += (link ? (unsigned)kHuffFirstBits : 0u) + ((e >> 8) & 0xff);
-    rw_step(r, b.pos);
-    rw_ask(r);
-    // linbits and signs of both values: <= 28 bits.  (v >> 1) >> (31 - n) == v >> (32 - n) for n = 1..31 and 0 for n = 0
-    uint32_t w2 = rw_peek(r, b.pos);
-    int x = (int)((e >> 4) & 15), y = (int)(e & 15);
-    const unsigned lbx = (x == 15) ? linbits : 0;
-    x += (int)((w2 >> 1) >> (31 - lbx));
-    w2 <<= lbx;
-    const unsigned nzx = x != 0;
-    x = (nzx && (w2 >> 31)) ? -x : x;
-    w2 <<= nzx;
-    const unsigned lby = (y == 15) ? linbits : 0;
-    y += (int)((w2 >> 1) >> (31 - lby));
-    w2 <<= lby;
-    const unsigned nzy = y != 0;
-    y = (nzy && (w2 >> 31)) ? -y : y;
-    b.pos += lbx + nzx + lby + nzy;
-    rw_step(r, b.pos);
-    store_pair(is, pos, x, y);
-  }
-  if (pos < nbig) pos = unpack_pairs_slow(lut, b, base_r[0], base_r[1], base_r[2], lin_r[0], lin_r[1], lin_r[2], e0, e1, nbig, pos, is);
-  return pos;
-}
-
 // the rest of the count1 quads once the bit position has left the fast region (corrupt streams only)
 PD_COLD unsigned unpack_quads_slow(const uint32_t* lut, BitPos& b, unsigned qbase, unsigned end, unsigned pos, int16_t* is) {
   while (pos <= 572 && b.pos <= end) {
@@ -336,9 +293,144 @@ PD_COLD unsigned unpack_quads_slow(const uint32_t* lut, BitPos& b, unsigned qbas
   return pos;
 }
 
+// ---------------------------------------------------------------------------
+// The symbols of one granule-channel (Read_Huffman P:2051-2115; cf. decode_pairs in pdmp3_host.c), in two stages.
+//
+// What makes the loop sequential is only WHERE the next code word starts.  unpack_step() does just that much per
+// symbol -- the code book lookup and the bits the symbol takes in all: code word, linbits, sign bits, the last three
+// out of the leaf entry without looking at them -- and hands a record to unpack_value(), which reads the values
+// and signs at leisure and stores the lines: on the device in OTHER waves (engine.hip k_unpack: one wave walks 64
+// bit streams, three take the records out of an LDS ring), in the host build right away.
+//
+// ONE loop for the big_values pairs of the three regions and the count1 quads: the lanes of a wave sit in different
+// regions with different tables, and a loop per kind costs the longest lane of each kind (406 trips per wave of 64
+// for a 320 kbps stream) instead of the longest lane (<= 288: 2 pairs + 4 quads <= 576 lines).  A region whose
+// table has no code words (0, 4, 14) reads no bits and leaves its (pre-zeroed) lines alone.
+// ---------------------------------------------------------------------------
+// three words of the row in registers: d0 holds bit 32 wi.  A symbol takes at most 19 + 2 + 2 x 13 = 47 bits, so
+// the window moves by at most two words per step, and the two words behind it are asked for before the lookups.
+struct Win3 {
+  const uint32_t* row;
+  uint32_t d0, d1, d2;
+  unsigned wi;
+};
+PD_HD void w3_open(Win3& r, const uint8_t* buf, unsigned pos) {
+  r.row = reinterpret_cast<const uint32_t*>(buf);
+  r.wi = pos >> 5;
+  if (r.wi > kFastLimit / 32) r.wi = kFastLimit / 32;      // (a position out there is never read through the window)
+  r.d0 = __builtin_bswap32(r.row[r.wi]);
+  r.d1 = __builtin_bswap32(r.row[r.wi + 1]);
+  r.d2 = __builtin_bswap32(r.row[r.wi + 2]);
+}
+
+// what the loop needs of the side info, per lane
+struct SymPlan {                 // (scalars, not arrays: the compiler moves a struct with arrays to LDS and the loop reads it from there)
+  int base0, base1, base2;       // first-level table of the region's book, -1: none
+  unsigned lin0, lin1, lin2;
+  unsigned qbase;                // count1 book
+  unsigned e0, e1, nbig;         // line where region 0 / 1 / the pairs end
+  unsigned end;                  // last bit of the granule-channel
+};
+struct SymState {
+  unsigned pos;                  // bit position
+  unsigned line;
+};
+
+// record of one symbol:  x = pos | quad << 15 | line << 16 | linbits << 26 | (tag << 30: the ring's business)
+//                        y = the leaf entry (0: values are zero) | kRecEnd
+constexpr unsigned kRecNopLine = 1023;           // "nothing to store" (lines >= 576 are dropped, H8)
+constexpr uint32_t kRecEnd = 0x80000000u;        // (a leaf never has the link bit)
+struct SymRec {
+  uint32_t x, y;
+};
+
+// does the reference's loop go on?  Pairs: to the last pair whatever the position (P:2071-2097); quads: while lines and
+// bits are left (P:2099-2105).  Past kFastLimit the window is not valid: the byte-wise forms below take over.
+PD_HD bool sym_active(unsigned nbig, unsigned end, const SymState& s) {
+  const bool more = (s.line < nbig) | ((s.line <= 572) & (s.pos <= end));     // (no short cuts: plain compares, no branches)
+  return more & (s.pos <= kFastLimit);
+}
+
+// one symbol: `w` at s.pos (wi == s.pos >> 5), active lane
+// (the plan as separate values: handed over as a struct the device compiler keeps it in memory and turns the selects
+// below into loads from a selected address, at the head of every trip's dependent chain)
+PD_HD SymRec unpack_step(const uint32_t* lut, int base0, int base1, int base2, unsigned lin0, unsigned lin1, unsigned lin2,
+                         unsigned qbase, unsigned e0, unsigned e1, unsigned nbig, SymState& s, Win3& w) {
+  const uint32_t n0 = w.row[w.wi + 3], n1 = w.row[w.wi + 4];
+  const bool pair = s.line < nbig;
+  const int base_p = s.line < e0 ? base0 : s.line < e1 ? base1 : base2;
+  const unsigned lin_p = s.line < e0 ? lin0 : s.line < e1 ? lin1 : lin2;
+  const int base = pair ? base_p : (int)qbase;
+  const unsigned lin = pair ? lin_p : 0u;
+  const bool none = base < 0;
+  const uint32_t bits = (uint32_t)(((((uint64_t)w.d0) << 32) | w.d1) >> (32 - (s.pos & 31)));   // (32 - s is 1..32)
+  const unsigned i1 = (none ? 0u : (unsigned)base) + (bits >> (32 - kHuffFirstBits));
+  const uint32_t l1 = lut[i1];
+  // second level: books deeper than 8 bits; sub_bits is 1..11.  Unconditional -- some lane of the 64 needs it in
+  // nearly every trip, and a branch around it only adds its own cost
+  const bool link = (l1 & 0x80000000u) != 0;
+  const unsigned sb = link ? (l1 >> 24) & 0x1f : 1u;
+  const unsigned i2 = link ? (l1 & 0xffffffu) + ((bits << kHuffFirstBits) >> (32 - sb)) : i1;
+  const uint32_t l2 = lut[i2];
+  const uint32_t e = none ? 0u : l2;
+  SymRec rec;
+  rec.x = s.pos | (pair ? 0u : 1u << 15) | ((none ? kRecNopLine : s.line) << 16) | (lin << 26);
+  rec.y = e;
+  s.pos += leaf_adv(e) + PD_MUL24(leaf_nlin(e), lin);
+  s.line += pair ? 2u : 4u;
+  // the window follows
+  const unsigned nwi = s.pos >> 5, k = nwi - w.wi;
+  const uint32_t s0 = __builtin_bswap32(n0), s1 = __builtin_bswap32(n1);
+  const uint32_t a0 = k == 1 ? w.d1 : w.d2, a1 = k == 1 ? w.d2 : s0, a2 = k == 1 ? s0 : s1;
+  w.d0 = k ? a0 : w.d0;
+  w.d1 = k ? a1 : w.d1;
+  w.d2 = k ? a2 : w.d2;
+  w.wi = nwi;
+  return rec;
+}
+
+// values and signs of a record's symbol, stored to the lines of its granule-channel
+PD_HD void unpack_value(const uint8_t* row, const SymRec rec, int16_t* is) {
+  const unsigned line = (rec.x >> 16) & 0x3ff;
+  if (line >= 576) return;
+  const uint32_t e = rec.y;
+  const unsigned linbits = (rec.x >> 26) & 15;
+  BitPos b{row, rec.x & 0x7fffu};
+  uint64_t w = peek64(b) << leaf_clen(e);                  // what follows the code word: <= 28 bits are looked at
+  if (rec.x & (1u << 15)) {                                // v w x y: a sign bit follows each nonzero one
+    int q[4];
+    for (int k = 0; k < 4; k++) {
+      const unsigned nz = (e >> (3 - k)) & 1;
+      q[k] = (nz && (w >> 63)) ? -1 : (int)nz;
+      w <<= nz;
+    }
+    store_pair(is, line, q[0], q[1]);
+    store_pair(is, line + 2, q[2], q[3]);
+  } else {                                                 // (v >> 1) >> (63 - n) == v >> (64 - n) for n = 1..63 and 0 for n = 0
+    int x = (int)((e >> 4) & 15), y = (int)(e & 15);
+    const unsigned lbx = (x == 15) ? linbits : 0;
+    x += (int)((w >> 1) >> (63 - lbx));
+    w <<= lbx;
+    const unsigned nzx = x != 0;
+    x = (nzx && (w >> 63)) ? -x : x;
+    w <<= nzx;
+    const unsigned lby = (y == 15) ? linbits : 0;
+    y += (int)((w >> 1) >> (63 - lby));
+    w <<= lby;
+    y = (y != 0 && (w >> 63)) ? -y : y;
+    store_pair(is, line, x, y);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// one granule-channel = unpack_head (side fields, scalefactors, the plan of the symbol loop)
+//                     + the symbol loop (host: unpack_gc below; device: k_unpack)
+//                     + unpack_tail (byte-wise rest on corrupt streams, the overshoot rule, count1)
 // `spectra_gc` (576 int16) must be zero on entry.  `rec` and `raw` are fully written.
-PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* res, const pdmp3_frame_bits& F, int g,
-                     int16_t* spectra_gc, pdmp3_gc_side* rec, GcRaw* raw) {
+// ---------------------------------------------------------------------------
+// false: no Huffman data (channel absent, or part2_3_length == 0: spectra stay zero, count1 keeps its old value, H6)
+PD_HD bool unpack_head(const UnpackTables& U, const uint8_t* res, const pdmp3_frame_bits& F, int g, pdmp3_gc_side* rec,
+                       GcRaw* raw, SymPlan& P, SymState& st) {
   const int gr = g >> 1, ch = g & 1;
   const int nch = ((F.frame & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
   const int sfreq = (F.frame & PDMP3_FR_SFREQ_MASK) > 2 ? 2 : (F.frame & PDMP3_FR_SFREQ_MASK);
@@ -349,7 +441,7 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
     for (int i = 0; i < 20; i++) w32[i] = 0;
   }
   rec->frame = F.frame & (uint8_t)~PDMP3_FR_NEWSTREAM;
-  if (ch >= nch) return;
+  if (ch >= nch) return false;
   const pdmp3_gc_bits& s = F.gc[g];
   rec->global_gain = s.global_gain;
   rec->flags = s.flags;
@@ -396,9 +488,9 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
     raw->sf_l_copy = (uint8_t)copy;
   }
 
-  // ---- Huffman (P:2051-2115)
-  if (s.part2_3_length == 0) return;               // spectra stay zero; count1 keeps its old value (H6)
-  const unsigned end = part2_start + s.part2_3_length - 1;
+  // ---- Huffman (P:2051-2115): the plan
+  if (s.part2_3_length == 0) return false;
+  P.end = part2_start + s.part2_3_length - 1;
   unsigned r1, r2;
   if (wsf && bt == 2) { r1 = 36; r2 = 576; }
   else {
@@ -406,45 +498,55 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
     r1 = i1 < 23 ? U.sfb_l[sfreq][i1] : U.sfb_s[sfreq][i1 - 23];      // H7
     r2 = i2 < 23 ? U.sfb_l[sfreq][i2] : U.sfb_s[sfreq][i2 - 23];
   }
-  const unsigned nbig = s.big_values * 2u;
-  unsigned e0 = (r1 + 1) & ~1u, e1 = (r2 + 1) & ~1u;
-  if (e0 > nbig) e0 = nbig;
-  if (e1 > nbig) e1 = nbig;
-  if (e1 < e0) e1 = e0;
-  unsigned pos = unpack_pairs(U, lut, b, r, s, e0, e1, nbig, spectra_gc);
-  // count1 region: table 32 or the reference's mis-pointed table 33 (H1); both books are <= 8 bits deep
-  const unsigned qbase = U.book_base[U.book_of_table[32 + s.count1table_select]];
-  while (pos <= 572 && b.pos <= end && b.pos <= kFastLimit) {     // both count1 books are <= 8 bits deep: one lookup
-    rw_ask(r);
-    uint32_t w = rw_peek(r, b.pos);                // code (<= 6 bits) and up to four signs
-    const uint32_t e = lut[qbase + (w >> (32 - kHuffFirstBits))];
-    const unsigned len = (e >> 8) & 0xff;
-    w <<= len;
-    unsigned used = len;
-    int q[4];
-    for (int k = 0; k < 4; k++) {                  // v w x y: a sign bit follows each nonzero one
-      const unsigned nz = (e >> (3 - k)) & 1;
-      q[k] = (nz && (w >> 31)) ? -1 : (int)nz;
-      w <<= nz;
-      used += nz;
-    }
-    b.pos += used;
-    rw_step(r, b.pos);
-    store_pair(spectra_gc, pos, q[0], q[1]);
-    store_pair(spectra_gc, pos + 2, q[2], q[3]);
-    pos += 4;
+  P.nbig = s.big_values * 2u;
+  P.e0 = (r1 + 1) & ~1u; P.e1 = (r2 + 1) & ~1u;
+  if (P.e0 > P.nbig) P.e0 = P.nbig;
+  if (P.e1 > P.nbig) P.e1 = P.nbig;
+  if (P.e1 < P.e0) P.e1 = P.e0;
+  {
+    const int b0 = U.book_of_table[s.table_select[0]], b1 = U.book_of_table[s.table_select[1]], b2 = U.book_of_table[s.table_select[2]];
+    P.base0 = b0 < 0 ? -1 : (int)U.book_base[b0];
+    P.base1 = b1 < 0 ? -1 : (int)U.book_base[b1];
+    P.base2 = b2 < 0 ? -1 : (int)U.book_base[b2];
+    P.lin0 = U.linbits[s.table_select[0]]; P.lin1 = U.linbits[s.table_select[1]]; P.lin2 = U.linbits[s.table_select[2]];
   }
-  if (pos <= 572 && b.pos <= end) pos = unpack_quads_slow(lut, b, qbase, end, pos, spectra_gc);
+  // count1 region: table 32 or the reference's mis-pointed table 33 (H1); both books are <= 8 bits deep
+  P.qbase = U.book_base[U.book_of_table[32 + s.count1table_select]];
+  st.pos = b.pos;
+  st.line = 0;
+  return true;
+}
+
+// after the symbol loop, once every record's lines are stored
+PD_HD void unpack_tail(const uint32_t* lut, const uint8_t* res, const SymPlan& P, SymState st, int16_t* spectra_gc, GcRaw* raw) {
+  BitPos b{res, st.pos};
+  unsigned pos = st.line;
+  if (pos < P.nbig)
+    pos = unpack_pairs_slow(lut, b, P.base0, P.base1, P.base2, P.lin0, P.lin1, P.lin2, P.e0, P.e1, P.nbig, pos, spectra_gc);
+  if (pos <= 572 && b.pos <= P.end) pos = unpack_quads_slow(lut, b, P.qbase, P.end, pos, spectra_gc);
   // Overshoot: the reference takes the last four lines back (P:2106-2108) -- the last quad, or, when no quad
   // was read, the last two PAIRS -- and zero-fills from there.  (pos < 4 wraps like the reference's unsigned:
   // count1 becomes 576 and nothing is zeroed.)
-  if (b.pos > end + 1) {
+  if (b.pos > P.end + 1) {
     pos -= 4;
     for (unsigned i = pos; i < 576 && i < pos + 4; i++) spectra_gc[i] = 0;
   }
   if (pos > 576) pos = 576;
   raw->count1 = (uint16_t)pos;
   raw->count1_set = 1;
+}
+
+// the three in a row (host test build; reference form of what k_unpack does with four waves)
+PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* res, const pdmp3_frame_bits& F, int g,
+                     int16_t* spectra_gc, pdmp3_gc_side* rec, GcRaw* raw) {
+  SymPlan P;
+  SymState st;
+  if (!unpack_head(U, res, F, g, rec, raw, P, st)) return;
+  Win3 w;
+  w3_open(w, res, st.pos);
+  while (sym_active(P.nbig, P.end, st))
+    unpack_value(res, unpack_step(lut, P.base0, P.base1, P.base2, P.lin0, P.lin1, P.lin2, P.qbase, P.e0, P.e1, P.nbig, st, w), spectra_gc);
+  unpack_tail(lut, res, P, st, spectra_gc, raw);
 }
 
 // ---------------------------------------------------------------------------
