@@ -126,6 +126,7 @@ constexpr int kFrameBitsW = sizeof(pdmp3_frame_bits) / 4;   // 20
 // later, so the zeroes are there before any wave stores a line).
 constexpr int kRingRows = 32;                              // trips the walker may be ahead of the value waves
 constexpr int kRingCheck = 8;                              // ... looked at every so many trips
+static_assert(kRingRows % kRingCheck == 0 && kRingCheck >= 3, "blocks of trips do not wrap around the ring");
 struct UnpackRing {
   SymRec rec[kRingRows][kUnpackLanes];                     // tag (trip / kRingRows) & 3 in bits 30-31 of .x: the row is of THIS turn
   unsigned next[3];                                        // value wave c: the first trip it has not taken yet
@@ -142,11 +143,14 @@ __device__ __forceinline__ void ring_store(SymRec* p, uint32_t x, uint32_t y) {
 
 __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* tabs, const pdmp3_frame_bits* bits,
                                                             const uint8_t* res, int n_frames, int16_t* spectra,
-                                                            pdmp3_gc_side* side, GcRaw* raw) {
+                                                            pdmp3_gc_side* side, GcRaw* raw, unsigned long long* prof) {
   __shared__ UnpackTables U;
   __shared__ uint32_t rows[kUnpackRows * kRowStrideW + 4];
   __shared__ uint32_t fbits[kUnpackRows * kFrameBitsW];
   __shared__ UnpackRing ring;
+  // development only (PDMP3_HIP_UNPACK_PROF=1): s_memtime of workgroup's wave 0 at the steps of its first pass
+#define PD_UP_STAMP(k) do { if (prof && threadIdx.x == 0) prof[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+  PD_UP_STAMP(0);
   {
     const uint4* src = reinterpret_cast<const uint4*>(tabs);
     uint4* dst = reinterpret_cast<uint4*>(&U);
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
       const uint32_t* src = reinterpret_cast<const uint32_t*>(res + (size_t)f0 * kRowBytes);
       for (int i = threadIdx.x; i < nrows * (kRowBytes / 4); i += kUnpackThreads) {
         const int r = i / (kRowBytes / 4), c = i - r * (kRowBytes / 4);
-        rows[r * kRowStrideW + c] = src[i];
+        rows[r * kRowStrideW + c] = __builtin_bswap32(src[i]);       // (unpack_core.h PD_ROW_BE: big-endian words as numbers)
       }
       const uint32_t* fsrc = reinterpret_cast<const uint32_t*>(bits + f0);
       for (int i = threadIdx.x; i < nrows * kFrameBitsW; i += kUnpackThreads) fbits[i] = fsrc[i];
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
       if (threadIdx.x < 3) ring.next[threadIdx.x] = threadIdx.x;
     }
     __syncthreads();
+    PD_UP_STAMP(1);
     const size_t idx = (size_t)(f0 + fl) * 4 + g;
     const uint8_t* row = reinterpret_cast<const uint8_t*>(rows + fl * kRowStrideW);
     int16_t* is = spectra + idx * 576;
@@ -182,43 +187,36 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
       // ---- the walker
       if (fl < nrows)
         live = unpack_head(U, row, *reinterpret_cast<const pdmp3_frame_bits*>(fbits + fl * kFrameBitsW), g, side + idx, raw + idx, P, st);
-      Win3 w;
-      if (live) w3_open(w, row, st.pos);
+      PD_UP_STAMP(2);
+      Win2 w;
+      w2_open(w, row, live ? st.pos : 0u);
+      if (!live) { st.pos = 0; st.line = 0; }
       // the plan in REGISTERS (as a struct it stays in memory and every trip starts with a load of its table base)
-      int qb0 = P.base0, qb1 = P.base1, qb2 = P.base2;
-      unsigned ql0 = P.lin0, ql1 = P.lin1, ql2 = P.lin2, qq = P.qbase, qe0 = P.e0, qe1 = P.e1, qn = P.nbig, qend = P.end;
-      PD_PIN(qb0); PD_PIN(qb1); PD_PIN(qb2); PD_PIN(ql0); PD_PIN(ql1); PD_PIN(ql2);
-      PD_PIN(qq); PD_PIN(qe0); PD_PIN(qe1); PD_PIN(qn); PD_PIN(qend);
+      unsigned qt0 = P.tab0, qt1 = P.tab1, qt2 = P.tab2, qq = P.qbase, qe0 = P.e0, qe1 = P.e1, qn = P.nbig, qend = P.end;
+      PD_PIN(qt0); PD_PIN(qt1); PD_PIN(qt2); PD_PIN(qq); PD_PIN(qe0); PD_PIN(qe1); PD_PIN(qn); PD_PIN(qend);
+      // kRingCheck trips at a time: room in the ring and "is any lane still at it" are looked at once per block (a lone
+      // wave issues an instruction every ~6 cycles whatever it is: the loop's own bookkeeping was a third of a trip)
+      const unsigned ztab = U.book_base[kZeroBook];
       unsigned trip = 0;
-      for (;; ++trip) {
-        if ((trip & (kRingCheck - 1)) == 0) {              // room for the next kRingCheck rows?  (rarely not: three waves take them out)
-          for (;;) {
-            const unsigned n0 = PD_LDS_FLAG(&ring.next[0]), n1 = PD_LDS_FLAG(&ring.next[1]), n2 = PD_LDS_FLAG(&ring.next[2]);
-            const unsigned lo = n0 < n1 ? (n0 < n2 ? n0 : n2) : (n1 < n2 ? n1 : n2);
-            if (__builtin_amdgcn_readfirstlane(lo) + kRingRows >= trip + kRingCheck) break;
-            PD_SLEEP();
-          }
+      for (;; trip += kRingCheck) {
+        for (;;) {                                         // room for the block's rows?  (rarely not: three waves take them out)
+          const unsigned n0 = PD_LDS_FLAG(&ring.next[0]), n1 = PD_LDS_FLAG(&ring.next[1]), n2 = PD_LDS_FLAG(&ring.next[2]);
+          const unsigned lo = n0 < n1 ? (n0 < n2 ? n0 : n2) : (n1 < n2 ? n1 : n2);
+          if (__builtin_amdgcn_readfirstlane(lo) + kRingRows >= trip + kRingCheck) break;
+          PD_SLEEP();
         }
-        const bool act = live && sym_active(qn, qend, st);
-        if (!__any(act)) break;
-        uint32_t rx = kRecNopLine << 16, ry = 0;
-        if (act) {
-          const SymRec r = unpack_step(U.lut, qb0, qb1, qb2, ql0, ql1, ql2, qq, qe0, qe1, qn, st, w);
-          rx = r.x; ry = r.y;
+        if (!__any(live && sym_active(qn, qend, st))) break;
+        SymRec* blk = &ring.rec[trip % kRingRows][lane];   // (kRingRows is a multiple of kRingCheck: the block does not wrap)
+        const uint32_t tag = ((trip / kRingRows) & 3u) << 30;
+        PD_UNROLL for (int j = 0; j < kRingCheck; ++j) {
+          const SymRec r = unpack_step(U.lut, qt0, qt1, qt2, qq, ztab, qe0, qe1, qn, live && sym_active(qn, qend, st), st, w);
+          ring_store(blk + j * kUnpackLanes, r.x | tag, r.y);
         }
-        ring_store(&ring.rec[trip % kRingRows][lane], rx | ((trip / kRingRows) & 3u) << 30, ry);
       }
-      for (int k = 0; k < 3; ++k, ++trip) {                // one end row per value wave (room: kRingCheck > 3 rows were checked for)
-        if ((trip & (kRingCheck - 1)) == 0) {
-          for (;;) {
-            const unsigned n0 = PD_LDS_FLAG(&ring.next[0]), n1 = PD_LDS_FLAG(&ring.next[1]), n2 = PD_LDS_FLAG(&ring.next[2]);
-            const unsigned lo = n0 < n1 ? (n0 < n2 ? n0 : n2) : (n1 < n2 ? n1 : n2);
-            if (__builtin_amdgcn_readfirstlane(lo) + kRingRows >= trip + kRingCheck) break;
-            PD_SLEEP();
-          }
-        }
-        ring_store(&ring.rec[trip % kRingRows][lane], (kRecNopLine << 16) | ((trip / kRingRows) & 3u) << 30, kRecEnd);
-      }
+      PD_UP_STAMP(3);
+      if (prof && threadIdx.x == 0) prof[blockIdx.x * 8 + 6] = trip;
+      for (int k = 0; k < 3; ++k)                          // one end row per value wave (the block's room was checked)
+        ring_store(&ring.rec[(trip + k) % kRingRows][lane], (kRecNopLine << 16) | (((trip + k) / kRingRows) & 3u) << 30, kRecEnd);
     } else {
       // ---- a value wave: rows wave - 1, wave + 2, ...
       for (unsigned trip = (unsigned)wave - 1;; trip += 3) {
@@ -236,8 +234,11 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
       }
     }
     __syncthreads();                                       // every line of every record is stored
-    if (wave == 0 && live) unpack_tail(U.lut, row, P, st, is, raw + idx);
+    PD_UP_STAMP(4);
+    if (wave == 0 && live) unpack_tail(U, U.lut, row, P, st, is, raw + idx);
+    PD_UP_STAMP(5);
   }
+#undef PD_UP_STAMP
 }
 
 // reservoir rows from the pool (unpack_core.h row_word): one workgroup per frame, a 4-byte word per thread and trip
@@ -328,6 +329,7 @@ struct pdmp3_hip_ctx {
   int device;
   int wave_slots;           // waves of k_decode the device holds at once (CUs x 4 SIMDs x 2)
   UnpackTables* d_unpack;
+  unsigned long long* d_uprof;   // development only: PDMP3_HIP_UNPACK_PROF=1
   float* d_pow43;
   uint16_t* d_linetab;
   float* d_win;
@@ -373,6 +375,7 @@ extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   (void)hipFree(c->d_frag);
   (void)hipFree(c->d_tab_image);
   (void)hipFree(c->d_unpack);
+  (void)hipFree(c->d_uprof);
   for (ChainBuf& b : c->chain) { (void)hipFree(b.state); (void)hipFree(b.flag); }
   delete c;
 }
@@ -420,6 +423,8 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     CREATE_STEP(hipMalloc(&c->d_frag, (10 + 10 + 8 + 16) * 64 * sizeof(float)), "hipMalloc frag")
     CREATE_STEP(hipMalloc(&c->d_tab_image, 3 * sizeof(TabLds)), "hipMalloc table images")
     CREATE_STEP(hipMalloc((void**)&c->d_unpack, sizeof(UnpackTables)), "hipMalloc unpack tables")
+    { const char* up = getenv("PDMP3_HIP_UNPACK_PROF");
+      if (up && *up == '1') CREATE_STEP(hipMalloc((void**)&c->d_uprof, 2048 * 8 * sizeof(unsigned long long)), "hipMalloc unpack prof") }
     CREATE_STEP(hipMemcpy(c->d_pow43, H.pow43.data(), H.pow43.size() * sizeof(float), hipMemcpyHostToDevice), "upload pow43")
     CREATE_STEP(hipMemcpy(c->d_linetab, H.linetab.data(), H.linetab.size() * sizeof(uint16_t), hipMemcpyHostToDevice), "upload linetab")
     CREATE_STEP(hipMemcpy(c->d_win, H.win.data(), H.win.size() * sizeof(float), hipMemcpyHostToDevice), "upload win")
@@ -988,8 +993,23 @@ static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_
     int blocks = (n_frames + kUnpackRows - 1) / kUnpackRows;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(kUnpackThreads), 0, t.stream, hs->ctx->d_unpack, t.d_bits, t.d_res,
-                       n_frames, t.d_spectra, t.d_side, t.d_raw);
+                       n_frames, t.d_spectra, t.d_side, t.d_raw, hs->ctx->d_uprof);
     HIP_TRY(hipGetLastError(), "launch k_unpack");
+    if (hs->ctx->d_uprof) {                            // development only: serialises, prints one line per launch
+      static std::vector<unsigned long long> hp(2048 * 8);
+      HIP_TRY(hipStreamSynchronize(t.stream), "unpack prof sync");
+      HIP_TRY(hipMemcpy(hp.data(), hs->ctx->d_uprof, (size_t)blocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost), "unpack prof D2H");
+      double d[5] = {0, 0, 0, 0, 0}, trips = 0, tmax = 0;
+      for (int b = 0; b < blocks; b++) {
+        for (int k = 0; k < 5; k++) d[k] += (double)(hp[b * 8 + k + 1] - hp[b * 8 + k]);
+        trips += (double)hp[b * 8 + 6];
+        const double tot = (double)(hp[b * 8 + 5] - hp[b * 8]);
+        if (tot > tmax) tmax = tot;
+      }
+      fprintf(stderr, "k_unpack prof: %d frames %d wgs | ticks/wg: setup %.0f head %.0f loop %.0f drain %.0f tail %.0f | trips %.1f -> %.1f ticks/trip | longest wg %.0f\n",
+              n_frames, blocks, d[0] / blocks, d[1] / blocks, d[2] / blocks, d[3] / blocks, d[4] / blocks, trips / blocks,
+              trips > 0 ? d[2] / trips : 0.0, tmax);
+    }
   }
   // everything from here on continues the previous batch (scalefactor / count1 carry, synthesis state)
   if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");

@@ -215,19 +215,23 @@ inline bool build_unpack_tables(UnpackTables& U) {
         nsign = ((val >> 4) != 0) + ((val & 15) != 0);
         nlin = ((val >> 4) == 15) + ((val & 15) == 15);
       }
-      const uint32_t tail = ((uint32_t)len << 13) | (nsign << 18) | (nlin << 21) | (((uint32_t)len + nsign) << 23) | val;
+      const uint32_t leaf = val | ((uint32_t)len << 8) | (((uint32_t)len + nsign) << 16) | (nlin << 24);
       if (len <= HL) {
         const uint32_t base = codes[i].code << (HL - len);
-        for (uint32_t k = 0; k < (1u << (HL - len)); k++) first[base + k] = ((uint32_t)len << 8) | tail;
+        for (uint32_t k = 0; k < (1u << (HL - len)); k++) first[base + k] = leaf;
       } else {
         const uint32_t p = codes[i].code >> (len - HL);
         const int sb = deepest[p], extra = len - HL;
         uint32_t* sub = U.lut + (first[p] & 0xffffffu);
         const uint32_t base = (codes[i].code & ((1u << extra) - 1)) << (sb - extra);
-        for (uint32_t k = 0; k < (1u << (sb - extra)); k++) sub[base + k] = ((uint32_t)extra << 8) | tail;
+        for (uint32_t k = 0; k < (1u << (sb - extra)); k++) sub[base + k] = leaf;
       }
     }
   }
+  if (n + (1u << HL) > (uint32_t)kHuffLutMax) return false;
+  static_assert(kZeroBook < 20 && kZeroBook >= PDMP3_NUM_HUFF_BOOKS, "the zero book takes a free slot of book_base");
+  U.book_base[kZeroBook] = (uint16_t)n;                  // (memset above: 256 zeroes)
+  n += 1u << HL;
   U.n_lut = n;
   return true;
 }

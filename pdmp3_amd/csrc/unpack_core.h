@@ -36,27 +36,33 @@
 
 #include "decode_core.h"
 
+// A row's 32-bit word as the big-endian number it is in the stream.  The kernel keeps its rows byte-swapped in LDS
+// (engine.hip k_unpack swaps while it copies them in): one v_perm per word and symbol less in the loops.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PD_ROW_BE(w) (w)
+#else
+#define PD_ROW_BE(w) __builtin_bswap32(w)
+#endif
+
 namespace pdmp3 {
 
 constexpr int kHuffFirstBits = 8;
-constexpr int kHuffLutMax = 8448;                 // entries; the 18 books need 8290 (host_tables.h checks)
+constexpr int kHuffLutMax = 8576;                 // entries; the 18 books need 8290, the zero book 256 (host_tables.h checks)
 constexpr unsigned kResBytes = PDMP3_RESERVOIR_BYTES;
 constexpr unsigned kFastLimit = (kResBytes - 8) * 8u;   // bit positions from which an 8-byte load stays inside the row
 
 // One contiguous blob; every workgroup copies it into LDS.
-// lut entry: leaf  = (x << 4 | y) or v w x y             bits 0-7
-//                    | len << 8                          bits 8-12: bits of THIS level
-//                    | clen << 13                        bits 13-17: the whole code word (8 + len in a second level)
-//                    | nsign << 18                       bits 18-20: values != 0, each followed by a sign bit
-//                    | nlin << 21                        bits 21-22: values == 15 of a pair (linbits follow, if the table has any)
-//                    | (clen + nsign) << 23              bits 23-27
+// lut entry: leaf  = byte 0: (x << 4 | y) or v w x y
+//                    byte 1: clen, the bits of the whole code word (both levels)
+//                    byte 2: clen + the number of values != 0 (a sign bit follows each)
+//                    byte 3: the number of values == 15 of a pair (linbits follow each, if the table has any); <= 2
 //            link  = 0x80000000 | sub_bits << 24 | offset of the second-level table (entries from lut[0])
 //            0     = no code word ends here (the reference's error path: nothing is consumed, the values are 0)
-constexpr unsigned kLeafLenMask = 31;
-PD_HD unsigned leaf_len(uint32_t e) { return (e >> 8) & kLeafLenMask; }
-PD_HD unsigned leaf_clen(uint32_t e) { return (e >> 13) & 31; }
-PD_HD unsigned leaf_nlin(uint32_t e) { return (e >> 21) & 3; }
-PD_HD unsigned leaf_adv(uint32_t e) { return (e >> 23) & 31; }
+// book_base[kZeroBook] is a first level of 256 zeroes: what a table without code words (0, 4, 14) "decodes" to.
+constexpr int kZeroBook = 19;
+PD_HD unsigned leaf_clen(uint32_t e) { return (e >> 8) & 0xff; }
+PD_HD unsigned leaf_adv(uint32_t e) { return (e >> 16) & 0xff; }
+PD_HD unsigned leaf_nlin(uint32_t e) { return e >> 24; }
 struct UnpackTables {
   uint16_t book_base[20];        // first-level table of book b starts at lut[book_base[b]]
   int8_t book_of_table[36];      // ISO table number (0..33) -> book, -1: no code words (tables 0, 4, 14)
@@ -115,9 +121,11 @@ struct BitPos {
 };
 
 PD_HD uint32_t peek32(const BitPos& b) {            // next 25+ valid bits, MSB first; clamped at the row's end
-  const unsigned byte = b.pos >> 3;
-  const uint8_t* p = b.buf + (byte < kResBytes - 5 ? byte : kResBytes - 5);
-  const uint64_t w = ((uint64_t)p[0] << 32) | ((uint64_t)p[1] << 24) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 8) | p[4];
+  unsigned byte = b.pos >> 3;
+  if (byte > kResBytes - 5) byte = kResBytes - 5;
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(b.buf) + (byte >> 2);              // the 8 bytes around: 5 from byte & 3 on
+  const uint64_t two = ((uint64_t)PD_ROW_BE(q[0]) << 32) | PD_ROW_BE(q[1]);
+  const uint64_t w = (two << (8 * (byte & 3))) >> 24;                                      // bytes byte .. byte + 4
   return (uint32_t)(w >> (8 - (b.pos & 7)));
 }
 PD_HD uint64_t peek64(const BitPos& b);
@@ -134,7 +142,7 @@ PD_HD unsigned get_bits(BitPos& b, unsigned n) {    // n <= 16
 // reach the result do.
 PD_HD uint64_t peek64(const BitPos& b) {
   const uint32_t* p = reinterpret_cast<const uint32_t*>(b.buf) + (b.pos >> 5);
-  const uint32_t d0 = __builtin_bswap32(p[0]), d1 = __builtin_bswap32(p[1]), d2 = __builtin_bswap32(p[2]);
+  const uint32_t d0 = PD_ROW_BE(p[0]), d1 = PD_ROW_BE(p[1]), d2 = PD_ROW_BE(p[2]);
   const unsigned s = b.pos & 31;
   const uint64_t two = ((uint64_t)d0 << 32) | d1;
   return s ? (two << s) | (uint64_t)(d2 >> (32 - s)) : two;
@@ -155,8 +163,8 @@ PD_HD void rw_open(RegWin& r, const uint8_t* buf, unsigned pos) {
   r.row = reinterpret_cast<const uint32_t*>(buf);
   r.wi = pos >> 5;
   if (r.wi > kFastLimit / 32) r.wi = kFastLimit / 32;      // (a position out there is never read through the window)
-  r.d0 = __builtin_bswap32(r.row[r.wi]);
-  r.d1 = __builtin_bswap32(r.row[r.wi + 1]);
+  r.d0 = PD_ROW_BE(r.row[r.wi]);
+  r.d1 = PD_ROW_BE(r.row[r.wi + 1]);
   r.nx = 0;
 }
 PD_HD uint32_t rw_peek(const RegWin& r, unsigned pos) {     // 32 bits from bit `pos` (pos >> 5 == r.wi)
@@ -168,7 +176,7 @@ PD_HD uint32_t rw_peek(const RegWin& r, unsigned pos) {     // 32 bits from bit 
 PD_HD void rw_ask(RegWin& r) { r.nx = r.row[r.wi + 2]; }
 PD_HD void rw_step(RegWin& r, unsigned pos) {               // pos has moved by < 32 bits since rw_ask()
   const bool adv = (pos >> 5) != r.wi;
-  const uint32_t sw = __builtin_bswap32(r.nx);
+  const uint32_t sw = PD_ROW_BE(r.nx);
   r.d0 = adv ? r.d1 : r.d0;
   r.d1 = adv ? sw : r.d1;
   r.wi = pos >> 5;
@@ -188,13 +196,11 @@ PD_HD unsigned get_field(BitPos& b, RegWin& r, unsigned n) {   // n <= 16
 // one code word from a 64-bit window: returns leaf value, adds its length to `used`
 PD_HD unsigned lut_symbol(const uint32_t* lut, unsigned base, uint64_t w, unsigned& used) {
   uint32_t e = lut[base + (unsigned)(w >> (64 - kHuffFirstBits))];
-  unsigned len = 0;
   if (e & 0x80000000u) {
     const unsigned sb = (e >> 24) & 0x1f;
     e = lut[(e & 0xffffffu) + (unsigned)((w << kHuffFirstBits) >> (64 - sb))];
-    len = kHuffFirstBits;
   }
-  used += len + leaf_len(e);
+  used += leaf_clen(e);
   return e & 0xff;
 }
 PD_HD unsigned lut_symbol_slow(const uint32_t* lut, unsigned base, BitPos& b) {
@@ -307,30 +313,31 @@ PD_COLD unsigned unpack_quads_slow(const uint32_t* lut, BitPos& b, unsigned qbas
 // for a 320 kbps stream) instead of the longest lane (<= 288: 2 pairs + 4 quads <= 576 lines).  A region whose
 // table has no code words (0, 4, 14) reads no bits and leaves its (pre-zeroed) lines alone.
 // ---------------------------------------------------------------------------
-// three words of the row in registers: d0 holds bit 32 wi.  A symbol takes at most 19 + 2 + 2 x 13 = 47 bits, so
-// the window moves by at most two words per step, and the two words behind it are asked for before the lookups.
-struct Win3 {
+// the 64 bits around the position in registers: d0 holds bit 32 (pos >> 5).  A symbol takes up to 19 + 2 + 2 x 13 = 47
+// bits, so the window is simply read again where the symbol ends (one aligned 8-byte LDS read; sliding a register
+// window by 0, 1 or 2 words took five times the instructions, and a lone wave pays for instructions, not for latency)
+struct Win2 {
   const uint32_t* row;
-  uint32_t d0, d1, d2;
-  unsigned wi;
+  uint32_t d0, d1;
 };
-PD_HD void w3_open(Win3& r, const uint8_t* buf, unsigned pos) {
+PD_HD void w2_load(Win2& r, unsigned pos) {                // (pos <= kFastLimit + 47: the second word is <= 4 bytes past the row)
+  const uint32_t* p = r.row + (pos >> 5);
+  r.d0 = PD_ROW_BE(p[0]);
+  r.d1 = PD_ROW_BE(p[1]);
+}
+PD_HD void w2_open(Win2& r, const uint8_t* buf, unsigned pos) {
   r.row = reinterpret_cast<const uint32_t*>(buf);
-  r.wi = pos >> 5;
-  if (r.wi > kFastLimit / 32) r.wi = kFastLimit / 32;      // (a position out there is never read through the window)
-  r.d0 = __builtin_bswap32(r.row[r.wi]);
-  r.d1 = __builtin_bswap32(r.row[r.wi + 1]);
-  r.d2 = __builtin_bswap32(r.row[r.wi + 2]);
+  w2_load(r, pos <= kFastLimit ? pos : kFastLimit);        // (a position out there is never read through the window)
 }
 
 // what the loop needs of the side info, per lane
-struct SymPlan {                 // (scalars, not arrays: the compiler moves a struct with arrays to LDS and the loop reads it from there)
-  int base0, base1, base2;       // first-level table of the region's book, -1: none
-  unsigned lin0, lin1, lin2;
+struct SymPlan {
+  unsigned tab0, tab1, tab2;     // per region: first-level table of its book (kZeroBook's: no code words) | linbits << 16
   unsigned qbase;                // count1 book
   unsigned e0, e1, nbig;         // line where region 0 / 1 / the pairs end
   unsigned end;                  // last bit of the granule-channel
 };
+PD_HD int plan_base(unsigned tab, unsigned zero_base) { return (tab & 0xffffu) == zero_base ? -1 : (int)(tab & 0xffffu); }   // as the byte-wise forms want it
 struct SymState {
   unsigned pos;                  // bit position
   unsigned line;
@@ -354,46 +361,38 @@ PD_HD bool sym_active(unsigned nbig, unsigned end, const SymState& s) {
 // one symbol: `w` at s.pos (wi == s.pos >> 5), active lane
 // (the plan as separate values: handed over as a struct the device compiler keeps it in memory and turns the selects
 // below into loads from a selected address, at the head of every trip's dependent chain)
-PD_HD SymRec unpack_step(const uint32_t* lut, int base0, int base1, int base2, unsigned lin0, unsigned lin1, unsigned lin2,
-                         unsigned qbase, unsigned e0, unsigned e1, unsigned nbig, SymState& s, Win3& w) {
-  const uint32_t n0 = w.row[w.wi + 3], n1 = w.row[w.wi + 4];
+// `act` false: the lane is through (or not there): it looks at the zero book, takes no bits, stays where it is and its
+// record says "zeroes" -- no branch around the step, whose bookkeeping would cost more than the step's idle lanes
+PD_HD SymRec unpack_step(const uint32_t* lut, unsigned tab0, unsigned tab1, unsigned tab2, unsigned qbase, unsigned ztab,
+                         unsigned e0, unsigned e1, unsigned nbig, bool act, SymState& s, Win2& w) {
   const bool pair = s.line < nbig;
-  const int base_p = s.line < e0 ? base0 : s.line < e1 ? base1 : base2;
-  const unsigned lin_p = s.line < e0 ? lin0 : s.line < e1 ? lin1 : lin2;
-  const int base = pair ? base_p : (int)qbase;
-  const unsigned lin = pair ? lin_p : 0u;
-  const bool none = base < 0;
-  const uint32_t bits = (uint32_t)(((((uint64_t)w.d0) << 32) | w.d1) >> (32 - (s.pos & 31)));   // (32 - s is 1..32)
-  const unsigned i1 = (none ? 0u : (unsigned)base) + (bits >> (32 - kHuffFirstBits));
+  const unsigned tab_p = s.line < e0 ? tab0 : s.line < e1 ? tab1 : tab2;
+  const unsigned tab_a = pair ? tab_p : qbase;             // (linbits 0 in the upper half)
+  const unsigned tab = act ? tab_a : ztab;
+  const unsigned lin = tab >> 16;
+  const uint32_t bits = (uint32_t)((((((uint64_t)w.d0) << 32) | w.d1) << (s.pos & 31)) >> 32);
+  const unsigned i1 = (tab & 0xffffu) + (bits >> (32 - kHuffFirstBits));
   const uint32_t l1 = lut[i1];
   // second level: books deeper than 8 bits; sub_bits is 1..11.  Unconditional -- some lane of the 64 needs it in
   // nearly every trip, and a branch around it only adds its own cost
   const bool link = (l1 & 0x80000000u) != 0;
   const unsigned sb = link ? (l1 >> 24) & 0x1f : 1u;
   const unsigned i2 = link ? (l1 & 0xffffffu) + ((bits << kHuffFirstBits) >> (32 - sb)) : i1;
-  const uint32_t l2 = lut[i2];
-  const uint32_t e = none ? 0u : l2;
+  const uint32_t e = lut[i2];
   SymRec rec;
-  rec.x = s.pos | (pair ? 0u : 1u << 15) | ((none ? kRecNopLine : s.line) << 16) | (lin << 26);
+  rec.x = s.pos | (pair ? 0u : 1u << 15) | (s.line << 16) | (lin << 26);
   rec.y = e;
   s.pos += leaf_adv(e) + PD_MUL24(leaf_nlin(e), lin);
-  s.line += pair ? 2u : 4u;
-  // the window follows
-  const unsigned nwi = s.pos >> 5, k = nwi - w.wi;
-  const uint32_t s0 = __builtin_bswap32(n0), s1 = __builtin_bswap32(n1);
-  const uint32_t a0 = k == 1 ? w.d1 : w.d2, a1 = k == 1 ? w.d2 : s0, a2 = k == 1 ? s0 : s1;
-  w.d0 = k ? a0 : w.d0;
-  w.d1 = k ? a1 : w.d1;
-  w.d2 = k ? a2 : w.d2;
-  w.wi = nwi;
+  s.line += act ? (pair ? 2u : 4u) : 0u;
+  w2_load(w, s.pos);
   return rec;
 }
 
 // values and signs of a record's symbol, stored to the lines of its granule-channel
 PD_HD void unpack_value(const uint8_t* row, const SymRec rec, int16_t* is) {
   const unsigned line = (rec.x >> 16) & 0x3ff;
-  if (line >= 576) return;
   const uint32_t e = rec.y;
+  if (line >= 576 || e == 0) return;                       // (e == 0: zeroes, and the lines are zero)
   const unsigned linbits = (rec.x >> 26) & 15;
   BitPos b{row, rec.x & 0x7fffu};
   uint64_t w = peek64(b) << leaf_clen(e);                  // what follows the code word: <= 28 bits are looked at
@@ -505,10 +504,9 @@ PD_HD bool unpack_head(const UnpackTables& U, const uint8_t* res, const pdmp3_fr
   if (P.e1 < P.e0) P.e1 = P.e0;
   {
     const int b0 = U.book_of_table[s.table_select[0]], b1 = U.book_of_table[s.table_select[1]], b2 = U.book_of_table[s.table_select[2]];
-    P.base0 = b0 < 0 ? -1 : (int)U.book_base[b0];
-    P.base1 = b1 < 0 ? -1 : (int)U.book_base[b1];
-    P.base2 = b2 < 0 ? -1 : (int)U.book_base[b2];
-    P.lin0 = U.linbits[s.table_select[0]]; P.lin1 = U.linbits[s.table_select[1]]; P.lin2 = U.linbits[s.table_select[2]];
+    P.tab0 = U.book_base[b0 < 0 ? kZeroBook : b0] | (unsigned)U.linbits[s.table_select[0]] << 16;
+    P.tab1 = U.book_base[b1 < 0 ? kZeroBook : b1] | (unsigned)U.linbits[s.table_select[1]] << 16;
+    P.tab2 = U.book_base[b2 < 0 ? kZeroBook : b2] | (unsigned)U.linbits[s.table_select[2]] << 16;
   }
   // count1 region: table 32 or the reference's mis-pointed table 33 (H1); both books are <= 8 bits deep
   P.qbase = U.book_base[U.book_of_table[32 + s.count1table_select]];
@@ -518,11 +516,15 @@ PD_HD bool unpack_head(const UnpackTables& U, const uint8_t* res, const pdmp3_fr
 }
 
 // after the symbol loop, once every record's lines are stored
-PD_HD void unpack_tail(const uint32_t* lut, const uint8_t* res, const SymPlan& P, SymState st, int16_t* spectra_gc, GcRaw* raw) {
+PD_HD void unpack_tail(const UnpackTables& U, const uint32_t* lut, const uint8_t* res, const SymPlan& P, SymState st, int16_t* spectra_gc,
+                       GcRaw* raw) {
   BitPos b{res, st.pos};
   unsigned pos = st.line;
-  if (pos < P.nbig)
-    pos = unpack_pairs_slow(lut, b, P.base0, P.base1, P.base2, P.lin0, P.lin1, P.lin2, P.e0, P.e1, P.nbig, pos, spectra_gc);
+  if (pos < P.nbig) {
+    const unsigned z = U.book_base[kZeroBook];
+    pos = unpack_pairs_slow(lut, b, plan_base(P.tab0, z), plan_base(P.tab1, z), plan_base(P.tab2, z), P.tab0 >> 16, P.tab1 >> 16,
+                            P.tab2 >> 16, P.e0, P.e1, P.nbig, pos, spectra_gc);
+  }
   if (pos <= 572 && b.pos <= P.end) pos = unpack_quads_slow(lut, b, P.qbase, P.end, pos, spectra_gc);
   // Overshoot: the reference takes the last four lines back (P:2106-2108) -- the last quad, or, when no quad
   // was read, the last two PAIRS -- and zero-fills from there.  (pos < 4 wraps like the reference's unsigned:
@@ -542,11 +544,11 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
   SymPlan P;
   SymState st;
   if (!unpack_head(U, res, F, g, rec, raw, P, st)) return;
-  Win3 w;
-  w3_open(w, res, st.pos);
+  Win2 w;
+  w2_open(w, res, st.pos);
   while (sym_active(P.nbig, P.end, st))
-    unpack_value(res, unpack_step(lut, P.base0, P.base1, P.base2, P.lin0, P.lin1, P.lin2, P.qbase, P.e0, P.e1, P.nbig, st, w), spectra_gc);
-  unpack_tail(lut, res, P, st, spectra_gc, raw);
+    unpack_value(res, unpack_step(lut, P.tab0, P.tab1, P.tab2, P.qbase, U.book_base[kZeroBook], P.e0, P.e1, P.nbig, true, st, w), spectra_gc);
+  unpack_tail(U, lut, res, P, st, spectra_gc, raw);
 }
 
 // ---------------------------------------------------------------------------
