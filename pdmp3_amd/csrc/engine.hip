@@ -122,14 +122,14 @@ constexpr int kFrameBitsW = sizeof(pdmp3_frame_bits) / 4;   // 20
 // per symbol and lane in the ring; WAVES 1-3 take turns with the ring's rows (row i belongs to wave 1 + i % 3), read
 // linbits and signs and store the lines (unpack_value).  Round 2's single loop did all of it in wave 0, a loop per
 // symbol kind: 406 trips of ~700 cycles per window, 140 us; this one: <= 288 trips of the walker's half.
-// The lines go straight to HBM: the workgroup zeroes its 16 frames' spectra with coalesced stores first (a barrier
-// later, so the zeroes are there before any wave stores a line).
+// The lines go straight to HBM, into spectra that two of the value waves zero with coalesced stores first.
 constexpr int kRingRows = 32;                              // trips the walker may be ahead of the value waves
 constexpr int kRingCheck = 8;                              // ... looked at every so many trips
 static_assert(kRingRows % kRingCheck == 0 && kRingCheck >= 3, "blocks of trips do not wrap around the ring");
 struct UnpackRing {
   SymRec rec[kRingRows][kUnpackLanes];                     // tag (trip / kRingRows) & 3 in bits 30-31 of .x: the row is of THIS turn
   unsigned next[3];                                        // value wave c: the first trip it has not taken yet
+  unsigned zeroed;                                         // value waves 2 and 3: my half of the pass's spectra is zero
 };
 typedef unsigned ring_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ring_u32x2 ring_load(const SymRec* p) {
@@ -143,7 +143,7 @@ __device__ __forceinline__ void ring_store(SymRec* p, uint32_t x, uint32_t y) {
 
 __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* tabs, const pdmp3_frame_bits* bits,
                                                             const uint8_t* res, int n_frames, int16_t* spectra,
-                                                            pdmp3_gc_side* side, GcRaw* raw, unsigned long long* prof) {
+                                                            pdmp3_gc_side* side, GcRaw* raw, int tab_n16, unsigned long long* prof) {
   __shared__ UnpackTables U;
   __shared__ uint32_t rows[kUnpackRows * kRowStrideW + 4];
   __shared__ uint32_t fbits[kUnpackRows * kFrameBitsW];
@@ -151,29 +151,42 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
   // development only (PDMP3_HIP_UNPACK_PROF=1): s_memtime of workgroup's wave 0 at the steps of its first pass
 #define PD_UP_STAMP(k) do { if (prof && threadIdx.x == 0) prof[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
   PD_UP_STAMP(0);
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(tabs);
-    uint4* dst = reinterpret_cast<uint4*>(&U);
-    const int n16 = (int)((offsetof(UnpackTables, lut) + (size_t)tabs->n_lut * 4 + 15) / 16);
-    for (int i = threadIdx.x; i < n16; i += kUnpackThreads) dst[i] = src[i];
-  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int fl = lane >> 2, g = lane & 3;                  // the granule-channel of this lane, in every wave
+  bool first = true;
   for (int f0 = blockIdx.x * kUnpackRows; f0 < n_frames; f0 += gridDim.x * kUnpackRows) {
     const int nrows = n_frames - f0 < kUnpackRows ? n_frames - f0 : kUnpackRows;
-    __syncthreads();                                       // (previous pass done with the buffers; first pass: U complete)
+    if (!first) __syncthreads();                           // (previous pass done with the buffers)
     {
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(res + (size_t)f0 * kRowBytes);
-      for (int i = threadIdx.x; i < nrows * (kRowBytes / 4); i += kUnpackThreads) {
-        const int r = i / (kRowBytes / 4), c = i - r * (kRowBytes / 4);
-        rows[r * kRowStrideW + c] = __builtin_bswap32(src[i]);       // (unpack_core.h PD_ROW_BE: big-endian words as numbers)
+      // the pass's rows, 16 bytes per lane and trip, all asked for before the tables (first pass) so that the two
+      // round trips to HBM overlap
+      constexpr int kRow16 = kRowBytes / 16, kRowTrips = (kUnpackRows * kRow16 + kUnpackThreads - 1) / kUnpackThreads;
+      static_assert(kRowBytes % 16 == 0, "rows are copied 16 bytes at a time");
+      const uint4* src = reinterpret_cast<const uint4*>(res + (size_t)f0 * kRowBytes);
+      uint4 rv[kRowTrips];
+      PD_UNROLL for (int k = 0; k < kRowTrips; ++k) {
+        const int i = (int)threadIdx.x + k * kUnpackThreads;
+        if (i < nrows * kRow16) rv[k] = src[i];
+      }
+      if (first) {
+        const uint4* tsrc = reinterpret_cast<const uint4*>(tabs);
+        uint4* dst = reinterpret_cast<uint4*>(&U);
+        for (int i = threadIdx.x; i < tab_n16; i += kUnpackThreads) dst[i] = tsrc[i];
+      }
+      PD_UNROLL for (int k = 0; k < kRowTrips; ++k) {
+        const int i = (int)threadIdx.x + k * kUnpackThreads;
+        if (i < nrows * kRow16) {
+          const int r = i / kRow16, c = i - r * kRow16;
+          uint32_t* d = rows + r * kRowStrideW + 4 * c;    // (unpack_core.h PD_ROW_BE: big-endian words as numbers)
+          d[0] = __builtin_bswap32(rv[k].x); d[1] = __builtin_bswap32(rv[k].y);
+          d[2] = __builtin_bswap32(rv[k].z); d[3] = __builtin_bswap32(rv[k].w);
+        }
       }
       const uint32_t* fsrc = reinterpret_cast<const uint32_t*>(bits + f0);
       for (int i = threadIdx.x; i < nrows * kFrameBitsW; i += kUnpackThreads) fbits[i] = fsrc[i];
-      uint4* z = reinterpret_cast<uint4*>(spectra + (size_t)f0 * 4 * 576);
-      for (int i = threadIdx.x; i < nrows * 4 * 72; i += kUnpackThreads) z[i] = make_uint4(0, 0, 0, 0);
       for (int i = threadIdx.x; i < kRingRows * kUnpackLanes; i += kUnpackThreads) (&ring.rec[0][0])[i].x = 3u << 30;   // "the turn before trip 0"
       if (threadIdx.x < 3) ring.next[threadIdx.x] = threadIdx.x;
+      if (threadIdx.x == 3) ring.zeroed = 0;
     }
     __syncthreads();
     PD_UP_STAMP(1);
@@ -185,8 +198,7 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
     bool live = false;
     if (wave == 0) {
       // ---- the walker
-      if (fl < nrows)
-        live = unpack_head(U, row, *reinterpret_cast<const pdmp3_frame_bits*>(fbits + fl * kFrameBitsW), g, side + idx, raw + idx, P, st);
+      if (fl < nrows) live = unpack_plan(U, *reinterpret_cast<const pdmp3_frame_bits*>(fbits + fl * kFrameBitsW), g, P, st);
       PD_UP_STAMP(2);
       Win2 w;
       w2_open(w, row, live ? st.pos : 0u);
@@ -218,7 +230,21 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
       for (int k = 0; k < 3; ++k)                          // one end row per value wave (the block's room was checked)
         ring_store(&ring.rec[(trip + k) % kRingRows][lane], (kRecNopLine << 16) | (((trip + k) / kRingRows) & 3u) << 30, kRecEnd);
     } else {
-      // ---- a value wave: rows wave - 1, wave + 2, ...
+      // ---- a value wave: rows wave - 1, wave + 2, ...  The first one writes the records' side fields and scalefactors
+      // before it joins in (the ring holds what the walker produces meanwhile; the other two are taking rows out already)
+      // and the other two zero the pass's spectra (lines are stored only where the stream has any) -- all of it beside
+      // the walker's first trips instead of in front of them
+      if (wave == 1) {
+        if (fl < nrows)
+          unpack_records(U, row, *reinterpret_cast<const pdmp3_frame_bits*>(fbits + fl * kFrameBitsW), g, side + idx, raw + idx);
+      } else {
+        uint4* z = reinterpret_cast<uint4*>(spectra + (size_t)f0 * 4 * 576);
+        for (int i = (int)threadIdx.x - 128; i < nrows * 4 * 72; i += 128) z[i] = make_uint4(0, 0, 0, 0);
+        PD_VMEM_DRAIN();                                   // the zeroes have arrived before any wave stores a line
+        if (lane == 0) atomicAdd(&ring.zeroed, 1u);
+      }
+      while (PD_UNIFORM(PD_LDS_FLAG(&ring.zeroed)) < 2) PD_SLEEP();
+      asm volatile("" ::: "memory");
       for (unsigned trip = (unsigned)wave - 1;; trip += 3) {
         const SymRec* slot = &ring.rec[trip % kRingRows][lane];
         const unsigned tag = (trip / kRingRows) & 3u;
@@ -233,10 +259,11 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
         unpack_value(row, SymRec{r.x, r.y}, is);
       }
     }
-    __syncthreads();                                       // every line of every record is stored
+    __syncthreads();                                       // every line of every record is stored, and wave 1's part of `raw`
     PD_UP_STAMP(4);
     if (wave == 0 && live) unpack_tail(U, U.lut, row, P, st, is, raw + idx);
     PD_UP_STAMP(5);
+    first = false;
   }
 #undef PD_UP_STAMP
 }
@@ -329,6 +356,7 @@ struct pdmp3_hip_ctx {
   int device;
   int wave_slots;           // waves of k_decode the device holds at once (CUs x 4 SIMDs x 2)
   UnpackTables* d_unpack;
+  int unpack_n16;                // its used part, in 16-byte units
   unsigned long long* d_uprof;   // development only: PDMP3_HIP_UNPACK_PROF=1
   float* d_pow43;
   uint16_t* d_linetab;
@@ -434,6 +462,7 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     CREATE_STEP(hipMemcpy(c->d_frag + 28 * 64, H.taps.data(), 16 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload taps")
     CREATE_STEP(hipMemcpy(c->d_tab_image, H.tab_image.data(), 3 * sizeof(TabLds), hipMemcpyHostToDevice), "upload table images")
     CREATE_STEP(hipMemcpy(c->d_unpack, U, sizeof(UnpackTables), hipMemcpyHostToDevice), "upload unpack tables")
+    c->unpack_n16 = (int)((offsetof(UnpackTables, lut) + (size_t)U->n_lut * 4 + 15) / 16);
     CREATE_STEP(hipDeviceSynchronize(), "sync after uploads")
   } while (0);
 #undef CREATE_STEP
@@ -993,7 +1022,7 @@ static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_
     int blocks = (n_frames + kUnpackRows - 1) / kUnpackRows;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(kUnpackThreads), 0, t.stream, hs->ctx->d_unpack, t.d_bits, t.d_res,
-                       n_frames, t.d_spectra, t.d_side, t.d_raw, hs->ctx->d_uprof);
+                       n_frames, t.d_spectra, t.d_side, t.d_raw, hs->ctx->unpack_n16, hs->ctx->d_uprof);
     HIP_TRY(hipGetLastError(), "launch k_unpack");
     if (hs->ctx->d_uprof) {                            // development only: serialises, prints one line per launch
       static std::vector<unsigned long long> hp(2048 * 8);

@@ -422,17 +422,30 @@ PD_HD void unpack_value(const uint8_t* row, const SymRec rec, int16_t* is) {
 }
 
 // ---------------------------------------------------------------------------
-// one granule-channel = unpack_head (side fields, scalefactors, the plan of the symbol loop)
+// one granule-channel = unpack_records (side fields and scalefactors into the records)
+//                     + unpack_plan    (where the Huffman data starts and what the symbol loop needs: side info only)
 //                     + the symbol loop (host: unpack_gc below; device: k_unpack)
-//                     + unpack_tail (byte-wise rest on corrupt streams, the overshoot rule, count1)
+//                     + unpack_tail    (byte-wise rest on corrupt streams, the overshoot rule, count1)
+// The first two do not depend on each other -- the scalefactors' widths are in the side info, so the position behind
+// them is too -- and k_unpack gives them to different waves: the walker starts on the symbols at once.
 // `spectra_gc` (576 int16) must be zero on entry.  `rec` and `raw` are fully written.
 // ---------------------------------------------------------------------------
-// false: no Huffman data (channel absent, or part2_3_length == 0: spectra stay zero, count1 keeps its old value, H6)
-PD_HD bool unpack_head(const UnpackTables& U, const uint8_t* res, const pdmp3_frame_bits& F, int g, pdmp3_gc_side* rec,
-                       GcRaw* raw, SymPlan& P, SymState& st) {
+// bit position of granule-channel g's part 2: every one before it ends at start + part2_3_length -- or, when that is
+// zero, right after its scalefactors (P:2062: Read_Huffman returns before touching the position)
+PD_HD unsigned part2_start_of(const UnpackTables& U, const pdmp3_frame_bits& F, int g, int nch) {
+  unsigned pos = 0;
+  for (int q = 0; q < g; q++) {
+    if ((q & 1) >= nch) continue;
+    const unsigned p23 = F.gc[q].part2_3_length;
+    pos += p23 ? p23 : part2_bits(U, F, q >> 1, q & 1);
+  }
+  return pos;
+}
+
+PD_HD void unpack_records(const UnpackTables& U, const uint8_t* res, const pdmp3_frame_bits& F, int g, pdmp3_gc_side* rec,
+                          GcRaw* raw) {
   const int gr = g >> 1, ch = g & 1;
   const int nch = ((F.frame & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
-  const int sfreq = (F.frame & PDMP3_FR_SFREQ_MASK) > 2 ? 2 : (F.frame & PDMP3_FR_SFREQ_MASK);
   {
     uint32_t* r32 = reinterpret_cast<uint32_t*>(rec);
     for (int i = 0; i < 32; i++) r32[i] = 0;
@@ -440,24 +453,15 @@ PD_HD bool unpack_head(const UnpackTables& U, const uint8_t* res, const pdmp3_fr
     for (int i = 0; i < 20; i++) w32[i] = 0;
   }
   rec->frame = F.frame & (uint8_t)~PDMP3_FR_NEWSTREAM;
-  if (ch >= nch) return false;
+  if (ch >= nch) return;
   const pdmp3_gc_bits& s = F.gc[g];
   rec->global_gain = s.global_gain;
   rec->flags = s.flags;
   rec->subblock_gain[0] = s.subblock_gain[0]; rec->subblock_gain[1] = s.subblock_gain[1]; rec->subblock_gain[2] = s.subblock_gain[2];
   if (g == 3) rec->scalefac_s[12][0] = rec->scalefac_s[12][1] = rec->scalefac_s[12][2] = PDMP3_SF_PEEK;
 
-  // where this granule-channel starts: every one before it ends at start + part2_3_length -- or, when that is
-  // zero, right after its scalefactors (P:2062: Read_Huffman returns before touching the position)
-  BitPos b{res, 0};
-  for (int q = 0; q < g; q++) {
-    if ((q & 1) >= nch) continue;
-    const unsigned p23 = F.gc[q].part2_3_length;
-    b.pos += p23 ? p23 : part2_bits(U, F, q >> 1, q & 1);
-  }
-  const unsigned part2_start = b.pos;
-
   // ---- scalefactors (P:1383-1430)
+  BitPos b{res, part2_start_of(U, F, g, nch)};
   const unsigned slen1 = U.slen[s.scalefac_compress * 2], slen2 = U.slen[s.scalefac_compress * 2 + 1];
   const bool wsf = (s.flags & PDMP3_GC_WIN_SWITCH) != 0;
   const unsigned bt = (s.flags & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT;
@@ -486,9 +490,20 @@ PD_HD bool unpack_head(const UnpackTables& U, const uint8_t* res, const pdmp3_fr
     raw->sf_l_set = set;
     raw->sf_l_copy = (uint8_t)copy;
   }
+}
 
-  // ---- Huffman (P:2051-2115): the plan
+// false: no Huffman data (channel absent, or part2_3_length == 0: spectra stay zero, count1 keeps its old value, H6)
+PD_HD bool unpack_plan(const UnpackTables& U, const pdmp3_frame_bits& F, int g, SymPlan& P, SymState& st) {
+  const int gr = g >> 1, ch = g & 1;
+  const int nch = ((F.frame & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
+  const int sfreq = (F.frame & PDMP3_FR_SFREQ_MASK) > 2 ? 2 : (F.frame & PDMP3_FR_SFREQ_MASK);
+  if (ch >= nch) return false;
+  const pdmp3_gc_bits& s = F.gc[g];
   if (s.part2_3_length == 0) return false;
+  const unsigned part2_start = part2_start_of(U, F, g, nch);
+  const bool wsf = (s.flags & PDMP3_GC_WIN_SWITCH) != 0;
+  const unsigned bt = (s.flags & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT;
+  // ---- Huffman (P:2051-2115)
   P.end = part2_start + s.part2_3_length - 1;
   unsigned r1, r2;
   if (wsf && bt == 2) { r1 = 36; r2 = 576; }
@@ -510,7 +525,7 @@ PD_HD bool unpack_head(const UnpackTables& U, const uint8_t* res, const pdmp3_fr
   }
   // count1 region: table 32 or the reference's mis-pointed table 33 (H1); both books are <= 8 bits deep
   P.qbase = U.book_base[U.book_of_table[32 + s.count1table_select]];
-  st.pos = b.pos;
+  st.pos = part2_start + part2_bits(U, F, gr, ch);
   st.line = 0;
   return true;
 }
@@ -543,7 +558,8 @@ PD_HD void unpack_gc(const UnpackTables& U, const uint32_t* lut, const uint8_t* 
                      int16_t* spectra_gc, pdmp3_gc_side* rec, GcRaw* raw) {
   SymPlan P;
   SymState st;
-  if (!unpack_head(U, res, F, g, rec, raw, P, st)) return;
+  unpack_records(U, res, F, g, rec, raw);
+  if (!unpack_plan(U, F, g, P, st)) return;
   Win2 w;
   w2_open(w, res, st.pos);
   while (sym_active(P.nbig, P.end, st))
