@@ -44,10 +44,16 @@
 /* ------------------------------------------------------------------------ */
 #define HL_BITS 10
 typedef struct {
-  uint16_t first[1 << HL_BITS];   /* len<<8 | val   or   0x8000 | subtable index */
-  uint16_t* sub;                  /* subtables of 1 << sub_bits entries: len<<8 | val (len = bits beyond HL_BITS) */
+  uint16_t first[1 << HL_BITS];   /* adv<<8 | val   or   0x8000 | subtable index */
+  uint16_t* sub;                  /* subtables of 1 << sub_bits entries: adv<<8 | val */
   int sub_bits;
+  int quads;                      /* count1 book: val = v w x y */
 } huff_lut;
+/* adv = bits of the whole code word + one sign bit per value != 0: what a symbol without linbits takes in all, so that
+ * the position of the next symbol -- the loop's dependent chain -- is one table lookup and one add away */
+static inline unsigned leaf_nsign(int quads, unsigned val) {
+  return quads ? (val & 1) + (val >> 1 & 1) + (val >> 2 & 1) + (val >> 3 & 1) : (unsigned)((val >> 4) != 0) + (unsigned)((val & 15) != 0);
+}
 
 static huff_lut g_lut[PDMP3_NUM_HUFF_BOOKS];
 static pthread_once_t g_lut_once = PTHREAD_ONCE_INIT;
@@ -60,6 +66,7 @@ static void build_luts(void) {
     int maxlen = 0;
     for (int i = 0; i < n; i++) if (codes[i].len > maxlen) maxlen = codes[i].len;
     L->sub_bits = maxlen > HL_BITS ? maxlen - HL_BITS : 0;
+    L->quads = b == kHuffBookOfTable[32] || b == kHuffBookOfTable[33];
     int nsub = 0;
     memset(L->first, 0, sizeof L->first);
     for (int i = 0; i < n; i++) {
@@ -74,7 +81,7 @@ static void build_luts(void) {
       const uint16_t val = codes[i].err ? 0 : codes[i].val;
       if (len <= HL_BITS) {
         const uint32_t base = codes[i].code << (HL_BITS - len);
-        for (uint32_t k = 0; k < (1u << (HL_BITS - len)); k++) L->first[base + k] = (uint16_t)((len << 8) | val);
+        for (uint32_t k = 0; k < (1u << (HL_BITS - len)); k++) L->first[base + k] = (uint16_t)(((len + leaf_nsign(L->quads, val)) << 8) | val);
       } else {
         const uint32_t prefix = codes[i].code >> (len - HL_BITS);
         const int si = L->first[prefix] & 0x7fff;
@@ -82,7 +89,7 @@ static void build_luts(void) {
         const uint32_t rest = codes[i].code & ((1u << extra) - 1);
         const uint32_t base = rest << (L->sub_bits - extra);
         for (uint32_t k = 0; k < (1u << (L->sub_bits - extra)); k++)
-          L->sub[((size_t)si << L->sub_bits) + base + k] = (uint16_t)((extra << 8) | val);
+          L->sub[((size_t)si << L->sub_bits) + base + k] = (uint16_t)(((len + leaf_nsign(L->quads, val)) << 8) | val);
       }
     }
   }
@@ -546,11 +553,9 @@ static inline unsigned huff_symbol(bitreader* b, int book) {
   unsigned e = L->first[w >> (32 - HL_BITS)];
   if (e & 0x8000) {
     const unsigned rest = (w << HL_BITS) >> (32 - L->sub_bits);
-    const unsigned e2 = L->sub[((size_t)(e & 0x7fff) << L->sub_bits) + rest];
-    b->bitpos += HL_BITS + (e2 >> 8);
-    return e2 & 0xff;
+    e = L->sub[((size_t)(e & 0x7fff) << L->sub_bits) + rest];
   }
-  b->bitpos += e >> 8;
+  b->bitpos += (e >> 8) - leaf_nsign(L->quads, e & 0xff);     /* the code word alone: the caller reads the signs */
   return e & 0xff;
 }
 
@@ -572,7 +577,50 @@ static inline uint64_t peek64(const bitreader* b) {           /* >= 57 valid bit
   return __builtin_bswap64(w) << (b->bitpos & 7);
 }
 
-/* pairs [pos, end) of one region.  A pair is at most 19 + 2 * (13 + 1) = 47 bits: one window per pair. */
+/* pairs [pos, end) of one region.  A pair is at most 19 + 2 * (13 + 1) = 47 bits: one window per pair.
+ * The body is branch-free apart from the second-level lookup: on dense material "is x zero", "is it negative" are
+ * coin flips, and three mispredicted branches per pair were most of this loop's time (7 us per 320 kbps frame).
+ * `lin` is a compile-time flag: the tables without linbits (1-15) get a loop without the linbits arithmetic. */
+static inline __attribute__((always_inline)) unsigned decode_pairs_body(bitreader* b, const huff_lut* L, int book, unsigned linbits,
+                                                                        const int lin, unsigned pos, unsigned end, int16_t* is) {
+  for (; pos < end; pos += 2) {
+    int x, y;
+    if (__builtin_expect(b->bitpos <= FAST_LIMIT, 1)) {
+      const uint64_t w = peek64(b);
+      unsigned e = L->first[w >> (64 - HL_BITS)];
+      if (__builtin_expect(e & 0x8000, 0)) {
+        const unsigned rest = (unsigned)((w << HL_BITS) >> (64 - L->sub_bits));
+        e = L->sub[((size_t)(e & 0x7fff) << L->sub_bits) + rest];
+      }
+      if (!lin) b->bitpos += e >> 8;               /* (the next pair's window does not wait for the values) */
+      x = (e >> 4) & 15; y = e & 15;
+      uint64_t v = w << ((e >> 8) - (x != 0) - (y != 0));   /* what follows the code word: <= 28 bits are looked at */
+      unsigned lx = 0, ly = 0;
+      if (lin) {                                   /* ((v >> 1) >> (63 - n)) == v >> (64 - n) for n = 1..63 and 0 for n = 0 */
+        lx = x == 15 ? linbits : 0;
+        x += (int)((v >> 1) >> (63 - lx));
+        v <<= lx;
+      }
+      const unsigned nzx = x != 0;
+      const int sx = (int)(v >> 63) & (int)nzx;    /* a sign bit follows a value != 0 */
+      x = (x ^ -sx) + sx;
+      v <<= nzx;
+      if (lin) {
+        ly = y == 15 ? linbits : 0;
+        y += (int)((v >> 1) >> (63 - ly));
+        v <<= ly;
+      }
+      const unsigned nzy = y != 0;
+      const int sy = (int)(v >> 63) & (int)nzy;
+      y = (y ^ -sy) + sy;
+      if (lin) b->bitpos += (e >> 8) + lx + ly;
+    } else pair_slow(b, book, linbits, &x, &y);
+    if (pos < 576) is[pos] = (int16_t)x;           /* big_values > 288 is not checked by the reference (H8) */
+    if (pos + 1 < 576) is[pos + 1] = (int16_t)y;
+  }
+  return pos;
+}
+
 static unsigned decode_pairs(bitreader* b, unsigned tn, unsigned pos, unsigned end, int16_t* is) {
   const int book = kHuffBookOfTable[tn];
   if (book < 0) {                                  /* table 0 (and the unused 4, 14): no bits, zeros */
@@ -582,29 +630,9 @@ static unsigned decode_pairs(bitreader* b, unsigned tn, unsigned pos, unsigned e
     }
     return pos;
   }
-  const huff_lut* L = &g_lut[book];
   const unsigned linbits = kHuffLinbits[tn];
-  for (; pos < end; pos += 2) {
-    int x, y;
-    if (__builtin_expect(b->bitpos <= FAST_LIMIT, 1)) {
-      const uint64_t w = peek64(b);
-      unsigned e = L->first[w >> (64 - HL_BITS)], used;
-      if (e & 0x8000) {
-        const unsigned rest = (unsigned)((w << HL_BITS) >> (64 - L->sub_bits));
-        e = L->sub[((size_t)(e & 0x7fff) << L->sub_bits) + rest];
-        used = HL_BITS + (e >> 8);
-      } else used = e >> 8;
-      x = (e >> 4) & 15; y = e & 15;
-      if (linbits && x == 15) { x += (int)((w << used) >> (64 - linbits)); used += linbits; }
-      if (x) { if ((w << used) >> 63) x = -x; used++; }
-      if (linbits && y == 15) { y += (int)((w << used) >> (64 - linbits)); used += linbits; }
-      if (y) { if ((w << used) >> 63) y = -y; used++; }
-      b->bitpos += used;
-    } else pair_slow(b, book, linbits, &x, &y);
-    if (pos < 576) is[pos] = (int16_t)x;           /* big_values > 288 is not checked by the reference (H8) */
-    if (pos + 1 < 576) is[pos + 1] = (int16_t)y;
-  }
-  return pos;
+  return linbits ? decode_pairs_body(b, &g_lut[book], book, linbits, 1, pos, end, is)
+                 : decode_pairs_body(b, &g_lut[book], book, 0, 0, pos, end, is);
 }
 
 /* P:2051-2115 */
@@ -651,13 +679,15 @@ static void decode_huffman(bitreader* b, const frame_header* H, const side_info*
     if (__builtin_expect(b->bitpos <= FAST_LIMIT && Q->sub_bits == 0, 1)) {
       const uint64_t w = peek64(b);
       const unsigned e = Q->first[w >> (64 - HL_BITS)];
-      unsigned used = e >> 8;
+      b->bitpos += e >> 8;
       leaf = e & 0xff;
-      for (int k = 0; k < 4; k++) {                /* v w x y */
-        q[k] = (int)(leaf >> (3 - k)) & 1;
-        if (q[k]) { if ((w << used) >> 63) q[k] = -1; used++; }
+      uint64_t v = w << ((e >> 8) - leaf_nsign(1, leaf));
+      for (int k = 0; k < 4; k++) {                /* v w x y, branch-free like the pairs */
+        const unsigned nz = (leaf >> (3 - k)) & 1;
+        const int sg = (int)(v >> 63) & (int)nz;
+        q[k] = ((int)nz ^ -sg) + sg;
+        v <<= nz;
       }
-      b->bitpos += used;
     } else {
       leaf = huff_symbol(b, qbook);
       for (int k = 0; k < 4; k++) {
