@@ -29,6 +29,7 @@
 #include <fcntl.h>
 #include <pthread.h>
 #include <sched.h>
+#include <stdatomic.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -177,6 +178,7 @@ struct pdmp3_handle {
   } ra[BATCH_MAX];
   int ra_head, ra_n, ra_inflight;  /* ra_inflight: the batch is still on the GPU */
   parse_snap ra_before[BATCH_MAX]; /* the parser as it was before each of these frames */
+  main_out ra_out[BATCH_MAX];      /* their decoded main data (the helpers of read_ahead write these) */
   /* engine */
   pdmp3_hip_stream* hs;
   int host_only;                   /* test hook: parse without an engine (no decode possible) */
@@ -963,8 +965,110 @@ static int ra_rollback(pdmp3_handle* id) {
   return rc;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Helpers for a read-ahead batch.  What is sequential in a frame -- ring,    */
+/* header, side info, bit reservoir -- is a fraction of a microsecond; its    */
+/* main data (scalefactors + Huffman, 4-5 us at 320 kbps) only needs the      */
+/* reservoir as that frame left it, and read_ahead has a copy of exactly that */
+/* per frame (the snapshots it keeps for undoing frames).  So a batch's main  */
+/* data is decoded by the caller AND a few helper threads, frame by frame off */
+/* one counter; the merge into the state that survives frames (apply_main)    */
+/* stays sequential.  The helpers are per process, started on first use, spin */
+/* for a short while after a batch (the next one is usually 50-100 us away)   */
+/* and then sleep.  PDMP3_STREAM_THREADS = helpers (default min(3, CPUs - 1); */
+/* 0: none).  A second handle that reads while the helpers are busy decodes   */
+/* its batch alone.                                                           */
+/* ------------------------------------------------------------------------ */
+#define HP_MAX 15
+typedef struct { const uint8_t* res; const frame_header* H; const side_info* S; main_out* out; } hp_job;
+static struct {
+  pthread_mutex_t own;             /* one batch at a time */
+  pthread_mutex_t m; pthread_cond_t cv;
+  int started, n, sleepers;
+  hp_job job[BATCH_MAX];
+  _Atomic uint64_t state;          /* batch number << 32 | frames of the batch << 16 | next frame: ONE word, so that a
+                                      helper that is late for a batch can never take a frame of it by the numbers of the next */
+  _Atomic int done;
+} g_hp = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, {{0, 0, 0, 0}}, 0, 0};
+
+static inline void hp_pause(void) {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  sched_yield();
+#endif
+}
+/* Takes frames until the current batch has none left; returns that batch's number.  Whatever the fetch-and-add
+ * returns IS a claim -- batch, frame count and index come out of one word -- also for a helper that arrives here
+ * still thinking of the batch before: it must decode the frame it drew, nobody else will. */
+static uint32_t hp_take(void) {
+  for (;;) {
+    const uint64_t v = atomic_fetch_add_explicit(&g_hp.state, 1, memory_order_acq_rel);
+    const uint32_t k = (uint32_t)(v & 0xffff), n = (uint32_t)(v >> 16 & 0xffff);
+    if (k >= n) return (uint32_t)(v >> 32);
+    const hp_job* j = &g_hp.job[k];
+    decode_main(j->res, j->H, j->S, j->out);
+    atomic_fetch_add_explicit(&g_hp.done, 1, memory_order_release);
+  }
+}
+static void* hp_worker(void* arg) {
+  (void)arg;
+  uint32_t seen = 0;
+  for (;;) {
+    int spins = 0;
+    while ((uint32_t)(atomic_load_explicit(&g_hp.state, memory_order_acquire) >> 32) == seen) {
+      if (++spins < 20000) { hp_pause(); continue; }          /* ~0.2-0.5 ms of looking, then sleep */
+      pthread_mutex_lock(&g_hp.m);
+      g_hp.sleepers++;
+      while ((uint32_t)(atomic_load_explicit(&g_hp.state, memory_order_acquire) >> 32) == seen) pthread_cond_wait(&g_hp.cv, &g_hp.m);
+      g_hp.sleepers--;
+      pthread_mutex_unlock(&g_hp.m);
+      spins = 0;
+    }
+    seen = hp_take();
+  }
+  return NULL;
+}
+static int usable_cpus(void);
+static void hp_start(void) {                                   /* (g_hp.own held) */
+  g_hp.started = 1;
+  const char* e = getenv("PDMP3_STREAM_THREADS");
+  int n = e ? atoi(e) : usable_cpus() - 1;
+  if (!e && n > 3) n = 3;
+  if (n > HP_MAX) n = HP_MAX;
+  for (int i = 0; i < n; i++) {
+    pthread_t t;
+    if (pthread_create(&t, NULL, hp_worker, NULL) != 0) break;
+    pthread_detach(t);
+    g_hp.n++;
+  }
+}
+/* decode_main of jobs[0..n) */
+static void hp_run(const hp_job* jobs, int n) {
+  if (n > 1 && pthread_mutex_trylock(&g_hp.own) == 0) {
+    if (!g_hp.started) hp_start();
+    if (g_hp.n > 0) {
+      memcpy(g_hp.job, jobs, (size_t)n * sizeof *jobs);
+      atomic_store_explicit(&g_hp.done, 0, memory_order_relaxed);
+      const uint32_t batch = (uint32_t)(atomic_load_explicit(&g_hp.state, memory_order_relaxed) >> 32) + 1;
+      atomic_store_explicit(&g_hp.state, (uint64_t)batch << 32 | (uint64_t)n << 16, memory_order_release);
+      pthread_mutex_lock(&g_hp.m);
+      if (g_hp.sleepers) pthread_cond_broadcast(&g_hp.cv);
+      pthread_mutex_unlock(&g_hp.m);
+      (void)hp_take();
+      while (atomic_load_explicit(&g_hp.done, memory_order_acquire) < n) hp_pause();
+      pthread_mutex_unlock(&g_hp.own);
+      return;
+    }
+    pthread_mutex_unlock(&g_hp.own);
+  }
+  for (int i = 0; i < n; i++) decode_main(jobs[i].res, jobs[i].H, jobs[i].S, jobs[i].out);
+}
+
 /* Parse the frame the reference parses now and, behind it, every frame that qualifies; send them to the engine.
- * Called with nothing read ahead (parser == logical view).  Returns the code of the FIRST frame's Read_Frame. */
+ * Called with nothing read ahead (parser == logical view).  Returns the code of the FIRST frame's Read_Frame.
+ * Three steps: everything that touches the ring, frame after frame; the frames' main data (hp_run); the merge
+ * into the scalefactor / count1 state and the records, frame after frame. */
 static int read_ahead(pdmp3_handle* id) {
   static _Thread_local int16_t scratch_sp[BATCH_MAX * 2304];      /* parse-only test handles: records go nowhere */
   static _Thread_local pdmp3_gc_side scratch_sd[BATCH_MAX * 4];
@@ -974,13 +1078,13 @@ static int read_ahead(pdmp3_handle* id) {
   const size_t pos = id->processed;
   const unsigned mark = id->istart;
   snap_save(id, &id->ra_before[0]);
-  int res = read_frame(id, spectra);
-  if (res != PDMP3_OK && res != PDMP3_NEW_FORMAT) {       /* failed: rewind to the frame start (P:2459-2462) */
+  const int res = read_frame_staged(id);
+  if (res != PDMP3_OK) {                                  /* failed: rewind to the frame start (P:2459-2462) */
     id->processed = pos; id->istart = mark;
     sync_logical(id);                                     /* (the header it read stays, as in the reference) */
     return res;
   }
-  emit_records(id, &id->hdr, &id->si, id->need_reset, spectra, side);
+  const int reset0 = id->need_reset;
   id->need_reset = 0;
   ra_push(id);
   const int cap = getenv("PDMP3_NO_READAHEAD") ? 1 : BATCH_MAX;
@@ -991,21 +1095,39 @@ static int read_ahead(pdmp3_handle* id) {
     const unsigned have = ring_filled_logical(id);
     const unsigned avail = have > ahead ? (unsigned)(have - ahead) : 0;
     if (avail < 1152) break;                              /* H10: the reference would not attempt it yet */
-    parse_snap* snapp = &id->ra_before[id->ra_n];
-    snap_save(id, snapp);
-#define snap (*snapp)
+    parse_snap* snap = &id->ra_before[id->ra_n];
+    snap_save(id, snap);
     id->ring_short = 0;
-    int16_t* sp = spectra + (size_t)id->ra_n * 2304;
-    const int r = read_frame(id, sp);
+    const int r = read_frame_staged(id);
     /* undone unless it succeeded on bytes that were all there */
-    if ((r != PDMP3_OK && r != PDMP3_NEW_FORMAT) || id->ring_short || id->processed - snap.processed > avail) {
-      snap_restore(id, &snap);
+    if (r != PDMP3_OK || id->ring_short || id->processed - snap->processed > avail) {
+      snap_restore(id, snap);
       break;
     }
-#undef snap
-    emit_records(id, &id->hdr, &id->si, id->need_reset, sp, side + (size_t)id->ra_n * 4);
-    id->need_reset = 0;
     ra_push(id);
+  }
+  /* frame i's header, side info and reservoir: what the snapshot taken before frame i + 1 holds -- the parser itself for the last */
+  const int n = id->ra_n;
+  hp_job jobs[BATCH_MAX];
+  for (int i = 0; i < n; i++) {
+    const parse_snap* nx = i + 1 < n ? &id->ra_before[i + 1] : NULL;
+    jobs[i].res = nx ? nx->main_vec : id->main_vec;
+    jobs[i].H = nx ? &nx->hdr : &id->hdr;
+    jobs[i].S = nx ? &nx->si : &id->si;
+    jobs[i].out = &id->ra_out[i];
+    id->ra_out[i].is = spectra + (size_t)i * 2304;
+  }
+  hp_run(jobs, n);
+  for (int i = 0; i < n; i++) {
+    if (i) {                                              /* the snapshot before frame i gets the state the frames before it left */
+      parse_snap* sn = &id->ra_before[i];
+      memcpy(sn->scalefac_l, id->scalefac_l, sizeof sn->scalefac_l);
+      memcpy(sn->scalefac_s, id->scalefac_s, sizeof sn->scalefac_s);
+      memcpy(sn->count1, id->count1, sizeof sn->count1);
+      sn->tap_n = id->tap_n;
+    }
+    apply_main(id, jobs[i].H, jobs[i].out);
+    emit_records(id, jobs[i].H, jobs[i].S, i == 0 ? reset0 : 0, spectra + (size_t)i * 2304, side + (size_t)i * 4);
   }
   if (id->hs) {
     if (pdmp3_hip_stream_submit(id->hs, 0, id->ra_n) != PDMP3_HIP_OK) {
