@@ -172,8 +172,9 @@ inline void build_tab_images(HostTables& H) {
 }
 
 // Code books (tables_data.h: kHuffBooks, derived from the reference's tree arrays P:160-520) -> the two-level
-// lookup of unpack_core.h: 8-bit first level, and under every prefix that longer codes share a second level just
-// wide enough for the longest of them.  Returns false if the blob does not fit.
+// lookup of unpack_core.h: 8-bit first level whose every entry leads to a second-level table -- under a prefix that
+// longer codes share, one just wide enough for the longest of them; for a code word of <= 8 bits its one leaf.
+// Returns false if the blob does not fit.
 inline bool build_unpack_tables(UnpackTables& U) {
   memset(&U, 0, sizeof U);
   for (int t = 0; t < 34; t++) { U.book_of_table[t] = (int8_t)kHuffBookOfTable[t]; U.linbits[t] = (uint8_t)kHuffLinbits[t]; }
@@ -184,7 +185,8 @@ inline bool build_unpack_tables(UnpackTables& U) {
     for (int i = 0; i < 14; i++) U.sfb_s[sf][i] = sfb_short_of(sf)[i];
   }
   constexpr int HL = kHuffFirstBits;
-  uint32_t n = 0;
+  auto link = [](int sub_bits, uint32_t index) { return (uint32_t)(31 - sub_bits) | (index << 10); };   // (byte offset << 8)
+  uint32_t n = 1;                                        // lut[0] = 0: the leaf of "no code word"
   for (int b = 0; b < PDMP3_NUM_HUFF_BOOKS; b++) {
     const pdmp3_hcode* codes = kHuffBooks[b];
     const int nc = kHuffBookSize[b];
@@ -192,6 +194,7 @@ inline bool build_unpack_tables(UnpackTables& U) {
     U.book_base[b] = (uint16_t)n;
     uint32_t* first = U.lut + n;
     n += 1u << HL;
+    for (int p = 0; p < (1 << HL); p++) first[p] = link(0, 0);
     int deepest[1 << HL];
     for (int p = 0; p < (1 << HL); p++) deepest[p] = 0;
     for (int i = 0; i < nc; i++)
@@ -199,10 +202,12 @@ inline bool build_unpack_tables(UnpackTables& U) {
         const uint32_t p = codes[i].code >> (codes[i].len - HL);
         if (codes[i].len - HL > deepest[p]) deepest[p] = codes[i].len - HL;
       }
+    uint32_t sub_of[1 << HL];
     for (int p = 0; p < (1 << HL); p++)
       if (deepest[p]) {
         if (n + (1u << deepest[p]) > (uint32_t)kHuffLutMax) return false;
-        first[p] = 0x80000000u | ((uint32_t)deepest[p] << 24) | n;
+        sub_of[p] = n;
+        first[p] = link(deepest[p], n);
         n += 1u << deepest[p];
       }
     const bool quads = b == kHuffBookOfTable[32] || b == kHuffBookOfTable[33];
@@ -217,12 +222,15 @@ inline bool build_unpack_tables(UnpackTables& U) {
       }
       const uint32_t leaf = val | ((uint32_t)len << 8) | (((uint32_t)len + nsign) << 16) | (nlin << 24);
       if (len <= HL) {
+        if (n + 1 > (uint32_t)kHuffLutMax) return false;
+        U.lut[n] = leaf;
         const uint32_t base = codes[i].code << (HL - len);
-        for (uint32_t k = 0; k < (1u << (HL - len)); k++) first[base + k] = leaf;
+        for (uint32_t k = 0; k < (1u << (HL - len)); k++) first[base + k] = link(0, n);
+        n++;
       } else {
         const uint32_t p = codes[i].code >> (len - HL);
         const int sb = deepest[p], extra = len - HL;
-        uint32_t* sub = U.lut + (first[p] & 0xffffffu);
+        uint32_t* sub = U.lut + sub_of[p];
         const uint32_t base = (codes[i].code & ((1u << extra) - 1)) << (sb - extra);
         for (uint32_t k = 0; k < (1u << (sb - extra)); k++) sub[base + k] = leaf;
       }
@@ -230,7 +238,8 @@ inline bool build_unpack_tables(UnpackTables& U) {
   }
   if (n + (1u << HL) > (uint32_t)kHuffLutMax) return false;
   static_assert(kZeroBook < 20 && kZeroBook >= PDMP3_NUM_HUFF_BOOKS, "the zero book takes a free slot of book_base");
-  U.book_base[kZeroBook] = (uint16_t)n;                  // (memset above: 256 zeroes)
+  U.book_base[kZeroBook] = (uint16_t)n;
+  for (int p = 0; p < (1 << HL); p++) U.lut[n + p] = link(0, 0);
   n += 1u << HL;
   U.n_lut = n;
   return true;

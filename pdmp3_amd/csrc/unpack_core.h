@@ -47,22 +47,39 @@
 namespace pdmp3 {
 
 constexpr int kHuffFirstBits = 8;
-constexpr int kHuffLutMax = 8576;                 // entries; the 18 books need 8290, the zero book 256 (host_tables.h checks)
+constexpr int kHuffLutMax = 9728;                 // entries: 19 first levels, the second levels and a leaf per short code word (host_tables.h checks)
 constexpr unsigned kResBytes = PDMP3_RESERVOIR_BYTES;
 constexpr unsigned kFastLimit = (kResBytes - 8) * 8u;   // bit positions from which an 8-byte load stays inside the row
 
 // One contiguous blob; every workgroup copies it into LDS.
-// lut entry: leaf  = byte 0: (x << 4 | y) or v w x y
-//                    byte 1: clen, the bits of the whole code word (both levels)
-//                    byte 2: clen + the number of values != 0 (a sign bit follows each)
-//                    byte 3: the number of values == 15 of a pair (linbits follow each, if the table has any); <= 2
-//            link  = 0x80000000 | sub_bits << 24 | offset of the second-level table (entries from lut[0])
-//            0     = no code word ends here (the reference's error path: nothing is consumed, the values are 0)
-// book_base[kZeroBook] is a first level of 256 zeroes: what a table without code words (0, 4, 14) "decodes" to.
+// lut entries.  EVERY symbol is two lookups -- 46 % of a 320 kbps stream's code words are longer than the 8 bits of the
+// first level, so with 64 lanes per wave the second one is needed in practically every trip anyway, and making it
+// unconditional takes the "is it a link" test and the select out of the loop's dependent chain:
+//   first level (256 per book, index = the next 8 bits):   (31 - sub_bits) | byte offset of a second-level table << 8
+//              sub_bits = 0: a code word of <= 8 bits; its "table" is the one leaf
+//   leaf  = byte 0: (x << 4 | y) or v w x y
+//           byte 1: clen, the bits of the whole code word (both levels)
+//           byte 2: clen + the number of values != 0 (a sign bit follows each)
+//           byte 3: the number of values == 15 of a pair (linbits follow each, if the table has any); <= 2
+//   lut[0] = 0: the leaf of every prefix no code word begins with (the reference's error path: nothing is consumed,
+//           the values are 0)
+// book_base[kZeroBook] is a first level whose 256 entries all lead to lut[0]: what a table without code words (0, 4,
+// 14) "decodes" to.
 constexpr int kZeroBook = 19;
 PD_HD unsigned leaf_clen(uint32_t e) { return (e >> 8) & 0xff; }
 PD_HD unsigned leaf_adv(uint32_t e) { return (e >> 16) & 0xff; }
 PD_HD unsigned leaf_nlin(uint32_t e) { return e >> 24; }
+// index of the leaf that the first-level entry l1 and the bits behind the first 8 (t31 = those bits from bit 30 down,
+// bit 31 clear) lead to
+PD_HD unsigned leaf_index(uint32_t l1, uint32_t t31) { return (l1 >> 10) + (t31 >> (l1 & 31)); }
+PD_HD uint32_t leaf_at(const uint32_t* lut, uint32_t l1, uint32_t t31) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (bits 5-9 of l1 are clear: l1 >> 8 is the table's BYTE offset, and the address is one shift-and-add away)
+  return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lut) + (l1 >> 8) + ((t31 >> (l1 & 31)) << 2));
+#else
+  return lut[leaf_index(l1, t31)];
+#endif
+}
 struct UnpackTables {
   uint16_t book_base[20];        // first-level table of book b starts at lut[book_base[b]]
   int8_t book_of_table[36];      // ISO table number (0..33) -> book, -1: no code words (tables 0, 4, 14)
@@ -195,11 +212,8 @@ PD_HD unsigned get_field(BitPos& b, RegWin& r, unsigned n) {   // n <= 16
 
 // one code word from a 64-bit window: returns leaf value, adds its length to `used`
 PD_HD unsigned lut_symbol(const uint32_t* lut, unsigned base, uint64_t w, unsigned& used) {
-  uint32_t e = lut[base + (unsigned)(w >> (64 - kHuffFirstBits))];
-  if (e & 0x80000000u) {
-    const unsigned sb = (e >> 24) & 0x1f;
-    e = lut[(e & 0xffffffu) + (unsigned)((w << kHuffFirstBits) >> (64 - sb))];
-  }
+  const uint32_t l1 = lut[base + (unsigned)(w >> (64 - kHuffFirstBits))];
+  const uint32_t e = leaf_at(lut, l1, (uint32_t)((w << kHuffFirstBits) >> 33));
   used += leaf_clen(e);
   return e & 0xff;
 }
@@ -373,12 +387,7 @@ PD_HD SymRec unpack_step(const uint32_t* lut, unsigned tab0, unsigned tab1, unsi
   const uint32_t bits = (uint32_t)((((((uint64_t)w.d0) << 32) | w.d1) << (s.pos & 31)) >> 32);
   const unsigned i1 = (tab & 0xffffu) + (bits >> (32 - kHuffFirstBits));
   const uint32_t l1 = lut[i1];
-  // second level: books deeper than 8 bits; sub_bits is 1..11.  Unconditional -- some lane of the 64 needs it in
-  // nearly every trip, and a branch around it only adds its own cost
-  const bool link = (l1 & 0x80000000u) != 0;
-  const unsigned sb = link ? (l1 >> 24) & 0x1f : 1u;
-  const unsigned i2 = link ? (l1 & 0xffffffu) + ((bits << kHuffFirstBits) >> (32 - sb)) : i1;
-  const uint32_t e = lut[i2];
+  const uint32_t e = leaf_at(lut, l1, (bits << kHuffFirstBits) >> 1);
   SymRec rec;
   rec.x = s.pos | (pair ? 0u : 1u << 15) | (s.line << 16) | (lin << 26);
   rec.y = e;
@@ -388,36 +397,43 @@ PD_HD SymRec unpack_step(const uint32_t* lut, unsigned tab0, unsigned tab1, unsi
   return rec;
 }
 
-// values and signs of a record's symbol, stored to the lines of its granule-channel
+// values and signs of a record's symbol, stored to the lines of its granule-channel.  What follows the code word --
+// linbits and signs, <= 28 bits -- is one 32-bit window (two aligned words of the row, one funnel shift); everything
+// behind that is 32-bit arithmetic (64-bit shifts are quarter rate on the device, and this is the value waves' loop).
 PD_HD void unpack_value(const uint8_t* row, const SymRec rec, int16_t* is) {
   const unsigned line = (rec.x >> 16) & 0x3ff;
   const uint32_t e = rec.y;
   if (line >= 576 || e == 0) return;                       // (e == 0: zeroes, and the lines are zero)
   const unsigned linbits = (rec.x >> 26) & 15;
-  BitPos b{row, rec.x & 0x7fffu};
-  uint64_t w = peek64(b) << leaf_clen(e);                  // what follows the code word: <= 28 bits are looked at
+  const unsigned pv = (rec.x & 0x7fffu) + leaf_clen(e);    // <= kFastLimit + 19: the second word is inside the row
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(row) + (pv >> 5);
+  uint32_t w = (uint32_t)((((((uint64_t)PD_ROW_BE(p[0])) << 32) | PD_ROW_BE(p[1])) << (pv & 31)) >> 32);
   if (rec.x & (1u << 15)) {                                // v w x y: a sign bit follows each nonzero one
     int q[4];
     for (int k = 0; k < 4; k++) {
       const unsigned nz = (e >> (3 - k)) & 1;
-      q[k] = (nz && (w >> 63)) ? -1 : (int)nz;
+      q[k] = (nz && (w >> 31)) ? -1 : (int)nz;
       w <<= nz;
     }
-    store_pair(is, line, q[0], q[1]);
-    store_pair(is, line + 2, q[2], q[3]);
-  } else {                                                 // (v >> 1) >> (63 - n) == v >> (64 - n) for n = 1..63 and 0 for n = 0
+    // (the walker reads a quad only while line <= 572, P:2099: all four lines exist; line is even: one 8-byte store)
+    const uint32_t v[2] = {(uint32_t)(uint16_t)(int16_t)q[0] | ((uint32_t)(uint16_t)(int16_t)q[1] << 16),
+                           (uint32_t)(uint16_t)(int16_t)q[2] | ((uint32_t)(uint16_t)(int16_t)q[3] << 16)};
+    __builtin_memcpy(__builtin_assume_aligned(is + line, 4), v, 8);
+  } else {                                                 // (v >> 1) >> (31 - n) == v >> (32 - n) for n = 1..31 and 0 for n = 0
     int x = (int)((e >> 4) & 15), y = (int)(e & 15);
     const unsigned lbx = (x == 15) ? linbits : 0;
-    x += (int)((w >> 1) >> (63 - lbx));
+    x += (int)((w >> 1) >> (31 - lbx));
     w <<= lbx;
     const unsigned nzx = x != 0;
-    x = (nzx && (w >> 63)) ? -x : x;
+    x = (nzx && (w >> 31)) ? -x : x;
     w <<= nzx;
     const unsigned lby = (y == 15) ? linbits : 0;
-    y += (int)((w >> 1) >> (63 - lby));
+    y += (int)((w >> 1) >> (31 - lby));
     w <<= lby;
-    y = (y != 0 && (w >> 63)) ? -y : y;
-    store_pair(is, line, x, y);
+    y = (y != 0 && (w >> 31)) ? -y : y;
+    // (line is even and < 576: both lines exist)
+    const uint32_t v = (uint32_t)(uint16_t)(int16_t)x | ((uint32_t)(uint16_t)(int16_t)y << 16);
+    __builtin_memcpy(__builtin_assume_aligned(is + line, 4), &v, 4);
   }
 }
 

@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--c4", type=int, default=0, metavar="JOBS",
                     help="SURVEY 8d C4 instead: the mixed corpus (64 files x >= 4096 frames), JOBS decoders in parallel")
-    ap.add_argument("--device-out", action="store_true", help="--c4: PCM into device memory (torch tensors): it never leaves the GPU")
+    ap.add_argument("--device-out", action="store_true", help="PCM into device memory (torch tensors): it never leaves the GPU")
     ap.add_argument("--pinned", action="store_true", help="PCM into pinned host buffers (pdmp3_amd_pcm_alloc): no host copy")
     ap.add_argument("--gpus", type=int, default=1, help="--c4: decoder j runs on GPU j %% GPUS")
     ap.add_argument("--host-huffman", action="store_true", help="scalefactors + Huffman on the host pool instead of the device")
@@ -97,6 +97,10 @@ def main():
            "runs": []}
     pin = api.PinnedPCM(total // 2) if args.pinned else None
     pcm = pin.array if pin else np.empty(total // 2, dtype=np.int16)
+    dout = None
+    if args.device_out:                        # PCM stays in HBM (a torch tensor as the destination)
+        import torch
+        dout = torch.empty(max(total, 2) // 2, dtype=torch.int16, device="cuda:0")
     for th in [int(x) for x in args.threads.split(",")]:
         b = api.BulkDecoder(threads=th, window_frames=args.window, parse_only=args.parse_only, host_huffman=args.host_huffman)
         best = None
@@ -104,6 +108,9 @@ def main():
             t0 = time.perf_counter()
             if args.parse_only:
                 b.parse(a)
+            elif dout is not None:
+                got, _, _ = b.decode_into_device(a, dout, wait=True)
+                assert got == total
             else:
                 got, _, _ = b.decode_into(a, pcm)
                 assert got == total
@@ -112,7 +119,7 @@ def main():
         b.close()
         out["runs"].append({"threads": th, "seconds": round(best, 4), "frames_per_s": round(frames / best, 1),
                             "x_realtime": round(frames / best / rt, 1), "mode": "parse" if args.parse_only else ("decode, host Huffman" if args.host_huffman else "decode, device Huffman"),
-                            "pcm": "pinned" if args.pinned else "pageable"})
+                            "pcm": "device" if dout is not None else "pinned" if args.pinned else "pageable"})
     print(json.dumps(out))
 
 
