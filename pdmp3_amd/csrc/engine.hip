@@ -275,17 +275,16 @@ __global__ __launch_bounds__(128) void k_rows(const pdmp3_row_desc* desc, const 
   for (int w = threadIdx.x; w < kRowBytes / 4; w += 128) out[w] = row_word(d, pool, 4u * (unsigned)w);
 }
 
-// inclusive "last lane that has a value" scan over the wave; lanes without any take `carry`.  (has, 16-bit value) in
-// one register, Hillis-Steele inside each row of 16 lanes with DPP row shifts, then the two row broadcasts of the
-// classic GCN wave scan -- 6 cross-lane moves at VALU rate.  (With __shfl_up = ds_bpermute the 24 dependent LDS round
-// trips of a step were most of k_merge's 43 us per window.)
-__device__ __forceinline__ unsigned scan_last(bool has, unsigned val, unsigned carry, int lane) {
-  (void)lane;
-  unsigned r = (has ? 0x10000u : 0u) | (val & 0xffffu);
+// inclusive "last lane that has a value" scan over the wave, (has << 16 | 16-bit value) in one register: Hillis-Steele
+// inside each row of 16 lanes with DPP row shifts, then the two row broadcasts of the classic GCN wave scan -- 6
+// cross-lane moves at VALU rate.  (With __shfl_up = ds_bpermute the 24 dependent LDS round trips of a step were most of
+// round 1's 43 us per window.)
+constexpr unsigned kHas = 0x10000u;
+__device__ __forceinline__ unsigned scan_packed(unsigned r) {
 #define PD_SCAN_STEP(ctrl, row_mask)                                                                     \
   {                                                                                                      \
     const unsigned s_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r, ctrl, row_mask, 0xf, false);    \
-    r = (r & 0x10000u) ? r : s_;                                                                         \
+    r = (r & kHas) ? r : s_;                                                                             \
   }
   PD_SCAN_STEP(0x111, 0xf)     // row_shr:1
   PD_SCAN_STEP(0x112, 0xf)     // row_shr:2
@@ -294,22 +293,36 @@ __device__ __forceinline__ unsigned scan_last(bool has, unsigned val, unsigned c
   PD_SCAN_STEP(0x142, 0xa)     // row_bcast:15 into rows 1, 3
   PD_SCAN_STEP(0x143, 0xc)     // row_bcast:31 into rows 2, 3
 #undef PD_SCAN_STEP
-  return (r & 0x10000u) ? (r & 0xffffu) : carry;
+  return r;
 }
+__device__ __forceinline__ unsigned pack_has(bool has, unsigned val) { return (has ? kHas : 0u) | (val & 0xffffu); }
 
-// one wave per surviving value (unpack_core.h merge_slot), 64 frames per step
-__global__ __launch_bounds__(64) void k_merge(const GcRaw* raw, const pdmp3_frame_bits* bits, int n_frames,
-                                               const uint16_t* state_in, uint16_t* state_out, pdmp3_gc_side* side) {
-  const int t = blockIdx.x, lane = threadIdx.x;
+// One workgroup of eight waves per surviving value (unpack_core.h merge_slot).  A step is 2048 frames = 32 blocks of 64,
+// four blocks per wave: every wave asks for its four blocks' inputs at once (one round trip to memory for the whole
+// step), scans each block by itself, leaves the block's outcome -- "a frame of mine wrote the value: this one" -- in
+// LDS, and after a barrier finds what reaches its blocks from the left with one more scan over those 32 outcomes.
+// A slot of granule 1 that may copy granule 0's value (scfsi) does this twice: the twin's chain first, then its own.
+// (Round 2: one wave per value walking 256 frames per trip on its carry chain, 33 us per window.)
+constexpr int kMergeWaves = 8, kMergeBlocks = 4 * kMergeWaves, kMergeStep = 64 * kMergeBlocks;
+__device__ __forceinline__ unsigned merge_carry_in(const unsigned* sums, unsigned carry, int blk, int lane, unsigned* carry_out) {
+  // lane i < 32: outcome of block i; inclusive scan; block blk takes what block blk - 1 ends with
+  const unsigned inc = scan_packed(lane < kMergeBlocks ? sums[lane] : 0u);
+  const unsigned left = (unsigned)__shfl((int)inc, blk > 0 ? blk - 1 : 0);
+  const unsigned last = (unsigned)__shfl((int)inc, kMergeBlocks - 1);
+  *carry_out = (last & kHas) ? (last & 0xffffu) : carry;
+  return (blk > 0 && (left & kHas)) ? (left & 0xffffu) : carry;
+}
+__global__ __launch_bounds__(64 * kMergeWaves) void k_merge(const GcRaw* raw, const pdmp3_frame_bits* bits, int n_frames,
+                                                             const uint16_t* state_in, uint16_t* state_out, pdmp3_gc_side* side) {
+  __shared__ unsigned sum0[kMergeBlocks], sum1[kMergeBlocks];
+  const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tw = merge_twin(t);
   unsigned carry = state_in[t], carry0 = tw >= 0 ? state_in[tw] : 0;
-  // 256 frames per trip: the loads of four 64-frame steps are issued together (one memory round trip), then the
-  // four scans run back to back on the carry chain
-  for (int base = 0; base < n_frames; base += 256) {
+  for (int base = 0; base < n_frames; base += kMergeStep) {
     MergeIn m[4];
     uint8_t fr[4];
     PD_UNROLL for (int q = 0; q < 4; q++) {
-      const int f = base + 64 * q + lane;
+      const int f = base + 64 * (4 * wave + q) + lane;
       m[q] = MergeIn{false, false, false, 0, 0};
       fr[q] = 0;
       if (f < n_frames) {
@@ -317,23 +330,44 @@ __global__ __launch_bounds__(64) void k_merge(const GcRaw* raw, const pdmp3_fram
         m[q] = merge_load(t, raw + (size_t)f * 4, (fr[q] & PDMP3_FR_NEWSTREAM) != 0);
       }
     }
-    PD_UNROLL for (int q = 0; q < 4; q++) {
-      const int f = base + 64 * q + lane;
-      unsigned v0 = 0;
-      if (tw >= 0) {                                 // wave-uniform
-        v0 = scan_last(m[q].set0, m[q].val0, carry0, lane);
-        carry0 = __shfl(v0, 63);
+    if (base) __syncthreads();                       // (the step before is done with the outcomes)
+    unsigned v0[4] = {0, 0, 0, 0};
+    if (tw >= 0) {                                   // uniform for the workgroup
+      unsigned loc[4];
+      PD_UNROLL for (int q = 0; q < 4; q++) {
+        loc[q] = scan_packed(pack_has(m[q].set0, m[q].val0));
+        const unsigned end = (unsigned)__shfl((int)loc[q], 63);
+        if (lane == 0) sum0[4 * wave + q] = end;
       }
-      const unsigned v = scan_last(m[q].set || m[q].copy, m[q].copy ? v0 : m[q].val, carry, lane);
-      carry = __shfl(v, 63);
+      __syncthreads();
+      unsigned next0 = carry0;
+      PD_UNROLL for (int q = 0; q < 4; q++) {
+        const unsigned in = merge_carry_in(sum0, carry0, 4 * wave + q, lane, &next0);
+        v0[q] = (loc[q] & kHas) ? (loc[q] & 0xffffu) : in;
+      }
+      carry0 = next0;
+    }
+    unsigned loc[4];
+    PD_UNROLL for (int q = 0; q < 4; q++) {
+      loc[q] = scan_packed(pack_has(m[q].set || m[q].copy, m[q].copy ? v0[q] : m[q].val));
+      const unsigned end = (unsigned)__shfl((int)loc[q], 63);
+      if (lane == 0) sum1[4 * wave + q] = end;
+    }
+    __syncthreads();
+    unsigned next = carry;
+    PD_UNROLL for (int q = 0; q < 4; q++) {
+      const int f = base + 64 * (4 * wave + q) + lane;
+      const unsigned in = merge_carry_in(sum1, carry, 4 * wave + q, lane, &next);
+      const unsigned v = (loc[q] & kHas) ? (loc[q] & 0xffffu) : in;
       if (f < n_frames) {
         pdmp3_frame_bits F;
         F.frame = fr[q];
         merge_store(t, F, side + (size_t)f * 4, v);
       }
     }
+    carry = next;
   }
-  if (lane == 0) state_out[t] = (uint16_t)carry;
+  if (threadIdx.x == 0) state_out[t] = (uint16_t)carry;
 }
 
 // Scratch of a chained launch (DecodeArgs::chain_*): launches that are ordered one after the other share a buffer --
@@ -1042,7 +1076,7 @@ static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_
   }
   // everything from here on continues the previous batch (scalefactor / count1 carry, synthesis state)
   if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
-  hipLaunchKernelGGL(k_merge, dim3(kMergeSlots), dim3(64), 0, t.stream, t.d_raw, t.d_bits, n_frames,
+  hipLaunchKernelGGL(k_merge, dim3(kMergeSlots), dim3(64 * kMergeWaves), 0, t.stream, t.d_raw, t.d_bits, n_frames,
                      hs->d_sfstate + 256 * hs->sf_cur, hs->d_sfstate + 256 * (hs->sf_cur ^ 1), t.d_side);
   HIP_TRY(hipGetLastError(), "launch k_merge");
   hs->sf_cur ^= 1;
