@@ -395,7 +395,8 @@ def main():
                 res[key] = {"frames_per_s": round(fr / dt_s, 1), "x_realtime": round(fr / dt_s / RT_FRAMES_PER_S, 1),
                             "frames": int(fr), "seconds": round(dt_s, 4), "feed_bytes": feed, "read_bytes": read}
             out["streaming_api"] = {"workload": "C3-style stream (44.1 kHz joint stereo 320 kbps CBR) through pdmp3_feed / pdmp3_read "
-                                                "(include/pdmp3.h), host Huffman, one thread, read-ahead batches of up to 16 frames", **res}
+                                                "(include/pdmp3.h), host Huffman by the calling thread and the library's helper threads "
+                                                "(PDMP3_STREAM_THREADS, default 3), read-ahead batches of up to 16 frames", **res}
         except Exception as e:
             out["streaming_api"] = {"error": repr(e)}
     if cpu is not None:

@@ -22,6 +22,13 @@ timeout 600 python3 bench.py 2> /dev/null > $OUT/bench.json; echo "bench rc=$?";
 timeout 600 python3 tools/bulk_bench.py --frames 137813 --threads 2 2> /dev/null | tail -1 > $OUT/bulk_decode.json; cat $OUT/bulk_decode.json
 timeout 600 python3 tools/bulk_bench.py --frames 137813 --threads 1,8,16,32 --host-huffman 2> /dev/null | tail -1 > $OUT/bulk_decode_host_huffman.json; cat $OUT/bulk_decode_host_huffman.json
 for j in 1 4 6; do timeout 600 python3 tools/bulk_bench.py --c4 $j 2> /dev/null | tail -1; done > $OUT/bulk_c4.json; cat $OUT/bulk_c4.json
+# PCM staying in HBM (a device pointer as destination), one stream and the C4 corpus; where the pipeline's time goes
+{ timeout 600 python3 tools/bulk_bench.py --frames 137813 --threads 2 --device-out 2> /dev/null | tail -1; for j in 1 2 4; do timeout 600 python3 tools/bulk_bench.py --c4 $j --device-out 2> /dev/null | tail -1; done; } > $OUT/bulk_device_out.json; cat $OUT/bulk_device_out.json
+PDMP3_BULK_TRACE=1 timeout 300 python3 tools/bulk_bench.py --frames 137813 --threads 2 --device-out --reps 1 2>&1 > /dev/null | grep "bulk trace" | tail -2 > $OUT/bulk_trace.txt; cat $OUT/bulk_trace.txt
+# the drop-in streaming API against the number of helper threads; a batch's round trip; k_unpack's phases
+for t in 0 1 3 7 11; do PDMP3_STREAM_THREADS=$t timeout 300 python3 tools/stream_api_bench.py 2> /dev/null; done > $OUT/stream_api.json; cat $OUT/stream_api.json
+gcc -O2 -Iinclude -o /tmp/rtt tools/stream_rtt.c -Lpdmp3_amd -lpdmp3_hip -Wl,-rpath,$PWD/pdmp3_amd && timeout 120 /tmp/rtt > $OUT/stream_rtt.txt; cat $OUT/stream_rtt.txt
+PDMP3_HIP_UNPACK_PROF=1 timeout 300 python3 tools/bulk_bench.py --frames 20000 --threads 2 --reps 1 2>&1 > /dev/null | grep "k_unpack prof" | tail -2 > $OUT/unpack_phases.txt; cat $OUT/unpack_phases.txt
 timeout 300 python3 tools/phase_profile.py 131072 32 > $OUT/phase_profile.txt 2>&1; timeout 300 python3 tools/phase_profile.py 2048 1 >> $OUT/phase_profile.txt 2>&1
 # the same for a C5-shard-sized launch
 pmcb() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 tools/pmc_target.py 131072 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
