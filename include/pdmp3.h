@@ -22,6 +22,10 @@
  *      layout (pdmp3_amd/csrc/tables_data.h);
  *   4. synthesis state is per handle instead of process-global; the handle starts zeroed (H13);
  *   5. additions, all prefixed pdmp3_amd_: float output below, whole-stream decoding in pdmp3_bulk.h.
+ * Not a difference in results, but visible to a process: pdmp3_read decodes the frames the ring already holds as one
+ * batch and uses helper threads for their scalefactors + Huffman data (started on first use, shared by all handles,
+ * asleep between reads).  Environment: PDMP3_STREAM_THREADS = number of helpers (default min(3, CPUs - 1); 0 = the
+ * calling thread only), PDMP3_NO_READAHEAD = one frame per batch, PDMP3_DEVICE = HIP device of new handles.
  * There is no CPU decode path: pdmp3_new() returns NULL (and sets *error when given) if no HIP device / engine
  * library is available.
  */
