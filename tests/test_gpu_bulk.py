@@ -60,6 +60,23 @@ def test_bulk_long_vbr_stream(oracle):
     assert np.array_equal(got, via_host_huffman)        # device Huffman == host Huffman, bit for bit
 
 
+def test_windows_larger_than_a_merge_step():
+    """windows of 5000 and 7001 frames: k_merge walks a window in steps of 2048 frames with a carry between them, k_unpack
+    gets 313 / 438 workgroups -- same PCM, bit for bit, as with the default window and as with host Huffman"""
+    from pdmp3_amd import api
+    mp3 = packer.generate(n_frames=15000, seed=79, vbr=True, block_pct=(40, 10, 40, 10), mixed_pct=30)
+    outs = []
+    for window, hh in ((2048, False), (5000, False), (7001, False), (4096, True)):
+        b = api.BulkDecoder(threads=4, window_frames=window, host_huffman=hh)
+        try:
+            outs.append(b.decode(mp3))
+        finally:
+            b.close()
+    assert outs[0].size >= 14990 * 2304
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+
+
 def test_bulk_output_smaller_than_stream():
     """pcm_cap below the stream's size: the prefix is written, the full size returned"""
     from pdmp3_amd import api
