@@ -14,14 +14,17 @@
 //
 //   unpack_gc    lane = (frame, gr, ch).  The start bit of a granule-channel
 //                inside the reservoir follows from the side info alone
-//                (part2_3_length of the ones before it, P:2110), so the four
-//                of a frame decode independently.  Two-level code-book lookup
-//                (8-bit first level, per-prefix second level); the kernel keeps
-//                the books, the reservoir rows and the output lines of its 16
-//                frames in LDS, so the symbol loop never waits for HBM.  Writes
-//                int16 lines [0, count1) (the buffer is zero on entry), the
-//                fields of the side record that come straight from the side
-//                info, and a GcRaw: the scalefactors it read and which ones.
+//                (part2_3_length of the ones before it, P:2110; the widths of
+//                its scalefactors), so the four of a frame decode independently
+//                and a granule-channel splits into independent jobs:
+//                unpack_records (side fields, scalefactors), unpack_plan +
+//                unpack_step (where each code word starts: the one sequential
+//                chain), unpack_value (values and signs of a symbol, lines
+//                [0, count1) as int16 into a zeroed buffer), unpack_tail (the
+//                reference's overshoot rule, count1).  Two-level code-book
+//                lookup (8-bit first level, per-prefix second level or leaf).
+//                k_unpack (engine.hip) gives the jobs to four waves that share
+//                books and reservoir rows in LDS; unpack_gc runs them in a row.
 //   merge_slot   thread = one of the 232 values that survive frames
 //                (scalefac_l[2][2][21], scalefac_s[2][2][12][3], count1[2][2];
 //                SURVEY H4-H6): walks the window's frames in order, keeps
