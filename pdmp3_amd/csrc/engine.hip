@@ -900,7 +900,10 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
   // launch, two event records, one wait.  (PDMP3_HIP_DIRECT_MAX: largest such batch in frames, 0 = never.)
   t.direct = 0;
   if (n_frames <= hs->ctx->direct_max_frames && (!host_dst || row == PDMP3_FRAME_PCM_BYTES)) {
-    if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
+    // (a stream object with ONE slot -- the streaming API's -- has one HIP stream: its batches are in order anyway, and
+    //  its wait is for that stream: no events at all, each of which is a call here and a packet of its own on the queue)
+    const bool lone = hs->n_slots == 1;
+    if (!lone && hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
     void* dst = host_dst ? host_dst : (void*)t.h_pcm;
     int rc = hs->f32
         ? launch_decode(hs->ctx, t.h_spectra, t.h_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)dst, hs, true)
@@ -910,11 +913,13 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
     hs->d_state_prev = hs->d_state;            // (what pdmp3_hip_stream_rewind goes back to)
     hs->d_state = hs->d_state_tmp;             // the kernel left the new state here
     hs->d_state_tmp = was_prev;
-    HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
-    hs->have_state_ev = 1;
-    HIP_TRY(hipEventRecord(t.done, t.stream), "record done event");
+    if (!lone) {
+      HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
+      hs->have_state_ev = 1;
+      HIP_TRY(hipEventRecord(t.done, t.stream), "record done event");
+    }
     t.busy = 1;
-    t.direct = 1;
+    t.direct = lone ? 2 : 1;                   // 2: pdmp3_hip_stream_wait synchronises the stream
     return PDMP3_HIP_OK;
   }
   HIP_TRY(hipMemcpyAsync(t.d_spectra, t.h_spectra, n * PDMP3_FRAME_SPECTRA_BYTES, hipMemcpyHostToDevice, t.stream), "H2D spectra");
@@ -940,7 +945,8 @@ extern "C" int pdmp3_hip_stream_wait(pdmp3_hip_stream* hs, int slot) {
   StreamSlot& t = hs->s[slot];
   if (!t.busy) return PDMP3_HIP_OK;
   HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
-  HIP_TRY(hipEventSynchronize(t.done), "event sync");
+  if (t.direct == 2) HIP_TRY(hipStreamSynchronize(t.stream), "stream sync");
+  else HIP_TRY(hipEventSynchronize(t.done), "event sync");
   t.busy = 0;
   return PDMP3_HIP_OK;
 }
