@@ -1602,7 +1602,6 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   // (the last one publishes with stores it has to see acknowledged, the first one reads past its caches): the last wave
   // runs ahead of the other three of its SIMD until it has published, the first one catches up after it has taken
   const bool far_sender = gp.w == gp.wpw - 1 && next_takes;
-  const bool far_taker = gp.w == 0 && from_chain;
   if (far_sender) PD_SETPRIO(2);
   PD_PHASE(lane_init(lane, L, R, cb, T))
   if (gr == 1 && h5) {
