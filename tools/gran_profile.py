@@ -57,5 +57,5 @@ for nm, m in (("H5", h5), ("short, not H5", any_short & ~h5), ("long", ~any_shor
     if m.any():
         print("  %-14s n %5d  lifetime median %7.0f  p90 %7.0f  max %7.0f" % (nm, m.sum(), np.median(life[m]), np.percentile(life[m], 90), life[m].max()))
 # phases of the long-block waves against the short-block ones
-for nm, m in (("long", ~any_short), ("short", any_short & ~h5)):
+for nm, m in (("long", ~any_short), ("short", any_short & ~h5), ("H5", h5)):
     print("  phases (median ticks) %-6s: %s" % (nm, " ".join("%.0f" % np.median(d[m, k]) for k in range(11))))
