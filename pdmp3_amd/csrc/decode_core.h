@@ -1301,7 +1301,12 @@ constexpr int kGranFloats = 64 * (kOvlRegs + kHistSlots);          // tails [18]
 // (its transforms up to the IMDCT need nothing from anybody).  LDS operations of a wave execute in order, so the
 // flag follows the data.  Only the workgroup's last wave publishes through memory -- chain_state[g], device scope,
 // flags in chain_flag -- and only its first wave reads that.
-struct GranMb { unsigned free, tails_full, rows_full, pad; };       // LDS, one per wave of the workgroup, zero at entry
+struct GranMb {                       // LDS, one per wave of the workgroup, zero at entry
+  unsigned free, tails_full, rows_full;
+  unsigned peek_full;                 // H5 frames: the three tail values below are there (from the wave of the frame's first granule)
+  float peek_tail[3];
+  unsigned pad;
+};
 struct GranPos {
   WaveData* wl;          // the workgroup's per-wave LDS blocks
   GranMb* mb;            // [wpw]
@@ -1604,40 +1609,51 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   const bool far_sender = gp.w == gp.wpw - 1 && next_takes;
   if (far_sender) PD_SETPRIO(2);
   PD_PHASE(lane_init(lane, L, R, cb, T))
-  if (gr == 1 && h5) {
-    PD_SETPRIO(3);     // (this wave has a fifth more to do than the other three of its SIMD, and a launch ends with its last wave)
-    // (wave-uniform) granule 1 / channel 1 is a short block: its scales read three hybrid outputs of granule 0.
-    // Waiting for other waves to get there would put this wave most of a granule behind all others -- and a launch
-    // ends with its last wave -- so it derives the three numbers itself, from data only: lines 0..63 of the granule
-    // before the frame requantised, one alias boundary, three IMDCT tails (ph_peek_tail, as in run_chunk); the same of
-    // granule 0 with the three first-half outputs (what ph_imdct computes for them); their sum is what
-    // ph_overlap_matrix of granule 0's wave leaves in peek[].
-    LaneRegs R0, R1;
-    R1.ovl[0] = 0.0f;
-    float tail = 0.0f;
+  if (h5 && (gr == 1 || !fresh)) {
+    PD_SETPRIO(3);     // (these waves have an eighth more to do than the others of their SIMDs, and a launch ends with its last wave)
+    // (wave-uniform) granule 1 / channel 1 of this frame is a short block: its scales read three hybrid outputs of granule 0
+    // (SURVEY H5): the first-half IMDCT outputs p = 0..2 of granule 0's (channel 0, subband 0) plus the tails of the
+    // granule before the frame.  Waiting for the waves that compute them anyway would put granule 1's wave most of a
+    // granule behind all others -- and a launch ends with its last wave -- so the numbers are derived from data only:
+    // lines 0..63 requantised, one alias boundary, three 18-term sums per granule (the sums ph_imdct forms for them).
+    // The TWO waves of the frame share the work -- granule 0's wave takes the granule before the frame (its tails:
+    // ph_peek_tail, as in run_chunk) and leaves the three values in the mailbox of granule 1's wave, which takes granule
+    // 0 meanwhile: each is late by one pass instead of one of them by two (7.8 k ticks in front of its own granule:
+    // the 115 such waves of a C2 launch made it 2 us longer; so shared, 0.5).
+    float pk = 0.0f;
     gran_tabs_wait(gp);
-    PD_PHASE(
-      ph_prefetch(lane, R0, a.spectra + (size_t)(g - 1) * 1152, a.side + (size_t)(g - 1) * 2);
-      if (!fresh) ph_prefetch(lane, R1, a.spectra + (size_t)(g - 2) * 1152, a.side + (size_t)(g - 2) * 2);
-    )
-    if (fresh) {
-      if (f == 0 && a.state_in && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET) && lane < 3) tail = a.state_in[lane];
-    } else {
+    if (gr == 0) {
+      LaneRegs R1;
+      R1.ovl[0] = 0.0f;
+      PD_PHASE(ph_prefetch(lane, R1, a.spectra + (size_t)(g - 1) * 1152, a.side + (size_t)(g - 1) * 2))
       PD_PHASE(ph_commit(lane, L, R1))
       PD_PHASE(ph_scales(lane, L))
       PD_PHASE((ph_requant<false, 1, false, true>(lane, L, S, cb, T, nullptr, nullptr)))
       PD_PHASE(ph_antialias(lane, L, cb, true))
       PD_PHASE(ph_peek_tail(lane, L, S, R1, T))
-      tail = lane < 3 ? R1.ovl[0] : 0.0f;
+      GranMb& mb = gp.mb[gp.w + 1];          // (a frame's two granules are neighbours in one workgroup: WPW is even)
+      if (lane < 3) mb.peek_tail[lane] = R1.ovl[0];
+      PD_WAVE_SYNC();
+      gran_lds_flag(lane, &mb.peek_full);
+    } else {
+      LaneRegs R0;
+      float tail = 0.0f;
+      PD_PHASE(ph_prefetch(lane, R0, a.spectra + (size_t)(g - 1) * 1152, a.side + (size_t)(g - 1) * 2))
+      if (fresh && f == 0 && a.state_in && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET) && lane < 3) tail = a.state_in[lane];
+      PD_PHASE(ph_commit(lane, L, R0))
+      PD_PHASE(ph_scales(lane, L))
+      PD_PHASE((ph_requant<false, 1, false, true>(lane, L, S, cb, T, nullptr, nullptr)))
+      PD_PHASE(ph_antialias(lane, L, cb, true))
+      const float head = ph_peek_head(lane, L, S, T);
+      PD_WAVE_SYNC();
+      if (!fresh) {
+        gran_lds_wait(&gp.mb[gp.w].peek_full);
+        tail = lane < 3 ? gp.mb[gp.w].peek_tail[lane] : 0.0f;
+      }
+      pk = head + tail;
     }
-    PD_PHASE(ph_commit(lane, L, R0))
-    PD_PHASE(ph_scales(lane, L))
-    PD_PHASE((ph_requant<false, 1, false, true>(lane, L, S, cb, T, nullptr, nullptr)))
-    PD_PHASE(ph_antialias(lane, L, cb, true))
-    const float pk = ph_peek_head(lane, L, S, T) + tail;
-    PD_WAVE_SYNC();
     PD_PHASE(ph_commit(lane, L, R))
-    PD_PHASE(if (lane < 3) L.peek[lane] = pk)
+    if (gr == 1) { PD_PHASE(if (lane < 3) L.peek[lane] = pk) }
   } else {
     PD_PHASE(ph_commit(lane, L, R))
   }

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   // the wave's own input first: its round trip passes under the workgroup's table loads
   LaneRegs pf;
   if (valid) ph_prefetch(tid & 63, pf, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2);
-  if (tid < W * 4) reinterpret_cast<unsigned*>(mb)[tid] = 0u;
+  if (tid < W * (int)(sizeof(GranMb) / 4)) reinterpret_cast<unsigned*>(mb)[tid] = 0u;
   if (tid == 0) tabs_ready = 0u;
   __syncthreads();                       // (nothing to wait for in front of it: the waves arrive together)
   // the workgroup's tables; the line tables are for the sampling frequency the caller expects (granules of another
