@@ -57,5 +57,10 @@ for nm, m in (("H5", h5), ("short, not H5", any_short & ~h5), ("long", ~any_shor
     if m.any():
         print("  %-14s n %5d  lifetime median %7.0f  p90 %7.0f  max %7.0f" % (nm, m.sum(), np.median(life[m]), np.percentile(life[m], 90), life[m].max()))
 # phases of the long-block waves against the short-block ones
-for nm, m in (("long", ~any_short), ("short", any_short & ~h5), ("H5", h5)):
+for nm, m in (("long", ~any_short), ("short", any_short & ~h5), ("H5", h5), ("place 0", (place == 0) & ~any_short), ("last", (place == W - 1) & ~any_short), ("middle", (place > 0) & (place < W - 1) & ~any_short)):
     print("  phases (median ticks) %-6s: %s" % (nm, " ".join("%.0f" % np.median(d[m, k]) for k in range(11))))
+
+print("  by place in the workgroup (long-block granules): median ticks of requant | aa+imdct | wait tails | lifetime")
+for pl in range(W):
+    m = (place == pl) & ~any_short
+    print("    place %2d: %6.0f %6.0f %6.0f %7.0f" % (pl, np.median(d[m, 2]), np.median(d[m, 3]), np.median(d[m, 5]), np.median(life[m])))
