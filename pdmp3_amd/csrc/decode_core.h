@@ -1619,7 +1619,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
     // The TWO waves of the frame share the work -- granule 0's wave takes the granule before the frame (its tails:
     // ph_peek_tail, as in run_chunk) and leaves the three values in the mailbox of granule 1's wave, which takes granule
     // 0 meanwhile: each is late by one pass instead of one of them by two (7.8 k ticks in front of its own granule:
-    // the 115 such waves of a C2 launch made it 2 us longer; so shared, 0.5).
+    // the 115 such waves of a C2 launch made it 2 us longer; so shared, 0.7).
     float pk = 0.0f;
     gran_tabs_wait(gp);
     if (gr == 0) {
