@@ -45,6 +45,9 @@ typedef struct bulk pdmp3_amd_bulk;
  * 2048 frames per GPU batch (at most 32768).  Returns NULL when there is no transform engine
  * (no CPU fallback). */
 pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
+/* Environment: PDMP3_BULK_HOST_HUFFMAN=1 (below), PDMP3_BULK_SNAPSHOT_ROWS=1 (upload 2064-byte reservoir snapshots per frame
+ * instead of the compact pool + row descriptors: tests), PDMP3_BULK_TRACE=1 (one summary of the pipeline's waits per decode on
+ * stderr). */
 /* host_huffman = 0 (what pdmp3_amd_bulk_new gives unless PDMP3_BULK_HOST_HUFFMAN=1 is set): the host only runs
  * the sequential scan and ships side info + reservoir snapshots; scalefactors, Huffman and the frame-to-frame
  * merge run on the device (pdmp3_hip_stream_submit_bits) and the pool just copies PCM out.  host_huffman = 1:

@@ -94,6 +94,16 @@ typedef struct pdmp3_hip_ctx pdmp3_hip_ctx;
  * P:2127-2128, P:2144-2146, generated on the host with the same expressions). */
 int pdmp3_hip_create(int device, pdmp3_hip_ctx** out);
 void pdmp3_hip_destroy(pdmp3_hip_ctx* ctx);
+/* Environment read by pdmp3_hip_create() (none of them changes a result):
+ *   PDMP3_HIP_CHAIN=0             every launch takes the chunk kernel (a chunk of frames per wave, halo)
+ *   PDMP3_HIP_GRAN_MAX=n          largest launch, in frames, that takes the granule kernel (default 12288 on an MI355X)
+ *   PDMP3_HIP_DIRECT_MAX=n        largest batch of a stream object that runs on the pinned host buffers directly (default 32; 0: never)
+ *   PDMP3_HIP_SF_HINT=0|1|2       sampling frequency whose line table the granule kernel keeps in LDS (default 0 = 44.1 kHz;
+ *                                 granules of another one read the table from memory)
+ *   PDMP3_HIP_DEBUG_FAR_TIMEOUT=1 tests: every wait for another workgroup gives up at once (the independent way is taken)
+ *   PDMP3_HIP_UNPACK_PROF=1       development: shader-clock stamps of k_unpack's steps, one line per launch on stderr
+ * and by the host library (libpdmp3.so): PDMP3_DEVICE, PDMP3_STREAM_THREADS, PDMP3_NO_READAHEAD (include/pdmp3.h),
+ * PDMP3_BULK_HOST_HUFFMAN, PDMP3_BULK_SNAPSHOT_ROWS, PDMP3_BULK_TRACE (include/pdmp3_bulk.h), PDMP3_CLI_STREAMING, PDMP3_CLI_WAV. */
 const char* pdmp3_hip_last_error(void);
 
 /* Bytes of one stream's carried synthesis state (replaces the function-static
