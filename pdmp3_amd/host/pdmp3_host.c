@@ -59,7 +59,10 @@ static inline unsigned leaf_nsign(int quads, unsigned val) {
 static huff_lut g_lut[PDMP3_NUM_HUFF_BOOKS];
 static pthread_once_t g_lut_once = PTHREAD_ONCE_INIT;
 
+static uint16_t g_frame_q[15][3];       /* frame sizes without padding (frame_bytes); filled here: handles are created on any thread */
 static void build_luts(void) {
+  for (unsigned b = 1; b < 15; b++)
+    for (unsigned f = 0; f < 3; f++) g_frame_q[b][f] = (uint16_t)(144u * kBitratesL3[b] / kSampleRates[f]);
   for (int b = 0; b < PDMP3_NUM_HUFF_BOOKS; b++) {
     huff_lut* L = &g_lut[b];
     const pdmp3_hcode* codes = kHuffBooks[b];
@@ -388,11 +391,7 @@ static inline unsigned side_bits(side_cur* c, unsigned n) {          /* n <= 12 
 }
 
 static unsigned frame_bytes(const frame_header* H) {   /* P:1135-1138; the 42 quotients there are, computed once */
-  static uint16_t q[15][3];
-  if (!q[1][0])
-    for (unsigned b = 1; b < 15; b++)
-      for (unsigned f = 0; f < 3; f++) q[b][f] = (uint16_t)(144u * kBitratesL3[b] / kSampleRates[f]);
-  return q[H->bitrate_index][H->sfreq] + H->padding;
+  return g_frame_q[H->bitrate_index][H->sfreq] + H->padding;
 }
 
 static void read_side_info(pdmp3_handle* id) {

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Sanitizer runs of the host library's thread paths on the CPU build (no GPU: parse-only handles; the engine library is
+# only linked).  ThreadSanitizer, then AddressSanitizer + UBSan, over (a) three handles reading concurrently through
+# pdmp3_feed / pdmp3_read with the helper pool, (b) the whole-stream parser on 2 / 4 / 6 pool threads.
+#   bash tools/sanitize/run.sh file.mp3      (e.g. python -m pdmp3_amd.packer c3 /tmp/c3; any stream of a few thousand frames)
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+OUT=${TMPDIR:-/tmp}/pdmp3_sanitize
+mkdir -p $OUT
+for san in thread address,undefined; do
+  for t in stream_threads bulk_threads; do
+    gcc -O1 -g -fsanitize=$san -I$ROOT/include -I$ROOT/pdmp3_amd/csrc -o $OUT/$t $ROOT/tools/sanitize/$t.c $ROOT/pdmp3_amd/host/pdmp3_host.c \
+        -L$ROOT/pdmp3_amd -lpdmp3_hip -lpthread -Wl,-rpath,$ROOT/pdmp3_amd 2> /dev/null
+    echo "== $san $t"
+    ASAN_OPTIONS=detect_leaks=0 $OUT/$t "$1" 2>&1 | tail -4
+  done
+done
