@@ -126,6 +126,41 @@ def _mp_run(_):
     return dec.time_decode(sp, sd, reps)
 
 
+def parity_checker():
+    """the CPU decoder the bench line's `parity` field is measured against: the compiled reference (oracle/_ref, kind
+    "reference") when its prebuilt library travelled with the repo, else the oracle's restatement ("port").  Checker
+    only: called after the timed region, never part of what is measured."""
+    from oracle import oracle as orc
+    o = orc.Oracle()
+    return (orc.Reference(), "reference", o) if orc.have_ref() else (o, "port", o)
+
+
+def parity_of(got, want, frames, against, what):
+    import numpy as np
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    return {"max_abs_diff_lsb": int(d.max()) if d.size else 0, "samples_differing": int((d > 0).sum()), "samples": int(d.size),
+            "frames": int(frames), "against": against, "what": what, "tolerance_lsb": 1, "ok": bool(d.size == 0 or d.max() <= 1)}
+
+
+def boundary_parity(gathered, seed, n_per_rank, world):
+    """N > 1, rank 0: the gathered PCM against the CPU decoder on every frame within +-2 of a shard boundary, the first
+    4 frames of the stream and the last 2 (the CPU decoder starts cold 8 frames in front of each window; the
+    synthesis state reaches 2 granules back).  gathered: int16 [world * n_per_rank][2304]"""
+    import numpy as np
+    dec, against, o = parity_checker()
+    total = world * n_per_rank
+    wins = [(0, 4)] + [(r * n_per_rank - 2, r * n_per_rank + 2) for r in range(1, world)] + [(total - 2, total)]
+    got, want = [], []
+    for a, b in wins:
+        w0 = max(0, a - 8)
+        sp, sd = o.generate(seed, w0, b - w0)
+        sd["frame"][0] |= 0x40                                  # PDMP3_FR_RESET: the CPU decoder starts from zero here
+        want.append(dec.decode(sp, sd)[a - w0:])
+        got.append(gathered[a:b])
+    return parity_of(np.concatenate(got), np.concatenate(want), sum(b - a for a, b in wins), against,
+                     "gathered PCM, frames within +-2 of each of the %d shard boundaries + stream head and tail" % (world - 1))
+
+
 def measured_traffic(frames, n_halo):
     """HBM bytes per launch of k_decode from the committed PMC passes
     (profiles/*_pmc_summary.json; separate rocprofv3 --pmc runs of this same
@@ -163,6 +198,7 @@ def main():
     ap.add_argument("--cpu-all-seconds", type=float, default=6.0, help="all-host-cores leg of the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bitstream-to-PCM extra")
+    ap.add_argument("--shard", type=int, default=SHARD_FRAMES, help="N = 1: frames of the extra C5-shard figure (0 = skip)")
     ap.add_argument("--big", type=int, default=131072, help="frames of the extra large-batch roofline probe (0 = skip)")
     args = ap.parse_args()
 
@@ -232,10 +268,18 @@ def main():
     kern_ms = ev0.elapsed_time(ev1) / args.steps
     kernel_name = eng.last_launch_kernel()
 
+    parity = None
+    per_rank = None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # what every rank ran, for the reader of a scaling curve: the kernel (the engine's choice, read back), its launch
+        # time from the rank's own HIP events, the device
+        mine_info = {"rank": rank, "device": dev_index, "kernel": kernel_name, "avg_launch_ms": round(kern_ms, 5),
+                     "frames": n, "halo_frames": halo, "first_frame": first}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_info)
         # the path's one exchange: final PCM gather to rank 0 (RCCL over xGMI: grouped point-to-point, the root's
         # ingress links in parallel), outside the timed region.  A one-element gather first: communicator set-up
         # is not part of the exchange.
@@ -250,9 +294,16 @@ def main():
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         gather_bytes = int(mine.numel()) * (world - 1)                  # what crosses links into rank 0
-        if rank == 0 and args.dump_gathered:
+        if rank == 0:
             import numpy as np
-            np.save(args.dump_gathered, torch.cat([b.cpu() for b in bufs]).numpy().view(np.int16).reshape(-1, 2304))
+            gathered = torch.cat([b.cpu() for b in bufs]).numpy().view(np.int16).reshape(-1, 2304)
+            if args.dump_gathered:
+                np.save(args.dump_gathered, gathered)
+            try:
+                parity = boundary_parity(gathered, seed, n, world)
+            except Exception as e:                                       # a check beside the number, never fatal
+                parity = {"error": repr(e)}
+            del gathered
     else:
         gather_ms = None
 
@@ -292,8 +343,9 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-            # (which kernel that was is the engine's decision -- granule kernel up to 8192 frames, else independent
-            #  chunks -- and is read back from it: pdmp3_hip_last_launch_kind)
+            # (which kernel that was is the engine's decision -- the granule kernel for launches of up to
+            #  PDMP3_HIP_GRAN_MAX frames, 12288 on an MI355X, else independent chunks -- and is read back from it:
+            #  pdmp3_hip_last_launch_kind)
             "kernel": kernel_name, "avg_launch_ms": round(kern_ms, 5),
             "algorithmic_bytes_per_launch": launch_bytes,
         },
@@ -305,11 +357,55 @@ def main():
     out["roofline_fp32"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(tf / FP32_PEAK_TFLOPS, 5), "algorithmic_flop_per_frame": ALGO_FLOP_PER_FRAME,
                             "dtype": "f32 (v_mfma_f32_16x16x4_f32 + VALU)"}
+    if world == 1:
+        # BASELINE.json's metric, second half ("PCM max-abs-diff vs ref"): the PCM the last timed step left in HBM, all
+        # of it, against the CPU decoder on the same generated frames.  After the timed region; the checker is never timed.
+        try:
+            dec, against, o = parity_checker()
+            sp_h, sd_h = o.generate(seed, first, n)
+            parity = parity_of(pcm.cpu().numpy(), dec.decode(sp_h, sd_h), n, against,
+                               "the whole batch of the last timed step (int16 PCM, P:2028-2031)")
+        except Exception as e:
+            parity = {"error": repr(e)}
+    out["parity"] = parity
+    if per_rank is not None:
+        out["ranks"] = per_rank
+        out["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0
+        out["collective_backend"] = "rccl" if backend == "nccl" else backend
     if gather_ms is not None:
         out["gather_ms"] = round(gather_ms, 3)
         out["gather_bytes"] = gather_bytes
         out["gather_GBps"] = round(gather_bytes / (gather_ms * 1e-3) / 1e9, 2)
         out["gather_backend"] = "rccl" if backend == "nccl" else backend
+
+    if args.shard and world == 1:
+        # what ONE rank of an N > 1 run does, on this GPU alone: the C5 shard of rank 1 -- 125 000 frames from a 2-frame
+        # halo, same seed, same engine call, hence the same kernel -- so that the driver's 1 -> N curve compares like
+        # with like (the N = 1 headline is C2, another workload and another kernel).  Outside the timed region.
+        ns = args.shard
+        sp3, sd3, pcm3 = eng.alloc_frames(ns + 2)
+        eng.generate(SEED_C5, ns - 2, ns + 2, sp3, sd3)
+        for _ in range(5):
+            eng.decode(sp3, sd3, pcm3, chunk_frames=args.chunk)
+        torch.cuda.synchronize()
+        reps = 20
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0 = time.perf_counter()
+        a.record()
+        for _ in range(reps):
+            eng.decode(sp3, sd3, pcm3, chunk_frames=args.chunk)
+        b.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - w0) / reps
+        ms = a.elapsed_time(b) / reps
+        ach = (ns + 2) * ALGO_BYTES_PER_FRAME / (ms * 1e-3) / 1e9
+        out["c5_shard_1gpu"] = {
+            "workload": "C5 shard of rank 1 (BASELINE configs[4]): frames [%d, %d) of the 1M-frame stream decoded from a 2-frame "
+                        "halo, one GPU, what each rank of an N > 1 run does per step" % (ns, 2 * ns),
+            "frames": ns, "halo_frames": 2, "kernel": eng.last_launch_kernel(), "avg_launch_ms": round(ms, 4),
+            "ms_per_step": round(wall * 1e3, 4), "frames_per_s": round(ns / wall, 1),
+            "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
+        del sp3, sd3, pcm3
 
     if args.big and world == 1:
         # kernel quality at throughput size (SURVEY 8d C5 shard scale), outside the timed region

@@ -18,6 +18,7 @@
 #include "gen_core.h"
 #include "host_tables.h"
 #include "unpack_core.h"
+#include <atomic>
 #include <mutex>
 #include <new>
 
@@ -402,7 +403,7 @@ struct pdmp3_hip_ctx {
   int gran_max_frames;      // launches up to this many frames take the granule kernel (PDMP3_HIP_GRAN_MAX)
   int wave_slots_gran;      // waves of k_decode_g the device holds at once (CUs x 4 SIMDs x 4)
   unsigned debug_flags;     // PDMP3_HIP_DEBUG_FAR_TIMEOUT=1: every wait for another workgroup gives up at once (tests)
-  int last_kind;            // PDMP3_HIP_LAUNCH_* of the latest decode launch (reports only)
+  std::atomic<int> last_kind;   // PDMP3_HIP_LAUNCH_* of the latest decode launch, any thread (reports only)
   int direct_max_frames;    // record batches of a stream up to this size run on the pinned host buffers directly (PDMP3_HIP_DIRECT_MAX)
   int sf_hint;              // sampling-frequency index the granule kernel's line tables are loaded for (PDMP3_HIP_SF_HINT; 0 = 44.1 kHz)
   std::mutex chain_mu;
@@ -426,7 +427,7 @@ static int fail(int code, const char* what, hipError_t e) {
 extern "C" const char* pdmp3_hip_last_error(void) { return g_err; }
 
 extern "C" size_t pdmp3_hip_state_bytes(void) { return (size_t)kStateFloats * sizeof(float); }
-extern "C" int pdmp3_hip_last_launch_kind(const pdmp3_hip_ctx* c) { return c ? c->last_kind : PDMP3_HIP_LAUNCH_NONE; }
+extern "C" int pdmp3_hip_last_launch_kind(const pdmp3_hip_ctx* c) { return c ? c->last_kind.load(std::memory_order_relaxed) : PDMP3_HIP_LAUNCH_NONE; }
 
 extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   if (!c) return;
@@ -899,7 +900,15 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
   // it -- and the three state buffers rotate instead of being copied (previous <- current <- next).  Per batch: one
   // launch, two event records, one wait.  (PDMP3_HIP_DIRECT_MAX: largest such batch in frames, 0 = never.)
   t.direct = 0;
-  if (n_frames <= hs->ctx->direct_max_frames && (!host_dst || row == PDMP3_FRAME_PCM_BYTES)) {
+  // (the kernel itself stores into host_dst on this path: only where it certainly can -- pinned host memory, or memory of
+  //  THIS device; registered / managed memory and another GPU's memory take the copy path, whose hipMemcpyAsync sorts it out)
+  bool dst_ok = true;
+  if (host_dst) {
+    hipPointerAttribute_t pa;
+    if (hipPointerGetAttributes(&pa, host_dst) != hipSuccess) { (void)hipGetLastError(); dst_ok = false; }
+    else dst_ok = (pa.type == hipMemoryTypeHost && !pa.isManaged) || (pa.type == hipMemoryTypeDevice && pa.device == hs->ctx->device);
+  }
+  if (n_frames <= hs->ctx->direct_max_frames && dst_ok && (!host_dst || row == PDMP3_FRAME_PCM_BYTES)) {
     // (a stream object with ONE slot -- the streaming API's -- has one HIP stream: its batches are in order anyway, and
     //  its wait is for that stream: no events at all, each of which is a call here and a packet of its own on the queue)
     const bool lone = hs->n_slots == 1;
@@ -1047,6 +1056,7 @@ static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
   const size_t n = (size_t)n_frames;
+  t.direct = 0;               // (the records of this submit are the device's: a rewind replays d_spectra, never h_spectra)
   if (pool_bytes) {           // compact input: descriptors, side info and pool up in one copy, rows rebuilt on the device
     // (Tried: k_rows reading descriptors, side info and pool straight from the pinned host block, no copy at all -- the
     //  kernel then runs at PCIe speed and the pipeline, which is bound by the kernels of a window, lost 20 %.)

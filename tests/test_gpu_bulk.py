@@ -387,7 +387,7 @@ def test_corrupted_streams_pcm_against_the_oracle(oracle):
     transforms: +-1 LSB wherever the signal is within a few times full scale; where a flipped global_gain drives the
     synthesis to 100x .. 4000x full scale the bar is the north-star float tolerance, 1e-5 of that amplitude"""
     from pdmp3_amd import api
-    from util import pcm_tolerance
+    from util import pcm_tolerance_scaled
     rs = np.random.RandomState(777)
     bases = [np.frombuffer(packer.generate(n_frames=60, seed=500 + k, **kw), dtype=np.uint8) for k, kw in enumerate([
         dict(vbr=True, block_pct=(40, 10, 40, 10), mixed_pct=50), dict(mode=1, mode_ext=2, bitrate_index=14, big_pct=200, gain=(100, 140)),
@@ -421,7 +421,7 @@ def test_corrupted_streams_pcm_against_the_oracle(oracle):
             hist[:2] = np.maximum(hist[:2], amp[:2].max())
             quiet = hist < 1.0
             assert (d[quiet] <= 1).all(), (it, np.nonzero(quiet & (d > 1))[0][:4])
-            assert d.max() <= pcm_tolerance(st[:, :, :, 3]), it
+            assert d.max() <= pcm_tolerance_scaled(st[:, :, :, 3]), it
             loud += int((~quiet).any())
             streams += 1
     finally:

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 from pdmp3_amd.packer import packer
-from util import assert_pcm_close
+from util import assert_pcm_close, level, oracle_decode_many
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -93,11 +93,15 @@ def test_c4_mixed_corpus(oracle):
     assert worst <= 1
 
 
-def _c4_files(n_base=40, n_mod=50, hi_32k=13):
+LOUD = (145, 160)           # packer global_gain range that puts the PCM at a realistic level: median |sample| 70-250 LSB,
+                            # 99th percentile at full scale, 1-4 % of the samples clipped (default 110..150: median 1-9 LSB)
+
+
+def _c4_files(n_base=40, n_mod=50, hi_32k=13, seed0=400):
     """hi_32k: top bitrate index at 32 kHz.  13 = 256 kbps = 1152-byte frames, the H10 limit -- long streams of
     those drive the reference into replaying its input ring (include/pdmp3_bulk.h PDMP3_BULK_REPLAY), so the
-    full-size corpus stops at 12."""
-    files, seed = [], 400
+    full-size corpus stops at 12.  Every other file is LOUD (the +-1 LSB bar on a signal that is not nearly silent)."""
+    files, seed = [], seed0
     for mode, mext in ((3, 0), (0, 0), (1, 2)):
         for sfreq in (0, 1, 2):
             for vbr in (False, True):
@@ -106,27 +110,31 @@ def _c4_files(n_base=40, n_mod=50, hi_32k=13):
                     hi = hi_32k if sfreq == 2 else 14
                     files.append(packer.generate(n_frames=n_base + seed % n_mod, seed=seed, sfreq=sfreq, mode=mode, mode_ext=mext,
                                                  vbr=vbr, vbr_lo=4, vbr_hi=hi, bitrate_index=min(12, hi), block_pct=blocks,
-                                                 mixed_pct=50 if blocks[2] else 0))
+                                                 mixed_pct=50 if blocks[2] else 0, gain=LOUD if seed % 2 else (110, 150)))
     return files
 
 
 def test_c4_bulk_decoders_in_parallel(oracle):
-    """the C4 corpus through the bulk decoder (device Huffman), several decoders live at once on their own host
-    threads and HIP streams: nothing is shared between them but read-only tables.
-    PDMP3_FULL_C4=1: the full-size corpus of SURVEY 8d (>= 64 files x >= 4096 frames; slow on the CPU side: oracle)."""
+    """BASELINE configs[3] at FULL size (>= 64 files x >= 4096 frames; 64 files, 264 k frames): {mono, stereo,
+    joint-MS} x {32, 44.1, 48 kHz} x {CBR, VBR} x {long, start/short/stop, mixed}, half of the files LOUD, through the
+    bulk decoder (device Huffman), six decoders live at once on their own host threads and HIP streams, files dealt
+    largest-first like ranks would take them; every sample against the oracle (a thread pool: 36 s of reference-speed
+    work on one core), +-1 LSB.  PDMP3_SHORT_C4=1: 54 files x 41-89 frames."""
     import threading
     from pdmp3_amd import api
-    full = bool(os.environ.get("PDMP3_FULL_C4"))
-    files = _c4_files(4096, 64, 12) + _c4_files(4096, 64, 12)[:10] if full else _c4_files()
-    assert len(files) >= (64 if full else 54)
-    want = [np.frombuffer(oracle.decode_buffer_like_cli(f), dtype=np.int16) for f in files]
-    got = [None] * len(files)
+    from pdmp3_amd.sharding import assign_files
+    short = bool(os.environ.get("PDMP3_SHORT_C4"))
+    files = _c4_files() if short else _c4_files(4096, 64, 12) + _c4_files(4096, 64, 12, seed0=900)[::5][:10]
+    assert len(files) >= (54 if short else 64)
     jobs = 6
+    plan = assign_files([len(f) for f in files], jobs)
+    assert sorted(sum(plan, [])) == list(range(len(files)))
+    got = [None] * len(files)
 
     def work(j):
-        b = api.BulkDecoder(threads=2, window_frames=512 if full else 16)
+        b = api.BulkDecoder(threads=2, window_frames=16 if short else 512)
         try:
-            for i in range(j, len(files), jobs):
+            for i in plan[j]:
                 got[i] = b.decode(files[i])
         finally:
             b.close()
@@ -137,12 +145,46 @@ def test_c4_bulk_decoders_in_parallel(oracle):
     for t in ts:
         t.join()
     dt = time.time() - t0
-    frames = 0
+    t0 = time.time()
+    want = oracle_decode_many(oracle, files)
+    dt_cpu = time.time() - t0
+    frames = worst = ndiff = 0
+    loud_med = []
     for i in range(len(files)):
+        nch = 1 if (files[i][3] >> 6) == 3 else 2
         assert got[i] is not None and got[i].shape == want[i].shape, i
-        assert_pcm_close(got[i], want[i], 1, "file %d" % i)
-        frames += got[i].size // 1152 // (1 if i < 18 else 2)
-    print("C4 bulk: %d files, %d frames, %d decoders in parallel: %.3f s = %.0f frames/s" % (len(files), frames, jobs, dt, frames / dt))
+        dmax, nd = assert_pcm_close(got[i], want[i], 1, "file %d" % i)
+        worst, ndiff = max(worst, dmax), ndiff + nd
+        frames += got[i].size // 1152 // nch
+        loud_med.append(level(want[i])[0])
+        want[i] = got[i] = None
+    assert short or frames >= 64 * 4096
+    print("C4 bulk: %d files, %d frames, %d decoders in parallel: %.3f s = %.0f frames/s; oracle %.1f s; max diff %d LSB (%d "
+          "samples); median |PCM| per file %d..%d LSB" % (len(files), frames, jobs, dt, frames / dt, dt_cpu, worst, ndiff,
+                                                         min(loud_med), max(loud_med)))
+
+
+@pytest.mark.parametrize("mode,mext", [(3, 0), (2, 0), (0, 0), (1, 2), (1, 0)], ids=["mono", "dual", "stereo", "joint_ms", "joint_off"])
+@pytest.mark.parametrize("sfreq", [0, 1, 2], ids=["441", "480", "320"])
+def test_loud_streams_every_mode(oracle, mode, mext, sfreq):
+    """+-1 LSB on streams that are neither silent nor clipped, per mode x rate: 600 frames with
+    long / start / short / stop / MIXED blocks at the LOUD gain, through the streaming API (host Huffman) and the
+    whole-stream decoder (device Huffman) -- the level is asserted, not assumed"""
+    from pdmp3_amd import api
+    mp3 = packer.generate(n_frames=600, seed=0x10D + 16 * mode + sfreq, sfreq=sfreq, mode=mode, mode_ext=mext,
+                          bitrate_index=12 if sfreq == 2 else 13, block_pct=(40, 15, 30, 15), mixed_pct=50, gain=LOUD)
+    want = np.frombuffer(oracle.decode_buffer_like_cli(mp3), dtype=np.int16)
+    med, p99, clipped = level(want)
+    assert med >= 40 and p99 >= 8000 and clipped < 0.06, (med, p99, clipped)
+    got = _as16(api.decode_like_cli(mp3))
+    assert got.shape == want.shape
+    assert_pcm_close(got, want, 1, "streaming API")
+    b = api.BulkDecoder(threads=2, window_frames=64)
+    try:
+        bulk = b.decode(mp3)
+    finally:
+        b.close()
+    assert np.array_equal(bulk, got), "bulk != streaming API"
 
 
 def test_cli_writes_raw(oracle, tmp_path):

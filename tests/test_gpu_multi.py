@@ -31,6 +31,12 @@ def test_bench_two_ranks_gathered_pcm_equals_unsharded(engine, tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_gpu"] == n
     assert d["gather_bytes"] == n * 4608 and d["gather_ms"] > 0 and d["value"] > 0
+    # the line explains itself: what each rank ran, how many ranks the collective library saw (0 here:
+    # gloo stands in for RCCL on the one GPU), and the parity of the gathered PCM around the shard boundary
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all("k_decode" in r["kernel"] for r in d["ranks"])
+    assert d["ranks"][1]["halo_frames"] == 2 and d["ranks"][1]["first_frame"] == n - 2
+    assert d["rccl_ranks"] == 0 and d["collective_backend"] == "gloo"
+    assert d["parity"]["ok"] and d["parity"]["max_abs_diff_lsb"] <= 1 and d["parity"]["frames"] == 4 + 4 + 2, d["parity"]
     got = np.load(out)
     assert got.shape == (2 * n, 2304)
     spectra, side, pcm = engine.alloc_frames(2 * n)

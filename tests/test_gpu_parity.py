@@ -3,9 +3,15 @@
 seeded inputs, against the committed golden fixtures of the reference, and --
 at BASELINE.json's full sizes -- through size-independent properties.
 
-Bars: int16 PCM within +-1 LSB (north_star); float stage dumps within 1e-5
-absolute relative to the stage amplitude (stages 0-2 are expected bit-exact:
-they only use separately rounded mul/add like the reference).
+Bars, as literal numbers (tests/corpus.py PCM_TOL_LSB / F32_TOL_ABS):
+
+  int16 PCM   +-1 LSB (north_star) on all 30 record corpora but one: the 15 loud cases (global_gain 120..170,
+              6-37 % of the samples clipped), their 15 `_fs` twins at a realistic level (peaks 13-32 k, median
+              100-670 LSB, nothing clipped); ms_loud_clip (4.5e5 x full scale, 99 % clipped): 32 LSB
+  float PCM   1e-5 absolute on the 15 `_fs` twins; the loud cases' sums are 19..141 x full scale where one binary32
+              ulp is 2e-6..1.5e-5: a literal number per case (2 x the measured difference = 1.5..3.5 ulp)
+  stages 0-2  bit-exact (separately rounded mul/add like the reference); stage 3 (hybrid) 1e-5 x amplitude
+  64 frames per case; the reference fixture holds the PCM's hash, head and last frame.
 """
 import os
 import sys
@@ -15,7 +21,7 @@ import pytest
 
 import corpus
 from conftest import C2_SEED
-from util import assert_pcm_close, nch_of, pcm_tolerance, sha
+from util import assert_pcm_close, nch_of, sha
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -42,13 +48,13 @@ def test_native_library_is_loaded(engine):
     assert os.path.basename(pdmp3_amd.library_path()) in maps
 
 
-@pytest.mark.parametrize("name", list(corpus.CASES))
+@pytest.mark.parametrize("name", list(corpus.ALL_CASES))
 def test_gpu_vs_oracle_and_golden(engine, oracle, name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    n = g["pcm"].shape[0]
+    n = int(g["n_frames"][0])
     sp, sd = corpus.case(name, n=n)
     want, ws = oracle.decode(sp, sd, stages=True)
-    assert np.array_equal(want, g["pcm"]), "oracle drifted from the reference fixture"
+    assert sha(want) == str(g["pcm_sha"][0]), "oracle drifted from the reference fixture"
     got, gs = gpu_decode(engine, sp, sd, stages=True)
     nch = nch_of(sd)
     for k in range(3):
@@ -57,11 +63,13 @@ def test_gpu_vs_oracle_and_golden(engine, oracle, name):
     amp = max(1.0, float(np.abs(ws[:, :, :nch, 3]).max()))
     err = float(np.abs(ws[:, :, :nch, 3] - gs[:, :, :nch, 3]).max())
     assert err <= 1e-5 * amp, "hybrid output differs by %g (amplitude %g)" % (err, amp)
-    tol = pcm_tolerance(ws[:, :, :, 3])
-    assert_pcm_close(got, g["pcm"], tol, name + " vs reference fixture")
-    # the normal (non-dump) kernel, chunked
-    got2 = gpu_decode(engine, sp, sd, chunk=1)
-    assert_pcm_close(got2, g["pcm"], tol, name + " chunked")
+    tol = corpus.PCM_TOL_LSB[name]
+    assert_pcm_close(got, want, tol, name + " vs oracle (= reference fixture by hash)")
+    assert_pcm_close(got[:4], g["pcm_head"], tol, name + " vs reference fixture, head")
+    assert_pcm_close(got[-1:], g["pcm_last"], tol, name + " vs reference fixture, last frame")
+    # the normal (non-dump) kernels: chunk form with a halo per wave, granule form
+    for chunk in (1, 5, 0):
+        assert_pcm_close(gpu_decode(engine, sp, sd, chunk=chunk), want, tol, name + " chunk=%d" % chunk)
 
 
 def test_gpu_generator_matches_oracle(engine, oracle):
@@ -202,14 +210,13 @@ def test_gpu_channel1_state_survives_mono_runs(engine, oracle, chunk):
         assert np.array_equal(np.concatenate(parts), whole), cuts
 
 
-@pytest.mark.parametrize("name", list(corpus.CASES))
+@pytest.mark.parametrize("name", list(corpus.ALL_CASES))
 def test_gpu_float_pcm(engine, oracle, name):
     """float PCM (pdmp3_hip_decode_frames_f32): the synthesis sums before P:2028's scaling, against the
-    oracle's (whose int16 = clip(trunc(float * 32767)) is the reference's, bit for bit): 1e-5 absolute, relative to
-    the amplitude where a corpus drives the synthesis beyond full scale; int16 form and float form agree"""
+    oracle's (whose int16 = clip(trunc(float * 32767)) is the reference's, bit for bit): 1e-5 absolute on the `_fs`
+    cases, the literal per-case number of corpus.F32_TOL_ABS on the loud ones; int16 form and float form agree"""
     import torch
-    g = np.load(os.path.join(GOLD, name + ".npz"))
-    n = g["pcm"].shape[0]
+    n = corpus.N_GOLDEN
     sp, sd = corpus.case(name, n=n)
     _, want = oracle.decode_f32(sp, sd)
     dsp, dsd = engine.upload(sp, sd)
@@ -217,8 +224,8 @@ def test_gpu_float_pcm(engine, oracle, name):
     engine.decode_f32(dsp, dsd, out, chunk_frames=3)
     torch.cuda.synchronize()
     got = out.cpu().numpy()
-    tol = 1e-5 * max(1.0, float(np.abs(want).max()))
-    assert float(np.abs(got - want).max()) <= tol, name
+    err = float(np.abs(got - want).max())
+    assert err <= corpus.F32_TOL_ABS[name], "%s: float PCM differs by %g > %g" % (name, err, corpus.F32_TOL_ABS[name])
     q = np.clip(np.trunc(got.astype(np.float64) * 32767.0), -32767, 32767)
     q[got > 65538.0] = -32767                      # P:2028-2031 on x86-64: the wrap-around of cvttsd2si
     nch = nch_of(sd)
@@ -236,7 +243,8 @@ def test_gpu_float_pcm_c2(engine, oracle):
     sp, sd = oracle.generate(C2_SEED, 0, 96)
     _, want = oracle.decode_f32(sp, sd)
     got = out[:96].cpu().numpy()
-    assert float(np.abs(got - want).max()) <= 1e-5 * max(1.0, float(np.abs(want).max()))
+    assert float(np.abs(want).max()) < 4.0                      # C2 stays within 4 x full scale: the bar is literal
+    assert float(np.abs(got - want).max()) <= 1e-5
     pcm = torch.zeros((n, 2304), dtype=torch.int16, device=engine.tdev)
     engine.decode(spectra, side, pcm)
     torch.cuda.synchronize()
@@ -270,3 +278,37 @@ def test_gpu_granule_launches_equal_independent_chunks(engine):
     [t.start() for t in th]
     [t.join() for t in th]
     assert all(out.get(k) for k in range(4)), out
+
+
+def test_gpu_granule_kernel_gives_up_waiting_for_other_workgroups(monkeypatch, oracle):
+    """the granule kernel's give-up path ON THE DEVICE.  An engine created with
+    PDMP3_HIP_DEBUG_FAR_TIMEOUT=1 makes every wait for another workgroup time out at once: the first wave of each
+    workgroup derives its frame's opening state the independent way (gran_slow_chunk(..., state_only): run_chunk's halo
+    as a called function on generic LDS pointers).  PCM and carried state must equal the chunk kernel's bit for bit:
+    launch sizes of one workgroup up to several rounds of them, the H5-heavy / mono / RESET corpora, float PCM."""
+    import torch
+    import pdmp3_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from soak_chain import one
+    monkeypatch.setenv("PDMP3_HIP_DEBUG_FAR_TIMEOUT", "1")
+    eng = pdmp3_amd.Engine(0)
+    monkeypatch.delenv("PDMP3_HIP_DEBUG_FAR_TIMEOUT")
+    try:
+        for k, n in enumerate((9, 65, 2048, 4099, 12288)):
+            assert one(eng, 0x5EED00F000 + k, n), n
+        for name in ("ms_short_heavy_480", "mono_441", "ms_resets", "ms_mixed_blocks_441_fs", "ms_is_short_480_fs"):
+            sp, sd = corpus.case(name)
+            a = gpu_decode(eng, sp, sd, chunk=1)                 # granule kernel, every far wait given up
+            b = gpu_decode(eng, sp, sd, chunk=2)                 # independent chunks
+            assert np.array_equal(a, b), name
+            assert_pcm_close(a, oracle.decode(sp, sd), corpus.PCM_TOL_LSB[name], name)
+        sp, sd = oracle.generate(C2_SEED, 0, 300)
+        dsp, dsd = eng.upload(sp, sd)
+        f1 = torch.zeros((300, 2304), dtype=torch.float32, device=eng.tdev)
+        f2 = torch.zeros_like(f1)
+        eng.decode_f32(dsp, dsd, f1, chunk_frames=1)
+        eng.decode_f32(dsp, dsd, f2, chunk_frames=3)
+        torch.cuda.synchronize()
+        assert torch.equal(f1, f2)
+    finally:
+        eng.close()

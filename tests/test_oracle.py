@@ -18,13 +18,17 @@ from util import sha, nch_of
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("name", list(corpus.CASES))
+@pytest.mark.parametrize("name", list(corpus.ALL_CASES))
 def test_oracle_matches_golden(oracle, name):
+    """64 frames per case from the compiled reference: PCM of all frames by hash, head and last frame by value"""
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    sp, sd = corpus.case(name, n=g["pcm"].shape[0])
+    n = int(g["n_frames"][0])
+    assert n >= 64
+    sp, sd = corpus.case(name, n=n)
     assert [sha(sp), sha(sd)] == list(g["input_sha"]), "corpus generator drifted from the fixtures"
     pcm, stg = oracle.decode(sp, sd, stages=True)
-    assert np.array_equal(pcm, g["pcm"])
+    assert sha(pcm) == str(g["pcm_sha"][0])
+    assert np.array_equal(pcm[:4], g["pcm_head"]) and np.array_equal(pcm[-1:], g["pcm_last"])
     nch = nch_of(sd)
     assert [sha(stg[:, :, :nch, k]) for k in range(4)] == list(g["stage_sha"])
     assert np.array_equal(stg[:2, :, :nch, 3].view(np.uint32), g["stage3_head"][:, :, :nch].view(np.uint32))
@@ -39,7 +43,7 @@ def test_oracle_matches_golden_c2(oracle):
     assert sha(pcm) == str(g["pcm_sha_2048"][0])
 
 
-@pytest.mark.parametrize("name", list(corpus.CASES))
+@pytest.mark.parametrize("name", list(corpus.ALL_CASES))
 def test_oracle_bit_exact_vs_reference(oracle, reference, name):
     sp, sd = corpus.case(name, n=10, seed=1234)
     p1, s1 = oracle.decode(sp, sd, stages=True)

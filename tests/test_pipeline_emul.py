@@ -11,7 +11,7 @@ import pytest
 
 import corpus
 from conftest import C2_SEED
-from util import assert_pcm_close, nch_of, pcm_tolerance
+from util import assert_pcm_close, nch_of
 
 
 def _p(a):
@@ -26,9 +26,10 @@ def emul_decode(emul, sp, sd, chunk=0, state=None, stages=False):
     return (pcm, stg) if stages else pcm
 
 
-@pytest.mark.parametrize("name", list(corpus.CASES))
+@pytest.mark.parametrize("name", list(corpus.ALL_CASES))
 def test_emul_vs_oracle(oracle, emul, name):
-    sp, sd = corpus.case(name, n=8)
+    """the bars of test_gpu_parity.py, literally: corpus.PCM_TOL_LSB (1 LSB but for ms_loud_clip: 32), 64 frames"""
+    sp, sd = corpus.case(name)
     want, ws = oracle.decode(sp, sd, stages=True)
     got, gs = emul_decode(emul, sp, sd, stages=True)
     nch = nch_of(sd)
@@ -37,7 +38,7 @@ def test_emul_vs_oracle(oracle, emul, name):
     amp = max(1.0, float(np.abs(ws[:, :, :nch, 3]).max()))
     err = float(np.abs(ws[:, :, :nch, 3] - gs[:, :, :nch, 3]).max())
     assert err <= 1e-5 * amp, "hybrid output differs by %g (amplitude %g)" % (err, amp)
-    assert_pcm_close(got, want, pcm_tolerance(ws[:, :, :, 3]), name)
+    assert_pcm_close(got, want, corpus.PCM_TOL_LSB[name], name)
     # the stage dumps come from the general formulation of every phase; without them the wave takes the fast paths
     # (ph_requant_long for granules of long blocks): the same arithmetic per line, so the same PCM bit for bit
     assert np.array_equal(emul_decode(emul, sp, sd), got), "fast paths differ from the general formulation"
@@ -139,17 +140,16 @@ def test_oracle_float_pcm_is_what_the_int16_comes_from(oracle):
     assert np.abs(f32).max() > 0.5
 
 
-@pytest.mark.parametrize("name", ["ms_long_441", "mono_441", "ms_short_heavy_480", "ms_loud_clip"])
+@pytest.mark.parametrize("name", list(corpus.ALL_CASES))
 def test_emul_float_pcm(oracle, emul, name):
-    """pdmp3_hip_decode_frames_f32 on the host build: 1e-5 absolute (north_star's float tolerance; relative to the
-    amplitude where the signal is driven beyond full scale), chunked == unchunked"""
-    sp, sd = corpus.case(name, n=8)
+    """pdmp3_hip_decode_frames_f32 on the host build: 1e-5 absolute (north_star's float tolerance) on the `_fs` cases,
+    corpus.F32_TOL_ABS's literal number on the loud ones; chunked == unchunked"""
+    sp, sd = corpus.case(name)
     _, want = oracle.decode_f32(sp, sd)
     n = sp.shape[0]
     got = np.zeros((n, 2304), np.float32)
     emul.emul_decode_frames_f32(_p(sp), _p(sd), n, None, _p(got), 0)
-    tol = 1e-5 * max(1.0, float(np.abs(want).max()))
-    assert float(np.abs(got - want).max()) <= tol
+    assert float(np.abs(got - want).max()) <= corpus.F32_TOL_ABS[name]
     got2 = np.zeros((n, 2304), np.float32)
     emul.emul_decode_frames_f32(_p(sp), _p(sd), n, None, _p(got2), 3)
     assert np.array_equal(got, got2)

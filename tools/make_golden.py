@@ -6,8 +6,9 @@ Fixtures are data: expected outputs of the reference for inputs that the tests
 re-derive from (case name, seed) -- tests/corpus.py -- or from the integer-only
 C2 generator.  Nothing of the reference's source is stored.
 
-  tests/golden/<case>.npz       pcm int16 [n][2304]; stage3 float32 of the first 2 frames;
-                                sha256 of each of the 4 stage dumps (all frames)
+  tests/golden/<case>.npz       64 frames per case, kept small: sha256 of the int16 PCM of all frames and
+                                of each of the 4 stage dumps, PCM of the first 4 frames and of the last one, stage3
+                                float32 of the first 2 frames, sha256 of the inputs
   tests/golden/c2_prefix.npz    PCM of the first 32 frames of the C2 stream + sha256 of the
                                 PCM of all 2048 frames
 """
@@ -24,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import corpus  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
-N_FRAMES = 6
+N_FRAMES = corpus.N_GOLDEN
 C2_SEED = 0x5EED0000C2
 
 
@@ -38,13 +39,14 @@ def main():
     o = orc.Oracle()
     gold = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
-    for name in corpus.CASES:
+    for name in corpus.ALL_CASES:
         sp, sd = corpus.case(name, n=N_FRAMES)
         pcm, stg = ref.decode(sp, sd, stages=True)
         nch = 1 if ((int(sd["frame"][0, 0, 0]) >> 2) & 3) == 3 else 2
         np.savez_compressed(
             os.path.join(gold, name + ".npz"),
-            pcm=pcm, stage3_head=stg[:2, :, :, 3],
+            n_frames=np.array([N_FRAMES]), pcm_sha=np.array([sha(pcm)]), pcm_head=pcm[:4], pcm_last=pcm[-1:],
+            stage3_head=stg[:2, :, :, 3],
             stage_sha=np.array([sha(stg[:, :, :nch, k]) for k in range(4)]),
             input_sha=np.array([sha(sp), sha(sd)]))
         print("%-24s pcm sha %s" % (name, sha(pcm)[:16]))
