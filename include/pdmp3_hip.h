@@ -137,6 +137,7 @@ size_t pdmp3_hip_state_bytes(void);
  *
  * Asynchronous on `stream`.
  */
+#define PDMP3_HIP_CHUNK_PERSISTENT (-3)   /* chunk_frames: take the persistent granule kernel whatever the launch size (tests, tools) */
 int pdmp3_hip_decode_frames(pdmp3_hip_ctx* ctx,
                             const int16_t* d_spectra,
                             const pdmp3_gc_side* d_side,
@@ -154,6 +155,7 @@ int pdmp3_hip_decode_frames(pdmp3_hip_ctx* ctx,
 #define PDMP3_HIP_LAUNCH_CHUNKS    1
 #define PDMP3_HIP_LAUNCH_GRANULES8  8
 #define PDMP3_HIP_LAUNCH_GRANULES16 16
+#define PDMP3_HIP_LAUNCH_PERSISTENT 32   /* k_decode_p: workgroups of 16 wavefronts going round a range of frames each */
 int pdmp3_hip_last_launch_kind(const pdmp3_hip_ctx* ctx);
 
 /* Float PCM (not in the reference, whose only output is int16): the same decode, but what is stored is

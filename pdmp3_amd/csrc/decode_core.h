@@ -1313,7 +1313,14 @@ struct GranPos {
   int w;                 // place of the granule within its workgroup
   int wpw;
   unsigned* tabs_ready;  // LDS: waves of the workgroup that have stored their part of the tables
+  // persistent form (run_granule_ring): the workgroup's waves go round a RANGE of granules [g_base, g_end), wave w taking
+  // g_base + w, + wpw, ...; the mailboxes are a ring (place wpw - 1 hands on to place 0) and their flags carry the
+  // receiving granule's number in the range + 1 instead of 0 / 1; nothing is handed on beyond g_end
+  int ring;              // 0: one granule per wave, flags 0 -> 1 (k_decode_g)
+  int g_base, g_end;
 };
+PD_FN int gran_next_place(const GranPos& gp) { return (gp.ring && gp.w + 1 == gp.wpw) ? 0 : gp.w + 1; }
+PD_FN unsigned gran_tag(const GranPos& gp, int g) { return gp.ring ? (unsigned)(g - gp.g_base + 1) : 1u; }
 static_assert(sizeof(WaveData::xr) >= kOvlRegs * 64 * sizeof(float), "tails mailbox");
 static_assert(offsetof(WaveData, scale) + sizeof(WaveData::scale) - offsetof(WaveData, spec) >= kHistSlots * 64 * sizeof(float) &&
               offsetof(WaveData, xr) >= offsetof(WaveData, scale) + sizeof(WaveData::scale), "rows mailbox");
@@ -1328,6 +1335,12 @@ PD_FN void gran_tabs_wait(const GranPos& gp) {
 }
 PD_FN void gran_lds_wait(unsigned* p) {
   while (PD_UNIFORM(PD_LDS_FLAG(p)) == 0) PD_SLEEP();
+  asm volatile("" ::: "memory");
+}
+// ring form: the flag carries the number of the granule it is meant for
+PD_FN void gran_lds_flag_tag(int lane, unsigned* p, unsigned tag) { if (lane == 0) PD_LDS_FLAG(p) = tag; }
+PD_FN void gran_lds_wait_tag(unsigned* p, unsigned tag) {
+  while ((unsigned)PD_UNIFORM(PD_LDS_FLAG(p)) != tag) PD_SLEEP();
   asm volatile("" ::: "memory");
 }
 PD_FN void gran_far_signal(int lane, const DecodeArgs& a, int g, int k) {
@@ -1365,6 +1378,28 @@ PD_FN void gran_send_rows(int lane, const WaveData& L, const DecodeArgs& a, int 
     gran_lds_flag(lane, &mb.rows_full);
   }
 }
+// ring form of the two (persistent kernel): always through the next place's mailboxes, flags = the receiving granule's tag
+PD_FN void gran_send_tails_ring(int lane, const float* y2, int g, const GranPos& gp) {
+  const int nx = gran_next_place(gp);
+  const unsigned tag = gran_tag(gp, g + 1);
+  GranMb& mb = gp.mb[nx];
+  gran_lds_wait_tag(&mb.free, tag);
+  float* box = gran_tails_box(gp.wl[nx]);
+  for (int m = 0; m < kOvlRegs; m++) box[m * 64 + lane] = y2[m];
+  PD_WAVE_SYNC();
+  gran_lds_flag_tag(lane, &mb.tails_full, tag);
+}
+PD_FN void gran_send_rows_ring(int lane, const WaveData& L, int g, const GranPos& gp) {
+  const int ch = lane >> 5, i = lane & 31;
+  const int nx = gran_next_place(gp);
+  const unsigned tag = gran_tag(gp, g + 1);
+  GranMb& mb = gp.mb[nx];
+  gran_lds_wait_tag(&mb.free, tag);
+  float* box = gran_rows_box(gp.wl[nx]);
+  for (int s = 0; s < kHistSlots; s++) box[s * 64 + lane] = L.hyb[ch][3 + s][i];
+  PD_WAVE_SYNC();
+  gran_lds_flag_tag(lane, &mb.rows_full, tag);
+}
 // both parts from a wave that has the state in registers (run_chunk at the end of a frame), for granule g = the frame's
 // second (gp = ITS place): coefficient 16 + i is he of lane i < 16, coefficient 16 - i is ho of lane i <= 16 -- together
 // all 32 of a row
@@ -1375,6 +1410,23 @@ PD_FN void gran_publish_regs(int lane, const LaneRegs& R, const DecodeArgs& a, i
   const uint8_t nb = reinterpret_cast<const uint8_t*>(a.side + (size_t)fn * 4)[7];
   if (((nb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 || (nb & PDMP3_FR_RESET)) return;
   const int ch = lane >> 5, i = lane & 31;
+  if (gp.ring) {
+    if (g + 1 >= gp.g_end) return;              // (the next range derives its opening state itself)
+    const int nx = gran_next_place(gp);
+    const unsigned tag = gran_tag(gp, g + 1);
+    GranMb& mb = gp.mb[nx];
+    gran_lds_wait_tag(&mb.free, tag);
+    float* tb = gran_tails_box(gp.wl[nx]);
+    float* rb = gran_rows_box(gp.wl[nx]);
+    for (int m = 0; m < kOvlRegs; m++) tb[m * 64 + lane] = R.ovl[m];
+    for (int s = 0; s < kHistSlots; s++) {
+      if (i < 16) rb[s * 64 + ch * 32 + 16 + i] = R.he[s];
+      if (i <= 16) rb[s * 64 + ch * 32 + 16 - i] = R.ho[s];
+    }
+    PD_WAVE_SYNC();
+    if (lane == 0) { PD_LDS_FLAG(&mb.tails_full) = tag; PD_LDS_FLAG(&mb.rows_full) = tag; }
+    return;
+  }
   const bool far = gp.w == gp.wpw - 1;
   float* tails = far ? a.chain_state + (size_t)g * kGranFloats : nullptr;
   if (far) {
@@ -1590,15 +1642,29 @@ PD_SLOW_FN void gran_slow_chunk(DecodeArgs a, GlobalTables T, BankPtr cb, int f,
 // One granule of a stereo frame whose predecessor's state comes through the chain (or is the caller's / zero: `fresh`).
 // pf: the granule's spectra / side records, in flight since the kernel's entry; next_takes: the wave of granule g + 1
 // will take this one's state from the chain.
-template <bool F32>
+// RING (persistent kernel, run_granule_ring): the wave goes round a range of granules -- its constants Rp are loaded once,
+// the granule's input is in Rp->pf*, the hand-over is the ring form (no memory path); emit = false: a HALO granule in front
+// of the range (its PCM belongs to the workgroup before: nothing is windowed or stored, tails and rows are handed on);
+// zero_in: the first halo granule (whatever state it starts from does not reach the range: SURVEY 8e);
+// halo_in: the range's first granule when no halo frame can be run in front of it (mono frames there): the state at
+// its start is derived by this wave the independent way (run_chunk's halo as a called function);
+// g_pf: the granule whose input is asked for while this one is windowed (this wave's next), -1: none.
+template <bool F32, bool RING = false>
 PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int g, WaveData& L, TabLds& S, const GranPos& gp,
-                       bool fresh, bool h5, bool next_takes, const LaneRegs& pf) {
+                       bool fresh, bool h5, bool next_takes, const LaneRegs& pf, LaneRegs* Rp = nullptr, bool emit = true,
+                       bool zero_in = false, bool halo_in = false, int g_pf = -1) {
   LaneRegs R;
-  const int lane = PD_LANE();
+  (void)Rp;
+  int lane_ = PD_LANE();
+  // (persistent kernel: the lane number is laundered every turn, so that nothing derived from it -- addresses, masks,
+  //  table indices -- is hoisted out of the loop and held in registers across the whole body)
+  if (RING) PD_PIN(lane_);
+  const int lane = lane_;
   const int f = g >> 1, gr = g & 1;
   const bool from_caller = fresh && gr == 0 && f == 0 && a.state_in && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET);
-  const bool from_zero = fresh && gr == 0 && !from_caller;
+  const bool from_zero = (fresh && gr == 0 && !from_caller) || (RING && zero_in);
   const bool from_chain = !from_caller && !from_zero;
+  const unsigned tag = gran_tag(gp, g);
   // (development: shader-clock stamps per wave when a.prof is set -- tools/gran_profile.py)
 #define PD_GT(k) if (a.prof) { const unsigned long long t_ = PD_CLOCK(); if (lane == 0) a.prof[(size_t)g * kProfSlots + (k)] = t_; }
   PD_GT(1)
@@ -1606,11 +1672,11 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   // A launch ends with its slowest wave, and those are the two of every workgroup whose hand-over goes through memory
   // (the last one publishes with stores it has to see acknowledged, the first one reads past its caches): the last wave
   // runs ahead of the other three of its SIMD until it has published, the first one catches up after it has taken
-  const bool far_sender = gp.w == gp.wpw - 1 && next_takes;
+  const bool far_sender = !RING && gp.w == gp.wpw - 1 && next_takes;
   if (far_sender) PD_SETPRIO(2);
   PD_PHASE(lane_init(lane, L, R, cb, T))
   if (h5 && (gr == 1 || !fresh)) {
-    PD_SETPRIO(3);     // (these waves have an eighth more to do than the others of their SIMDs, and a launch ends with its last wave)
+    if (!RING) PD_SETPRIO(3);     // (these waves have an eighth more to do than the others of their SIMDs, and a launch ends with its last wave)
     // (wave-uniform) granule 1 / channel 1 of this frame is a short block: its scales read three hybrid outputs of granule 0
     // (SURVEY H5): the first-half IMDCT outputs p = 0..2 of granule 0's (channel 0, subband 0) plus the tails of the
     // granule before the frame.  Waiting for the waves that compute them anyway would put granule 1's wave most of a
@@ -1631,10 +1697,11 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
       PD_PHASE((ph_requant<false, 1, false, true>(lane, L, S, cb, T, nullptr, nullptr)))
       PD_PHASE(ph_antialias(lane, L, cb, true))
       PD_PHASE(ph_peek_tail(lane, L, S, R1, T))
-      GranMb& mb = gp.mb[gp.w + 1];          // (a frame's two granules are neighbours in one workgroup: WPW is even)
+      GranMb& mb = gp.mb[gran_next_place(gp)];          // (a frame's two granules are neighbours in one workgroup: WPW is even)
       if (lane < 3) mb.peek_tail[lane] = R1.ovl[0];
       PD_WAVE_SYNC();
-      gran_lds_flag(lane, &mb.peek_full);
+      if (RING) gran_lds_flag_tag(lane, &mb.peek_full, gran_tag(gp, g + 1));
+      else gran_lds_flag(lane, &mb.peek_full);
     } else {
       LaneRegs R0;
       float tail = 0.0f;
@@ -1647,7 +1714,8 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
       const float head = ph_peek_head(lane, L, S, T);
       PD_WAVE_SYNC();
       if (!fresh) {
-        gran_lds_wait(&gp.mb[gp.w].peek_full);
+        if (RING) gran_lds_wait_tag(&gp.mb[gp.w].peek_full, tag);
+        else gran_lds_wait(&gp.mb[gp.w].peek_full);
         tail = lane < 3 ? gp.mb[gp.w].peek_tail[lane] : 0.0f;
       }
       pk = head + tail;
@@ -1668,26 +1736,32 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   else { PD_PHASE(ph_imdct(lane, L, S, R, cb, T, y1, y2)) }
   PD_GT(4)
   // from here on the wave reads nothing of spec / side / scale / xr any more: its mailboxes are free
-  if (gp.w > 0) gran_lds_flag(lane, &gp.mb[gp.w].free);
-  if (next_takes) { PD_PHASE(gran_send_tails(lane, y2, a, g, gp)) }
+  if (RING) gran_lds_flag_tag(lane, &gp.mb[gp.w].free, tag);
+  else if (gp.w > 0) gran_lds_flag(lane, &gp.mb[gp.w].free);
+  if (next_takes) {
+    if (RING) { PD_PHASE(gran_send_tails_ring(lane, y2, g, gp)) }
+    else { PD_PHASE(gran_send_tails(lane, y2, a, g, gp)) }
+  }
   PD_GT(5)
   float ovl[kOvlRegs];
   bool have_halo = false;
   LaneRegs H;                  // (memory, and touched only if the wait below is given up)
   if (from_caller) { PD_UNROLL for (int m = 0; m < kOvlRegs; m++) ovl[m] = a.state_in[m * 64 + lane]; }
   else if (from_zero) { PD_UNROLL for (int m = 0; m < kOvlRegs; m++) ovl[m] = 0.0f; }
-  else if (gp.w > 0) {
-    gran_lds_wait(&gp.mb[gp.w].tails_full);
+  else if (RING ? !halo_in : gp.w > 0) {
+    if (RING) gran_lds_wait_tag(&gp.mb[gp.w].tails_full, tag);
+    else gran_lds_wait(&gp.mb[gp.w].tails_full);
     const float* box = gran_tails_box(L);
     PD_UNROLL for (int m = 0; m < kOvlRegs; m++) ovl[m] = box[m * 64 + lane];
     PD_WAVE_SYNC();
-  } else if (gran_far_wait(a, g, 0, true)) {
+  } else if (!RING && gran_far_wait(a, g, 0, true)) {
     const float* st = a.chain_state + (size_t)(g - 1) * kGranFloats;
     PD_UNROLL for (int m = 0; m < kOvlRegs; m++) ovl[m] = PD_LOAD_DEVICE(&st[m * 64 + lane]);
   } else {
     // The workgroup before this one has not delivered within the bound (it is not resident: a partitioned or shared
     // device, a dispatcher that does not go in order).  Do not depend on it: derive the state at the start of the
     // frame the independent way, from the granules before it (run_chunk's halo) -- waiting costs time, never progress.
+    // (Persistent kernel: the first granule of a range whose halo frame cannot be run in front of it.)
     PD_WAVE_SYNC();
     gran_slow_chunk<F32>(a, T, cb, f, &L, &S, gp, false, &H);
     PD_WAVE_SYNC();
@@ -1706,9 +1780,20 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
       so[(kOvlRegs + kHistSlots + s) * 64 + lane] = L.hyb[ch][3 + s][R.idx_o];
     }
   }
-  if (next_takes) { PD_PHASE(gran_send_rows(lane, L, a, g, gp)) }
+  if (next_takes) {
+    if (RING) { PD_PHASE(gran_send_rows_ring(lane, L, g, gp)) }
+    else { PD_PHASE(gran_send_rows(lane, L, a, g, gp)) }
+  }
   if (far_sender && !(gr == 1 && h5)) PD_SETPRIO(0);
   PD_GT(8)
+  (void)g_pf;
+  if (RING && !emit) {
+    // a halo granule: no PCM.  The rows the wave before it sends are not wanted, but they arrive in this wave's spec | side
+    // | scale: the next granule must not be committed there before they have
+    if (from_chain) gran_lds_wait_tag(&gp.mb[gp.w].rows_full, tag);
+    PD_GT(11)
+    return;
+  }
   float acc[18];
   if (PD_EXP_SKIP & 16) { PD_UNROLL for (int t = 0; t < 18; t++) acc[t] = L.hyb[0][t][lane & 31]; } else { PD_PHASE(ph_window_own(lane, L, R, acc)) }
   PD_GT(9)
@@ -1719,8 +1804,9 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
       R.ho[s] = a.state_in[(kOvlRegs + kHistSlots + s) * 64 + lane];
     }
   } else if (from_zero) { PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = 0.0f; R.ho[s] = 0.0f; } }
-  else if (gp.w > 0) {
-    gran_lds_wait(&gp.mb[gp.w].rows_full);
+  else if (RING || gp.w > 0) {
+    if (RING) gran_lds_wait_tag(&gp.mb[gp.w].rows_full, tag);
+    else gran_lds_wait(&gp.mb[gp.w].rows_full);
     const float* rows = gran_rows_box(L) + (lane >> 5) * 32;
     PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = rows[s * 64 + R.idx_e]; R.ho[s] = rows[s * 64 + R.idx_o]; }
   } else {
@@ -1738,9 +1824,10 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
 
 // The wave of granule g: which way its frame goes (wave-uniform facts from the side records; both waves of a frame
 // decide alike).  gp = this granule's place; pf = its input, prefetched.
-template <bool F32>
+// RING: see run_granule; g_emit = the range's first granule proper (granules before it are its halo frame).
+template <bool F32, bool RING = false>
 PD_FN void run_granule_wave(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int g, WaveData& L, TabLds& S, const GranPos& gp,
-                            const LaneRegs& pf) {
+                            const LaneRegs& pf, LaneRegs* Rp = nullptr, int g_emit = 0, bool halo_by_wave = false, int g_pf = -1) {
   const int f = g >> 1, gr = g & 1;
   const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)f * 4)[7];
   const uint8_t pb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f > 0 ? f - 1 : 0) * 4)[7];
@@ -1756,12 +1843,74 @@ PD_FN void run_granule_wave(const DecodeArgs& a, const GlobalTables& T, BankPtr 
     // who takes this granule's state from the chain: granule 1 of the same frame; or the next frame, if it is a stereo
     // frame that does not start from zero (this frame being stereo, it then goes this way too)
     next_takes = gr == 0 || (f + 1 < a.n_frames && ((nb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 && !(nb & PDMP3_FR_RESET));
-    run_granule<F32>(a, T, cb, g, L, S, gp, fresh, h5, next_takes, pf);
+    if (RING) {
+      if (g + 1 >= gp.g_end) next_takes = false;          // (the next range derives its opening state itself)
+      const bool halo_frame = g < g_emit;                 // (then this frame is chained or fresh: run_granule_ring chose it so)
+      run_granule<F32, true>(a, T, cb, g, L, S, gp, fresh, h5, next_takes, pf, Rp, !halo_frame, halo_frame && gr == 0 && !fresh,
+                             halo_by_wave && g == g_emit && !fresh, g_pf);
+    } else run_granule<F32, false>(a, T, cb, g, L, S, gp, fresh, h5, next_takes, pf);
     return;
   }
-  if (gr == 1) return;                                       // the frame is decoded by the wave of its first granule
-  const GranPos second{gp.wl, gp.mb, gp.w + 1, gp.wpw, gp.tabs_ready};     // (a frame's two granules are in one workgroup: WPW is even)
-  gran_slow_chunk<F32>(a, T, cb, f, &L, &S, second, true, nullptr);
+  if (gr == 0) {                                             // the frame is decoded by the wave of its first granule
+    GranPos second = gp;                                     // (a frame's two granules are in one workgroup: WPW is even)
+    second.w = gp.w + 1;
+    if (RING) {
+      // this wave's own input was asked for before the loop / during the last window: its registers are dead here
+      gran_slow_chunk<F32>(a, T, cb, f, &L, &S, second, true, nullptr);
+    } else gran_slow_chunk<F32>(a, T, cb, f, &L, &S, second, true, nullptr);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Persistent granule kernel (k_decode_p): the launches too large for one granule per wave.
+//
+// A workgroup of WPW = 16 waves takes a contiguous RANGE of frames [f0, f1) and goes round it: wave w decodes granules
+// 2 f0 + w, + 16, + 32, ... with run_granule's straight-line body (128 VGPRs, four waves per SIMD), its per-lane constants
+// and the workgroup's LDS tables loaded ONCE, tails and rows handed from place to place through the LDS mailboxes as a
+// ring (place 15 hands on to place 0; the flags carry the receiving granule's number).  The only loop-carried registers are
+// constants and the next granule's input in flight.  Nothing crosses a range boundary: a range's opening state is
+// derived from data -- ONE halo per range instead of one per wave (run_chunk) or a hand-over through memory
+// (k_decode_g): the frame before the range is run through the same pipeline with its PCM suppressed (2 of the range's
+// ~1000 granule slots; its own input state does not reach the range), or, where that frame does not go the
+// granule way (mono, stereo right after mono), by the first wave calling run_chunk's halo.
+// Same arithmetic in the same order as run_chunk / run_granule: PCM and carried state bit-identical (tests compare).
+// ---------------------------------------------------------------------------
+template <bool F32>
+PD_FN void run_granule_ring(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, WaveData& L, TabLds& S, GranPos gp, int f0, int f1) {
+  const int lane = PD_LANE();
+  // the halo (wave-uniform, the same for all waves of the workgroup)
+  int g_emit = 2 * f0;
+  bool halo_by_wave = false;
+  gp.ring = 1;
+  gp.g_base = g_emit;
+  gp.g_end = 2 * f1;
+  if (f0 > 0) {
+    const uint8_t b0 = reinterpret_cast<const uint8_t*>(a.side + (size_t)f0 * 4)[7];
+    const uint8_t b1 = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f0 - 1) * 4)[7];
+    const uint8_t b2 = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f0 > 1 ? f0 - 2 : 0) * 4)[7];
+    const bool st0 = ((b0 & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3, st1 = ((b1 & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
+    const bool st2 = ((b2 & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
+    const bool needs_state = st0 && !(b0 & PDMP3_FR_RESET) && st1;          // (else: zero, or the frame derives its own -- run_granule_wave)
+    if (needs_state) {
+      const bool prev_goes_granule_way = (b1 & PDMP3_FR_RESET) || f0 == 1 || st2;
+      if (prev_goes_granule_way) gp.g_base = g_emit - 2;
+      else halo_by_wave = true;
+    }
+  }
+  GlobalTables Tl = T;
+  for (int g = gp.g_base + gp.w; g < gp.g_end; g += gp.wpw) {
+    // (a turn is run_granule's straight-line body as it is: the per-lane constants are asked for again every turn -- they
+    //  come from the L1 / L2 -- because held across the loop they cost what the chunk kernel pays: spills and moves; the
+    //  table pointers are laundered so that the compiler does not hoist those loads out of the loop)
+#if defined(__HIPCC__)
+    asm volatile("" : "+s"(Tl.taps), "+s"(Tl.frag_long), "+s"(Tl.frag_mat));
+#endif
+    if (a.prof) { const unsigned long long t_ = PD_CLOCK(); if (lane == 0) a.prof[(size_t)g * kProfSlots] = t_; }
+    LaneRegs pf;
+    ph_prefetch(lane, pf, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2);
+    run_granule_wave<F32, true>(a, Tl, cb, g, L, S, gp, pf, nullptr, g_emit, halo_by_wave, -1);
+    PD_WAVE_SYNC();
+  }
 }
 
 }  // namespace pdmp3

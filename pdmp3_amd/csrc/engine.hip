@@ -89,6 +89,32 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   run_granule_wave<F32>(a, T, (BankPtr)&c_bank, g, L[w], S, gp, pf);
 }
 
+// Persistent form (decode_core.h run_granule_ring): a workgroup of 16 waves goes round a contiguous range of
+// `frames_per_wg` frames, one granule per wave and turn; constants and tables once per wave / workgroup, hand-over through
+// the LDS mailboxes as a ring, one halo per range.  One workgroup per CU (158 KB of LDS), four waves per SIMD.
+template <bool F32>
+__global__ __launch_bounds__(64 * 16) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_decode_p(DecodeArgs a, GlobalTables T, int frames_per_wg) {
+  constexpr int W = 16;
+  __shared__ WaveData L[W];
+  __shared__ TabLds S;
+  __shared__ GranMb mb[W];
+  __shared__ unsigned tabs_ready;
+  const int tid = (int)threadIdx.x;
+  const int w = tid >> 6;
+  if (tid < W * (int)(sizeof(GranMb) / 4)) reinterpret_cast<unsigned*>(mb)[tid] = 0u;
+  if (tid == 0) tabs_ready = 0u;
+  __syncthreads();
+  tab_load_image(tid, 64 * W, S, T, a.sf_hint);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if ((tid & 63) == 0) atomicAdd(&tabs_ready, 1u);
+  const int f0 = (int)blockIdx.x * frames_per_wg;
+  int f1 = f0 + frames_per_wg;
+  if (f1 > a.n_frames) f1 = a.n_frames;
+  const GranPos gp{L, mb, w, W, &tabs_ready, 1, 2 * f0, 2 * f1};
+  run_granule_ring<F32>(a, T, (BankPtr)&c_bank, L[w], S, gp, f0, f1);
+}
+
 // same kernel with shader-clock stamps after every phase (tools/phase_profile.py)
 __global__ __launch_bounds__(64, PDMP3_WAVES_PER_EU) void k_decode_prof(DecodeArgs a, GlobalTables T) {
   __shared__ WaveLds L[1];
@@ -401,6 +427,8 @@ struct pdmp3_hip_ctx {
   int chain_mode;           // PDMP3_HIP_CHAIN=0: independent chunks with halos everywhere; otherwise launches up to
                             // gran_max_frames take the granule kernel (k_decode_g)
   int gran_max_frames;      // launches up to this many frames take the granule kernel (PDMP3_HIP_GRAN_MAX)
+  int ring_min_frames;      // launches from this many frames on take the persistent granule kernel (PDMP3_HIP_RING_MIN; 0: never)
+  int cus;
   int wave_slots_gran;      // waves of k_decode_g the device holds at once (CUs x 4 SIMDs x 4)
   unsigned debug_flags;     // PDMP3_HIP_DEBUG_FAR_TIMEOUT=1: every wait for another workgroup gives up at once (tests)
   std::atomic<int> last_kind;   // PDMP3_HIP_LAUNCH_* of the latest decode launch, any thread (reports only)
@@ -470,6 +498,8 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     const char* d = getenv("PDMP3_HIP_DEBUG_FAR_TIMEOUT");
     c->debug_flags = (d && *d == '1') ? PD_DEBUG_FAR_TIMEOUT : 0u;
     const char* e = getenv("PDMP3_HIP_GRAN_MAX");
+    c->cus = cus;
+    { const char* rm = getenv("PDMP3_HIP_RING_MIN"); c->ring_min_frames = rm ? atoi(rm) : 0; }
     c->gran_max_frames = e && atoi(e) > 0 ? atoi(e) : c->wave_slots_gran * 3;     // (measured on MI355X: faster than chunks with halos up to about 14000 frames)
   }
   // every failure from here on releases what was allocated so far (pdmp3_hip_destroy takes a partly built context)
@@ -620,10 +650,15 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.chunk_frames = chunk_frames;
   a.prof = d_prof;
   a.chain_state = nullptr; a.chain_flag = nullptr; a.chain_epoch = 0; a.debug_flags = c->debug_flags; a.sf_hint = c->sf_hint;
-  bool gran = false;
+  bool gran = false, ring = false;
   const bool plain = !d_stages && !d_prof;
+  // the persistent granule kernel: launches of at least ring_min_frames frames (and chunk_frames = -3: always)
+  const bool ring_prof = d_prof && chunk_frames_arg == -4;          // (development: the persistent kernel with per-turn stamps)
+  if ((plain || ring_prof) && c->chain_mode != 0 && n_frames >= 16 &&
+      (chunk_frames_arg == PDMP3_HIP_CHUNK_PERSISTENT || ring_prof || (chunk_frames_arg <= 1 && chunk_frames_arg >= 0 && c->ring_min_frames > 0 && n_frames >= c->ring_min_frames)))
+    ring = true;
   const bool gran_prof = d_prof && chunk_frames_arg == -2;          // (development: the granule kernel with per-wave stamps)
-  if ((plain || gran_prof) && c->chain_mode != 0 && chunk_frames_arg <= 1 && n_frames <= c->gran_max_frames) {
+  if (!ring && (plain || gran_prof) && c->chain_mode != 0 && chunk_frames_arg <= 1 && n_frames <= c->gran_max_frames) {
     // one granule per wave (run_granule): tails and matrixing rows are handed from wave to wave, no halo.  Waits for
     // another workgroup are bounded (then: halo), so the launch finishes whatever part of it is resident; up to
     // gran_max_frames all of it is
@@ -636,7 +671,17 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   }
   GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64, c->d_frag + 28 * 64, c->d_tab_image};
   const int nchunks = (n_frames + a.chunk_frames - 1) / a.chunk_frames;
-  if (gran) {
+  if (ring) {
+    // one workgroup per CU while a range keeps at least 8 frames (= one turn of the 16 waves)
+    const int cus = c->cus > 0 ? c->cus : 256;
+    int per = (n_frames + cus - 1) / cus;
+    if (per < 8) per = 8;
+    const int n_wgs = (n_frames + per - 1) / per;
+    a.chunk_frames = 1;
+    c->last_kind = PDMP3_HIP_LAUNCH_PERSISTENT;
+    if (d_pcm_f32) hipLaunchKernelGGL((k_decode_p<true>), dim3(n_wgs), dim3(64 * 16), 0, s, a, T, per);
+    else hipLaunchKernelGGL((k_decode_p<false>), dim3(n_wgs), dim3(64 * 16), 0, s, a, T, per);
+  } else if (gran) {
     // (workgroups of 8 waves while that gives every CU at most one of them)
     const bool small = 2 * n_frames <= c->wave_slots_gran / 2;
     const int W = small ? 8 : 16;

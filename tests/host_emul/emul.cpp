@@ -97,6 +97,41 @@ extern "C" int emul_decode_frames_granules(const int16_t* spectra, const pdmp3_g
   return 0;
 }
 
+// the persistent granule kernel (run_granule_ring, engine.hip k_decode_p): workgroups of 16 waves, each going round a
+// contiguous range of `frames_per_wg` frames; the waves of a workgroup are live together, the workgroups run one after the other
+extern "C" int emul_decode_frames_ring(const int16_t* spectra, const pdmp3_gc_side* side, int n_frames,
+                                       float* state, int16_t* pcm, float* pcm_f32, int frames_per_wg, int sf_hint) {
+  static HostTables H;
+  static bool ready = false;
+  if (!ready) { build_host_tables(H); ready = true; }
+  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data(), H.taps.data(), H.tab_image.data()};
+  std::vector<float> state_next(kStateFloats);
+  DecodeArgs a{spectra, side, pcm, pcm_f32, state, state ? state_next.data() : nullptr, nullptr, n_frames, 1, nullptr,
+               nullptr, nullptr, 0u, 0u, sf_hint};
+  constexpr int WPW = 16;
+  auto L = std::make_unique<WaveData[]>(WPW);
+  auto S = std::make_unique<TabLds>();
+  emu::run_wave([&] { tab_load_image(emu::lane(), 64, *S, T, sf_hint); });
+  unsigned tabs_ready = WPW;
+  GranMb mb[WPW];
+  if (frames_per_wg < 1) frames_per_wg = 1;
+  for (int f0 = 0; f0 < n_frames; f0 += frames_per_wg) {
+    const int f1 = f0 + frames_per_wg < n_frames ? f0 + frames_per_wg : n_frames;
+    memset(mb, 0, sizeof mb);
+    std::function<void()> bodies[WPW];
+    for (int w = 0; w < WPW; ++w) {
+      bodies[w] = [&, w] {
+        const GranPos gp{L.get(), mb, w, WPW, &tabs_ready, 1, 2 * f0, 2 * f1};
+        if (pcm_f32) run_granule_ring<true>(a, T, &H.cb, L[w], *S, gp, f0, f1);
+        else run_granule_ring<false>(a, T, &H.cb, L[w], *S, gp, f0, f1);
+      };
+    }
+    emu::run_waves(bodies, WPW);
+  }
+  if (state) std::copy(state_next.begin(), state_next.end(), state);
+  return 0;
+}
+
 extern "C" size_t emul_state_floats() { return kStateFloats; }
 
 extern "C" void emul_generate_frames(uint64_t seed, int64_t first, int n, int16_t* spectra, pdmp3_gc_side* side) {

@@ -243,8 +243,7 @@ def test_gpu_float_pcm_c2(engine, oracle):
     sp, sd = oracle.generate(C2_SEED, 0, 96)
     _, want = oracle.decode_f32(sp, sd)
     got = out[:96].cpu().numpy()
-    assert float(np.abs(want).max()) < 4.0                      # C2 stays within 4 x full scale: the bar is literal
-    assert float(np.abs(got - want).max()) <= 1e-5
+    assert float(np.abs(got - want).max()) <= 1e-5              # literal (C2's sums reach 21 x full scale in these frames)
     pcm = torch.zeros((n, 2304), dtype=torch.int16, device=engine.tdev)
     engine.decode(spectra, side, pcm)
     torch.cuda.synchronize()

@@ -215,3 +215,55 @@ def test_emul_granule_waves_give_up_waiting_for_other_workgroups(emul, name):
     sp, sd = corpus.case(name, n=21)
     want = emul_decode(emul, sp, sd, 0)
     assert np.array_equal(emul_decode_granules(emul, sp, sd, debug=1), want)
+
+
+def emul_decode_ring(emul, sp, sd, per, state=None, f32=False, sf_hint=0):
+    n = sp.shape[0]
+    pcm = np.zeros((n, 2304), np.float32 if f32 else np.int16)
+    emul.emul_decode_frames_ring(_p(sp), _p(sd), n, _p(state), None if f32 else _p(pcm), _p(pcm) if f32 else None, per, sf_hint)
+    return pcm
+
+
+@pytest.mark.parametrize("name", list(corpus.ALL_CASES))
+def test_emul_persistent_granule_kernel_equals_independent_chunks(emul, name):
+    """run_granule_ring (k_decode_p: 16 waves going round a range of frames, ring of LDS mailboxes, one halo per range) is the
+    same arithmetic in the same order as run_chunk: PCM bit-identical on every corpus -- ranges of 8 frames (one turn of
+    the ring), 9 (odd: a range ends in the middle of a turn), 23 and the whole batch; H5 frames at range starts, mono
+    corpora (every frame through run_chunk inside the loop), RESET frames, intensity stereo"""
+    sp, sd = corpus.case(name, n=51)
+    want = emul_decode(emul, sp, sd, 0)
+    for per in (8, 9, 23, 51):
+        assert np.array_equal(emul_decode_ring(emul, sp, sd, per), want), per
+
+
+def test_emul_persistent_granule_kernel_states_and_mode_switches(emul, oracle):
+    """stereo / mono / stereo runs cut by range boundaries everywhere (the halo frame in front of a range is mono, or
+    stereo right after mono: the range's first wave derives the state with run_chunk's halo; a range that starts with a
+    mono frame or a RESET frame needs none), the carried state in and out batch after batch, float PCM, another
+    sampling frequency than the workgroup's tables"""
+    sp, sd = _mode_switch_records()
+    whole = emul_decode(emul, sp, sd, 0)
+    for per in (8, 9, 10, 11, 13):
+        assert np.array_equal(emul_decode_ring(emul, sp, sd, per), whole), per
+    sp, sd = oracle.generate(C2_SEED, 0, 96)
+    whole = emul_decode(emul, sp, sd, 0)
+    st = np.zeros(emul.emul_state_floats(), np.float32)
+    st_ref = np.zeros(emul.emul_state_floats(), np.float32)
+    cuts = [0, 17, 33, 34, 60, 96]
+    out = [emul_decode_ring(emul, sp[a:b], sd[a:b], 8, st) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(out), whole)
+    emul_decode(emul, sp, sd, 0, st_ref)
+    assert np.array_equal(st.view(np.uint32), st_ref.view(np.uint32))
+    sd2 = sd.copy()
+    for f in (16, 24, 41):                                  # RESET at a range start, right before one, in the middle
+        sd2["frame"][f] |= 0x40
+    assert np.array_equal(emul_decode_ring(emul, sp, sd2, 8), emul_decode(emul, sp, sd2, 0))
+    got = emul_decode_ring(emul, sp[:40], sd[:40], 8, f32=True)
+    want = np.zeros((40, 2304), np.float32)
+    emul.emul_decode_frames_f32(_p(sp[:40]), _p(sd[:40]), 40, None, _p(want), 0)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    a, sa = corpus.case("ms_long_441", n=12)
+    b, sb = corpus.case("ms_short_heavy_480", n=12)
+    sp4 = np.concatenate([a, b, a]); sd4 = np.concatenate([sa, sb, sa])
+    for hint in (0, 1):
+        assert np.array_equal(emul_decode_ring(emul, sp4, sd4, 8, sf_hint=hint), emul_decode(emul, sp4, sd4, 0)), hint

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box round: smoke, GPU parity tests, bench.
 # Usage (from the repo root): gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tag]'
-TAG=${1:-r02}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -9,7 +9,7 @@ echo "== smoke"
 timeout 600 python3 __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
 tail -3 $OUT/smoke.log
 echo "== pytest -m gpu"
-timeout 1200 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+timeout 2400 python3 -m pytest tests -m gpu -x -q -s --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -15 $OUT/pytest_gpu.log
 echo "== bench"
 timeout 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
