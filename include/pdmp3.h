@@ -66,6 +66,28 @@ int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding);
 #define PDMP3_ENC_FLOAT_32 0x200
 int pdmp3_amd_set_encoding(pdmp3_handle* id, int encoding);
 
+/* ISO-correct switches (NOT in the reference).  The reference departs from ISO 11172-3 in five places
+ *  and this library reproduces them by default -- that is what "drop-in" means.  A bit set here selects
+ * the standard's behaviour for that item instead, from the next frame parsed on:
+ *   PDMP3_ISO_TABLE33   H1  count1table_select = 1 decodes with the standard's table B (4-bit codes); the reference's
+ *                           table index points into the middle of table 24 (pdmp3.c:569)
+ *   PDMP3_ISO_MS_BOUND  H2  MS stereo up to the LARGER of the two channels' count1 (pdmp3.c:1920 stops at the smaller)
+ *   PDMP3_ISO_IS_SHORT  H3  intensity stereo on short blocks multiplies by the ratios, window by window
+ *                           (pdmp3.c:2191 keeps them in `unsigned`, 2212-2213 assign the sample to both channels)
+ *   PDMP3_ISO_SF21      H4  long scalefactor band 21 has scalefactor 0 (pdmp3.c:1896-1901 reads scalefac_l[21], the next
+ *                           array's first element)
+ *   PDMP3_ISO_SF12      H5  short scalefactor band 12 has scalefactor 0 (pdmp3.c:1864-1869 reads scalefac_s[12][w], for
+ *                           granule 1 / channel 1 the bits of the previous granule's output)
+ * Nothing in the reference defines these modes, so they are checked against the oracle's restatement of the same
+ * switches only ("parity unpinned").  Returns PDMP3_ERR for unknown bits. */
+#define PDMP3_ISO_TABLE33  0x01u
+#define PDMP3_ISO_MS_BOUND 0x02u
+#define PDMP3_ISO_IS_SHORT 0x04u
+#define PDMP3_ISO_SF21     0x08u
+#define PDMP3_ISO_SF12     0x10u
+#define PDMP3_ISO_ALL      0x1fu
+int pdmp3_amd_set_quirks(pdmp3_handle* id, unsigned iso_mask);
+
 /* CLI driver: NULL-terminated list of .mp3 paths ("-" = stdin); writes
  * <first file>.raw (interleaved native-endian int16), as the reference's
  * OUTPUT_RAW build does (pdmp3.c:2236-2257).  A leading "/dev/dsp*" argument

@@ -59,6 +59,9 @@ pdmp3_amd_bulk* pdmp3_amd_bulk_new_ex(int threads, int window_frames, int host_h
 pdmp3_amd_bulk* pdmp3_amd_bulk_new_on(int threads, int window_frames, int host_huffman, int device);
 void pdmp3_amd_bulk_delete(pdmp3_amd_bulk* b);
 int pdmp3_amd_bulk_threads(const pdmp3_amd_bulk* b);
+/* ISO-correct switches (include/pdmp3.h: PDMP3_ISO_*, pdmp3_amd_set_quirks) for the streams decoded from now on;
+ * 0 (the default) = the reference's behaviour, bit for bit.  The CLI driver reads the mask from $PDMP3_CLI_ISO. */
+int pdmp3_amd_bulk_set_quirks(pdmp3_amd_bulk* b, unsigned iso_mask);
 
 /* PCM bytes (return value) and frames pdmp3() would produce for this stream;
  * header / side-info / reservoir pass only, no Huffman, no GPU.  Use it to

@@ -78,8 +78,21 @@ typedef struct pdmp3_gc_side {
                                  read yields, resolved by the host     */
   uint8_t  scalefac_s[13][3]; /* P:98; [12][w] = out-of-bounds value
                                  or PDMP3_SF_PEEK                                  */
-  uint8_t  reserved[59];      /* must be zero                                      */
+  uint8_t  iso;               /* PDMP3_GC_ISO_*: 0 = the reference's behaviour (below)  */
+  uint8_t  reserved[58];      /* must be zero                                      */
 } pdmp3_gc_side;              /* 128 bytes                                         */
+
+/* pdmp3_gc_side.iso (identical in all gc records of one frame) -- SURVEY 8f #4, "ISO-correct switches".  The reference
+ * departs from ISO 11172-3 in five places; by default this engine reproduces them bit for bit.  A caller
+ * that wants the standard's behaviour sets these bits (include/pdmp3.h: pdmp3_amd_set_quirks does it for a handle).  Two
+ * of the five live in the transforms and travel in the record; the other three (H1 the count1 table, H4 / H5 the
+ * one-past-the-end scalefactors) are decided where the records are built: a record with scalefac_l[21] = 0 and
+ * scalefac_s[12][w] = 0 IS the standard's.  NOTHING in the reference pins these modes: parity is against the oracle's
+ * restatement of the same switches ("unpinned"). */
+#define PDMP3_GC_ISO_MS_ALL    0x01u  /* H2: MS stereo on every line below the LARGER count1 (P:1920 stops at the smaller) */
+#define PDMP3_GC_ISO_IS_SHORT  0x02u  /* H3: intensity stereo on short blocks multiplies by the ratios of the line's own
+                                         window (P:2191 holds them in `unsigned`, P:2212-2213 assign instead of multiply,
+                                         P:2203 takes the window from the un-reordered position) */
 
 #define PDMP3_GC_LINES          576
 #define PDMP3_FRAME_GCS         4                 /* [gr][ch] = 2 x 2                */
@@ -283,7 +296,11 @@ typedef struct pdmp3_gc_bits {              /* side info of one granule-channel,
 typedef struct pdmp3_frame_bits {
   uint8_t  frame;                           /* PDMP3_FR_* (+ PDMP3_FR_NEWSTREAM) */
   uint8_t  scfsi[2];                        /* [ch]: bit b = band group b reuses granule 0, P:73 */
-  uint8_t  reserved[13];
+  uint8_t  iso;                             /* PDMP3_ISO_* of include/pdmp3.h for this frame (0 = the reference's behaviour):
+                                               TABLE33 selects the code book, SF21 / SF12 keep the one-past-the-end
+                                               scalefactor slots of the records zero, MS_BOUND / IS_SHORT become the
+                                               records' PDMP3_GC_ISO_* bits */
+  uint8_t  reserved[12];
   pdmp3_gc_bits gc[4];                      /* [gr][ch] */
 } pdmp3_frame_bits;                         /* 80 bytes */
 

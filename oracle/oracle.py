@@ -15,7 +15,7 @@ SIDE_DTYPE = np.dtype([
     ("count1", "<u2"), ("global_gain", "u1"), ("flags", "u1"),
     ("subblock_gain", "u1", (3,)), ("frame", "u1"),
     ("scalefac_l", "u1", (22,)), ("scalefac_s", "u1", (13, 3)),
-    ("reserved", "u1", (59,)),
+    ("iso", "u1"), ("reserved", "u1", (58,)),
 ])
 assert SIDE_DTYPE.itemsize == 128
 
@@ -103,6 +103,16 @@ class Oracle:
     def nwin(self):
         return np.ctypeslib.as_array(self.lib.orc_table_nwin(), shape=(64, 32)).copy()
 
+    def decode_buffer_like_cli_iso(self, mp3: bytes, iso, tap_frames=0):
+        """the CLI loop with the ISO-correct switches `iso` (include/pdmp3.h PDMP3_ISO_*; NOT the reference: unpinned)
+        -> (pcm bytes, spectra, side records of up to tap_frames frames)"""
+        s = OracleStream(self)
+        s.set_quirks(iso)
+        try:
+            return s.decode_like_cli(mp3, tap_frames)
+        finally:
+            s.close()
+
     def decode_buffer_like_cli(self, mp3: bytes, tap_frames=0):
         buf = np.frombuffer(mp3, dtype=np.uint8)
         cap = (len(mp3) // 96 + 8) * 4608
@@ -169,7 +179,26 @@ class OracleStream:
         rc = self.L.orc_stream_getformat(self.s, C.byref(rate), C.byref(ch), C.byref(enc))
         return rc, rate.value, ch.value, enc.value
 
-    def decode_like_cli(self, mp3: bytes):
+    def set_quirks(self, iso_mask):
+        self.L.orc_stream_set_quirks.argtypes = [_p, C.c_uint]
+        self.L.orc_stream_set_quirks(self.s, iso_mask)
+
+    def decode_like_cli(self, mp3: bytes, tap_frames=0):
+        """tap_frames > 0: -> (pcm bytes, spectra, side) with the records of the first tap_frames frames"""
+        if tap_frames:
+            class Tap(C.Structure):
+                _fields_ = [("spectra", _p), ("side", _p), ("cap", C.c_int), ("n", C.c_int)]
+            sp = np.zeros((tap_frames, 2, 2, 576), dtype=np.int16)
+            sd = np.zeros((tap_frames, 2, 2), dtype=SIDE_DTYPE)
+            tap = Tap(_ptr(sp), _ptr(sd), tap_frames, 0)
+            self.L.orc_stream_set_tap.argtypes = [_p, _p]
+            self.L.orc_stream_set_tap(self.s, C.byref(tap))
+            try:
+                pcm = self.decode_like_cli(mp3)
+            finally:
+                self.L.orc_stream_set_tap(self.s, None)
+            k = min(tap.n, tap_frames)
+            return pcm, sp[:k], sd[:k]
         self.L.orc_stream_open_feed(self.s)
         out, pos = [], 0
         buf = (C.c_ubyte * 16384)()

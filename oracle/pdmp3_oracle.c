@@ -56,6 +56,7 @@ typedef struct frame_ws {
   uint32_t sf_l[2][2][22];      /* value as the reference would read it */
   uint32_t sf_s[2][2][13][3];
   int sf_s_peek[2][2];          /* H5: [12][w] comes from the bits of is[0][0][w] */
+  unsigned iso;                 /* PDMP3_GC_ISO_* of the frame's records: the standard's behaviour instead of H2 / H3 */
   unsigned sfreq, mode, mode_ext, nch;
 } frame_ws;
 
@@ -189,6 +190,28 @@ static void intensity_long(frame_ws* w, unsigned gr, unsigned sfb) {
  * emits (cvttss2si to 64 bit, low 32 bits kept).  Excluded from parity corpora. */
 static void intensity_short(frame_ws* w, unsigned gr, unsigned sfb) {
   unsigned win_len = sfb_s(w->sfreq, sfb + 1) - sfb_s(w->sfreq, sfb);
+  if (w->iso & PDMP3_GC_ISO_IS_SHORT) {
+    /* NOT the reference ("ISO-correct switches", unpinned): the band's lines are in reordered order by
+     * now (P:1786 ran before): line a + 3 j + win belongs to window win; left / right = the ratios of intensity_long
+     * times the sample */
+    unsigned a = sfb_s(w->sfreq, sfb) * 3;
+    for (unsigned i = a; i < a + 3 * win_len; i++) {
+      unsigned is_pos = w->sf_s[gr][0][sfb][(i - a) % 3];
+      if (is_pos == 7) continue;
+      float rl, rr;
+      if (is_pos == 6) { rl = 1.0f; rr = 0.0f; }
+      else {
+        float t = (is_pos < 6) ? ot_is_ratios[is_pos] : 0.0f;
+        rl = t / (1.0f + t);
+        rr = 1.0f / (1.0f + t);
+      }
+      float left = rl * w->is[gr][0][i];
+      float right = rr * w->is[gr][0][i];
+      w->is[gr][0][i] = left;
+      w->is[gr][1][i] = right;
+    }
+    return;
+  }
   for (unsigned win = 0; win < 3; win++) {
     unsigned is_pos = w->sf_s[gr][0][sfb][win];
     if (is_pos == 7) continue;
@@ -209,6 +232,7 @@ static void stage_stereo(frame_ws* w, unsigned gr) {
   if (w->mode_ext & 0x2) {
     unsigned c0 = w->count1[gr][0], c1 = w->count1[gr][1];
     unsigned max_pos = (c0 > c1) ? c1 : c0;            /* P:1920 picks the smaller (H2) */
+    if (w->iso & PDMP3_GC_ISO_MS_ALL) max_pos = (c0 > c1) ? c0 : c1;   /* the standard's (unpinned) */
     for (unsigned i = 0; i < max_pos; i++) {
       float left = (w->is[gr][0][i] + w->is[gr][1][i]) * (O_INV_SQRT_2);
       float right = (w->is[gr][0][i] - w->is[gr][1][i]) * (O_INV_SQRT_2);
@@ -346,6 +370,7 @@ static void unpack_frame(frame_ws* w, const int16_t* spectra, const pdmp3_gc_sid
   w->mode = (fr & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT;
   w->mode_ext = (fr & PDMP3_FR_MODEEXT_MASK) >> PDMP3_FR_MODEEXT_SHIFT;
   w->nch = (w->mode == 3) ? 1 : 2;
+  w->iso = side[0].iso;
   for (unsigned gr = 0; gr < 2; gr++)
     for (unsigned ch = 0; ch < 2; ch++) {
       const pdmp3_gc_side* s = &side[gr * 2 + ch];

@@ -86,6 +86,9 @@ typedef struct orc_tap {
   int n_frames;
 } orc_tap;
 void orc_stream_set_tap(orc_stream*, orc_tap* tap);
+/* NOT the reference: the ISO-correct switches of include/pdmp3.h (PDMP3_ISO_*, same bit values) restated, so that the
+ * library's modes have something to be compared with.  Nothing pins them ("parity unpinned"). */
+void orc_stream_set_quirks(orc_stream*, unsigned iso_mask);
 
 /* Whole-buffer convenience that mimics the CLI driver loop pdmp3() (P:2540):
  * read(16 KiB) -> on NEED_MORE feed 4096 bytes -> ... ; returns PCM bytes. */

@@ -46,7 +46,15 @@ struct orc_stream {
   int new_header;
   orc_synth synth;
   orc_tap* tap;
+  unsigned iso;                      /* ORC_ISO_*: NOT the reference -- the standard's behaviour for SURVEY H1-H5 (unpinned) */
 };
+/* the ISO-correct switches of include/pdmp3.h (same bit values), restated for the oracle */
+#define ORC_ISO_TABLE33 0x01u
+#define ORC_ISO_MS_BOUND 0x02u
+#define ORC_ISO_IS_SHORT 0x04u
+#define ORC_ISO_SF21 0x08u
+#define ORC_ISO_SF12 0x10u
+void orc_stream_set_quirks(orc_stream* s, unsigned iso_mask) { s->iso = iso_mask & 0x1fu; }
 
 orc_stream* orc_stream_new(void) { return (orc_stream*)calloc(1, sizeof(orc_stream)); }
 void orc_stream_delete(orc_stream* s) { free(s); }
@@ -254,6 +262,9 @@ static int huffman_decode(orc_stream* s, unsigned table, int* x, int* y, int* v,
   unsigned treelen = (unsigned)ot_huff_main[table].treelen, linbits = (unsigned)ot_huff_main[table].linbits;
   if (treelen == 0) { *x = *y = *v = *w = 0; return ORC_OK; }
   const uint16_t* ht = &ot_huff_nodes[ot_huff_main[table].off];
+  /* ORC_ISO_TABLE33: the tree the standard means by table 33 -- the last 31 nodes of the array (P:504-515); the
+   * reference's g_huffman_main[33] points at node 2261 instead (P:569, H1) */
+  if (table == 33 && (s->iso & ORC_ISO_TABLE33)) ht = &ot_huff_nodes[2804 - 31];
   do {
     if ((ht[point] & 0xff00) == 0) {
       error = 0;
@@ -425,7 +436,11 @@ static void frame_to_records(const orc_stream* s, int16_t* spectra, pdmp3_gc_sid
         r->scalefac_l[21] = (uint8_t)s->scalefac_s[0][0][0][0];
         for (unsigned w = 0; w < 3; w++) r->scalefac_s[12][w] = PDMP3_SF_PEEK;
       }
+      if (s->iso & ORC_ISO_SF21) r->scalefac_l[21] = 0;
+      if (s->iso & ORC_ISO_SF12) for (unsigned w = 0; w < 3; w++) r->scalefac_s[12][w] = 0;
     }
+  for (unsigned g = 0; g < 4; g++)
+    sd[g].iso = (uint8_t)(((s->iso & ORC_ISO_MS_BOUND) ? PDMP3_GC_ISO_MS_ALL : 0) | ((s->iso & ORC_ISO_IS_SHORT) ? PDMP3_GC_ISO_IS_SHORT : 0));
 }
 
 /* P:1024 Decode_L3 for the frame just parsed, via the record boundary */

@@ -13,7 +13,7 @@ PDMP3_OK, PDMP3_ERR, PDMP3_NEED_MORE, PDMP3_NEW_FORMAT, PDMP3_NO_SPACE = 0, -1, 
 PDMP3_ENC_SIGNED_16 = 0xD0
 _LIB = None
 
-BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads",
+BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads", "pdmp3_amd_bulk_set_quirks",
                 "pdmp3_amd_scan_buffer", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_decode_async", "pdmp3_amd_bulk_wait", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
                 "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits", "pdmp3_amd_bulk_parse_pool", "pdmp3_amd_pcm_alloc", "pdmp3_amd_pcm_free", "pdmp3_amd_stream_loop", "pdmp3_amd_write_wav"]
 
@@ -21,10 +21,12 @@ BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_n
 GC_BITS_DTYPE = np.dtype([("part2_3_length", "<u2"), ("big_values", "<u2"), ("global_gain", "u1"), ("scalefac_compress", "u1"),
                           ("flags", "u1"), ("table_select", "u1", (3,)), ("subblock_gain", "u1", (3,)),
                           ("region0_count", "u1"), ("region1_count", "u1"), ("count1table_select", "u1")])
-FRAME_BITS_DTYPE = np.dtype([("frame", "u1"), ("scfsi", "u1", (2,)), ("reserved", "u1", (13,)), ("gc", GC_BITS_DTYPE, (4,))])
+FRAME_BITS_DTYPE = np.dtype([("frame", "u1"), ("scfsi", "u1", (2,)), ("iso", "u1"), ("reserved", "u1", (12,)), ("gc", GC_BITS_DTYPE, (4,))])
 RESERVOIR_BYTES = 2064
 API_EXPORTS = ["pdmp3_new", "pdmp3_delete", "pdmp3_open_feed", "pdmp3_feed", "pdmp3_read",
-               "pdmp3_decode", "pdmp3_getformat", "pdmp3", "pdmp3_amd_set_encoding"]
+               "pdmp3_decode", "pdmp3_getformat", "pdmp3", "pdmp3_amd_set_encoding", "pdmp3_amd_set_quirks"]
+# include/pdmp3.h: the ISO-correct switches
+ISO_TABLE33, ISO_MS_BOUND, ISO_IS_SHORT, ISO_SF21, ISO_SF12, ISO_ALL = 0x01, 0x02, 0x04, 0x08, 0x10, 0x1f
 PDMP3_ENC_SIGNED_16, PDMP3_ENC_FLOAT_32 = 0xD0, 0x200
 
 
@@ -108,6 +110,12 @@ class Decoder:
     def open_feed(self):
         return self.lib.pdmp3_open_feed(self.h)
 
+    def set_quirks(self, iso_mask):
+        """pdmp3_amd_set_quirks: PDMP3_ISO_* bits = the standard's behaviour instead of the reference's"""
+        self.lib.pdmp3_amd_set_quirks.argtypes = [C.c_void_p, C.c_uint]
+        if self.lib.pdmp3_amd_set_quirks(self.h, iso_mask) != 0:
+            raise ValueError("pdmp3_amd_set_quirks: unknown bits in %#x" % iso_mask)
+
     def feed(self, data: bytes):
         buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
         return self.lib.pdmp3_feed(self.h, buf, len(data))
@@ -185,10 +193,12 @@ def decode_like_cli(mp3: bytes, dec: "Decoder" = None):
     return b"".join(out)
 
 
-def parse_like_cli(mp3: bytes, cap_frames):
+def parse_like_cli(mp3: bytes, cap_frames, iso=0):
     """Host stage only (no GPU): records the host parser emits when driven with
     the CLI's feed cadence."""
     dec = Decoder(parse_only=True)
+    if iso:
+        dec.set_quirks(iso)
     dec.set_tap(cap_frames)
     pos = 0
     while True:
@@ -248,6 +258,11 @@ class BulkDecoder:
         if self.h:
             self.lib.pdmp3_amd_bulk_delete(self.h)
             self.h = None
+
+    def set_quirks(self, iso_mask):
+        self.lib.pdmp3_amd_bulk_set_quirks.argtypes = [C.c_void_p, C.c_uint]
+        if self.lib.pdmp3_amd_bulk_set_quirks(self.h, iso_mask) != 0:
+            raise ValueError("pdmp3_amd_bulk_set_quirks: unknown bits in %#x" % iso_mask)
 
     def decode_into(self, mp3, out: np.ndarray):
         a = _as_u8(mp3)
@@ -326,10 +341,11 @@ class BulkDecoder:
         return sp[:n], sd[:n], pcm_bytes.value
 
 
-def parse_bits(mp3):
+def parse_bits(mp3, iso=0):
     """Stage A of the bulk pipeline alone: per frame the side info (pdmp3_frame_bits) and the reservoir snapshot
     that pdmp3_hip_stream_submit_bits is given.  No GPU."""
     lib = load_library()
+    lib.pdmp3_amd_bulk_set_quirks.argtypes = [C.c_void_p, C.c_uint]
     _, frames = scan_buffer(mp3)
     cap = frames + 1
     bits = np.zeros(cap, dtype=FRAME_BITS_DTYPE)
@@ -337,6 +353,7 @@ def parse_bits(mp3):
     assert FRAME_BITS_DTYPE.itemsize == 80
     a = _as_u8(mp3)
     h = lib.pdmp3_amd_bulk_new_parse_bits()
+    lib.pdmp3_amd_bulk_set_quirks(h, iso)
     pcm_bytes = C.c_longlong(0)
     n = lib.pdmp3_amd_bulk_parse_bits(h, a.ctypes.data_as(C.c_void_p), len(mp3), bits.ctypes.data_as(C.c_void_p),
                                       res.ctypes.data_as(C.c_void_p), cap, C.byref(pcm_bytes))

@@ -212,6 +212,7 @@ struct LaneRegs {
 // Uniform per-granule facts, decoded from the side records in LDS.
 struct GranuleInfo {
   int nch, sfreq, mode, mode_ext;
+  int iso;                 // PDMP3_GC_ISO_* of the frame's records (0: the reference's behaviour)
   int count1_0, count1_1, flags0, flags1;
   PD_MFN int flags(int ch) const { return ch ? flags1 : flags0; }
   PD_MFN bool is_short(int ch) const {
@@ -229,6 +230,7 @@ PD_FN GranuleInfo granule_info(const WaveData& L) {
   const uint32_t w0 = (uint32_t)PD_UNIFORM(*reinterpret_cast<const uint32_t*>(&L.side[0][0]));
   const uint32_t w1 = (uint32_t)PD_UNIFORM(*reinterpret_cast<const uint32_t*>(&L.side[1][0]));
   const int fr = PD_UNIFORM(L.side[0][7]);
+  g.iso = PD_UNIFORM(L.side[0][offsetof(pdmp3_gc_side, iso)]);
   g.sfreq = fr & PDMP3_FR_SFREQ_MASK;
   if (g.sfreq > 2) g.sfreq = 2;
   g.mode = (fr & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT;
@@ -421,7 +423,7 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
   const bool joint = (g.nch == 2) && (g.mode == 1) && (g.mode_ext != 0);
   const bool ms = joint && (g.mode_ext & 2);
   const bool is = joint && (g.mode_ext & 1);
-  const int cmin = (g.count1_0 > g.count1_1) ? g.count1_1 : g.count1_0;   // P:1920 (H2)
+  const int cmin = ((g.count1_0 > g.count1_1) != ((g.iso & PDMP3_GC_ISO_MS_ALL) != 0)) ? g.count1_1 : g.count1_0;   // P:1920 (H2): the smaller; ISO switch: the larger
   const int kind0 = g.kind(0), kind1 = g.kind(1);
   if (FAST && !DUMP && NI == 9) {
     if (kind0 == 0 && (g.nch == 1 || kind1 == 0) && !is) {     // wave-uniform
@@ -506,7 +508,8 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
         // band of POSITION d in the un-reordered [win][j] layout (P:2203)
         PD_NOUNROLL for (int b = 0; b < 13; b++) {
           const int lo = 3 * cb->sfb_s[g.sfreq][b], hi = 3 * cb->sfb_s[g.sfreq][b + 1];
-          if (d >= lo && d < hi) { sfb = b; win = (d - lo) / ((hi - lo) / 3); }
+          // (ISO switch: the lines are in reordered order by now, position lo + 3 j + w belongs to window w)
+          if (d >= lo && d < hi) { sfb = b; win = (g.iso & PDMP3_GC_ISO_IS_SHORT) ? (d - lo) % 3 : (d - lo) / ((hi - lo) / 3); }
         }
         do_short = (sfb < 12) && (kind0 == 1 || sfb >= 3);
       }
@@ -520,7 +523,11 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
       }
       if (do_short && 3 * (int)cb->sfb_s[g.sfreq][sfb] >= c1) {
         const int is_pos = sd0[30 + sfb * 3 + win];
-        if (is_pos != 7) {   // H3: sample forced through `unsigned` (x86-64 conversion semantics)
+        if (is_pos != 7 && (g.iso & PDMP3_GC_ISO_IS_SHORT)) {   // the standard's: the ratios of the long case, multiplied
+          const float l = cb->isr_l[is_pos & 15] * a0;
+          const float r = cb->isr_r[is_pos & 15] * a0;
+          a0 = l; a1 = r;
+        } else if (is_pos != 7) {   // H3: sample forced through `unsigned` (x86-64 conversion semantics)
           const float xv = a0;
           long long t = (xv >= 9.2233720368547758e18f || xv < -9.2233720368547758e18f || xv != xv)
                             ? (long long)0x8000000000000000ull : (long long)xv;
@@ -580,7 +587,7 @@ template <bool TG, bool SCALES>
 PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalTables& T, const GranuleInfo& g) {
   const bool two = g.nch == 2;
   const bool ms = two && (g.mode == 1) && (g.mode_ext & 2);
-  const int cmin = (g.count1_0 > g.count1_1) ? g.count1_1 : g.count1_0;   // P:1920 (H2)
+  const int cmin = ((g.count1_0 > g.count1_1) != ((g.iso & PDMP3_GC_ISO_MS_ALL) != 0)) ? g.count1_1 : g.count1_0;   // P:1920 (H2): the smaller; ISO switch: the larger
   const uint32_t* sp0 = reinterpret_cast<const uint32_t*>(&L.spec[0][0]);
   const uint32_t* sp1 = reinterpret_cast<const uint32_t*>(&L.spec[1][0]);
   const char* sc0 = reinterpret_cast<const char*>(&L.scale[0][0]);

@@ -178,6 +178,7 @@ inline void build_tab_images(HostTables& H) {
 inline bool build_unpack_tables(UnpackTables& U) {
   memset(&U, 0, sizeof U);
   for (int t = 0; t < 34; t++) { U.book_of_table[t] = (int8_t)kHuffBookOfTable[t]; U.linbits[t] = (uint8_t)kHuffLinbits[t]; }
+  U.book_of_table[34] = PDMP3_HUFF_BOOK_ISO33;           // count1table_select = 2: the standard's table B (PDMP3_ISO_TABLE33, not the reference's H1)
   for (int i = 0; i < 32; i++) U.slen[i] = kSlen[i];
   for (int sf = 0; sf < 3; sf++) {
     for (int i = 0; i < 23; i++) U.sfb_l[sf][i] = sfb_long_of(sf)[i];
@@ -210,7 +211,7 @@ inline bool build_unpack_tables(UnpackTables& U) {
         first[p] = link(deepest[p], n);
         n += 1u << deepest[p];
       }
-    const bool quads = b == kHuffBookOfTable[32] || b == kHuffBookOfTable[33];
+    const bool quads = b == kHuffBookOfTable[32] || b == kHuffBookOfTable[33] || b == PDMP3_HUFF_BOOK_ISO33;
     for (int i = 0; i < nc; i++) {
       const int len = codes[i].len;
       const uint32_t val = codes[i].err ? 0 : codes[i].val;

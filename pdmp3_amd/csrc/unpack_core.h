@@ -472,12 +472,14 @@ PD_HD void unpack_records(const UnpackTables& U, const uint8_t* res, const pdmp3
     for (int i = 0; i < 20; i++) w32[i] = 0;
   }
   rec->frame = F.frame & (uint8_t)~PDMP3_FR_NEWSTREAM;
+  // the ISO switches of the frame (include/pdmp3.h PDMP3_ISO_*: MS_BOUND = 2, IS_SHORT = 4) as the records' PDMP3_GC_ISO_* bits
+  rec->iso = (uint8_t)(((F.iso & 0x02u) ? PDMP3_GC_ISO_MS_ALL : 0u) | ((F.iso & 0x04u) ? PDMP3_GC_ISO_IS_SHORT : 0u));
   if (ch >= nch) return;
   const pdmp3_gc_bits& s = F.gc[g];
   rec->global_gain = s.global_gain;
   rec->flags = s.flags;
   rec->subblock_gain[0] = s.subblock_gain[0]; rec->subblock_gain[1] = s.subblock_gain[1]; rec->subblock_gain[2] = s.subblock_gain[2];
-  if (g == 3) rec->scalefac_s[12][0] = rec->scalefac_s[12][1] = rec->scalefac_s[12][2] = PDMP3_SF_PEEK;
+  if (g == 3 && !(F.iso & 0x10u)) rec->scalefac_s[12][0] = rec->scalefac_s[12][1] = rec->scalefac_s[12][2] = PDMP3_SF_PEEK;   // (PDMP3_ISO_SF12: stays 0)
 
   // ---- scalefactors (P:1383-1430)
   BitPos b{res, part2_start_of(U, F, g, nch)};
@@ -648,12 +650,12 @@ PD_HD void merge_store(int t, const pdmp3_frame_bits& F, pdmp3_gc_side* R /* rec
   if (t < 84) {
     const int g = t / 21, sfb = t - 21 * g;
     if (gc_active(F, g)) R[g].scalefac_l[sfb] = (uint8_t)val;
-    if (sfb == 0 && g >= 1 && gc_active(F, g - 1)) R[g - 1].scalefac_l[21] = (uint8_t)val;
+    if (sfb == 0 && g >= 1 && gc_active(F, g - 1) && !(F.iso & 0x08u)) R[g - 1].scalefac_l[21] = (uint8_t)val;   // (PDMP3_ISO_SF21: stays 0)
   } else if (t < 228) {
     const int u = t - 84, g = u / 36, k = u - 36 * g, sfb = k / 3, w = k - 3 * sfb;
     if (gc_active(F, g)) R[g].scalefac_s[sfb][w] = (uint8_t)val;
-    if (sfb == 0 && g >= 1 && gc_active(F, g - 1)) R[g - 1].scalefac_s[12][w] = (uint8_t)val;
-    if (k == 0 && g == 0 && gc_active(F, 3)) R[3].scalefac_l[21] = (uint8_t)val;                 // last block: scalefac_s follows
+    if (sfb == 0 && g >= 1 && gc_active(F, g - 1) && !(F.iso & 0x10u)) R[g - 1].scalefac_s[12][w] = (uint8_t)val;   // (PDMP3_ISO_SF12)
+    if (k == 0 && g == 0 && gc_active(F, 3) && !(F.iso & 0x08u)) R[3].scalefac_l[21] = (uint8_t)val;   // last block: scalefac_s follows
   } else {
     const int g = t - 228;
     if (gc_active(F, g)) R[g].count1 = (uint16_t)val;

@@ -17,7 +17,7 @@ SIDE_DTYPE = np.dtype([
     ("count1", "<u2"), ("global_gain", "u1"), ("flags", "u1"),
     ("subblock_gain", "u1", (3,)), ("frame", "u1"),
     ("scalefac_l", "u1", (22,)), ("scalefac_s", "u1", (13, 3)),
-    ("reserved", "u1", (59,)),
+    ("iso", "u1"), ("reserved", "u1", (58,)),
 ])
 FRAME_SPECTRA_INT16 = 4 * 576
 FRAME_PCM_INT16 = 2304
@@ -124,7 +124,8 @@ class Engine:
         """name of the kernel the latest decode launch ran (pdmp3_hip_last_launch_kind)"""
         k = self.lib.pdmp3_hip_last_launch_kind(self.h)
         return {1: "k_decode (independent chunks, halo)", 8: "k_decode_g<.., 8> (one granule per wave, 8 waves per workgroup)",
-                16: "k_decode_g<.., 16> (one granule per wave, 16 waves per workgroup)"}.get(k, "none")
+                16: "k_decode_g<.., 16> (one granule per wave, 16 waves per workgroup)",
+                32: "k_decode_p (persistent: 16 waves per workgroup going round a range of frames)"}.get(k, "none")
 
     # -- device buffers ----------------------------------------------------
     def alloc_frames(self, n_frames):

@@ -70,7 +70,7 @@ static void build_luts(void) {
     int maxlen = 0;
     for (int i = 0; i < n; i++) if (codes[i].len > maxlen) maxlen = codes[i].len;
     L->sub_bits = maxlen > HL_BITS ? maxlen - HL_BITS : 0;
-    L->quads = b == kHuffBookOfTable[32] || b == kHuffBookOfTable[33];
+    L->quads = b == kHuffBookOfTable[32] || b == kHuffBookOfTable[33] || b == PDMP3_HUFF_BOOK_ISO33;
     int nsub = 0;
     memset(L->first, 0, sizeof L->first);
     for (int i = 0; i < n; i++) {
@@ -185,6 +185,7 @@ struct pdmp3_handle {
   /* engine */
   pdmp3_hip_stream* hs;
   int host_only;                   /* test hook: parse without an engine (no decode possible) */
+  unsigned iso;                    /* PDMP3_ISO_*: the standard's behaviour instead of the reference's (pdmp3_amd_set_quirks) */
   /* record tap for tests (host logic without GPU) */
   int16_t* tap_spectra; pdmp3_gc_side* tap_side; int tap_cap, tap_n;
 };
@@ -431,6 +432,7 @@ static void read_side_info(pdmp3_handle* id) {
       S->preflag[gr][ch] = side_bits(&sc, 1);
       S->scalefac_scale[gr][ch] = side_bits(&sc, 1);
       S->count1table_select[gr][ch] = side_bits(&sc, 1);
+      if ((id->iso & PDMP3_ISO_TABLE33) && S->count1table_select[gr][ch]) S->count1table_select[gr][ch] = 2;
     }
   id->side_ptr = sc.pos >> 3;
   id->side_idx = sc.pos & 7;
@@ -491,8 +493,9 @@ static void read_side_info_bits(pdmp3_handle* id) {
         g->region1_count = (uint8_t)(y & 7);
       }
       g->flags = (uint8_t)flags;
-      g->count1table_select = (uint8_t)(tail & 1);
+      g->count1table_select = (uint8_t)(((tail & 1) && (id->iso & PDMP3_ISO_TABLE33)) ? 2 : (tail & 1));
     }
+  fb->iso = (uint8_t)id->iso;
   id->side_ptr = pos >> 3;
   id->side_idx = pos & 7;
   id->fb_valid = 1;
@@ -672,7 +675,8 @@ static void decode_huffman(bitreader* b, const frame_header* H, const side_info*
   pos = decode_pairs(b, S->table_select[gr][ch][2], pos, nbig, is);
   /* count1 region: table 32, or the reference's mis-pointed table 33 (H1).  The loop runs while a whole quad
    * fits below 576, so the reference's mid-quad bound check can never fire. */
-  const int qbook = kHuffBookOfTable[32 + S->count1table_select[gr][ch]];
+  /* (count1table_select = 2: PDMP3_ISO_TABLE33 was set when the side info was read -- the standard's table B) */
+  const int qbook = S->count1table_select[gr][ch] == 2 ? PDMP3_HUFF_BOOK_ISO33 : kHuffBookOfTable[32 + S->count1table_select[gr][ch]];
   const huff_lut* Q = &g_lut[qbook];
   while (pos <= 572 && b->bitpos <= end) {
     unsigned leaf;
@@ -819,6 +823,7 @@ static void emit_records(pdmp3_handle* id, const frame_header* H, const side_inf
     const unsigned gr = g >> 1, ch = g & 1;
     pdmp3_gc_side* r = &sd[g];
     r->frame = fr;
+    r->iso = (uint8_t)(((id->iso & PDMP3_ISO_MS_BOUND) ? PDMP3_GC_ISO_MS_ALL : 0) | ((id->iso & PDMP3_ISO_IS_SHORT) ? PDMP3_GC_ISO_IS_SHORT : 0));
     if (ch >= nch) { memset(spectra + g * 576, 0, 576 * sizeof(int16_t)); continue; }
     r->count1 = id->count1[gr][ch];
     r->global_gain = (uint8_t)S->global_gain[gr][ch];
@@ -841,6 +846,9 @@ static void emit_records(pdmp3_handle* id, const frame_header* H, const side_inf
       r->scalefac_l[21] = id->scalefac_s[0][0][0][0];
       r->scalefac_s[12][0] = r->scalefac_s[12][1] = r->scalefac_s[12][2] = PDMP3_SF_PEEK;
     }
+    /* the ISO switches (pdmp3_amd_set_quirks; not the reference): bands 21 / 12 have scalefactor 0 */
+    if (id->iso & PDMP3_ISO_SF21) r->scalefac_l[21] = 0;
+    if (id->iso & PDMP3_ISO_SF12) r->scalefac_s[12][0] = r->scalefac_s[12][1] = r->scalefac_s[12][2] = 0;
   }
   if (id->tap_side) {
     if (id->tap_n < id->tap_cap) {
@@ -1261,6 +1269,14 @@ int pdmp3_amd_set_encoding(pdmp3_handle* id, int encoding) {
 }
 
 /* P:2526-2535 */
+/* ISO-correct switches (include/pdmp3.h): from the next frame parsed on.  Frames that pdmp3_read has
+ * parsed ahead keep the mode they were parsed in. */
+int pdmp3_amd_set_quirks(pdmp3_handle* id, unsigned iso_mask) {
+  if (!id || (iso_mask & ~PDMP3_ISO_ALL)) return PDMP3_ERR;
+  id->iso = iso_mask;
+  return PDMP3_OK;
+}
+
 int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) {
   if (!(id && rate && channels && encoding)) return PDMP3_ERR;
   *encoding = id->enc_f32 ? PDMP3_ENC_FLOAT_32 : PDMP3_ENC_SIGNED_16;
@@ -1569,6 +1585,7 @@ static void fill_frame_bits(const pdmp3_handle* id, pdmp3_frame_bits* fb, int ne
   memset(fb, 0, sizeof *fb);
   fb->frame = (uint8_t)((H->sfreq & 3) | (H->mode << PDMP3_FR_MODE_SHIFT) | (H->mode_ext << PDMP3_FR_MODEEXT_SHIFT) |
                         (id->need_reset ? PDMP3_FR_RESET : 0) | (newstream ? PDMP3_FR_NEWSTREAM : 0));
+  fb->iso = (uint8_t)id->iso;
   for (unsigned ch = 0; ch < nch; ch++)
     for (unsigned g4 = 0; g4 < 4; g4++) if (S->scfsi[ch][g4]) fb->scfsi[ch] |= (uint8_t)(1u << g4);
   for (unsigned gr = 0; gr < 2; gr++)
@@ -1989,14 +2006,18 @@ struct bulk* pdmp3_amd_bulk_new(int threads, int window_frames) {
 struct bulk* pdmp3_amd_bulk_new_parse_only(int threads, int window_frames) { return bulk_new(threads, window_frames, 0, 0, 0); }
 struct bulk* pdmp3_amd_bulk_new_parse_bits(void) { return bulk_new(1, 1, 0, 1, 0); }
 int pdmp3_amd_bulk_threads(const struct bulk* b) { return b ? b->nth : 0; }
+/* the ISO-correct switches (include/pdmp3.h: pdmp3_amd_set_quirks) for the streams this decoder is given from now on */
+int pdmp3_amd_bulk_set_quirks(struct bulk* b, unsigned iso_mask) { return b ? pdmp3_amd_set_quirks(b->id, iso_mask) : PDMP3_ERR; }
 
 static void bulk_begin(struct bulk* b) {
   pdmp3_handle* id = b->id;
   /* a fresh handle per stream -- unless the caller is pdmp3(), which decodes all its files with ONE handle: parse
    * state left by the previous file shows in the next one, so it is kept (b->carry) */
   if (!b->carry) {
+    const unsigned iso = id->iso;                 /* (a setting of the decoder, not parse state: pdmp3_amd_bulk_set_quirks) */
     memset(id, 0, sizeof *id);
     id->host_only = 1;
+    id->iso = iso;
   }
   id->pool_sink = b->pool_mode ? b : NULL;
   id->side_to_bits = b->bits_mode && !getenv("PDMP3_BULK_SLOW_SIDE_INFO");
@@ -2300,6 +2321,10 @@ void pdmp3(char* const* mp3s) {
   if (!id) { fputs("Cannot open stream API (no transform engine)\n", stderr); exit(0); }
   const char* force = getenv("PDMP3_CLI_STREAMING");
   const int streaming_only = force && *force && *force != '0';
+  /* $PDMP3_CLI_ISO = mask of PDMP3_ISO_* (include/pdmp3.h): the standard's behaviour instead of the reference's; default 0 */
+  const char* iso_env = getenv("PDMP3_CLI_ISO");
+  const unsigned iso = iso_env ? (unsigned)strtoul(iso_env, NULL, 0) & PDMP3_ISO_ALL : 0u;
+  (void)pdmp3_amd_set_quirks(id, iso);
   struct bulk* b = NULL;
   int bulk_used = 0, loop_used = 0;
   for (; *mp3s; mp3s++) {
@@ -2325,7 +2350,7 @@ void pdmp3(char* const* mp3s) {
       }
     }
     if (data && total >= 0) {
-      if (!b) b = pdmp3_amd_bulk_new(0, 0);
+      if (!b) { b = pdmp3_amd_bulk_new(0, 0); if (b) (void)pdmp3_amd_bulk_set_quirks(b, iso); }
       unsigned char* pcm = (unsigned char*)malloc((size_t)total + 1);
       if (!b || !pcm) { fputs("Cannot open stream API (no transform engine)\n", stderr); exit(0); }
       b->carry = bulk_used;                       /* first file: fresh state, like the reference's new handle */

@@ -33,7 +33,7 @@ def resolve_aliases(side):
 
 def make_frames(n, seed, mode=MODE_JOINT, mode_ext=2, sfreq=0, block_mix=(70, 10, 10, 10),
                 mixed_prob=0.5, count1_range=(0, 576), gain_range=(120, 170), big_prob=1 / 200.0,
-                max_small=15, sf_max=8, reset_every=0, zero_gc_prob=0.05, is_pos_max=8):
+                max_small=15, sf_max=8, reset_every=0, zero_gc_prob=0.05, is_pos_max=8, iso=0):
     """Random frames.  block_mix = percentages of block types 0,1,2,3."""
     rs = np.random.RandomState(seed)
     spectra = np.zeros((n, 2, 2, 576), dtype=np.int16)
@@ -47,6 +47,7 @@ def make_frames(n, seed, mode=MODE_JOINT, mode_ext=2, sfreq=0, block_mix=(70, 10
             for c in range(2):
                 s = side[f, g, c]
                 s["frame"] = fr
+                s["iso"] = iso
                 lo, hi = count1_range
                 count1 = int(rs.randint(lo, hi + 1))
                 count1 -= count1 % 2
@@ -114,6 +115,18 @@ FS_GAIN_OF = {"ms_loud_clip": (122, 134)}         # big_prob 0.02: more linbits-
 CASES_FS = {name + "_fs": dict(kw, gain_range=FS_GAIN_OF.get(name, FS_GAIN)) for name, kw in CASES.items()}
 ALL_CASES = dict(CASES, **CASES_FS)
 
+# The ISO-correct switches (include/pdmp3_hip.h PDMP3_GC_ISO_*: 1 = MS up to the larger count1, 2 = intensity
+# stereo on short blocks by the standard) as record corpora.  UNPINNED: the reference has no such mode, the oracle's
+# restatement of the same switches is all there is to compare with -- no golden fixtures.
+ISO_CASES = {
+    "iso_ms_all_441": dict(CASES["ms_mixed_blocks_441"], iso=1, gain_range=FS_GAIN),
+    "iso_ms_count1_skew": dict(CASES["ms_count1_skew"], iso=1, gain_range=FS_GAIN),
+    "iso_is_short_441": dict(CASES["is_short_441"], iso=2, gain_range=FS_GAIN),
+    "iso_ms_is_short_480": dict(CASES["ms_is_short_480"], iso=3, gain_range=FS_GAIN),
+    "iso_ms_is_long_480": dict(CASES["ms_is_long_480"], iso=3, gain_range=FS_GAIN),
+    "iso_bits_on_stereo_plain": dict(CASES["stereo_plain_320"], iso=3, gain_range=FS_GAIN),      # (no joint stereo: the bits change nothing)
+}
+
 # int16 tolerance per case, in LSB, as literal numbers.  +-1 LSB (north_star; P:2028-2031 is the step an LSB is defined
 # by) for every case but ONE: ms_loud_clip is driven to 4.5e5 x full scale (99 % of its samples clip), where one ulp of
 # the binary32 sums is 0.03 = 1000 LSB, and the few samples that come back inside the int16 range differ by up to 21 LSB
@@ -134,7 +147,7 @@ N_GOLDEN = 64                                     # frames per golden fixture (S
 
 
 def case(name, n=N_GOLDEN, seed=None):
-    kw = ALL_CASES[name]
+    kw = ALL_CASES[name] if name in ALL_CASES else ISO_CASES[name]
     if seed is None:
         seed = (sum(ord(ch) * (i + 1) for i, ch in enumerate(name)) * 2654435761) & 0x7FFFFFFF
     return make_frames(n, seed, **kw)

@@ -1,0 +1,72 @@
+"""The ISO-correct switches on the GPU: the HIP engine on records that carry PDMP3_GC_ISO_*, the
+whole-stream decoder (device Huffman and host Huffman), the streaming API and the CLI with pdmp3_amd_set_quirks /
+$PDMP3_CLI_ISO -- against the oracle's restatement of the same switches.  PARITY UNPINNED: the reference has no such
+mode (tests/test_iso_switches.py says what is and is not being claimed); the bar is the usual one, +-1 LSB."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import corpus
+from test_gpu_parity import gpu_decode
+from test_iso_switches import _streams, ISO_TABLE33, ISO_MS_BOUND, ISO_IS_SHORT, ISO_SF21, ISO_SF12, ISO_ALL
+from util import assert_pcm_close, nch_of
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", list(corpus.ISO_CASES))
+def test_gpu_engine_on_iso_records(engine, oracle, name):
+    sp, sd = corpus.case(name)
+    want, ws = oracle.decode(sp, sd, stages=True)
+    got, gs = gpu_decode(engine, sp, sd, stages=True)
+    nch = nch_of(sd)
+    for k in range(3):
+        assert np.array_equal(ws[:, :, :nch, k].view(np.uint32), gs[:, :, :nch, k].view(np.uint32)), "stage %d" % k
+    assert_pcm_close(got, want, 1, name)
+    for chunk in (0, 1, 3, -3):                       # granule kernel, chunks with halos, persistent kernel
+        assert np.array_equal(gpu_decode(engine, sp, sd, chunk=chunk), got), chunk
+
+
+@pytest.mark.parametrize("iso", [ISO_TABLE33, ISO_MS_BOUND | ISO_IS_SHORT, ISO_SF21 | ISO_SF12, ISO_ALL])
+def test_gpu_streams_with_quirks(oracle, iso):
+    from pdmp3_amd import api
+    for name, mp3 in _streams().items():
+        want = np.frombuffer(oracle.decode_buffer_like_cli_iso(mp3, iso), dtype=np.int16)
+        ref = np.frombuffer(oracle.decode_buffer_like_cli(mp3), dtype=np.int16)
+        outs = []
+        for host_huffman in (False, True):
+            b = api.BulkDecoder(threads=2, window_frames=32, host_huffman=host_huffman)
+            try:
+                b.set_quirks(iso)
+                outs.append(b.decode(mp3))
+                b.set_quirks(0)
+                back = b.decode(mp3)                   # and back to the reference's behaviour
+            finally:
+                b.close()
+            assert back.shape == ref.shape
+            assert_pcm_close(back, ref, 1, name + " mask 0 again")
+        assert outs[0].shape == want.shape and np.array_equal(outs[0], outs[1]), name
+        assert_pcm_close(outs[0], want, 1, "%s bulk, iso %#x" % (name, iso))
+        d = api.Decoder()
+        d.set_quirks(iso)
+        got = np.frombuffer(api.decode_like_cli(mp3, d), dtype=np.int16)
+        d.close()
+        assert np.array_equal(got, outs[0]), "streaming API != whole-stream decoder"
+
+
+def test_cli_iso_env(oracle, tmp_path):
+    from pdmp3_amd.packer import packer
+    mp3 = _streams()["joint_ms_is_t33"]
+    path = tmp_path / "q.mp3"
+    path.write_bytes(mp3)
+    cli = os.path.join(ROOT, "pdmp3_amd", "pdmp3_cli")
+    for streaming in ("0", "1"):
+        subprocess.check_call([cli, str(path)], timeout=120, env=dict(os.environ, PDMP3_CLI_ISO="0x1f", PDMP3_CLI_STREAMING=streaming))
+        got = np.frombuffer((tmp_path / "q.mp3.raw").read_bytes(), dtype=np.int16)
+        (tmp_path / "q.mp3.raw").unlink()
+        want = np.frombuffer(oracle.decode_buffer_like_cli_iso(mp3, ISO_ALL), dtype=np.int16)
+        assert got.shape == want.shape
+        assert_pcm_close(got, want, 1, "CLI, PDMP3_CLI_ISO=0x1f, streaming=" + streaming)
