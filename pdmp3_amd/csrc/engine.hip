@@ -347,13 +347,14 @@ __global__ __launch_bounds__(64 * kMergeWaves) void k_merge(const GcRaw* raw, co
   unsigned carry = state_in[t], carry0 = tw >= 0 ? state_in[tw] : 0;
   for (int base = 0; base < n_frames; base += kMergeStep) {
     MergeIn m[4];
-    uint8_t fr[4];
+    uint8_t fr[4], iso[4];
     PD_UNROLL for (int q = 0; q < 4; q++) {
       const int f = base + 64 * (4 * wave + q) + lane;
       m[q] = MergeIn{false, false, false, 0, 0};
-      fr[q] = 0;
+      fr[q] = 0; iso[q] = 0;
       if (f < n_frames) {
         fr[q] = bits[f].frame;
+        iso[q] = bits[f].iso;
         m[q] = merge_load(t, raw + (size_t)f * 4, (fr[q] & PDMP3_FR_NEWSTREAM) != 0);
       }
     }
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(64 * kMergeWaves) void k_merge(const GcRaw* raw, co
       if (f < n_frames) {
         pdmp3_frame_bits F;
         F.frame = fr[q];
+        F.iso = iso[q];                              // (PDMP3_ISO_SF21 / SF12: the one-past-the-end slots stay zero)
         merge_store(t, F, side + (size_t)f * 4, v);
       }
     }
