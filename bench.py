@@ -467,12 +467,36 @@ def main():
                 got, _, _ = bd.decode_into(mp3, pcm_out)
                 dt_e = time.perf_counter() - t0
                 best = dt_e if best is None else min(best, dt_e)
-            bd.close()
             assert got == total
+            # the same stream with the PCM (i) into pinned host memory -- no host-side copy, what is left is PCIe: 4608 B per
+            # frame down at 50-odd GB/s is the ceiling of ANY destination in host memory, ~11 M frames/s -- and (ii) left in HBM
+            # (a device pointer as destination), where the host's sequential scan of the stream is the bound
+            pin = api.PinnedPCM(total // 2)
+            best_pin = None
+            for _ in range(4):
+                t0 = time.perf_counter()
+                bd.decode_into(mp3, pin.array)
+                dt_e = time.perf_counter() - t0
+                best_pin = dt_e if best_pin is None else min(best_pin, dt_e)
+            dout = torch.empty(total // 2, dtype=torch.int16, device=eng.tdev)
+            best_dev = None
+            for _ in range(4):
+                t0 = time.perf_counter()
+                bd.decode_into_device(mp3, dout, wait=True)
+                dt_e = time.perf_counter() - t0
+                best_dev = dt_e if best_dev is None else min(best_dev, dt_e)
+            same = bool(np.array_equal(dout.cpu().numpy(), pcm_out)) and bool(np.array_equal(pin.array[:total // 2], pcm_out))
+            pin.free()
+            del dout
+            bd.close()
             out["end_to_end"] = {"workload": "C3-style stream (44.1 kHz joint stereo 320 kbps CBR), %d frames, include/pdmp3_bulk.h" % frames,
                                  "frames_per_s": round(frames / best, 1), "x_realtime": round(frames / best / RT_FRAMES_PER_S, 1),
                                  "seconds": round(best, 4), "host_threads": bd.threads + 2, "huffman": "device",
-                                 "includes": "host header/side-info/reservoir scan, H2D, k_unpack, k_merge, k_decode, D2H, copy to pageable memory"}
+                                 "includes": "host header/side-info/reservoir scan, H2D, k_unpack, k_merge, k_decode, D2H, copy to pageable memory",
+                                 "pcm_to_pinned_host": {"frames_per_s": round(frames / best_pin, 1), "seconds": round(best_pin, 4),
+                                                        "pcie_GBps": round(frames * 4608 / best_pin / 1e9, 1)},
+                                 "pcm_left_in_hbm": {"frames_per_s": round(frames / best_dev, 1), "seconds": round(best_dev, 4)},
+                                 "three_destinations_same_pcm": same}
         except Exception as e:
             out["end_to_end"] = {"error": repr(e)}
         # BASELINE configs[2] (C3) through the drop-in API itself: pdmp3_feed / pdmp3_read driven by a C loop

@@ -23,8 +23,12 @@
  *   4. synthesis state is per handle instead of process-global; the handle starts zeroed (H13);
  *   5. additions, all prefixed pdmp3_amd_: float output below, whole-stream decoding in pdmp3_bulk.h.
  * Not a difference in results, but visible to a process: pdmp3_read decodes the frames the ring already holds as one
- * batch and uses helper threads for their scalefactors + Huffman data (started on first use, shared by all handles,
- * asleep between reads).  Environment: PDMP3_STREAM_THREADS = number of helpers (default min(3, CPUs - 1); 0 = the
+ * batch and uses helper threads for their scalefactors + Huffman data (started on first use, shared by all handles).
+ * After a batch the helpers SPIN for 0.2-0.5 ms before they go to sleep: a caller that reads every 50-100 us -- the
+ * reference driver's cadence -- keeps them awake, i.e. one streaming handle can hold 3 more cores at 100 %; and only ONE
+ * handle at a time gets them (a handle that reads while another one has the helpers decodes its batch alone), so with
+ * several handles reading at once the rate of each depends on who got the helpers.  PDMP3_STREAM_THREADS=0 turns them off.
+ * Environment: PDMP3_STREAM_THREADS = number of helpers (default min(3, CPUs - 1); 0 = the
  * calling thread only), PDMP3_NO_READAHEAD = one frame per batch, PDMP3_DEVICE = HIP device of new handles.
  * There is no CPU decode path: pdmp3_new() returns NULL (and sets *error when given) if no HIP device / engine
  * library is available.

@@ -110,6 +110,7 @@ void pdmp3_hip_destroy(pdmp3_hip_ctx* ctx);
 /* Environment read by pdmp3_hip_create() (none of them changes a result):
  *   PDMP3_HIP_CHAIN=0             every launch takes the chunk kernel (a chunk of frames per wave, halo)
  *   PDMP3_HIP_GRAN_MAX=n          largest launch, in frames, that takes the granule kernel (default 12288 on an MI355X)
+ *   PDMP3_HIP_RING_MIN=n          launches of at least n frames take the persistent granule kernel k_decode_p (default 0 = never)
  *   PDMP3_HIP_DIRECT_MAX=n        largest batch of a stream object that runs on the pinned host buffers directly (default 32; 0: never)
  *   PDMP3_HIP_SF_HINT=0|1|2       sampling frequency whose line table the granule kernel keeps in LDS (default 0 = 44.1 kHz;
  *                                 granules of another one read the table from memory)
@@ -137,6 +138,8 @@ size_t pdmp3_hip_state_bytes(void);
  *   chunk_frames  frames per wavefront ("chunk"); 0 = choose automatically.
  *              Chunks of several frames are independent: each re-derives the
  *              state at its start from a halo of preceding frames.
+ *              PDMP3_HIP_CHUNK_PERSISTENT (-3): the persistent granule kernel (k_decode_p; tests and tools: it is
+ *              bit-identical and, as measured in round 4, slower than the engine's own choice at every size).
  *              At 0 or 1, launches of up to 12288 frames (MI355X; PDMP3_HIP_GRAN_MAX)
  *              are decoded ONE GRANULE PER WAVEFRONT instead: the wavefronts hand
  *              IMDCT tails and polyphase rows on, no halo (scratch is kept per HIP
@@ -159,6 +162,12 @@ int pdmp3_hip_decode_frames(pdmp3_hip_ctx* ctx,
                             int16_t* d_pcm,
                             int chunk_frames,
                             void* stream);
+
+/* The granule kernel's hand-over scratch for bare calls is kept per HIP stream: 17 KB per frame of the largest such
+ * launch seen on the stream (207 MB at the 12288-frame ceiling), for up to 32 streams, least recently used first out.
+ * A caller that is done with a HIP stream -- or creates many short-lived ones -- gives the scratch back with this call
+ * (it waits for the stream's launches).  pdmp3_hip_stream objects own theirs and free it when destroyed. */
+int pdmp3_hip_release_stream_scratch(pdmp3_hip_ctx* ctx, void* stream);
 
 /* How the latest decode launch of this engine (any thread) was laid out:
  * PDMP3_HIP_LAUNCH_CHUNKS = independent chunks with halos (k_decode), otherwise

@@ -917,9 +917,18 @@ PD_FN void pcm_convert18(const float* sum, int* out) {
       : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]),
         "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15]), "+v"(p[16]), "+v"(p[17]));
 #undef PD_M
-  PD_UNROLL for (int t = 0; t < 18; t++) {
-    const int n = (int)__builtin_amdgcn_fmed3f(p[t], -32767.0f, 32767.0f);
-    out[t] = (sum[t] <= 65538.0f) ? n : -32767;
+  // The wrap-around is a property of signals driven 65 000 x past full scale: one test for the wave (the largest of the
+  // 18 sums of every lane; fmax passes over NaNs, which v_med3 turns into -32767 by itself -- its NaN rule is min3)
+  // instead of a compare and a select per sample.
+  float mx = sum[0];
+  PD_UNROLL for (int t = 1; t < 18; t++) mx = __builtin_fmaxf(mx, sum[t]);
+  if (PD_ANY(!(mx <= 65538.0f))) {
+    PD_UNROLL for (int t = 0; t < 18; t++) {
+      const int n = (int)__builtin_amdgcn_fmed3f(p[t], -32767.0f, 32767.0f);
+      out[t] = (sum[t] <= 65538.0f) ? n : -32767;
+    }
+  } else {
+    PD_UNROLL for (int t = 0; t < 18; t++) out[t] = (int)__builtin_amdgcn_fmed3f(p[t], -32767.0f, 32767.0f);
   }
 #else
   for (int t = 0; t < 18; t++) out[t] = pcm_from_sum(sum[t]);

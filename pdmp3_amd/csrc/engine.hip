@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64 * WPW, PDMP3_WAVES_PER_EU) void k_decode(DecodeA
 }
 
 // One granule per wave (decode_core.h run_granule): WPW consecutive granules per workgroup, the workgroup's place in the
-// chain from a ticket.  128 VGPRs and 9.3 KB of LDS per wave + one table block per workgroup: two workgroups = 16 waves
+// chain is its blockIdx.  128 VGPRs and 9.3 KB of LDS per wave + one table block per workgroup: two workgroups = 16 waves
 // per CU, four per SIMD.
 // W = 16: one workgroup per CU holds the CU's sixteen waves (a launch of 2048 frames is one workgroup on every CU of
 // an MI355X); W = 8 for the smaller launches: twice as many CUs share the work, two waves per SIMD.
@@ -714,6 +714,17 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
     if (e == hipSuccess && ef != hipSuccess) { what = "hipFreeAsync state"; e = ef; }
   }
   if (e != hipSuccess) return fail(PDMP3_HIP_EDEVICE, what, e);
+  return PDMP3_HIP_OK;
+}
+
+// The hand-over scratch the engine keeps for bare decode calls on `stream` (17 KB per frame of the largest granule-kernel
+// launch seen there, until 32 other streams have been used or the engine is destroyed): given back now.  Blocks until the
+// launches on that stream that use it are complete.
+extern "C" int pdmp3_hip_release_stream_scratch(pdmp3_hip_ctx* ctx, void* stream) {
+  if (!ctx) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_release_stream_scratch: NULL", hipSuccess);
+  HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "stream sync");
+  chain_release(ctx, (const void*)stream);
   return PDMP3_HIP_OK;
 }
 

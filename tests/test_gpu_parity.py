@@ -254,8 +254,8 @@ def test_gpu_float_pcm_c2(engine, oracle):
 
 
 def test_gpu_granule_launches_equal_independent_chunks(engine):
-    """one granule per wave with tails and rows handed from wave to wave (run_granule; what every launch of up to 8192
-    frames uses) against independent 2-frame chunks with halos: PCM and carried state bit-identical, over many synthetic
+    """one granule per wave with tails and rows handed from wave to wave (run_granule; what every launch of up to
+    12288 frames uses: PDMP3_HIP_GRAN_MAX) against independent 2-frame chunks with halos: PCM and carried state bit-identical, over many synthetic
     batches, sizes that leave the last workgroup partly filled, and host threads launching on their own streams"""
     import threading
     import torch

@@ -209,9 +209,9 @@ def test_emul_granule_waves_states_resets_mode_and_rate_switches(emul, oracle):
 
 @pytest.mark.parametrize("name", ["ms_long_441", "ms_short_heavy_480", "mono_441"])
 def test_emul_granule_waves_give_up_waiting_for_other_workgroups(emul, name):
-    """the bounded wait (gran_wait): with every wait for another workgroup giving up at once, the first wave of each
-    workgroup decodes its frame with a halo (run_chunk), tells the wave of the frame's second granule to leave and
-    publishes from there -- same PCM"""
+    """the bounded wait (gran_far_wait): with every wait for another workgroup giving up at once, the first wave of each
+    workgroup derives the state at the start of its frame the independent way (gran_slow_chunk(..., state_only): run_chunk's
+    halo as a called function) and goes on as a granule wave with it -- same PCM"""
     sp, sd = corpus.case(name, n=21)
     want = emul_decode(emul, sp, sd, 0)
     assert np.array_equal(emul_decode_granules(emul, sp, sd, debug=1), want)

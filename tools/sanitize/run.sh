@@ -10,7 +10,7 @@ mkdir -p $OUT
 for san in thread address,undefined; do
   for t in stream_threads bulk_threads; do
     gcc -O1 -g -fsanitize=$san -I$ROOT/include -I$ROOT/pdmp3_amd/csrc -o $OUT/$t $ROOT/tools/sanitize/$t.c $ROOT/pdmp3_amd/host/pdmp3_host.c \
-        -L$ROOT/pdmp3_amd -lpdmp3_hip -lpthread -Wl,-rpath,$ROOT/pdmp3_amd 2> /dev/null
+        -L$ROOT/pdmp3_amd -lpdmp3_hip -lpthread -Wl,-rpath,$ROOT/pdmp3_amd -w     # (warnings off, errors shown: a failed build stops the script with its message)
     echo "== $san $t"
     ASAN_OPTIONS=detect_leaks=0 $OUT/$t "$1" 2>&1 | tail -4
   done
