@@ -6,9 +6,9 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu --no-e2e --big 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats.log; echo "stats rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu --no-e2e --big 0 --shard 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats.log; echo "stats rc=$?"
 cat $OUT/stats/bench_kernel_stats.csv
-pmc() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 bench.py --steps 20 --warmup 2 --no-cpu --no-e2e --big 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
+pmc() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 bench.py --steps 20 --warmup 2 --no-cpu --no-e2e --big 0 --shard 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
@@ -30,6 +30,11 @@ for t in 0 1 3 7 11; do PDMP3_STREAM_THREADS=$t timeout 300 python3 tools/stream
 gcc -O2 -Iinclude -o /tmp/rtt tools/stream_rtt.c -Lpdmp3_amd -lpdmp3_hip -Wl,-rpath,$PWD/pdmp3_amd && timeout 120 /tmp/rtt > $OUT/stream_rtt.txt; cat $OUT/stream_rtt.txt
 PDMP3_HIP_UNPACK_PROF=1 timeout 300 python3 tools/bulk_bench.py --frames 20000 --threads 2 --reps 1 2>&1 > /dev/null | grep "k_unpack prof" | tail -2 > $OUT/unpack_phases.txt; cat $OUT/unpack_phases.txt
 timeout 300 python3 tools/phase_profile.py 131072 32 > $OUT/phase_profile.txt 2>&1; timeout 300 python3 tools/phase_profile.py 2048 1 >> $OUT/phase_profile.txt 2>&1
+# round 4: the persistent granule kernel against the engine's own choice, its per-turn stamps, the granule kernel's per-wave stamps,
+# the driver's short invocation of the bench
+timeout 300 python3 tools/ring_bench.py > $OUT/ring_bench.txt 2>&1; timeout 300 python3 tools/ring_profile.py 32768 > $OUT/ring_profile.txt 2>&1
+timeout 300 python3 tools/gran_profile.py 2048 > $OUT/gran_profile.txt 2>&1
+timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 2> /dev/null > $OUT/bench_driver_flags.json; cat $OUT/bench_driver_flags.json | cut -c1-400
 # the same for a C5-shard-sized launch
 pmcb() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 tools/pmc_target.py 131072 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
 pmcb big_fetch FETCH_SIZE
@@ -43,7 +48,9 @@ for d in sorted(glob.glob(os.path.join(out, "*", "p_counter_collection.csv"))):
     rows = list(csv.DictReader(open(d)))
     agg = collections.defaultdict(float); disp = set()
     for r in rows:
-        if "k_decode" not in r.get("Kernel_Name", ""): continue
+        # the C2 passes are the granule kernel's launches only; the big_* passes (tools/pmc_target.py) the chunk kernel's
+        want = "k_decode<" if name.startswith("big_") else "k_decode_g"
+        if want not in r.get("Kernel_Name", ""): continue
         agg[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
     n = max(1, len(disp))
     summary[name] = {"dispatches": n, "per_dispatch": {k: v / n for k, v in sorted(agg.items())}}
