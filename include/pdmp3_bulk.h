@@ -42,12 +42,16 @@ typedef struct bulk pdmp3_amd_bulk;
 
 /* threads <= 0: one worker per usable CPU (affinity and cgroup quota; at most 64; 4 with device Huffman, where the
  * pool only copies PCM out).  window_frames <= 0:
- * 2048 frames per GPU batch (at most 32768).  Returns NULL when there is no transform engine
+ * 4096 frames per GPU batch with device Huffman, 2048 with host Huffman (at most 32768).  Returns NULL when there is no transform engine
  * (no CPU fallback). */
 pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
 /* Environment: PDMP3_BULK_HOST_HUFFMAN=1 (below), PDMP3_BULK_SNAPSHOT_ROWS=1 (upload 2064-byte reservoir snapshots per frame
  * instead of the compact pool + row descriptors: tests), PDMP3_BULK_TRACE=1 (one summary of the pipeline's waits per decode on
- * stderr). */
+ * stderr), PDMP3_BULK_SCAN_THREADS=n (0 .. 8: scanner threads of the split scan -- a pre-pass hops from header to header and
+ * n threads run the scan from window boundaries, results identical to the one-thread scan; by default 8 / 4 / 2 with
+ * 16 / 12 / 6 usable CPUs and only when the PCM stays in device memory, where the scan is the bound; given explicitly: for
+ * every destination; 0: never), PDMP3_BULK_GATHER_THREADS=n (0 .. 4 helpers of the thread that copies a window's main
+ * data into the pinned upload buffer). */
 /* host_huffman = 0 (what pdmp3_amd_bulk_new gives unless PDMP3_BULK_HOST_HUFFMAN=1 is set): the host only runs
  * the sequential scan and ships side info + reservoir snapshots; scalefactors, Huffman and the frame-to-frame
  * merge run on the device (pdmp3_hip_stream_submit_bits) and the pool just copies PCM out.  host_huffman = 1:

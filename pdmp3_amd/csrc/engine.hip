@@ -150,7 +150,9 @@ constexpr int kFrameBitsW = sizeof(pdmp3_frame_bits) / 4;   // 20
 // linbits and signs and store the lines (unpack_value).  Round 2's single loop did all of it in wave 0, a loop per
 // symbol kind: 406 trips of ~700 cycles per window, 140 us; this one: <= 288 trips of the walker's half.
 // The lines go straight to HBM, into spectra that two of the value waves zero with coalesced stores first.
-constexpr int kRingRows = 32;                              // trips the walker may be ahead of the value waves
+constexpr int kRingRows = 16;                              // trips the walker may be ahead of the value waves (16, not 32: the ring's 8 KB
+                                                           // are what lets TWO workgroups share a CU -- 80.0 KB each --, which is worth more on the
+                                                           // windows of 4096 frames the whole-stream decoder now uses: 17.0 -> 18.5 M frames/s)
 constexpr int kRingCheck = 8;                              // ... looked at every so many trips
 static_assert(kRingRows % kRingCheck == 0 && kRingCheck >= 3, "blocks of trips do not wrap around the ring");
 struct UnpackRing {

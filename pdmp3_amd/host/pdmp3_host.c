@@ -876,6 +876,7 @@ static size_t drain_frame(pdmp3_handle* id, unsigned char* out, size_t buflen) {
 /* ------------------------------------------------------------------------ */
 struct bulk;
 static int bulk_push(struct bulk* b);             /* snapshot the frame read_frame_staged just staged */
+static int bulk_at_limit(const struct bulk* b);
 
 /* The whole-stream decoder's form of the read loop (`sink`): the call only does what touches the input ring and the
  * output cursor; main data decoding, the transforms and the PCM copy are the sink's business (bulk path below),
@@ -890,6 +891,7 @@ static int read_impl_sink(pdmp3_handle* id, size_t outsize, size_t* done, struct
   }
   while (outsize) {
     if (ring_filled(id) < 1152) { res = PDMP3_NEED_MORE; break; }      /* H10 */
+    if (bulk_at_limit(sink)) { res = PDMP3_OK; break; }                /* (split scan: this scanner's span ends here) */
     const size_t pos = id->processed;
     const unsigned mark = id->istart;
     res = read_frame_staged(id);
@@ -1306,6 +1308,7 @@ int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) 
 /*                   copied out while w-1 is on the GPU and w is in B.       */
 /* ------------------------------------------------------------------------ */
 #define BULK_SLOTS 6
+#define BULK_GATH_EXTRA 16             /* copy-list entries beyond one per frame: segment images of a split scan's windows */
 #include <time.h>
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 #define PDMP3_BULK_REPLAY (-2)         /* see bulk_drive */
@@ -1336,6 +1339,23 @@ typedef struct {                      /* a window that is on the GPU */
   uint8_t* nch;
   long long sub_seq;                  /* its place in the submitter's queue */
 } bulk_flight;
+
+/* split scan: a window as a scanner thread leaves it -- what bits_push / fill_reservoir_pool write into an engine slot,
+ * in private memory.  The bytes the scanner itself puts into the pool (a segment's image of the reservoir buffer) are
+ * kept in `arena` and entered in the copy list like the main data the submitter gathers from the stream. */
+#define PW_ARENA_BYTES (24u << 10)
+typedef struct pre_window {
+  long long index;                    /* window number within the stream */
+  int n, gath_n;
+  size_t pool_tail;
+  pdmp3_frame_bits* bits;
+  pdmp3_row_desc* desc;
+  uint8_t* nch;
+  void* gath;                         /* struct pool_copy[] */
+  uint8_t* arena;
+  size_t arena_len;
+} pre_window;
+struct par_scan;
 
 struct bulk {
   pdmp3_handle* id;
@@ -1396,6 +1416,22 @@ struct bulk {
   void* sub_dst[8];
   long long sub_head, sub_tail;       /* jobs enqueued / completed */
   size_t next_copy_row;               /* row size of the copy job bulk_collect last handed out */
+  /* split scan (par_scan below): a scanner that fills private windows (struct pre_window) instead of engine slots */
+  int scan_threads;                   /* scanners of the split scan (0: stage A on the calling thread alone) */
+  int scan_forced;                    /* PDMP3_BULK_SCAN_THREADS was given: split whatever the destination */
+  /* the submitter's helpers: a window's main data (1 KB per frame, out of the caller's stream into the slot's pinned pool)
+   * is copied by several threads at once -- on one thread it is 9 ms of an hour of audio, which is what bounds the
+   * pipeline once the scan is split */
+  pthread_t gh_th[4];
+  int gh_n, gh_quit, gh_parts, gh_next, gh_done;
+  uint8_t* gh_pool; const void* gh_list; int gh_count;
+  pthread_mutex_t gh_mu; pthread_cond_t gh_cv, gh_done_cv;
+  int win_sink;
+  struct pre_window* pw_cur;
+  struct par_scan* par;               /* where finished windows go */
+  long long limit_frames;             /* stop parsing when `frames` reaches this (0: no limit) */
+  uint8_t* priv_pool;                 /* win_sink: this scanner's pool of the window it is filling */
+  void* slot_arena[BULK_SLOTS];       /* the literal bytes (segment images) a slot's copy list points into, from a pre_window */
   double t_submit, t_gpuwait, t_poolwait;   /* PDMP3_BULK_TRACE=1: where the scanning thread waits */
   double t_sub_gather, t_sub_call, t_drive, t_subwait, t_tail;          /* ... and what the submitter thread spends on the main-data copies / the engine calls */
 };
@@ -1614,6 +1650,41 @@ static void fill_frame_bits(const pdmp3_handle* id, pdmp3_frame_bits* fb, int ne
 static void pool_gather(uint8_t* pool, const struct pool_copy* g, int n) {
   for (int i = 0; i < n; i++) if (g[i].n) memcpy(pool + g[i].dst, g[i].src, g[i].n);
 }
+static void gather_part(uint8_t* pool, const struct pool_copy* g, int n, int part, int parts) {
+  const int lo = (int)((long long)n * part / parts), hi = (int)((long long)n * (part + 1) / parts);
+  pool_gather(pool, g + lo, hi - lo);
+}
+static void* gather_helper(void* arg) {
+  struct bulk* b = (struct bulk*)arg;
+  pthread_mutex_lock(&b->gh_mu);
+  for (;;) {
+    while (!b->gh_quit && b->gh_next >= b->gh_parts) pthread_cond_wait(&b->gh_cv, &b->gh_mu);
+    if (b->gh_quit) break;
+    const int part = b->gh_next++, parts = b->gh_parts, n = b->gh_count;
+    uint8_t* pool = b->gh_pool;
+    const struct pool_copy* list = (const struct pool_copy*)b->gh_list;
+    pthread_mutex_unlock(&b->gh_mu);
+    gather_part(pool, list, n, part, parts);
+    pthread_mutex_lock(&b->gh_mu);
+    if (++b->gh_done == parts) pthread_cond_signal(&b->gh_done_cv);
+  }
+  pthread_mutex_unlock(&b->gh_mu);
+  return NULL;
+}
+/* pool_gather on the submitter and its helpers */
+static void pool_gather_par(struct bulk* b, uint8_t* pool, const struct pool_copy* g, int n) {
+  if (b->gh_n == 0 || n < 512) { pool_gather(pool, g, n); return; }
+  pthread_mutex_lock(&b->gh_mu);
+  b->gh_pool = pool; b->gh_list = g; b->gh_count = n;
+  b->gh_parts = b->gh_n + 1; b->gh_next = 1; b->gh_done = 0;     /* part 0 is the submitter's own */
+  pthread_cond_broadcast(&b->gh_cv);
+  pthread_mutex_unlock(&b->gh_mu);
+  gather_part(pool, g, n, 0, b->gh_n + 1);
+  pthread_mutex_lock(&b->gh_mu);
+  b->gh_done++;
+  while (b->gh_done < b->gh_parts) pthread_cond_wait(&b->gh_done_cv, &b->gh_mu);
+  pthread_mutex_unlock(&b->gh_mu);
+}
 static void* bulk_submitter(void* arg) {
   struct bulk* b = (struct bulk*)arg;
   for (;;) {
@@ -1626,7 +1697,7 @@ static void* bulk_submitter(void* arg) {
     const int gn = b->sub_gath[b->sub_tail & 7];
     pthread_mutex_unlock(&b->sub_mu);
     const double t0 = now_s();
-    if (pool) pool_gather(pdmp3_hip_stream_slot_pool(b->hs, slot), b->gath[slot], gn);
+    if (pool) pool_gather_par(b, pdmp3_hip_stream_slot_pool(b->hs, slot), b->gath[slot], gn);
     const double t1 = now_s();
     const int rc = pool ? pdmp3_hip_stream_submit_pool_to(b->hs, slot, n, pool, dst, row)
                         : pdmp3_hip_stream_submit_bits_to(b->hs, slot, n, dst, row);
@@ -1669,11 +1740,36 @@ static int sub_drain(struct bulk* b) {            /* every enqueued window has b
 
 /* make the slot of window `windows` writable: its previous occupant (window - BULK_SLOTS) must be off the GPU; its PCM
  * goes home on the worker pool while stage A fills the slot's input side */
+static int bulk_at_limit(const struct bulk* b) { return b->limit_frames && b->frames >= b->limit_frames; }
+static pre_window* pw_new(int cap, long long index);
+static void pw_free(pre_window* w);
+/* bytes the scanner itself puts into the window's pool (a segment's image of the reservoir buffer, a frame's own image):
+ * straight into the pool, and for a split scan's private window also into its arena and its copy list */
+static int pool_literal(struct bulk* b, size_t dst, const uint8_t* src, size_t n) {
+  memcpy(b->res_dst + dst, src, n);
+  if (!b->win_sink) return PDMP3_OK;
+  pre_window* w = b->pw_cur;
+  if (w->arena_len + n > PW_ARENA_BYTES || b->gath_n >= b->cap + BULK_GATH_EXTRA - 1) return PDMP3_ERR;
+  memcpy(w->arena + w->arena_len, src, n);
+  struct pool_copy* g = &b->gath_cur[b->gath_n++];
+  g->src = w->arena + w->arena_len; g->dst = (uint32_t)dst; g->n = (uint32_t)n;
+  w->arena_len += n;
+  return PDMP3_OK;
+}
 static int bits_open_window(struct bulk* b) {
   b->bits_n = 0;
   b->bits_open = 1;
   b->pool_tail = 0; b->need_segment = 1; b->seg_first = 0; b->cur_explicit = 0; b->cur_staged = 0; b->sky_n = 0;
   b->gath_n = 0;
+  if (b->win_sink) {                              /* split scan: a private window */
+    b->pw_cur = pw_new(b->cap, b->windows);
+    if (!b->pw_cur) return PDMP3_ERR;
+    b->bits_dst = b->pw_cur->bits; b->desc_dst = b->pw_cur->desc;
+    b->gath_cur = (struct pool_copy*)b->pw_cur->gath;
+    b->res_dst = b->priv_pool;
+    b->pool_cap = (size_t)b->cap * RESERVOIR_BYTES + PDMP3_POOL_SLACK_BYTES;
+    return PDMP3_OK;
+  }
   if (!b->hs) {                                   /* parse only: one "window" = the caller's arrays */
     b->bits_dst = b->rec_bits;
     b->res_dst = b->rec_res;
@@ -1695,6 +1791,7 @@ static int bits_open_window(struct bulk* b) {
   }
   if (bulk_collect(b, b->bits_slot, &src, &dst, &nbytes) != PDMP3_OK) return PDMP3_ERR;
   if (nbytes) bulk_start_b(b, NULL, src, dst, nbytes);
+  free(b->slot_arena[b->bits_slot]); b->slot_arena[b->bits_slot] = NULL;   /* (its window was gathered long ago) */
   b->bits_dst = pdmp3_hip_stream_slot_bits(b->hs, b->bits_slot);
   b->res_dst = pdmp3_hip_stream_slot_reservoir(b->hs, b->bits_slot);
   if (b->pool_mode) {
@@ -1716,7 +1813,11 @@ static void pool_ensure(struct bulk* b, size_t lo, size_t hi) {
   for (int i = b->gath_n - 1; i >= 0; i--) {
     struct pool_copy* g = &b->gath_cur[i];
     if ((size_t)g->dst + g->n <= lo && g->n) break;           /* (entries done earlier have n = 0: keep looking) */
-    if (g->n && g->dst < hi) { memcpy(b->res_dst + g->dst, g->src, g->n); g->n = 0; }
+    if (g->n && g->dst < hi) {
+      memcpy(b->res_dst + g->dst, g->src, g->n);
+      if (!b->win_sink) g->n = 0;                 /* (a split scan's private pool is not the one that goes up: the entry stays) */
+      else if ((size_t)g->dst < lo) break;
+    }
   }
 }
 static void pool_materialize(struct bulk* b) {
@@ -1755,9 +1856,9 @@ static int fill_reservoir_pool(pdmp3_handle* id, unsigned size, unsigned begin) 
   if (b->need_segment) {                          /* the buffer as it is now, then its valid tail once more */
     const unsigned h = id->main_top < 511 ? id->main_top : 511;
     b->seg_s_off = (uint32_t)b->pool_tail;
-    memcpy(b->res_dst + b->pool_tail, id->main_vec, RESERVOIR_BYTES);
+    if (pool_literal(b, b->pool_tail, id->main_vec, RESERVOIR_BYTES) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
     b->pool_tail += RESERVOIR_BYTES;
-    memcpy(b->res_dst + b->pool_tail, id->main_vec + id->main_top - h, h);
+    if (h && pool_literal(b, b->pool_tail, id->main_vec + id->main_top - h, h) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
     b->pool_tail += h;
     b->seg_first = b->bits_n;
     b->sky_n = 0;
@@ -1804,10 +1905,11 @@ static int bits_close_window(struct bulk* b) {
   return PDMP3_OK;
 }
 
+static int pw_close_window(struct bulk* b);       /* split scan, below */
 static int bits_push(struct bulk* b) {
   pdmp3_handle* id = b->id;
   if (!b->bits_open && bits_open_window(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
-  if (!b->hs && (size_t)b->frames > b->rec_cap) { b->failed = 1; return PDMP3_ERR; }
+  if (!b->hs && !b->win_sink && (size_t)b->frames > b->rec_cap) { b->failed = 1; return PDMP3_ERR; }
   const int i = b->bits_n++;
   if (id->fb_valid) {                             /* read_side_info_bits has built the record */
     const frame_header* H = &id->hdr;
@@ -1823,7 +1925,7 @@ static int bits_push(struct bulk* b) {
     if (b->cur_explicit) {                        /* its own image of the buffer (main_vec is live here) */
       d->row_off = d->s_off = (uint32_t)b->pool_tail;
       d->top = RESERVOIR_BYTES; d->back = 0; d->up = 0; d->reserved = 0;
-      memcpy(b->res_dst + b->pool_tail, id->main_vec, RESERVOIR_BYTES);
+      if (pool_literal(b, b->pool_tail, id->main_vec, RESERVOIR_BYTES) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
       b->pool_tail += RESERVOIR_BYTES;
       b->cur_explicit = 0;
     } else {
@@ -1838,9 +1940,12 @@ static int bits_push(struct bulk* b) {
     }
   } else memcpy(b->res_dst + (size_t)i * RESERVOIR_BYTES, id->main_vec, RESERVOIR_BYTES);
   if (b->hs) b->flight[b->bits_slot].nch[i] = (uint8_t)(id->hdr.mode == 3 ? 1 : 2);
+  if (b->win_sink) b->pw_cur->nch[i] = (uint8_t)(id->hdr.mode == 3 ? 1 : 2);
   const int full = b->bits_n == b->cap || (b->pool_mode && b->pool_tail + POOL_ROOM > b->pool_cap);
+  if (b->win_sink && full && pw_close_window(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
+  if (b->win_sink) return PDMP3_OK;
   if (b->hs && full && bits_close_window(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
-  if (!b->hs && b->pool_mode && b->pool_tail + POOL_ROOM > b->pool_cap) { b->failed = 1; return PDMP3_ERR; }
+  if (!b->hs && !b->win_sink && b->pool_mode && b->pool_tail + POOL_ROOM > b->pool_cap) { b->failed = 1; return PDMP3_ERR; }
   return PDMP3_OK;
 }
 
@@ -1893,6 +1998,467 @@ static long long bulk_drive(struct bulk* b, const unsigned char* mp3, size_t n) 
   return (long long)total;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Split scan (round 4).  Stage A is ~300 cycles of bit-field parsing and      */
+/* index arithmetic per frame on ONE thread (profiles/r04_scan_sections.txt),  */
+/* and with the PCM left on the device it is what bounds the whole-stream      */
+/* decoder.  What is strictly sequential in it is little: a frame's position   */
+/* follows from the header before it, the ring's indices from the CLI's feed   */
+/* cadence, the reservoir's fill from the frame before.  So: a PRE-PASS hops    */
+/* from header to header with the real ring arithmetic (pdmp3_feed on a        */
+/* scratch handle), checks that every frame takes the scanner's regular path    */
+/* and leaves, at a few window boundaries, what a scanner needs to start there  */
+/* -- ring indices, reservoir fill, which earlier frames' bytes are still in    */
+/* the reservoir buffer, which frames last set the side-info fields the         */
+/* reference leaves stale (H20); SCANNER threads run the unchanged stage-A code */
+/* from those points into private windows (pre_window); the calling thread      */
+/* moves the windows into the engine's slots in stream order.  Anything the     */
+/* pre-pass does not recognise as regular (resync, underflow H9, a frame the    */
+/* ring does not hold H18, a dropped feed H16, a replayed ring) makes the whole */
+/* stream go the one-thread way from the start: results are the sequential      */
+/* scanner's by construction, bit for bit (tests compare).                      */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  uint32_t x;                 /* offset of the frame's header in the stream */
+  uint32_t md_src;            /* offset of its main data */
+  uint64_t md_end;            /* main-data bytes of the stream up to and including this frame */
+  uint16_t fb, begin, top;    /* frame bytes, main_data_begin, reservoir fill after it */
+  uint8_t nch, crc;
+} hop_rec;
+
+typedef struct {              /* the scanner's state in front of frame `frame` (a window boundary) */
+  long long frame;
+  unsigned istart, iend;
+  size_t processed, vfed, fed;
+  unsigned main_top;
+  int sky_n;
+  int* sky;                   /* frames whose bytes are still visible in the reservoir buffer, oldest (largest top) first */
+  long long last_ws0[4], last_ws1[4];   /* the last frame before it whose gc g had win_switch_flag 0 / 1 (-1: none) */
+  int ready;
+} span_snap;
+
+struct par_scan {
+  struct bulk* b;
+  const unsigned char* mp3; size_t n;
+  int K;
+  long long bound[9];         /* scanner k takes frames [bound[k], bound[k+1]) (the last one: to the end of the stream) */
+  span_snap snap[8];
+  hop_rec* rec; long long rec_cap;
+  long long n_frames;         /* valid once prepass_done */
+  int prepass_done, irregular, abort;
+  pre_window** win; long long win_cap;    /* finished windows by stream index */
+  int scanners_done;
+  pthread_mutex_t mu; pthread_cond_t cv;
+  double t_prepass;
+};
+
+static pre_window* pw_new(int cap, long long index) {
+  pre_window* w = (pre_window*)calloc(1, sizeof *w);
+  if (!w) return NULL;
+  w->index = index;
+  w->bits = (pdmp3_frame_bits*)malloc((size_t)cap * sizeof(pdmp3_frame_bits));
+  w->desc = (pdmp3_row_desc*)malloc((size_t)cap * sizeof(pdmp3_row_desc));
+  w->nch = (uint8_t*)malloc((size_t)cap);
+  w->gath = malloc(((size_t)cap + BULK_GATH_EXTRA) * sizeof(struct pool_copy));
+  w->arena = (uint8_t*)malloc(PW_ARENA_BYTES);
+  if (!w->bits || !w->desc || !w->nch || !w->gath || !w->arena) { pw_free(w); return NULL; }
+  return w;
+}
+static void pw_free(pre_window* w) {
+  if (!w) return;
+  free(w->bits); free(w->desc); free(w->nch); free(w->gath); free(w->arena);
+  free(w);
+}
+/* the private window is complete: the reservoir buffer is brought up to date for the next one (as bits_close_window
+ * does) and the window goes to whoever stitches the stream together */
+static int pw_close_window(struct bulk* b) {
+  if (!b->bits_open) return PDMP3_OK;
+  pool_materialize(b);
+  b->bits_open = 0;
+  pre_window* w = b->pw_cur;
+  b->pw_cur = NULL;
+  if (!b->bits_n) { pw_free(w); return PDMP3_OK; }
+  w->n = b->bits_n; w->gath_n = b->gath_n; w->pool_tail = b->pool_tail;
+  struct par_scan* P = b->par;
+  pthread_mutex_lock(&P->mu);
+  if (w->index < P->win_cap && !P->win[w->index]) { P->win[w->index] = w; w = NULL; }
+  pthread_cond_broadcast(&P->cv);
+  pthread_mutex_unlock(&P->mu);
+  if (w) { pw_free(w); return PDMP3_ERR; }          /* (cannot happen: more windows than the stream has bytes for) */
+  b->windows++;
+  return PDMP3_OK;
+}
+
+static void header_fields(uint32_t h, frame_header* H) {
+  H->id = (h >> 19) & 1; H->layer = 4 - ((h >> 17) & 3); H->protection = (h >> 16) & 1;
+  H->bitrate_index = (h >> 12) & 15; H->sfreq = (h >> 10) & 3; H->padding = (h >> 9) & 1;
+  H->mode = (h >> 6) & 3; H->mode_ext = (h >> 4) & 3;
+}
+static inline uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+/* The pre-pass.  Returns 0 when the whole stream is regular (P->n_frames frames), -1 otherwise. */
+static int par_prepass(struct par_scan* P) {
+  const unsigned char* mp3 = P->mp3;
+  const size_t n = P->n;
+  pdmp3_handle* h = (pdmp3_handle*)calloc(1, sizeof *h);
+  int* sky = (int*)malloc((RESERVOIR_BYTES + 2) * sizeof(int));
+  if (!h || !sky) { free(h); free(sky); return -1; }
+  h->host_only = 1;
+  h->vsrc = mp3; h->vfed = 0;
+  size_t fed = 0;
+  unsigned main_top = 0;
+  uint64_t md_end = 0;
+  int sky_n = 0, next = 1, rc = -1;
+  long long f = 0, ws0[4] = {-1, -1, -1, -1}, ws1[4] = {-1, -1, -1, -1};
+  for (;;) {
+    if (P->abort) goto out;
+    if (next < P->K && f == P->bound[next]) {           /* a scanner starts here */
+      span_snap* S = &P->snap[next];
+      S->frame = f; S->istart = h->istart; S->iend = h->iend; S->processed = h->processed; S->vfed = h->vfed; S->fed = fed;
+      S->main_top = main_top; S->sky_n = sky_n;
+      S->sky = (int*)malloc((size_t)(sky_n + 1) * sizeof(int));
+      if (!S->sky) goto out;
+      memcpy(S->sky, sky, (size_t)sky_n * sizeof(int));
+      memcpy(S->last_ws0, ws0, sizeof ws0); memcpy(S->last_ws1, ws1, sizeof ws1);
+      pthread_mutex_lock(&P->mu);
+      S->ready = 1;
+      pthread_cond_broadcast(&P->cv);
+      pthread_mutex_unlock(&P->mu);
+      next++;
+    }
+    while (ring_filled(h) < 1152) {                     /* H10 + the CLI's feeds (bulk_drive) */
+      const size_t take = n - fed < 4096 ? n - fed : 4096;
+      if (!take) { rc = 0; goto out; }                  /* the stream ends here: what is left is dropped, as the CLI drops it */
+      if (take > ring_free_logical(h)) goto out;        /* a feed the CLI would drop (H16) */
+      if (pdmp3_feed(h, mp3 + fed, take) != PDMP3_OK) goto out;
+      fed += take;
+    }
+    const size_t x = h->vfed - ring_filled(h);
+    const unsigned avail = ring_filled(h);
+    const uint32_t hw = be32(mp3 + x);
+    if ((hw & 0xfff00000u) != 0xfff00000u) goto out;    /* the scanner would search for the next sync */
+    frame_header H;
+    header_fields(hw, &H);
+    if (H.id != 1 || H.bitrate_index == 0 || H.bitrate_index == 15 || H.sfreq == 3 || H.layer != 3) goto out;
+    const unsigned nch = H.mode == 3 ? 1 : 2, nbytes = nch == 1 ? 17 : 32, crc = H.protection == 0 ? 2 : 0;
+    const unsigned fb = frame_bytes(&H);
+    if (fb > 2000 || fb > avail) goto out;              /* (a frame the ring does not hold completely: H18) */
+    /* this loop is a chain of dependent cache misses -- where the next header is follows from this one -- unless the lines
+     * are asked for ahead of time: frames of a constant-bitrate stream are as long as each other to within the padding
+     * byte, so the header and side info of the 12th frame from here lie within 12 bytes of x + 12 fb (two lines cover
+     * them); on a variable-bitrate stream the guess is wrong and costs nothing */
+    __builtin_prefetch(mp3 + x + 12u * fb, 0, 3);
+    __builtin_prefetch(mp3 + x + 12u * fb + 64, 0, 3);
+    const unsigned char* v = mp3 + x + 4 + crc;
+    const unsigned begin = ((unsigned)v[0] << 1) | (v[1] >> 7);
+    const unsigned size = fb - nbytes - 4 - crc;
+    if (!(begin <= main_top && begin + size <= RESERVOIR_BYTES)) goto out;      /* reservoir underflow (H9) / overflow */
+    if (f >= P->rec_cap) goto out;
+    hop_rec* r = &P->rec[f];
+    md_end += size;
+    r->x = (uint32_t)x; r->md_src = (uint32_t)(x + 4 + crc + nbytes); r->md_end = md_end;
+    r->fb = (uint16_t)fb; r->begin = (uint16_t)begin; r->top = (uint16_t)(begin + size); r->nch = (uint8_t)nch; r->crc = (uint8_t)crc;
+    main_top = begin + size;
+    while (sky_n && P->rec[sky[sky_n - 1]].top <= main_top) sky_n--;
+    sky[sky_n++] = (int)f;
+    for (unsigned gr = 0; gr < 2; gr++)                 /* which frame last set the fields the reference leaves stale (H20) */
+      for (unsigned ch = 0; ch < nch; ch++) {
+        const unsigned pos = (nch == 1 ? 18u : 20u) + 59u * (gr * nch + ch) + 33u;
+        if ((v[pos >> 3] >> (7 - (pos & 7))) & 1) ws1[gr * 2 + ch] = f; else ws0[gr * 2 + ch] = f;
+      }
+    h->istart = (h->istart + fb) % INBUF_SIZE;
+    h->processed += fb;
+    h->l_istart = h->istart; h->l_processed = h->processed;
+    if (h->processed > fed) goto out;                   /* (a replayed ring) */
+    f++;
+  }
+out:
+  free(h); free(sky);
+  pthread_mutex_lock(&P->mu);
+  P->n_frames = f;
+  P->irregular = rc != 0;
+  P->prepass_done = 1;
+  pthread_cond_broadcast(&P->cv);
+  pthread_mutex_unlock(&P->mu);
+  return rc;
+}
+static void* par_prepass_thread(void* arg) {
+  struct par_scan* P = (struct par_scan*)arg;
+  const double t0 = now_s();
+  (void)par_prepass(P);
+  P->t_prepass = now_s() - t0;
+  return NULL;
+}
+
+/* `len` bytes of the stream's main data, from position `off` of their concatenation, whose last byte belongs to frame `g` or an earlier one */
+static void md_read(const struct par_scan* P, long long g, uint64_t off, unsigned len, uint8_t* out) {
+  while (g > 0 && P->rec[g - 1].md_end > off) g--;      /* the frame that holds byte `off` */
+  while (len) {
+    const hop_rec* r = &P->rec[g];
+    const uint64_t start = r->md_end - (uint64_t)(r->top - r->begin);
+    const unsigned in = (unsigned)(off - start), have = (unsigned)(r->md_end - off);
+    const unsigned k = have < len ? have : len;
+    memcpy(out, P->mp3 + r->md_src + in, k);
+    out += k; off += k; len -= k; g++;
+  }
+}
+
+/* a scanner's handle as the sequential scanner's would be in front of frame S->frame */
+static void span_init(const struct par_scan* P, const span_snap* S, pdmp3_handle* id) {
+  id->vsrc = P->mp3; id->vfed = S->vfed;
+  id->istart = S->istart; id->iend = S->iend; id->processed = S->processed;
+  id->l_istart = S->istart; id->l_processed = S->processed;
+  id->new_header = 1; id->l_new_header = 1; id->need_reset = 0; id->ostart = 0;
+  const hop_rec* last = &P->rec[S->frame - 1];
+  header_fields(be32(P->mp3 + last->x), &id->hdr);
+  id->l_hdr = id->hdr;
+  id->last_nch = last->nch;
+  /* the reservoir buffer: [0, top) of the newest frame, above it what older frames with larger tops left (sky), zero
+   * where no frame ever reached */
+  id->main_top = S->main_top;
+  memset(id->main_vec, 0, sizeof id->main_vec);
+  unsigned covered = 0;
+  for (int i = S->sky_n - 1; i >= 0; i--) {
+    const long long g = S->sky[i];
+    const hop_rec* r = &P->rec[g];
+    if (r->top <= covered) continue;
+    md_read(P, g, r->md_end - r->top + covered, r->top - covered, id->main_vec + covered);
+    covered = r->top;
+  }
+  /* side-info fields that a frame only sets on one side of win_switch_flag and otherwise leaves as they were (H20) */
+  for (unsigned g = 0; g < 4; g++) {
+    const unsigned gr = g >> 1, ch = g & 1;
+    for (int which = 0; which < 2; which++) {
+      const long long f = which ? S->last_ws1[g] : S->last_ws0[g];
+      if (f < 0) continue;
+      const hop_rec* r = &P->rec[f];
+      const uint8_t* v = P->mp3 + r->x + 4 + r->crc;
+      const unsigned pos = (r->nch == 1 ? 18u : 20u) + 59u * (gr * r->nch + ch);
+      uint8_t tmp[48];
+      memcpy(tmp, v, 40); memset(tmp + 40, 0, 8);       /* (side_word reads 8 bytes at a time) */
+      const uint64_t xw = side_word(tmp, pos);
+      const unsigned y = (unsigned)(xw >> 8) & 0x3fffff;
+      if (which) for (unsigned w = 0; w < 3; w++) id->si.subblock_gain[gr][ch][w] = (y >> (6 - 3 * w)) & 7;
+      else id->si.table_select[gr][ch][2] = (y >> 7) & 31;
+    }
+  }
+}
+
+typedef struct { struct par_scan* P; int k; int rc; } scanner_arg;
+static void* par_scanner(void* arg) {
+  scanner_arg* A = (scanner_arg*)arg;
+  struct par_scan* P = A->P;
+  const int k = A->k;
+  A->rc = -1;
+  struct bulk* wb = (struct bulk*)calloc(1, sizeof *wb);
+  pdmp3_handle* id = (pdmp3_handle*)calloc(1, sizeof *id);
+  uint8_t* pool = (uint8_t*)malloc((size_t)P->b->cap * RESERVOIR_BYTES + PDMP3_POOL_SLACK_BYTES + 64);
+  if (!wb || !id || !pool) goto done;
+  if (k > 0) {                                          /* wait for the pre-pass to reach this scanner's first frame */
+    pthread_mutex_lock(&P->mu);
+    while (!P->snap[k].ready && !P->prepass_done && !P->abort) pthread_cond_wait(&P->cv, &P->mu);
+    const int ready = P->snap[k].ready && !P->abort;
+    pthread_mutex_unlock(&P->mu);
+    if (!ready) { A->rc = 0; goto done; }               /* the stream ended (or went irregular) before it */
+  }
+  id->host_only = 1;
+  id->iso = P->b->id->iso;
+  id->side_to_bits = 1;
+  id->pool_sink = wb;
+  wb->id = id; wb->cap = P->b->cap; wb->bits_mode = 1; wb->pool_mode = 1; wb->win_sink = 1; wb->par = P; wb->priv_pool = pool;
+  wb->carry = P->b->carry;
+  size_t fed = 0;
+  if (k == 0) { pdmp3_open_feed(id); id->vsrc = P->mp3; id->vfed = 0; }
+  else {
+    const span_snap* S = &P->snap[k];
+    span_init(P, S, id);
+    fed = S->fed;
+    wb->frames = S->frame;
+    wb->windows = S->frame / wb->cap;
+  }
+  wb->limit_frames = k + 1 < P->K ? P->bound[k + 1] : 0;
+  {
+    size_t done;
+    int res;
+    while (!bulk_at_limit(wb) && (res = read_impl_sink(id, INBUF_SIZE, &done, wb)) != PDMP3_ERR) {
+      if (P->abort || wb->failed) break;
+      if (id->processed > fed) break;                   /* (the pre-pass will have said so) */
+      if (res == PDMP3_NEED_MORE) {
+        const size_t take = P->n - fed < 4096 ? P->n - fed : 4096;
+        if (!take) break;
+        if (take > ring_free_logical(id)) break;
+        (void)pdmp3_feed(id, P->mp3 + fed, take);
+        fed += take;
+      }
+    }
+    if (!wb->failed && !P->abort && pw_close_window(wb) == PDMP3_OK) A->rc = 0;      /* the stream's last, partly filled window */
+  }
+done:
+  if (wb && wb->pw_cur) pw_free(wb->pw_cur);
+  free(pool); free(id); free(wb);
+  pthread_mutex_lock(&P->mu);
+  if (A->rc != 0) P->abort = 1;
+  P->scanners_done++;
+  pthread_cond_broadcast(&P->cv);
+  pthread_mutex_unlock(&P->mu);
+  return NULL;
+}
+
+/* Starts the pre-pass and the scanners for `mp3`; NULL when the stream is too short to bother or frame 0 is not where
+ * a regular stream has it. */
+#define PAR_MIN_WINDOWS 4
+static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size_t n, int K, pthread_t* th, scanner_arg* args) {
+  if (K < 1 || n < 4096 || (mp3[0] != 0xff) || (mp3[1] & 0xf0) != 0xf0) return NULL;
+  frame_header H;
+  header_fields(be32(mp3), &H);
+  if (H.id != 1 || H.bitrate_index == 0 || H.bitrate_index == 15 || H.sfreq == 3 || H.layer != 3) return NULL;
+  const unsigned fb0 = frame_bytes(&H);
+  const long long est = (long long)(n / fb0), est_windows = (est + b->cap - 1) / b->cap;
+  if (est_windows < PAR_MIN_WINDOWS) return NULL;
+  if (K > 8) K = 8;
+  if (K > est_windows) K = (int)est_windows;
+  struct par_scan* P = (struct par_scan*)calloc(1, sizeof *P);
+  if (!P) return NULL;
+  P->b = b; P->mp3 = mp3; P->n = n; P->K = K;
+  const long long per = (est_windows + K - 1) / K;      /* windows per scanner, by the first frame's size (VBR: a guess) */
+  for (int k = 0; k <= K; k++) P->bound[k] = (long long)k * per * b->cap;
+  P->rec_cap = (long long)(n / 96) + 8;                 /* (no Layer III frame is shorter than 96 bytes) */
+  P->rec = (hop_rec*)malloc((size_t)P->rec_cap * sizeof(hop_rec));
+  P->win_cap = P->rec_cap / b->cap + 2;
+  P->win = (pre_window**)calloc((size_t)P->win_cap, sizeof(pre_window*));
+  if (!P->rec || !P->win) { free(P->rec); free(P->win); free(P); return NULL; }
+  pthread_mutex_init(&P->mu, NULL); pthread_cond_init(&P->cv, NULL);
+  int started = 0;
+  if (pthread_create(&th[0], NULL, par_prepass_thread, P) == 0) started = 1;
+  for (int k = 0; started && k < K; k++) {
+    args[k].P = P; args[k].k = k; args[k].rc = -1;
+    if (pthread_create(&th[1 + k], NULL, par_scanner, &args[k]) != 0) {
+      pthread_mutex_lock(&P->mu); P->abort = 1; P->K = k; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
+      break;
+    }
+  }
+  if (!started) { pthread_mutex_destroy(&P->mu); pthread_cond_destroy(&P->cv); free(P->rec); free(P->win); free(P); return NULL; }
+  return P;
+}
+/* joins the threads and frees everything; returns the pre-pass's verdict: 0 = the stream was regular and complete */
+static int par_finish(struct par_scan* P, pthread_t* th) {
+  pthread_join(th[0], NULL);
+  for (int k = 0; k < P->K; k++) pthread_join(th[1 + k], NULL);
+  const int ok = !P->irregular && !P->abort;
+  for (long long w = 0; w < P->win_cap; w++) pw_free(P->win[w]);
+  for (int k = 0; k < 8; k++) free(P->snap[k].sky);
+  pthread_mutex_destroy(&P->mu); pthread_cond_destroy(&P->cv);
+  free(P->rec); free(P->win); free(P);
+  return ok ? 0 : -1;
+}
+/* next finished window in stream order, or NULL: the stream is complete (*end = 1) or the scan was given up (*end = -1) */
+static pre_window* par_next_window(struct par_scan* P, long long w, int* end) {
+  pre_window* pw = NULL;
+  *end = 0;
+  pthread_mutex_lock(&P->mu);
+  for (;;) {
+    if (P->abort || (P->prepass_done && P->irregular)) { *end = -1; break; }
+    if (w < P->win_cap && P->win[w]) { pw = P->win[w]; P->win[w] = NULL; break; }
+    if (P->prepass_done && w >= (P->n_frames + P->b->cap - 1) / P->b->cap) { *end = 1; break; }
+    if (P->scanners_done == P->K && P->prepass_done) { *end = -1; break; }      /* (a window is missing: should not happen) */
+    pthread_cond_wait(&P->cv, &P->mu);
+  }
+  pthread_mutex_unlock(&P->mu);
+  return pw;
+}
+
+/* The whole-stream decoder's stage A on several threads.  Returns the PCM byte count like bulk_drive, or -3: the stream is
+ * not one the split scan takes (nothing has been changed), or -4: it was given up half way (windows of the stream's start
+ * may have gone to the engine: the caller drains the pipeline and decodes the stream again the sequential way -- same
+ * PCM for the frames both saw, so nothing wrong is ever left in the caller's buffer). */
+#define PAR_NOT_TAKEN (-3)
+#define PAR_GIVEN_UP (-4)
+static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, int K) {
+  pthread_t th[9];
+  scanner_arg args[8];
+  struct par_scan* P = par_start(b, mp3, n, K, th, args);
+  if (!P) return PAR_NOT_TAKEN;
+  long long total = 0, frames = 0;
+  int end = 0, engine_ok = 1;
+  for (long long w = 0;; w++) {
+    pre_window* pw = par_next_window(P, w, &end);
+    if (!pw) break;
+    if (engine_ok && bits_open_window(b) == PDMP3_OK) {
+      memcpy(b->bits_dst, pw->bits, (size_t)pw->n * sizeof(pdmp3_frame_bits));
+      memcpy(b->desc_dst, pw->desc, (size_t)pw->n * sizeof(pdmp3_row_desc));
+      memcpy(b->gath_cur, pw->gath, (size_t)pw->gath_n * sizeof(struct pool_copy));
+      memcpy(b->flight[b->bits_slot].nch, pw->nch, (size_t)pw->n);
+      b->bits_n = pw->n; b->pool_tail = pw->pool_tail; b->gath_n = pw->gath_n;
+      b->slot_arena[b->bits_slot] = pw->arena; pw->arena = NULL;       /* (the copy list points into it until the submitter is through) */
+      for (int i = 0; i < pw->n; i++) total += 2304 * pw->nch[i];
+      frames += pw->n;
+      b->frames = frames;
+      if (bits_close_window(b) != PDMP3_OK) engine_ok = 0;
+    } else engine_ok = 0;
+    pw_free(pw);
+    if (!engine_ok) { pthread_mutex_lock(&P->mu); P->abort = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu); break; }
+  }
+  const double t_pre = P->t_prepass;
+  const long long nf = P->n_frames;
+  uint32_t last_hw = 0;
+  if (end == 1 && nf > 0) last_hw = be32(mp3 + P->rec[nf - 1].x);
+  const int ok = par_finish(P, th) == 0 && end == 1 && engine_ok && frames == nf;
+  if (!engine_ok) { b->failed = 1; return -1; }
+  if (!ok) return PAR_GIVEN_UP;
+  if (nf > 0) { header_fields(last_hw, &b->id->hdr); b->id->l_hdr = b->id->hdr; }
+  if (getenv("PDMP3_BULK_TRACE")) fprintf(stderr, "bulk trace: split scan, %d scanners, %lld frames, pre-pass %.2f ms\n", K, nf, t_pre * 1e3);
+  return total;
+}
+
+/* Host tests (no engine): the split scan's windows of a stream, in order, as one byte string -- per window n, the copy
+ * list's length, the pool's fill, the side-info records, the row descriptors, the channel counts and the copy list (an
+ * entry whose source is the stream as its offset, one whose source is the window's arena as its bytes).  K = 1 is the
+ * unchanged stage-A code on one scanner from frame 0; K > 1 must give the same string.  Returns its length, -3 / -4 like
+ * par_drive, -1 when `out` is too small. */
+long long pdmp3_amd_test_split_scan(const unsigned char* mp3, size_t n, int window_frames, int K, unsigned iso,
+                                    unsigned char* out, size_t out_cap, long long* frames) {
+  pthread_once(&g_lut_once, build_luts);
+  struct bulk* b = (struct bulk*)calloc(1, sizeof *b);
+  if (!b) return -1;
+  b->cap = window_frames > 0 ? window_frames : 2048;
+  b->id = (pdmp3_handle*)calloc(1, sizeof *b->id);
+  if (!b->id) { free(b); return -1; }
+  b->id->iso = iso;
+  pthread_t th[9];
+  scanner_arg args[8];
+  struct par_scan* P = par_start(b, mp3, n, K, th, args);
+  if (!P) { free(b->id); free(b); return PAR_NOT_TAKEN; }
+  size_t o = 0;
+  int end = 0, fit = 1;
+  long long nf = 0;
+#define PUT(ptr, len) do { if (o + (len) <= out_cap) memcpy(out + o, (ptr), (len)); else fit = 0; o += (len); } while (0)
+  for (long long w = 0;; w++) {
+    pre_window* pw = par_next_window(P, w, &end);
+    if (!pw) break;
+    const int32_t hd[2] = {pw->n, pw->gath_n};
+    const uint64_t pt = pw->pool_tail;
+    PUT(hd, sizeof hd); PUT(&pt, sizeof pt);
+    PUT(pw->bits, (size_t)pw->n * sizeof(pdmp3_frame_bits)); PUT(pw->desc, (size_t)pw->n * sizeof(pdmp3_row_desc)); PUT(pw->nch, (size_t)pw->n);
+    const struct pool_copy* g = (const struct pool_copy*)pw->gath;
+    for (int i = 0; i < pw->gath_n; i++) {
+      const int lit = !(g[i].src >= mp3 && g[i].src < mp3 + n);
+      const uint32_t e[3] = {(uint32_t)lit, g[i].dst, g[i].n};
+      PUT(e, sizeof e);
+      if (lit) PUT(g[i].src, g[i].n);
+      else { const uint64_t off = (uint64_t)(g[i].src - mp3); PUT(&off, sizeof off); }
+    }
+    nf += pw->n;
+    pw_free(pw);
+  }
+#undef PUT
+  const long long pf = P->n_frames;
+  const int ok = par_finish(P, th) == 0 && end == 1 && nf == pf;
+  free(b->id); free(b);
+  if (frames) *frames = nf;
+  if (!ok) return PAR_GIVEN_UP;
+  return fit ? (long long)o : -1;
+}
+
 void pdmp3_amd_bulk_delete(struct bulk* b) {
   if (!b) return;
   if (b->th) {
@@ -1911,9 +2477,15 @@ void pdmp3_amd_bulk_delete(struct bulk* b) {
     pthread_mutex_unlock(&b->sub_mu);
     pthread_join(b->sub_th, NULL);
     pthread_mutex_destroy(&b->sub_mu); pthread_cond_destroy(&b->sub_cv); pthread_cond_destroy(&b->sub_done_cv);
+    pthread_mutex_lock(&b->gh_mu);
+    b->gh_quit = 1;
+    pthread_cond_broadcast(&b->gh_cv);
+    pthread_mutex_unlock(&b->gh_mu);
+    for (int i = 0; i < b->gh_n; i++) pthread_join(b->gh_th[i], NULL);
+    pthread_mutex_destroy(&b->gh_mu); pthread_cond_destroy(&b->gh_cv); pthread_cond_destroy(&b->gh_done_cv);
   }
   for (int i = 0; i < 2; i++) { free(b->win[i].jobs); free(b->win[i].outs); }
-  for (int i = 0; i < BULK_SLOTS; i++) { free(b->flight[i].nch); free(b->gath[i]); }
+  for (int i = 0; i < BULK_SLOTS; i++) { free(b->flight[i].nch); free(b->gath[i]); free(b->slot_arena[i]); }
   if (b->hs) pdmp3_hip_stream_destroy(b->hs);
   free(b->id);
   free(b);
@@ -1948,11 +2520,24 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
     threads = c > 64 ? 64 : c;
     if (bits_mode && threads > 4) threads = 4;   /* the pool only copies PCM out */
   }
-  if (window_frames <= 0) window_frames = 2048;
+  /* frames per GPU batch.  Bits mode: 4096 -- k_unpack is bound by the length of one lane's chain, not by throughput, and
+   * two of its workgroups fit a CU: a window of 4096 frames costs little more than one of 2048 (72 -> ~78 us), larger ones
+   * make the first window late (measured: 2048 / 4096 / 8192 frames = 13.8 / 18.5 / 16.5 M frames/s end to end) */
+  if (window_frames <= 0) window_frames = bits_mode ? 4096 : 2048;
   if (window_frames > 32768) window_frames = 32768;
   struct bulk* b = (struct bulk*)calloc(1, sizeof *b);
   if (!b) return NULL;
   b->cap = window_frames;
+  {
+    /* split scan (par_drive): 8 scanners where the process has 16 CPUs (they live for the few milliseconds of a stream's
+     * scan), fewer on smaller quotas, none below 6 CPUs; PDMP3_BULK_SCAN_THREADS = 0 .. 8 overrides (0: one thread, as before) */
+    const int c = usable_cpus();
+    const char* e = getenv("PDMP3_BULK_SCAN_THREADS");
+    b->scan_threads = e ? atoi(e) : (c >= 16 ? 8 : c >= 12 ? 4 : c >= 6 ? 2 : 0);
+    b->scan_forced = e != NULL;
+    if (b->scan_threads < 0) b->scan_threads = 0;
+    if (b->scan_threads > 8) b->scan_threads = 8;
+  }
   b->bits_mode = bits_mode;
   b->id = (pdmp3_handle*)calloc(1, sizeof *b->id);
   if (!b->id) { free(b); return NULL; }
@@ -1972,7 +2557,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
     }
     for (int i = 0; i < BULK_SLOTS; i++) {
       b->flight[i].nch = (uint8_t*)malloc((size_t)b->cap);
-      b->gath[i] = (struct pool_copy*)malloc(((size_t)b->cap + 1) * sizeof(struct pool_copy));
+      b->gath[i] = (struct pool_copy*)malloc(((size_t)b->cap + BULK_GATH_EXTRA) * sizeof(struct pool_copy));
       if (!b->flight[i].nch || !b->gath[i]) { pdmp3_amd_bulk_delete(b); return NULL; }
     }
     if (bits_mode) {
@@ -1981,6 +2566,14 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
       pthread_mutex_init(&b->sub_mu, NULL); pthread_cond_init(&b->sub_cv, NULL); pthread_cond_init(&b->sub_done_cv, NULL);
       if (pthread_create(&b->sub_th, NULL, bulk_submitter, b) != 0) { pdmp3_amd_bulk_delete(b); return NULL; }
       b->sub_started = 1;
+      pthread_mutex_init(&b->gh_mu, NULL); pthread_cond_init(&b->gh_cv, NULL); pthread_cond_init(&b->gh_done_cv, NULL);
+      {
+        const char* ge = getenv("PDMP3_BULK_GATHER_THREADS");      /* helpers of the submitter's main-data copy (0 .. 4) */
+        int want = ge ? atoi(ge) : (b->scan_threads > 0 ? 3 : 0);
+        if (want > 4) want = 4;
+        for (b->gh_n = 0; b->gh_n < want; b->gh_n++)
+          if (pthread_create(&b->gh_th[b->gh_n], NULL, gather_helper, b) != 0) break;
+      }
     }
   }
   pthread_mutex_init(&b->mu, NULL); pthread_cond_init(&b->cv_work, NULL); pthread_cond_init(&b->cv_done, NULL);
@@ -2067,9 +2660,24 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
    * streams follow each other through the pipeline without a stop.  Host Huffman: the pipeline is idle here. */
   if (!b->bits_mode && !b->carry && pdmp3_hip_stream_reset(b->hs) != PDMP3_HIP_OK) return -1;
   b->pcm = pcm; b->pcm_cap = pcm_cap;
-  b->pcm_pinned = pcm_cap && pdmp3_hip_host_is_pinned(pcm, pcm_cap);
+  b->pcm_pinned = pcm_cap ? pdmp3_hip_host_is_pinned(pcm, pcm_cap) : 0;      /* 1 pinned host memory, 2 device memory */
   const double t_in = now_s();
-  const long long total = bulk_drive(b, mp3, n);
+  long long total = PAR_NOT_TAKEN;
+  /* The split scan pays where the scan is the bound: with the PCM left in device memory (13 -> 18 M frames/s).  Towards host
+   * memory the PCIe link bounds the pipeline and the extra threads only take memory bandwidth from the DMA engines
+   * (measured: pinned 10.4 -> 8.3 M frames/s, pageable 9.1 -> 7.9 M) -- there the one-thread scan stays, unless
+   * PDMP3_BULK_SCAN_THREADS asks for the split explicitly. */
+  if (b->bits_mode && b->pool_mode && !b->carry && b->scan_threads > 0 && (b->pcm_pinned == 2 || b->scan_forced)) {
+    total = par_drive(b, mp3, n, b->scan_threads);
+    if (total == PAR_GIVEN_UP) {
+      /* not a stream the split scan can take after all (something irregular further in): what has gone to the engine
+       * is let through, then the stream is decoded again from its first frame by the one-thread scanner */
+      (void)bulk_drain(b);
+      bulk_begin(b);
+      b->pcm = pcm; b->pcm_cap = pcm_cap;
+    }
+  }
+  if (total == PAR_NOT_TAKEN || total == PAR_GIVEN_UP) total = bulk_drive(b, mp3, n);
   const double t_driven = now_s();
   b->t_drive += t_driven - t_in;
   int ok = !b->failed;

@@ -466,3 +466,49 @@ def test_compact_upload_equals_snapshot_rows(streams, monkeypatch):
     finally:
         a.close()
         s.close()
+
+
+@pytest.mark.parametrize("scanners,window", [(4, 16), (3, 7), (8, 64)])
+def test_split_scan_decodes_what_the_one_thread_scan_decodes(streams, monkeypatch, scanners, window):
+    """pdmp3_host.c par_drive (round 4): pre-pass + scanner threads + stitch in window order, forced on for host
+    destinations too (by default it is taken for device destinations only).  Regular streams go the split way, irregular
+    ones (resync, tags, truncation) are turned down before or half way -- then the windows that have gone up are let
+    through and the stream is decoded again by the one-thread scan: either way the PCM is the one-thread decoder's, bit
+    for bit, and a decoder is reusable after both"""
+    from pdmp3_amd import api
+    from test_split_scan import _regular_streams
+    allst = dict(streams)
+    allst.update(_regular_streams())
+    monkeypatch.setenv("PDMP3_BULK_SCAN_THREADS", "0")
+    ref = api.BulkDecoder(threads=2, window_frames=window)
+    monkeypatch.setenv("PDMP3_BULK_SCAN_THREADS", str(scanners))
+    par = api.BulkDecoder(threads=2, window_frames=window)
+    monkeypatch.delenv("PDMP3_BULK_SCAN_THREADS")
+    try:
+        for name, mp3 in allst.items():
+            want = ref.decode(mp3)
+            got = par.decode(mp3)
+            assert got.shape == want.shape and np.array_equal(got, want), name
+    finally:
+        ref.close()
+        par.close()
+
+
+def test_split_scan_is_the_default_for_device_destinations(monkeypatch):
+    import torch
+    from pdmp3_amd import api
+    mp3 = packer.generate(n_frames=30000, seed=0xD5, sfreq=0, mode=1, mode_ext=2, bitrate_index=14)
+    total, frames = api.scan_buffer(mp3)
+    monkeypatch.setenv("PDMP3_BULK_SCAN_THREADS", "0")
+    ref = api.BulkDecoder(threads=2)
+    monkeypatch.delenv("PDMP3_BULK_SCAN_THREADS")
+    dev = api.BulkDecoder(threads=2)
+    try:
+        want = ref.decode(mp3)
+        out = torch.zeros(total // 2, dtype=torch.int16, device="cuda:0")
+        dev.decode_into_device(mp3, out)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+    finally:
+        ref.close()
+        dev.close()

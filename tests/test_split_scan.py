@@ -1,0 +1,102 @@
+"""The whole-stream decoder's split scan (pdmp3_host.c par_drive; round 4): a pre-pass that hops from header to header,
+K scanner threads that start at window boundaries from the state the pre-pass leaves there, a stitch in stream order.
+The scanners run the unchanged stage-A code, so ONE scanner from frame 0 (K = 1) is the sequential scanner with private
+windows; what has to hold is that K = 2, 3, 4, 8 give the same windows byte for byte -- side-info records (the fields
+the reference leaves stale, H20, included), row descriptors, copy lists, the segments' images of the reservoir buffer
+(the bytes beyond the reservoir's fill included: corrupt main data reads them) -- and that every stream the pre-pass
+does not recognise as regular is turned down (the decoder then takes it the one-thread way).  No GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pdmp3_amd.packer import packer
+from tests.test_bulk_host import _streams as _host_streams
+
+NOT_TAKEN, GIVEN_UP = -3, -4
+
+
+def split_scan(mp3, window, k, iso=0):
+    from pdmp3_amd import api
+    lib = api.load_library()
+    f = lib.pdmp3_amd_test_split_scan
+    f.restype = C.c_longlong
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_longlong)]
+    a = np.frombuffer(mp3, dtype=np.uint8) if len(mp3) else np.zeros(1, np.uint8)
+    out = np.zeros(len(mp3) * 3 + (1 << 20), dtype=np.uint8)
+    frames = C.c_longlong(0)
+    n = f(a.ctypes.data_as(C.c_void_p), len(mp3), window, k, iso, out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(frames))
+    return (n, frames.value, out[:max(n, 0)].tobytes())
+
+
+def _regular_streams():
+    s = {
+        "cbr_320": packer.generate(n_frames=700, seed=0x51, sfreq=0, mode=1, mode_ext=2, bitrate_index=14),
+        "vbr_mixed_blocks": packer.generate(n_frames=600, seed=0x52, sfreq=1, mode=0, vbr=True, vbr_lo=3, vbr_hi=14,
+                                            block_pct=(30, 15, 40, 15), mixed_pct=50),
+        "mono_crc_320": packer.generate(n_frames=500, seed=0x53, sfreq=2, mode=3, bitrate_index=9, crc=True,
+                                        block_pct=(20, 10, 60, 10)),
+        "long_blocks_only": packer.generate(n_frames=400, seed=0x54, bitrate_index=11, block_pct=(100, 0, 0, 0)),      # subblock_gain never set (H20: stale = 0)
+        "short_blocks_only": packer.generate(n_frames=400, seed=0x55, bitrate_index=11, block_pct=(0, 0, 100, 0)),    # table_select[2] never set
+        "no_reservoir": packer.generate(n_frames=400, seed=0x56, bitrate_index=9, reservoir=False),
+        "stereo_mono_stereo": (packer.generate(n_frames=150, seed=0x57, bitrate_index=9) +
+                               packer.generate(n_frames=170, seed=0x58, mode=3, bitrate_index=7) +
+                               packer.generate(n_frames=160, seed=0x59, mode=1, mode_ext=2, bitrate_index=11, block_pct=(10, 10, 70, 10))),
+    }
+    # corrupt MAIN DATA only (headers and side info intact up to main_data_begin): the pre-pass sees a regular stream, the
+    # scanners' windows must still agree -- part2_3_length overruns read the reservoir buffer's stale bytes
+    rs = np.random.RandomState(11)
+    body = bytearray(packer.generate(n_frames=500, seed=0x5A, bitrate_index=12, block_pct=(40, 10, 40, 10)))
+    pos = 0
+    while pos + 1045 < len(body):
+        for _ in range(3):
+            k = pos + 40 + int(rs.randint(0, 900))
+            body[k] ^= 1 << int(rs.randint(0, 8))
+        pos += 1044 + (1 if body[pos + 2] & 2 else 0)
+    s["main_data_flipped"] = bytes(body)
+    return s
+
+
+@pytest.fixture(scope="module")
+def regular():
+    return _regular_streams()
+
+
+@pytest.mark.parametrize("window", [16, 37, 64])
+def test_k_scanners_give_the_one_scanners_windows(regular, window):
+    from pdmp3_amd import api
+    for name, mp3 in regular.items():
+        n1, f1, blob1 = split_scan(mp3, window, 1)
+        _, frames = api.scan_buffer(mp3)
+        if name == "main_data_flipped" and n1 in (NOT_TAKEN, GIVEN_UP):
+            continue                                      # (a flip landed in a header after all: turned down, fine)
+        assert n1 > 0 and f1 == frames, (name, n1, f1, frames)
+        for k in (2, 3, 4, 8):
+            nk, fk, blobk = split_scan(mp3, window, k)
+            assert (nk, fk) == (n1, f1), (name, window, k)
+            assert blobk == blob1, (name, window, k)
+
+
+def test_iso_switches_reach_every_scanner(regular):
+    mp3 = regular["vbr_mixed_blocks"]
+    a = split_scan(mp3, 32, 1, iso=0x1f)
+    assert a[0] > 0 and a[2] != split_scan(mp3, 32, 1)[2]
+    assert split_scan(mp3, 32, 4, iso=0x1f) == a
+
+
+def test_irregular_streams_are_turned_down():
+    """resync in the middle, a leading tag, truncation inside a frame, an underflowing reservoir, too short a stream: the
+    split scan says no (before or after it has started), the decoder then scans on one thread"""
+    hs = _host_streams()
+    body = packer.generate(n_frames=400, seed=0x5B, bitrate_index=9)
+    cases = {
+        "junk_resync": body[:80000] + b"\x00" * 333 + body[80000:],
+        "long_tag": bytes(2000) + body,
+        "cut_mid_frame": body[:100000] + body[100400:],
+        "underflow": body[417 * 200:],                      # starts where main_data_begin > 0: the first frames underflow (H9)
+        "tiny": hs["tiny"], "empty": hs["empty"], "clip": hs["clip"],
+    }
+    for name, mp3 in cases.items():
+        for k in (1, 3):
+            n, _, _ = split_scan(mp3, 16, k)
+            assert n in (NOT_TAKEN, GIVEN_UP), (name, k, n)

@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=${TMPDIR:-/tmp}/pdmp3_sanitize
 mkdir -p $OUT
 for san in thread address,undefined; do
-  for t in stream_threads bulk_threads; do
+  for t in stream_threads bulk_threads split_scan; do
     gcc -O1 -g -fsanitize=$san -I$ROOT/include -I$ROOT/pdmp3_amd/csrc -o $OUT/$t $ROOT/tools/sanitize/$t.c $ROOT/pdmp3_amd/host/pdmp3_host.c \
         -L$ROOT/pdmp3_amd -lpdmp3_hip -lpthread -Wl,-rpath,$ROOT/pdmp3_amd -w     # (warnings off, errors shown: a failed build stops the script with its message)
     echo "== $san $t"
