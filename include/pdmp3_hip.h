@@ -368,6 +368,9 @@ int pdmp3_hip_stream_submit_pool_to(pdmp3_hip_stream* hs, int slot, int n_frames
 int pdmp3_hip_stream_fetch_records(pdmp3_hip_stream* hs, int slot, int n_frames, int16_t* spectra, pdmp3_gc_side* side);
 /* block until the slot's PCM is in its pinned buffer (no-op if nothing is in flight) */
 int pdmp3_hip_stream_wait(pdmp3_hip_stream* hs, int slot);
+/* 1: the wait above would return at once (nothing in flight on the slot, or the GPU is through with it), 0: not yet,
+ * < 0: bad argument.  Never blocks. */
+int pdmp3_hip_stream_done(pdmp3_hip_stream* hs, int slot);
 
 /* Host-side twin of the generator (fills host buffers); used to build
  * identical inputs for the CPU baseline without a device round trip. */

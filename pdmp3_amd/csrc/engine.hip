@@ -1020,6 +1020,18 @@ extern "C" int pdmp3_hip_stream_wait(pdmp3_hip_stream* hs, int slot) {
   return PDMP3_HIP_OK;
 }
 
+// 1: pdmp3_hip_stream_wait(hs, slot) would return at once (nothing submitted, or the GPU is through with it); 0: not yet.
+// For the thread that would call the wait (the whole-stream decoder asks how much the GPU still has to do before it
+// decides how many frames the next window gets).
+extern "C" int pdmp3_hip_stream_done(pdmp3_hip_stream* hs, int slot) {
+  if (!SLOT_OK(hs, slot)) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_done: bad argument", hipSuccess);
+  StreamSlot& t = hs->s[slot];
+  if (!t.busy) return 1;
+  const hipError_t e = t.direct == 2 ? hipStreamQuery(t.stream) : hipEventQuery(t.done);
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  return 1;                                     // (done, or an error the wait will report)
+}
+
 // Undo the slot's latest pdmp3_hip_stream_submit beyond its first keep_frames frames: the carried synthesis state
 // becomes what it was after frame keep_frames - 1 of that batch (the state before the batch, then the kept frames
 // again -- their records are still in the slot's device buffers).  Blocks until done.

@@ -1309,6 +1309,7 @@ int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) 
 /* ------------------------------------------------------------------------ */
 #define BULK_SLOTS 6
 #define BULK_GATH_EXTRA 16             /* copy-list entries beyond one per frame: segment images of a split scan's windows */
+#define PAR_MAX_BATCH 64               /* private windows of a split scan that go into one window of the engine, at most */
 #include <time.h>
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 #define PDMP3_BULK_REPLAY (-2)         /* see bulk_drive */
@@ -1344,8 +1345,11 @@ typedef struct {                      /* a window that is on the GPU */
  * in private memory.  The bytes the scanner itself puts into the pool (a segment's image of the reservoir buffer) are
  * kept in `arena` and entered in the copy list like the main data the submitter gathers from the stream. */
 #define PW_ARENA_BYTES (24u << 10)
+struct par_cache;
 typedef struct pre_window {
   long long index;                    /* window number within the stream */
+  int cap;                            /* frames its arrays hold */
+  struct par_cache* home;             /* where it goes when the stitcher is through with it (NULL: freed) */
   int n, gath_n;
   size_t pool_tail;
   pdmp3_frame_bits* bits;
@@ -1354,6 +1358,7 @@ typedef struct pre_window {
   void* gath;                         /* struct pool_copy[] */
   uint8_t* arena;
   size_t arena_len;
+  double t_take, t_begin, t_done;     /* trace: taken by a scanner, its snapshot there, pushed */
 } pre_window;
 struct par_scan;
 
@@ -1419,6 +1424,7 @@ struct bulk {
   /* split scan (par_scan below): a scanner that fills private windows (struct pre_window) instead of engine slots */
   int scan_threads;                   /* scanners of the split scan (0: stage A on the calling thread alone) */
   int scan_forced;                    /* PDMP3_BULK_SCAN_THREADS was given: split whatever the destination */
+  long long stream_win;               /* windows of the CURRENT stream closed so far (the first ones are short: win_frames) */
   /* the submitter's helpers: a window's main data (1 KB per frame, out of the caller's stream into the slot's pinned pool)
    * is copied by several threads at once -- on one thread it is 9 ms of an hour of audio, which is what bounds the
    * pipeline once the scan is split */
@@ -1429,9 +1435,12 @@ struct bulk {
   int win_sink;
   struct pre_window* pw_cur;
   struct par_scan* par;               /* where finished windows go */
+  struct par_cache* pc;               /* the split scan's memory, kept from stream to stream */
   long long limit_frames;             /* stop parsing when `frames` reaches this (0: no limit) */
+  double tr_take, tr_begin;           /* trace stamps for the window being scanned */
   uint8_t* priv_pool;                 /* win_sink: this scanner's pool of the window it is filling */
-  void* slot_arena[BULK_SLOTS];       /* the literal bytes (segment images) a slot's copy list points into, from a pre_window */
+  void* slot_arena[BULK_SLOTS][PAR_MAX_BATCH];   /* the literal bytes (segment images) a slot's copy list points into, from its pre_windows */
+  int slot_arena_n[BULK_SLOTS];
   double t_submit, t_gpuwait, t_poolwait;   /* PDMP3_BULK_TRACE=1: where the scanning thread waits */
   double t_sub_gather, t_sub_call, t_drive, t_subwait, t_tail;          /* ... and what the submitter thread spends on the main-data copies / the engine calls */
 };
@@ -1741,7 +1750,16 @@ static int sub_drain(struct bulk* b) {            /* every enqueued window has b
 /* make the slot of window `windows` writable: its previous occupant (window - BULK_SLOTS) must be off the GPU; its PCM
  * goes home on the worker pool while stage A fills the slot's input side */
 static int bulk_at_limit(const struct bulk* b) { return b->limit_frames && b->frames >= b->limit_frames; }
-static pre_window* pw_new(int cap, long long index);
+/* A stream's first windows are short -- cap / 8, cap / 8, cap / 4, cap / 2, then cap frames each: the GPU has something to
+ * do after an eighth of a window's scan instead of a whole one (0.33 ms of a 7 ms decode at 4096 frames, twice that at
+ * 8192), and the four together are exactly one full window, so every later window starts where it would have.  Device
+ * Huffman with the compact upload only, and only for windows large enough to notice. */
+static int win_ramp(const struct bulk* b) { return b->bits_mode && b->pool_mode && !b->win_sink && b->cap >= 1024 && b->cap % 8 == 0; }
+static int win_frames(const struct bulk* b, long long w) {
+  if (!win_ramp(b) || w >= 4) return b->cap;
+  return w < 2 ? b->cap / 8 : w == 2 ? b->cap / 4 : b->cap / 2;
+}
+static pre_window* pw_new_in(struct par_cache* pc, int cap, long long index);
 static void pw_free(pre_window* w);
 /* bytes the scanner itself puts into the window's pool (a segment's image of the reservoir buffer, a frame's own image):
  * straight into the pool, and for a split scan's private window also into its arena and its copy list */
@@ -1762,7 +1780,7 @@ static int bits_open_window(struct bulk* b) {
   b->pool_tail = 0; b->need_segment = 1; b->seg_first = 0; b->cur_explicit = 0; b->cur_staged = 0; b->sky_n = 0;
   b->gath_n = 0;
   if (b->win_sink) {                              /* split scan: a private window */
-    b->pw_cur = pw_new(b->cap, b->windows);
+    b->pw_cur = pw_new_in(b->pc, b->cap, b->stream_win);
     if (!b->pw_cur) return PDMP3_ERR;
     b->bits_dst = b->pw_cur->bits; b->desc_dst = b->pw_cur->desc;
     b->gath_cur = (struct pool_copy*)b->pw_cur->gath;
@@ -1791,7 +1809,8 @@ static int bits_open_window(struct bulk* b) {
   }
   if (bulk_collect(b, b->bits_slot, &src, &dst, &nbytes) != PDMP3_OK) return PDMP3_ERR;
   if (nbytes) bulk_start_b(b, NULL, src, dst, nbytes);
-  free(b->slot_arena[b->bits_slot]); b->slot_arena[b->bits_slot] = NULL;   /* (its window was gathered long ago) */
+  for (int i = 0; i < b->slot_arena_n[b->bits_slot]; i++) free(b->slot_arena[b->bits_slot][i]);       /* (its window was gathered long ago) */
+  b->slot_arena_n[b->bits_slot] = 0;
   b->bits_dst = pdmp3_hip_stream_slot_bits(b->hs, b->bits_slot);
   b->res_dst = pdmp3_hip_stream_slot_reservoir(b->hs, b->bits_slot);
   if (b->pool_mode) {
@@ -1902,6 +1921,7 @@ static int bits_close_window(struct bulk* b) {
     f->active = 1;
   }
   b->windows++;
+  b->stream_win++;
   return PDMP3_OK;
 }
 
@@ -1941,7 +1961,7 @@ static int bits_push(struct bulk* b) {
   } else memcpy(b->res_dst + (size_t)i * RESERVOIR_BYTES, id->main_vec, RESERVOIR_BYTES);
   if (b->hs) b->flight[b->bits_slot].nch[i] = (uint8_t)(id->hdr.mode == 3 ? 1 : 2);
   if (b->win_sink) b->pw_cur->nch[i] = (uint8_t)(id->hdr.mode == 3 ? 1 : 2);
-  const int full = b->bits_n == b->cap || (b->pool_mode && b->pool_tail + POOL_ROOM > b->pool_cap);
+  const int full = b->bits_n >= win_frames(b, b->stream_win) || (b->pool_mode && b->pool_tail + POOL_ROOM > b->pool_cap);
   if (b->win_sink && full && pw_close_window(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
   if (b->win_sink) return PDMP3_OK;
   if (b->hs && full && bits_close_window(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
@@ -2018,7 +2038,45 @@ static long long bulk_drive(struct bulk* b, const unsigned char* mp3, size_t n) 
 /* stream go the one-thread way from the start: results are the sequential      */
 /* scanner's by construction, bit for bit (tests compare).                      */
 /* ------------------------------------------------------------------------ */
-typedef struct {
+typedef struct {              /* what a frame's header and side info say by themselves (hop_parse) */
+  uint32_t x;
+  uint16_t fb, begin, top;    /* frame bytes, main_data_begin, begin + main-data bytes */
+  uint8_t nch, crc;
+  uint8_t ws;                 /* win_switch_flag of granule-channel g = gr * 2 + ch in bit g */
+  uint8_t pad;
+} hop1;
+/* The pre-pass is itself a chain -- where a header is follows from the one before -- but only from a known header on:
+ * HOP threads start at guessed places (the stream cut into equal parts), look for a header there that three more
+ * headers follow, and hop from it; the pre-pass proper walks the first part itself and from there on reads the hop
+ * threads' records instead of the stream (4 ns a frame instead of 27).  A guess is right when the part before it lands
+ * exactly on it; one that is not (a header-like pattern inside main data that chains three times) makes the stream go
+ * the one-thread way, as everything else the pre-pass does not like does. */
+enum { SEG_RUNNING = 0, SEG_AT_NEXT, SEG_AT_END, SEG_BAD };
+typedef struct pre_seg {
+  struct par_scan* P; int j;
+  size_t guess;
+  hop1* rec; long long cap;
+  long long count;            /* records written (atomic, release) */
+  int state;                  /* SEG_* (atomic, release; final once not SEG_RUNNING) */
+  long long x_start;          /* where its first header is: -2 not known yet, -1 none found (atomic) */
+  double t_sync, t_done;      /* trace */
+} pre_seg;
+#define PAR_MAX_SCANNERS 16
+#define PAR_MAX_SEGS 8
+#define PAR_AHEAD 64
+/* What the split scan allocates per stream is tens of megabytes in blocks large enough for malloc to map and unmap each
+ * time: every page of them faults in again on every stream, in threads that share one address space (3 ms of a 6 ms
+ * decode on a 256-core host).  The decoder keeps them instead: the records of the pre-pass, each scanner's scratch, the
+ * private windows (as many as can be in flight). */
+struct hop_rec_s;
+typedef struct par_cache {
+  pthread_mutex_t mu;
+  struct hop_rec_s* rec; long long rec_cap;
+  hop1* seg_rec[PAR_MAX_SEGS]; long long seg_cap[PAR_MAX_SEGS];
+  struct { struct bulk* wb; pdmp3_handle* id; uint8_t* pool; size_t pool_bytes; } scan[PAR_MAX_SCANNERS];
+  pre_window* spare[2 * PAR_AHEAD]; int n_spare;
+} par_cache;
+typedef struct hop_rec_s {
   uint32_t x;                 /* offset of the frame's header in the stream */
   uint32_t md_src;            /* offset of its main data */
   uint64_t md_end;            /* main-data bytes of the stream up to and including this frame */
@@ -2041,33 +2099,82 @@ struct par_scan {
   struct bulk* b;
   const unsigned char* mp3; size_t n;
   int K;
-  long long bound[9];         /* scanner k takes frames [bound[k], bound[k+1]) (the last one: to the end of the stream) */
-  span_snap snap[8];
+  /* Scanners take WINDOWS in turn (a shared counter): window w is scanned from the snapshot the pre-pass leaves at its
+   * first frame.  (Contiguous spans per scanner starve the GPU while the first scanner works through its span alone: one
+   * scanner produces windows at half the rate the GPU takes them.  Window by window, w is ready at
+   * w x [pre-pass time per window] + [scan time of one window], always ahead of the GPU's w x 157 us.) */
+  int sub;                    /* frames of a private window (the engine's windows are made of several: par_drive) */
+  long long next_win;         /* the next window nobody has taken yet */
+  long long stitched;         /* windows the stitcher has taken */
+  span_snap* snap; long long snap_cap;   /* by window index; [0] unused (a fresh handle) */
   hop_rec* rec; long long rec_cap;
   long long n_frames;         /* valid once prepass_done */
   int prepass_done, irregular, abort;
+  int quit;                   /* the stitcher has left: nobody wants further windows (not an error) */
   pre_window** win; long long win_cap;    /* finished windows by stream index */
   int scanners_done;
   pthread_mutex_t mu; pthread_cond_t cv;
-  double t_prepass;
+  double t_prepass, t_pre_part0, t_pre_wait, t0;
+  int J;                      /* parts of the pre-pass: [0] is the pre-pass thread's own, the others have a hop thread each */
+  pre_seg seg[PAR_MAX_SEGS];
+  pthread_t th_pre, th_hop[PAR_MAX_SEGS], th_scan[PAR_MAX_SCANNERS];
+  struct scanner_arg* args;
 };
 
-static pre_window* pw_new(int cap, long long index) {
-  pre_window* w = (pre_window*)calloc(1, sizeof *w);
+static void pw_destroy(pre_window* w) {
+  if (!w) return;
+  free(w->bits); free(w->desc); free(w->nch); free(w->gath); free(w->arena);
+  free(w);
+}
+static pre_window* pw_new_in(par_cache* pc, int cap, long long index) {
+  pre_window* w = NULL;
+  if (pc) {
+    pthread_mutex_lock(&pc->mu);
+    while (pc->n_spare && !w) {
+      w = pc->spare[--pc->n_spare];
+      if (w->cap != cap) { pw_destroy(w); w = NULL; }   /* (the decoder's window size has changed) */
+    }
+    pthread_mutex_unlock(&pc->mu);
+  }
+  if (w) {
+    w->index = index; w->n = w->gath_n = 0; w->pool_tail = 0; w->arena_len = 0;
+    if (!w->arena && !(w->arena = (uint8_t*)malloc(PW_ARENA_BYTES))) { pw_destroy(w); return NULL; }    /* (it went with a slot) */
+    return w;
+  }
+  w = (pre_window*)calloc(1, sizeof *w);
   if (!w) return NULL;
-  w->index = index;
+  w->index = index; w->cap = cap; w->home = pc;
   w->bits = (pdmp3_frame_bits*)malloc((size_t)cap * sizeof(pdmp3_frame_bits));
   w->desc = (pdmp3_row_desc*)malloc((size_t)cap * sizeof(pdmp3_row_desc));
   w->nch = (uint8_t*)malloc((size_t)cap);
   w->gath = malloc(((size_t)cap + BULK_GATH_EXTRA) * sizeof(struct pool_copy));
   w->arena = (uint8_t*)malloc(PW_ARENA_BYTES);
-  if (!w->bits || !w->desc || !w->nch || !w->gath || !w->arena) { pw_free(w); return NULL; }
+  if (!w->bits || !w->desc || !w->nch || !w->gath || !w->arena) { pw_destroy(w); return NULL; }
   return w;
 }
 static void pw_free(pre_window* w) {
   if (!w) return;
-  free(w->bits); free(w->desc); free(w->nch); free(w->gath); free(w->arena);
-  free(w);
+  par_cache* pc = w->home;
+  if (pc) {
+    pthread_mutex_lock(&pc->mu);
+    if (pc->n_spare < (int)(sizeof pc->spare / sizeof pc->spare[0])) { pc->spare[pc->n_spare++] = w; w = NULL; }
+    pthread_mutex_unlock(&pc->mu);
+  }
+  pw_destroy(w);
+}
+static par_cache* pc_new(void) {
+  par_cache* pc = (par_cache*)calloc(1, sizeof *pc);
+  if (pc) pthread_mutex_init(&pc->mu, NULL);
+  return pc;
+}
+static void pc_free(par_cache* pc) {
+  if (!pc) return;
+  for (int i = 0; i < pc->n_spare; i++) pw_destroy(pc->spare[i]);
+  for (int j = 0; j < PAR_MAX_SEGS; j++) free(pc->seg_rec[j]);
+  for (int k = 0; k < PAR_MAX_SCANNERS; k++) { free(pc->scan[k].wb); free(pc->scan[k].id); free(pc->scan[k].pool); }
+  free(pc->rec);
+  pthread_mutex_destroy(&pc->mu);
+  free(pc);
 }
 /* the private window is complete: the reservoir buffer is brought up to date for the next one (as bits_close_window
  * does) and the window goes to whoever stitches the stream together */
@@ -2079,6 +2186,7 @@ static int pw_close_window(struct bulk* b) {
   b->pw_cur = NULL;
   if (!b->bits_n) { pw_free(w); return PDMP3_OK; }
   w->n = b->bits_n; w->gath_n = b->gath_n; w->pool_tail = b->pool_tail;
+  w->t_take = b->tr_take; w->t_begin = b->tr_begin; w->t_done = now_s();
   struct par_scan* P = b->par;
   pthread_mutex_lock(&P->mu);
   if (w->index < P->win_cap && !P->win[w->index]) { P->win[w->index] = w; w = NULL; }
@@ -2086,6 +2194,7 @@ static int pw_close_window(struct bulk* b) {
   pthread_mutex_unlock(&P->mu);
   if (w) { pw_free(w); return PDMP3_ERR; }          /* (cannot happen: more windows than the stream has bytes for) */
   b->windows++;
+  b->stream_win++;
   return PDMP3_OK;
 }
 
@@ -2095,6 +2204,91 @@ static void header_fields(uint32_t h, frame_header* H) {
   H->mode = (h >> 6) & 3; H->mode_ext = (h >> 4) & 3;
 }
 static inline uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+/* A frame's own fields at offset x (at least 40 bytes of stream from there); -1: not a frame the regular path takes */
+static int hop_parse(const unsigned char* mp3, size_t x, hop1* r) {
+  const uint32_t hw = be32(mp3 + x);
+  if ((hw & 0xfff00000u) != 0xfff00000u) return -1;     /* the scanner would search for the next sync */
+  frame_header H;
+  header_fields(hw, &H);
+  if (H.id != 1 || H.bitrate_index == 0 || H.bitrate_index == 15 || H.sfreq == 3 || H.layer != 3) return -1;
+  const unsigned nch = H.mode == 3 ? 1 : 2, nbytes = nch == 1 ? 17 : 32, crc = H.protection == 0 ? 2 : 0;
+  const unsigned fb = frame_bytes(&H);
+  if (fb > 2000) return -1;
+  const unsigned char* v = mp3 + x + 4 + crc;
+  const unsigned begin = ((unsigned)v[0] << 1) | (v[1] >> 7);
+  const unsigned size = fb - nbytes - 4 - crc;
+  if (begin + size > RESERVOIR_BYTES) return -1;        /* (overflow of the reservoir buffer) */
+  unsigned ws = 0;
+  for (unsigned gr = 0; gr < 2; gr++)                   /* which frame last set the fields the reference leaves stale (H20) */
+    for (unsigned ch = 0; ch < nch; ch++) {
+      const unsigned pos = (nch == 1 ? 18u : 20u) + 59u * (gr * nch + ch) + 33u;
+      ws |= ((v[pos >> 3] >> (7 - (pos & 7))) & 1u) << (gr * 2 + ch);
+    }
+  r->x = (uint32_t)x; r->fb = (uint16_t)fb; r->begin = (uint16_t)begin; r->top = (uint16_t)(begin + size);
+  r->nch = (uint8_t)nch; r->crc = (uint8_t)crc; r->ws = (uint8_t)ws; r->pad = 0;
+  return 0;
+}
+/* this is a chain of dependent cache misses -- where the next header is follows from this one -- unless the lines are
+ * asked for ahead of time: frames of a constant-bitrate stream are as long as each other to within the padding byte, so
+ * the header and side info of the 12th frame from here lie within 12 bytes of x + 12 fb (two lines cover them); on a
+ * variable-bitrate stream the guess is wrong and costs nothing */
+static inline void hop_prefetch(const unsigned char* mp3, size_t x, unsigned fb) {
+  __builtin_prefetch(mp3 + x + 12u * fb, 0, 3);
+  __builtin_prefetch(mp3 + x + 12u * fb + 64, 0, 3);
+}
+#define HOP_END_BYTES 1152u   /* the CLI's loop stops asking once fewer bytes than this are left (H10) */
+static long long seg_wait_start(pre_seg* S) {           /* (found within microseconds of the thread's start) */
+  long long v;
+  while ((v = __atomic_load_n(&S->x_start, __ATOMIC_ACQUIRE)) == -2) {
+    if (S->P->abort) return -1;
+    sched_yield();
+  }
+  return v;
+}
+static void* par_hop_thread(void* arg) {
+  pre_seg* S = (pre_seg*)arg;
+  struct par_scan* P = S->P;
+  const unsigned char* mp3 = P->mp3;
+  const size_t n = P->n;
+  /* a header like the stream's first (MPEG-1 Layer III, same sampling rate) that three more follow */
+  const uint32_t like = be32(mp3) & 0xfffe0c00u;
+  long long found = -1;
+  const size_t stop = S->guess + 65536 < n ? S->guess + 65536 : n;
+  for (size_t x = S->guess; x < stop && x + 4u * 2000u + 64u <= n; x++) {
+    if (mp3[x] != 0xff || (be32(mp3 + x) & 0xfffe0c00u) != like) continue;
+    size_t y = x;
+    int ok = 1;
+    for (int k = 0; k < 4 && ok; k++) {
+      hop1 r;
+      if ((be32(mp3 + y) & 0xfffe0c00u) != like || hop_parse(mp3, y, &r) != 0) ok = 0;
+      else y += r.fb;
+    }
+    if (ok) { found = (long long)x; break; }
+  }
+  __atomic_store_n(&S->x_start, found, __ATOMIC_RELEASE);
+  S->t_sync = now_s() - P->t0;
+  int state = SEG_BAD;
+  if (found >= 0) {
+    long long next_start = -3;                          /* (-3: the last part) */
+    if (S->j + 1 < P->J) next_start = seg_wait_start(&P->seg[S->j + 1]);
+    size_t x = (size_t)found;
+    long long c = 0;
+    for (;;) {
+      if (next_start == -1 || P->abort) break;          /* (the next part has no start: given up) */
+      if (next_start >= 0 && x >= (size_t)next_start) { state = x == (size_t)next_start ? SEG_AT_NEXT : SEG_BAD; break; }
+      if (n - x < HOP_END_BYTES) { state = SEG_AT_END; break; }
+      if (c >= S->cap || hop_parse(mp3, x, &S->rec[c]) != 0) break;
+      hop_prefetch(mp3, x, S->rec[c].fb);
+      x += S->rec[c].fb;
+      c++;
+      __atomic_store_n(&S->count, c, __ATOMIC_RELEASE);
+    }
+  }
+  S->t_done = now_s() - P->t0;
+  __atomic_store_n(&S->state, state, __ATOMIC_RELEASE);
+  return NULL;
+}
 
 /* The pre-pass.  Returns 0 when the whole stream is regular (P->n_frames frames), -1 otherwise. */
 static int par_prepass(struct par_scan* P) {
@@ -2110,9 +2304,13 @@ static int par_prepass(struct par_scan* P) {
   uint64_t md_end = 0;
   int sky_n = 0, next = 1, rc = -1;
   long long f = 0, ws0[4] = {-1, -1, -1, -1}, ws1[4] = {-1, -1, -1, -1};
+  int part = 0;                                         /* whose records: 0 = none, the stream itself */
+  long long part_i = 0;
+  long long part_end = P->J > 1 ? seg_wait_start(&P->seg[1]) : -3;     /* where part 0 ends */
+  if (part_end == -1) goto out;
   for (;;) {
     if (P->abort) goto out;
-    if (next < P->K && f == P->bound[next]) {           /* a scanner starts here */
+    if (next < P->snap_cap && f == (long long)next * P->sub) {        /* window `next` starts here */
       span_snap* S = &P->snap[next];
       S->frame = f; S->istart = h->istart; S->iend = h->iend; S->processed = h->processed; S->vfed = h->vfed; S->fed = fed;
       S->main_top = main_top; S->sky_n = sky_n;
@@ -2126,7 +2324,7 @@ static int par_prepass(struct par_scan* P) {
       pthread_mutex_unlock(&P->mu);
       next++;
     }
-    while (ring_filled(h) < 1152) {                     /* H10 + the CLI's feeds (bulk_drive) */
+    while (ring_filled(h) < HOP_END_BYTES) {            /* H10 + the CLI's feeds (bulk_drive) */
       const size_t take = n - fed < 4096 ? n - fed : 4096;
       if (!take) { rc = 0; goto out; }                  /* the stream ends here: what is left is dropped, as the CLI drops it */
       if (take > ring_free_logical(h)) goto out;        /* a feed the CLI would drop (H16) */
@@ -2135,37 +2333,43 @@ static int par_prepass(struct par_scan* P) {
     }
     const size_t x = h->vfed - ring_filled(h);
     const unsigned avail = ring_filled(h);
-    const uint32_t hw = be32(mp3 + x);
-    if ((hw & 0xfff00000u) != 0xfff00000u) goto out;    /* the scanner would search for the next sync */
-    frame_header H;
-    header_fields(hw, &H);
-    if (H.id != 1 || H.bitrate_index == 0 || H.bitrate_index == 15 || H.sfreq == 3 || H.layer != 3) goto out;
-    const unsigned nch = H.mode == 3 ? 1 : 2, nbytes = nch == 1 ? 17 : 32, crc = H.protection == 0 ? 2 : 0;
-    const unsigned fb = frame_bytes(&H);
-    if (fb > 2000 || fb > avail) goto out;              /* (a frame the ring does not hold completely: H18) */
-    /* this loop is a chain of dependent cache misses -- where the next header is follows from this one -- unless the lines
-     * are asked for ahead of time: frames of a constant-bitrate stream are as long as each other to within the padding
-     * byte, so the header and side info of the 12th frame from here lie within 12 bytes of x + 12 fb (two lines cover
-     * them); on a variable-bitrate stream the guess is wrong and costs nothing */
-    __builtin_prefetch(mp3 + x + 12u * fb, 0, 3);
-    __builtin_prefetch(mp3 + x + 12u * fb + 64, 0, 3);
-    const unsigned char* v = mp3 + x + 4 + crc;
-    const unsigned begin = ((unsigned)v[0] << 1) | (v[1] >> 7);
-    const unsigned size = fb - nbytes - 4 - crc;
-    if (!(begin <= main_top && begin + size <= RESERVOIR_BYTES)) goto out;      /* reservoir underflow (H9) / overflow */
+    hop1 own;
+    const hop1* q = &own;
+    if (part == 0 && part_end >= 0 && x >= (size_t)part_end) {         /* part 0 is through: the hop threads' records from here */
+      if (x != (size_t)part_end) goto out;              /* (the guess was not a frame boundary) */
+      part = 1; part_i = 0;
+      P->t_pre_part0 = now_s() - P->t0;
+    }
+    if (part == 0) {
+      if (hop_parse(mp3, x, &own) != 0) goto out;
+      hop_prefetch(mp3, x, own.fb);
+    } else {
+      for (;;) {
+        pre_seg* G = &P->seg[part];
+        if (part_i < __atomic_load_n(&G->count, __ATOMIC_ACQUIRE)) { q = &G->rec[part_i++]; break; }
+        const int st = __atomic_load_n(&G->state, __ATOMIC_ACQUIRE);
+        if (st == SEG_RUNNING) { if (P->abort) goto out; const double tw = now_s(); sched_yield(); P->t_pre_wait += now_s() - tw; continue; }
+        if (part_i < __atomic_load_n(&G->count, __ATOMIC_ACQUIRE)) continue;   /* (its last records came with the state) */
+        if (st != SEG_AT_NEXT || part + 1 >= P->J) goto out;           /* a header the regular path does not take, or a guess that was none */
+        part++; part_i = 0;
+      }
+      if (q->x != x) goto out;
+    }
+    const unsigned nch = q->nch, nbytes = nch == 1 ? 17 : 32, crc = q->crc, fb = q->fb, begin = q->begin, top = q->top;
+    if (fb > avail) goto out;                           /* (a frame the ring does not hold completely: H18) */
+    if (begin > main_top) goto out;                     /* reservoir underflow (H9) */
     if (f >= P->rec_cap) goto out;
     hop_rec* r = &P->rec[f];
-    md_end += size;
+    md_end += top - begin;
     r->x = (uint32_t)x; r->md_src = (uint32_t)(x + 4 + crc + nbytes); r->md_end = md_end;
-    r->fb = (uint16_t)fb; r->begin = (uint16_t)begin; r->top = (uint16_t)(begin + size); r->nch = (uint8_t)nch; r->crc = (uint8_t)crc;
-    main_top = begin + size;
+    r->fb = (uint16_t)fb; r->begin = (uint16_t)begin; r->top = (uint16_t)top; r->nch = (uint8_t)nch; r->crc = (uint8_t)crc;
+    main_top = top;
     while (sky_n && P->rec[sky[sky_n - 1]].top <= main_top) sky_n--;
     sky[sky_n++] = (int)f;
-    for (unsigned gr = 0; gr < 2; gr++)                 /* which frame last set the fields the reference leaves stale (H20) */
-      for (unsigned ch = 0; ch < nch; ch++) {
-        const unsigned pos = (nch == 1 ? 18u : 20u) + 59u * (gr * nch + ch) + 33u;
-        if ((v[pos >> 3] >> (7 - (pos & 7))) & 1) ws1[gr * 2 + ch] = f; else ws0[gr * 2 + ch] = f;
-      }
+    for (unsigned g = 0; g < 4; g++) {
+      if ((g & 1) >= nch) continue;
+      if ((q->ws >> g) & 1) ws1[g] = f; else ws0[g] = f;
+    }
     h->istart = (h->istart + fb) % INBUF_SIZE;
     h->processed += fb;
     h->l_istart = h->istart; h->l_processed = h->processed;
@@ -2244,44 +2448,64 @@ static void span_init(const struct par_scan* P, const span_snap* S, pdmp3_handle
   }
 }
 
-typedef struct { struct par_scan* P; int k; int rc; } scanner_arg;
+typedef struct scanner_arg { struct par_scan* P; int k; int rc; } scanner_arg;
 static void* par_scanner(void* arg) {
   scanner_arg* A = (scanner_arg*)arg;
   struct par_scan* P = A->P;
-  const int k = A->k;
   A->rc = -1;
-  struct bulk* wb = (struct bulk*)calloc(1, sizeof *wb);
-  pdmp3_handle* id = (pdmp3_handle*)calloc(1, sizeof *id);
-  uint8_t* pool = (uint8_t*)malloc((size_t)P->b->cap * RESERVOIR_BYTES + PDMP3_POOL_SLACK_BYTES + 64);
+  par_cache* pc = P->b->pc;                             /* (scanner k's scratch is its own: no lock) */
+  const size_t pool_bytes = (size_t)P->sub * RESERVOIR_BYTES + PDMP3_POOL_SLACK_BYTES + 64;
+  if (!pc->scan[A->k].wb) pc->scan[A->k].wb = (struct bulk*)calloc(1, sizeof(struct bulk));
+  if (!pc->scan[A->k].id) pc->scan[A->k].id = (pdmp3_handle*)malloc(sizeof(pdmp3_handle));
+  if (pc->scan[A->k].pool_bytes < pool_bytes) {
+    free(pc->scan[A->k].pool);
+    pc->scan[A->k].pool = (uint8_t*)malloc(pool_bytes);
+    pc->scan[A->k].pool_bytes = pc->scan[A->k].pool ? pool_bytes : 0;
+  }
+  struct bulk* wb = pc->scan[A->k].wb;
+  pdmp3_handle* id = pc->scan[A->k].id;
+  uint8_t* pool = pc->scan[A->k].pool;
   if (!wb || !id || !pool) goto done;
-  if (k > 0) {                                          /* wait for the pre-pass to reach this scanner's first frame */
+  const int whole = P->K == 1;                          /* one scanner: the sequential stage A, from frame 0 to the end */
+  for (;;) {
     pthread_mutex_lock(&P->mu);
-    while (!P->snap[k].ready && !P->prepass_done && !P->abort) pthread_cond_wait(&P->cv, &P->mu);
-    const int ready = P->snap[k].ready && !P->abort;
+    const long long w = P->next_win++;
+    const double t_take = now_s();
+    /* (not further than PAR_AHEAD windows in front of the stitcher: finished windows are memory) */
+    int ready = 0;
+    while (!P->abort && !P->quit) {
+      const int known = w == 0 || (w < P->snap_cap && P->snap[w].ready);
+      if (!known && (P->prepass_done || w >= P->snap_cap)) break;      /* the stream ended (or went irregular) before this window */
+      if (known && w < P->stitched + PAR_AHEAD) { ready = 1; break; }
+      pthread_cond_wait(&P->cv, &P->mu);
+    }
+    const int stop = P->abort;
     pthread_mutex_unlock(&P->mu);
-    if (!ready) { A->rc = 0; goto done; }               /* the stream ended (or went irregular) before it */
-  }
-  id->host_only = 1;
-  id->iso = P->b->id->iso;
-  id->side_to_bits = 1;
-  id->pool_sink = wb;
-  wb->id = id; wb->cap = P->b->cap; wb->bits_mode = 1; wb->pool_mode = 1; wb->win_sink = 1; wb->par = P; wb->priv_pool = pool;
-  wb->carry = P->b->carry;
-  size_t fed = 0;
-  if (k == 0) { pdmp3_open_feed(id); id->vsrc = P->mp3; id->vfed = 0; }
-  else {
-    const span_snap* S = &P->snap[k];
-    span_init(P, S, id);
-    fed = S->fed;
-    wb->frames = S->frame;
-    wb->windows = S->frame / wb->cap;
-  }
-  wb->limit_frames = k + 1 < P->K ? P->bound[k + 1] : 0;
-  {
+    if (stop) break;
+    if (!ready || (whole && w > 0)) { A->rc = 0; break; }
+    memset(id, 0, sizeof *id);
+    memset(wb, 0, sizeof *wb);
+    id->host_only = 1;
+    id->iso = P->b->id->iso;
+    id->side_to_bits = 1;
+    id->pool_sink = wb;
+    wb->id = id; wb->cap = P->sub; wb->bits_mode = 1; wb->pool_mode = 1; wb->win_sink = 1; wb->par = P; wb->pc = pc; wb->priv_pool = pool;
+    wb->carry = P->b->carry;
+    wb->stream_win = w;
+    size_t fed = 0;
+    if (w == 0) { pdmp3_open_feed(id); id->vsrc = P->mp3; id->vfed = 0; }
+    else {
+      const span_snap* S = &P->snap[w];
+      span_init(P, S, id);
+      fed = S->fed;
+      wb->frames = S->frame;
+    }
+    wb->limit_frames = whole ? 0 : (w + 1) * P->sub;
+    wb->tr_take = t_take; wb->tr_begin = now_s();
     size_t done;
     int res;
     while (!bulk_at_limit(wb) && (res = read_impl_sink(id, INBUF_SIZE, &done, wb)) != PDMP3_ERR) {
-      if (P->abort || wb->failed) break;
+      if (P->abort || P->quit || wb->failed) break;
       if (id->processed > fed) break;                   /* (the pre-pass will have said so) */
       if (res == PDMP3_NEED_MORE) {
         const size_t take = P->n - fed < 4096 ? P->n - fed : 4096;
@@ -2291,11 +2515,12 @@ static void* par_scanner(void* arg) {
         fed += take;
       }
     }
-    if (!wb->failed && !P->abort && pw_close_window(wb) == PDMP3_OK) A->rc = 0;      /* the stream's last, partly filled window */
+    if (wb->failed || P->abort) break;
+    if (P->quit) { A->rc = 0; break; }
+    if (pw_close_window(wb) != PDMP3_OK) break;         /* (the window, full or -- the stream's last -- partly filled) */
   }
 done:
-  if (wb && wb->pw_cur) pw_free(wb->pw_cur);
-  free(pool); free(id); free(wb);
+  if (wb && wb->pw_cur) { pw_free(wb->pw_cur); wb->pw_cur = NULL; }
   pthread_mutex_lock(&P->mu);
   if (A->rc != 0) P->abort = 1;
   P->scanners_done++;
@@ -2304,109 +2529,247 @@ done:
   return NULL;
 }
 
-/* Starts the pre-pass and the scanners for `mp3`; NULL when the stream is too short to bother or frame 0 is not where
- * a regular stream has it. */
+/* Starts the hop threads, the pre-pass and the scanners for `mp3`; NULL when the stream is too short to bother or frame 0 is
+ * not where a regular stream has it. */
 #define PAR_MIN_WINDOWS 4
-static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size_t n, int K, pthread_t* th, scanner_arg* args) {
-  if (K < 1 || n < 4096 || (mp3[0] != 0xff) || (mp3[1] & 0xf0) != 0xf0) return NULL;
+#define PAR_MIN_PART_BYTES (1u << 20)
+static void par_free(struct par_scan* P) {          /* (the records and the hop threads' arrays are the cache's) */
+  if (P->snap) for (long long w = 0; w < P->snap_cap; w++) free(P->snap[w].sky);
+  free(P->win); free(P->snap); free(P->args); free(P);
+}
+static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size_t n, int K, int sub) {
+  if (K < 1 || n < 4096 || n > 0xfff00000u || (mp3[0] != 0xff) || (mp3[1] & 0xf0) != 0xf0) return NULL;
   frame_header H;
   header_fields(be32(mp3), &H);
   if (H.id != 1 || H.bitrate_index == 0 || H.bitrate_index == 15 || H.sfreq == 3 || H.layer != 3) return NULL;
   const unsigned fb0 = frame_bytes(&H);
-  const long long est = (long long)(n / fb0), est_windows = (est + b->cap - 1) / b->cap;
+  if (sub < 1 || sub > b->cap) return NULL;
+  const long long est = (long long)(n / fb0), est_windows = (est + sub - 1) / sub;
   if (est_windows < PAR_MIN_WINDOWS) return NULL;
-  if (K > 8) K = 8;
+  if (K > PAR_MAX_SCANNERS) K = PAR_MAX_SCANNERS;
   if (K > est_windows) K = (int)est_windows;
+  /* parts of the pre-pass: $PDMP3_BULK_PREPASS_THREADS, else by the host's cores; none shorter than a megabyte */
+  const long cores = sysconf(_SC_NPROCESSORS_ONLN);
+  int J = cores >= 32 ? 6 : cores >= 12 ? 3 : 1;
+  const char* ev = getenv("PDMP3_BULK_PREPASS_THREADS");
+  size_t min_part = PAR_MIN_PART_BYTES;
+  if (ev && atoi(ev) >= 1) { J = atoi(ev); min_part = 16384; }   /* (forced: tests split short streams) */
+  if (K == 1) J = 1;                                    /* (one scanner: the sequential stage A, nothing to hurry for) */
+  if (J > PAR_MAX_SEGS) J = PAR_MAX_SEGS;
+  while (J > 1 && n / (size_t)J < min_part) J--;
   struct par_scan* P = (struct par_scan*)calloc(1, sizeof *P);
   if (!P) return NULL;
-  P->b = b; P->mp3 = mp3; P->n = n; P->K = K;
-  const long long per = (est_windows + K - 1) / K;      /* windows per scanner, by the first frame's size (VBR: a guess) */
-  for (int k = 0; k <= K; k++) P->bound[k] = (long long)k * per * b->cap;
+  P->b = b; P->mp3 = mp3; P->n = n; P->K = K; P->J = J; P->sub = sub; P->t0 = now_s();
+  if (!b->pc && !(b->pc = pc_new())) { free(P); return NULL; }
+  par_cache* pc = b->pc;
   P->rec_cap = (long long)(n / 96) + 8;                 /* (no Layer III frame is shorter than 96 bytes) */
-  P->rec = (hop_rec*)malloc((size_t)P->rec_cap * sizeof(hop_rec));
-  P->win_cap = P->rec_cap / b->cap + 2;
-  P->win = (pre_window**)calloc((size_t)P->win_cap, sizeof(pre_window*));
-  if (!P->rec || !P->win) { free(P->rec); free(P->win); free(P); return NULL; }
-  pthread_mutex_init(&P->mu, NULL); pthread_cond_init(&P->cv, NULL);
-  int started = 0;
-  if (pthread_create(&th[0], NULL, par_prepass_thread, P) == 0) started = 1;
-  for (int k = 0; started && k < K; k++) {
-    args[k].P = P; args[k].k = k; args[k].rc = -1;
-    if (pthread_create(&th[1 + k], NULL, par_scanner, &args[k]) != 0) {
-      pthread_mutex_lock(&P->mu); P->abort = 1; P->K = k; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
-      break;
-    }
+  if (pc->rec_cap < P->rec_cap) {
+    free(pc->rec);
+    pc->rec = (hop_rec*)malloc((size_t)P->rec_cap * sizeof(hop_rec));
+    pc->rec_cap = pc->rec ? P->rec_cap : 0;
   }
-  if (!started) { pthread_mutex_destroy(&P->mu); pthread_cond_destroy(&P->cv); free(P->rec); free(P->win); free(P); return NULL; }
+  P->rec = pc->rec;
+  P->win_cap = P->rec_cap / sub + 8;
+  P->win = (pre_window**)calloc((size_t)P->win_cap, sizeof(pre_window*));
+  P->snap_cap = P->win_cap;
+  P->snap = (span_snap*)calloc((size_t)P->snap_cap, sizeof(span_snap));
+  P->args = (scanner_arg*)calloc((size_t)K, sizeof(scanner_arg));
+  int ok = P->rec && P->win && P->snap && P->args;
+  for (int j = 1; ok && j < J; j++) {
+    pre_seg* S = &P->seg[j];
+    S->P = P; S->j = j; S->guess = n / (size_t)J * (size_t)j; S->x_start = -2;
+    S->cap = (long long)((n / (size_t)J + 65536 + 4096) / 96) + 8;
+    if (pc->seg_cap[j] < S->cap) {
+      free(pc->seg_rec[j]);
+      pc->seg_rec[j] = (hop1*)malloc((size_t)S->cap * sizeof(hop1));
+      pc->seg_cap[j] = pc->seg_rec[j] ? S->cap : 0;
+    }
+    S->rec = pc->seg_rec[j];
+    if (!S->rec) ok = 0;
+  }
+  if (!ok) { par_free(P); return NULL; }
+  pthread_mutex_init(&P->mu, NULL); pthread_cond_init(&P->cv, NULL);
+  /* (a thread that cannot be started: the ones that run are told to stop, joined, and the stream goes the one-thread way) */
+  int n_hop = 0, n_scan = 0, pre = 0;
+  for (int j = 1; j < J; j++) { if (pthread_create(&P->th_hop[j], NULL, par_hop_thread, &P->seg[j]) != 0) break; n_hop++; }
+  if (n_hop == J - 1 && pthread_create(&P->th_pre, NULL, par_prepass_thread, P) == 0) pre = 1;
+  for (int k = 0; pre && k < K; k++) {
+    P->args[k].P = P; P->args[k].k = k; P->args[k].rc = -1;
+    if (pthread_create(&P->th_scan[k], NULL, par_scanner, &P->args[k]) != 0) break;
+    n_scan++;
+  }
+  if (n_hop != J - 1 || !pre || n_scan != K) {
+    pthread_mutex_lock(&P->mu); P->abort = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
+    for (int j = 1; j <= n_hop; j++) pthread_join(P->th_hop[j], NULL);
+    if (pre) pthread_join(P->th_pre, NULL);
+    for (int k = 0; k < n_scan; k++) pthread_join(P->th_scan[k], NULL);
+    pthread_mutex_destroy(&P->mu); pthread_cond_destroy(&P->cv);
+    par_free(P);
+    return NULL;
+  }
   return P;
 }
 /* joins the threads and frees everything; returns the pre-pass's verdict: 0 = the stream was regular and complete */
-static int par_finish(struct par_scan* P, pthread_t* th) {
-  pthread_join(th[0], NULL);
-  for (int k = 0; k < P->K; k++) pthread_join(th[1 + k], NULL);
-  const int ok = !P->irregular && !P->abort;
+static int par_finish(struct par_scan* P) {
+  pthread_mutex_lock(&P->mu); P->quit = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
+  pthread_join(P->th_pre, NULL);
+  for (int k = 0; k < P->K; k++) pthread_join(P->th_scan[k], NULL);
+  /* (the hop threads look at abort only: they are through before the pre-pass unless it gave up early) */
+  pthread_mutex_lock(&P->mu); const int ok = !P->irregular && !P->abort; P->abort = 1; pthread_mutex_unlock(&P->mu);
+  for (int j = 1; j < P->J; j++) pthread_join(P->th_hop[j], NULL);
   for (long long w = 0; w < P->win_cap; w++) pw_free(P->win[w]);
-  for (int k = 0; k < 8; k++) free(P->snap[k].sky);
   pthread_mutex_destroy(&P->mu); pthread_cond_destroy(&P->cv);
-  free(P->rec); free(P->win); free(P);
+  par_free(P);
   return ok ? 0 : -1;
 }
 /* next finished window in stream order, or NULL: the stream is complete (*end = 1) or the scan was given up (*end = -1) */
-static pre_window* par_next_window(struct par_scan* P, long long w, int* end) {
+static pre_window* par_next_window_wait(struct par_scan* P, long long w, int* end, double wait_s) {
   pre_window* pw = NULL;
   *end = 0;
   pthread_mutex_lock(&P->mu);
   for (;;) {
     if (P->abort || (P->prepass_done && P->irregular)) { *end = -1; break; }
-    if (w < P->win_cap && P->win[w]) { pw = P->win[w]; P->win[w] = NULL; break; }
-    if (P->prepass_done && w >= (P->n_frames + P->b->cap - 1) / P->b->cap) { *end = 1; break; }
+    if (w < P->win_cap && P->win[w]) { pw = P->win[w]; P->win[w] = NULL; P->stitched = w + 1; pthread_cond_broadcast(&P->cv); break; }
+    if (P->prepass_done && w >= (P->n_frames + P->sub - 1) / P->sub) { *end = 1; break; }
     if (P->scanners_done == P->K && P->prepass_done) { *end = -1; break; }      /* (a window is missing: should not happen) */
-    pthread_cond_wait(&P->cv, &P->mu);
+    if (wait_s < 0) { pthread_cond_wait(&P->cv, &P->mu); continue; }
+    if (wait_s == 0) break;                             /* (not there yet: *end stays 0) */
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    ts.tv_nsec += (long)(wait_s * 1e9);
+    if (ts.tv_nsec >= 1000000000L) { ts.tv_sec++; ts.tv_nsec -= 1000000000L; }
+    (void)pthread_cond_timedwait(&P->cv, &P->mu, &ts);
+    wait_s = 0;                                         /* (one more look, then back to the caller) */
   }
   pthread_mutex_unlock(&P->mu);
   return pw;
+}
+static pre_window* par_next_window(struct par_scan* P, long long w, int* end) { return par_next_window_wait(P, w, end, -1.0); }
+
+static void par_trace_prepass(const struct par_scan* P) {
+  fprintf(stderr, "  pre-pass in %d parts: its own part done at %.2f ms, waited %.2f ms for hop threads, through at %.2f ms;", P->J, P->t_pre_part0 * 1e3,
+          P->t_pre_wait * 1e3, P->t_prepass * 1e3);
+  for (int j = 1; j < P->J; j++) fprintf(stderr, " hop %d: start found %.2f, done %.2f (%lld frames);", j, P->seg[j].t_sync * 1e3, P->seg[j].t_done * 1e3, P->seg[j].count);
+  fprintf(stderr, "\n");
+}
+static void pw_trace(const pre_window* pw, long long w, double t_start, double t0, double t1) {
+  fprintf(stderr, "  window %lld: %d frames, taken %.2f, snapshot there %.2f, scanned %.2f, stitcher asked %.2f, got it %.2f ms\n", w, pw->n,
+          (pw->t_take - t_start) * 1e3, (pw->t_begin - t_start) * 1e3, (pw->t_done - t_start) * 1e3, (t0 - t_start) * 1e3, (t1 - t_start) * 1e3);
+}
+
+/* windows of the engine that are still the GPU's (or the submitter's: handed over, not yet launched) */
+static int bulk_in_flight(struct bulk* b) {
+  int n = 0;
+  for (int slot = 0; slot < BULK_SLOTS; slot++) {
+    const bulk_flight* f = &b->flight[slot];
+    if (!f->active) continue;
+    pthread_mutex_lock(&b->sub_mu);
+    const int launched = b->sub_tail > f->sub_seq;
+    pthread_mutex_unlock(&b->sub_mu);
+    if (!launched || pdmp3_hip_stream_done(b->hs, slot) == 0) n++;
+  }
+  return n;
+}
+/* a private window onto the end of the engine's open window: its pool behind what is there, offsets moved accordingly */
+static int par_fits(const struct bulk* b, const pre_window* pw) {
+  return b->bits_n + pw->n <= b->cap && b->pool_tail + pw->pool_tail + POOL_ROOM <= b->pool_cap &&
+         b->gath_n + pw->gath_n <= b->cap + BULK_GATH_EXTRA * (PAR_MAX_BATCH + 1) && b->slot_arena_n[b->bits_slot] < PAR_MAX_BATCH;
+}
+static void par_append(struct bulk* b, pre_window* pw) {
+  const int at = b->bits_n;
+  const uint32_t base = (uint32_t)b->pool_tail;
+  memcpy(b->bits_dst + at, pw->bits, (size_t)pw->n * sizeof(pdmp3_frame_bits));
+  memcpy(b->flight[b->bits_slot].nch + at, pw->nch, (size_t)pw->n);
+  pdmp3_row_desc* d = b->desc_dst + at;
+  for (int i = 0; i < pw->n; i++) { d[i] = pw->desc[i]; d[i].row_off += base; d[i].s_off += base; }
+  struct pool_copy* g = b->gath_cur + b->gath_n;
+  const struct pool_copy* gs = (const struct pool_copy*)pw->gath;
+  for (int i = 0; i < pw->gath_n; i++) { g[i] = gs[i]; g[i].dst += base; }
+  b->bits_n += pw->n; b->gath_n += pw->gath_n; b->pool_tail += pw->pool_tail;
+  b->slot_arena[b->bits_slot][b->slot_arena_n[b->bits_slot]++] = pw->arena; pw->arena = NULL;   /* (the copy list points into it until the submitter is through) */
 }
 
 /* The whole-stream decoder's stage A on several threads.  Returns the PCM byte count like bulk_drive, or -3: the stream is
  * not one the split scan takes (nothing has been changed), or -4: it was given up half way (windows of the stream's start
  * may have gone to the engine: the caller drains the pipeline and decodes the stream again the sequential way -- same
- * PCM for the frames both saw, so nothing wrong is ever left in the caller's buffer). */
+ * PCM for the frames both saw, so nothing wrong is ever left in the caller's buffer).
+ *
+ * The scanners' private windows are SHORT (`sub` frames: the first is there after 0.1 ms) and the engine's windows are
+ * made of as many of them as there are when a slot is free, up to the slot's capacity: the GPU has something to do at
+ * once, and once it is busy the windows grow by themselves to the size at which the device's Huffman stage fills the
+ * chip (k_unpack: one workgroup per 16 frames, two per CU -- 8192 frames).  While two windows or more are still the
+ * GPU's, a window that is not full waits for more. */
 #define PAR_NOT_TAKEN (-3)
 #define PAR_GIVEN_UP (-4)
 static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, int K) {
-  pthread_t th[9];
-  scanner_arg args[8];
-  struct par_scan* P = par_start(b, mp3, n, K, th, args);
+  const double t_start = now_s();
+  int sub = b->cap < 1024 ? b->cap : 1024;
+  const char* se = getenv("PDMP3_BULK_SUB_FRAMES");
+  if (se && atoi(se) >= 1) sub = atoi(se) < b->cap ? atoi(se) : b->cap;
+  struct par_scan* P = par_start(b, mp3, n, K, sub);
   if (!P) return PAR_NOT_TAKEN;
-  long long total = 0, frames = 0;
-  int end = 0, engine_ok = 1;
-  for (long long w = 0;; w++) {
-    pre_window* pw = par_next_window(P, w, &end);
+  long long total = 0, frames = 0, w = 0;
+  int end = 0, engine_ok = 1, n_windows = 0;
+  double t_win = 0, t_open = 0, t_fill = 0, t_more = 0;
+  const char* tr = getenv("PDMP3_BULK_TRACE");
+  const int trace2 = tr && atoi(tr) >= 2;
+  pre_window* held = NULL;                              /* taken from the scanners, did not fit the window before */
+  for (;;) {
+    const double t0 = now_s();
+    pre_window* pw = held ? held : par_next_window(P, w, &end);
+    held = NULL;
+    const double t1 = now_s();
+    t_win += t1 - t0;
     if (!pw) break;
-    if (engine_ok && bits_open_window(b) == PDMP3_OK) {
-      memcpy(b->bits_dst, pw->bits, (size_t)pw->n * sizeof(pdmp3_frame_bits));
-      memcpy(b->desc_dst, pw->desc, (size_t)pw->n * sizeof(pdmp3_row_desc));
-      memcpy(b->gath_cur, pw->gath, (size_t)pw->gath_n * sizeof(struct pool_copy));
-      memcpy(b->flight[b->bits_slot].nch, pw->nch, (size_t)pw->n);
-      b->bits_n = pw->n; b->pool_tail = pw->pool_tail; b->gath_n = pw->gath_n;
-      b->slot_arena[b->bits_slot] = pw->arena; pw->arena = NULL;       /* (the copy list points into it until the submitter is through) */
+    if (trace2) pw_trace(pw, w, t_start, t0, t1);
+    w++;
+    const int opened = engine_ok && bits_open_window(b) == PDMP3_OK;
+    const double t2 = now_s();
+    t_open += t2 - t1;
+    if (opened && par_fits(b, pw)) {
+      par_append(b, pw);
       for (int i = 0; i < pw->n; i++) total += 2304 * pw->nch[i];
       frames += pw->n;
+      pw_free(pw);
+      const double t3 = now_s();
+      t_fill += t3 - t2;
+      while (b->bits_n < b->cap) {                      /* what else is there, or worth waiting for */
+        int e2;
+        pre_window* more = par_next_window_wait(P, w, &e2, 0);
+        if (!more && e2 == 0 && bulk_in_flight(b) >= 2) more = par_next_window_wait(P, w, &e2, 50e-6);
+        if (!more) { if (e2 == 0 && bulk_in_flight(b) >= 2) continue; break; }
+        if (trace2) pw_trace(more, w, t_start, t3, now_s());
+        w++;
+        if (!par_fits(b, more)) { held = more; break; }
+        par_append(b, more);
+        for (int i = 0; i < more->n; i++) total += 2304 * more->nch[i];
+        frames += more->n;
+        pw_free(more);
+      }
+      const double t4 = now_s();
+      t_more += t4 - t3;
       b->frames = frames;
+      if (trace2) fprintf(stderr, "  -> window of %d frames to slot %d at %.2f ms\n", b->bits_n, b->bits_slot, (t4 - t_start) * 1e3);
+      n_windows++;
       if (bits_close_window(b) != PDMP3_OK) engine_ok = 0;
-    } else engine_ok = 0;
-    pw_free(pw);
+      t_fill += now_s() - t4;
+    } else { engine_ok = 0; pw_free(pw); }
     if (!engine_ok) { pthread_mutex_lock(&P->mu); P->abort = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu); break; }
   }
+  pw_free(held);
   const double t_pre = P->t_prepass;
   const long long nf = P->n_frames;
+  if (trace2) par_trace_prepass(P);
   uint32_t last_hw = 0;
   if (end == 1 && nf > 0) last_hw = be32(mp3 + P->rec[nf - 1].x);
-  const int ok = par_finish(P, th) == 0 && end == 1 && engine_ok && frames == nf;
+  const int ok = par_finish(P) == 0 && end == 1 && engine_ok && frames == nf;
   if (!engine_ok) { b->failed = 1; return -1; }
   if (!ok) return PAR_GIVEN_UP;
   if (nf > 0) { header_fields(last_hw, &b->id->hdr); b->id->l_hdr = b->id->hdr; }
-  if (getenv("PDMP3_BULK_TRACE")) fprintf(stderr, "bulk trace: split scan, %d scanners, %lld frames, pre-pass %.2f ms\n", K, nf, t_pre * 1e3);
+  if (getenv("PDMP3_BULK_TRACE"))
+    fprintf(stderr, "bulk trace: split scan, %d scanners, %lld frames in private windows of %d, %d windows to the engine, pre-pass %.2f ms; stitch %.2f ms = "
+            "waiting for the first private window of each %.2f + for slots %.2f + for more of them %.2f + filling and closing %.2f (this stream)\n",
+            K, nf, sub, n_windows, t_pre * 1e3, (now_s() - t_start) * 1e3, t_win * 1e3, t_open * 1e3, t_more * 1e3, t_fill * 1e3);
   return total;
 }
 
@@ -2415,26 +2778,42 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
  * entry whose source is the stream as its offset, one whose source is the window's arena as its bytes).  K = 1 is the
  * unchanged stage-A code on one scanner from frame 0; K > 1 must give the same string.  Returns its length, -3 / -4 like
  * par_drive, -1 when `out` is too small. */
+/* (the hook's stand-in for a decoder lives as long as the process, as a decoder's memory does from stream to stream;
+ * one caller at a time) */
+static pthread_mutex_t g_hook_mu = PTHREAD_MUTEX_INITIALIZER;
+static struct bulk* g_hook_b;
+static struct bulk* hook_get(void) {
+  pthread_mutex_lock(&g_hook_mu);
+  if (!g_hook_b) {
+    g_hook_b = (struct bulk*)calloc(1, sizeof *g_hook_b);
+    if (g_hook_b && !(g_hook_b->id = (pdmp3_handle*)calloc(1, sizeof *g_hook_b->id))) { free(g_hook_b); g_hook_b = NULL; }
+  }
+  if (!g_hook_b) pthread_mutex_unlock(&g_hook_mu);
+  return g_hook_b;
+}
+static void hook_put(struct bulk* b) { (void)b; pthread_mutex_unlock(&g_hook_mu); }
 long long pdmp3_amd_test_split_scan(const unsigned char* mp3, size_t n, int window_frames, int K, unsigned iso,
                                     unsigned char* out, size_t out_cap, long long* frames) {
   pthread_once(&g_lut_once, build_luts);
-  struct bulk* b = (struct bulk*)calloc(1, sizeof *b);
+  struct bulk* b = hook_get();
   if (!b) return -1;
   b->cap = window_frames > 0 ? window_frames : 2048;
-  b->id = (pdmp3_handle*)calloc(1, sizeof *b->id);
-  if (!b->id) { free(b); return -1; }
+  b->bits_mode = 1; b->pool_mode = 1;             /* (what the scanners' sinks are: the window schedule depends on it) */
   b->id->iso = iso;
-  pthread_t th[9];
-  scanner_arg args[8];
-  struct par_scan* P = par_start(b, mp3, n, K, th, args);
-  if (!P) { free(b->id); free(b); return PAR_NOT_TAKEN; }
+  const double t_start = now_s();
+  struct par_scan* P = par_start(b, mp3, n, K, b->cap);
+  if (!P) { hook_put(b); return PAR_NOT_TAKEN; }
   size_t o = 0;
   int end = 0, fit = 1;
   long long nf = 0;
 #define PUT(ptr, len) do { if (o + (len) <= out_cap) memcpy(out + o, (ptr), (len)); else fit = 0; o += (len); } while (0)
+  const char* tr = getenv("PDMP3_BULK_TRACE");
+  const int trace2 = tr && atoi(tr) >= 2;
   for (long long w = 0;; w++) {
+    const double t0 = trace2 ? now_s() : 0;
     pre_window* pw = par_next_window(P, w, &end);
     if (!pw) break;
+    if (trace2) pw_trace(pw, w, t_start, t0, now_s());
     const int32_t hd[2] = {pw->n, pw->gath_n};
     const uint64_t pt = pw->pool_tail;
     PUT(hd, sizeof hd); PUT(&pt, sizeof pt);
@@ -2452,8 +2831,9 @@ long long pdmp3_amd_test_split_scan(const unsigned char* mp3, size_t n, int wind
   }
 #undef PUT
   const long long pf = P->n_frames;
-  const int ok = par_finish(P, th) == 0 && end == 1 && nf == pf;
-  free(b->id); free(b);
+  if (trace2) par_trace_prepass(P);
+  const int ok = par_finish(P) == 0 && end == 1 && nf == pf;
+  hook_put(b);
   if (frames) *frames = nf;
   if (!ok) return PAR_GIVEN_UP;
   return fit ? (long long)o : -1;
@@ -2485,8 +2865,12 @@ void pdmp3_amd_bulk_delete(struct bulk* b) {
     pthread_mutex_destroy(&b->gh_mu); pthread_cond_destroy(&b->gh_cv); pthread_cond_destroy(&b->gh_done_cv);
   }
   for (int i = 0; i < 2; i++) { free(b->win[i].jobs); free(b->win[i].outs); }
-  for (int i = 0; i < BULK_SLOTS; i++) { free(b->flight[i].nch); free(b->gath[i]); free(b->slot_arena[i]); }
+  for (int i = 0; i < BULK_SLOTS; i++) {
+    free(b->flight[i].nch); free(b->gath[i]);
+    for (int k = 0; k < b->slot_arena_n[i]; k++) free(b->slot_arena[i][k]);
+  }
   if (b->hs) pdmp3_hip_stream_destroy(b->hs);
+  pc_free(b->pc);
   free(b->id);
   free(b);
 }
@@ -2536,7 +2920,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
     b->scan_threads = e ? atoi(e) : (c >= 16 ? 8 : c >= 12 ? 4 : c >= 6 ? 2 : 0);
     b->scan_forced = e != NULL;
     if (b->scan_threads < 0) b->scan_threads = 0;
-    if (b->scan_threads > 8) b->scan_threads = 8;
+    if (b->scan_threads > PAR_MAX_SCANNERS) b->scan_threads = PAR_MAX_SCANNERS;
   }
   b->bits_mode = bits_mode;
   b->id = (pdmp3_handle*)calloc(1, sizeof *b->id);
@@ -2557,7 +2941,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
     }
     for (int i = 0; i < BULK_SLOTS; i++) {
       b->flight[i].nch = (uint8_t*)malloc((size_t)b->cap);
-      b->gath[i] = (struct pool_copy*)malloc(((size_t)b->cap + BULK_GATH_EXTRA) * sizeof(struct pool_copy));
+      b->gath[i] = (struct pool_copy*)malloc(((size_t)b->cap + BULK_GATH_EXTRA * (PAR_MAX_BATCH + 1)) * sizeof(struct pool_copy));
       if (!b->flight[i].nch || !b->gath[i]) { pdmp3_amd_bulk_delete(b); return NULL; }
     }
     if (bits_mode) {
@@ -2618,6 +3002,7 @@ static void bulk_begin(struct bulk* b) {
   b->win[b->cur].n = 0;
   b->frames = 0; b->pcm_emitted = 0; b->count_only = 0; b->failed = 0;
   b->bits_open = 0; b->bits_n = 0;            /* (a failed submit stays failed: sub_rc is sticky) */
+  b->stream_win = 0;
 }
 
 /* frames and PCM bytes pdmp3() would produce for this stream: stage A alone */

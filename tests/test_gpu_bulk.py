@@ -468,13 +468,15 @@ def test_compact_upload_equals_snapshot_rows(streams, monkeypatch):
         s.close()
 
 
-@pytest.mark.parametrize("scanners,window", [(4, 16), (3, 7), (8, 64)])
-def test_split_scan_decodes_what_the_one_thread_scan_decodes(streams, monkeypatch, scanners, window):
+@pytest.mark.parametrize("scanners,window,sub", [(4, 16, 0), (3, 7, 0), (8, 64, 0), (4, 64, 8), (8, 256, 16), (3, 100, 7)])
+def test_split_scan_decodes_what_the_one_thread_scan_decodes(streams, monkeypatch, scanners, window, sub):
     """pdmp3_host.c par_drive (round 4): pre-pass + scanner threads + stitch in window order, forced on for host
     destinations too (by default it is taken for device destinations only).  Regular streams go the split way, irregular
     ones (resync, tags, truncation) are turned down before or half way -- then the windows that have gone up are let
     through and the stream is decoded again by the one-thread scan: either way the PCM is the one-thread decoder's, bit
-    for bit, and a decoder is reusable after both"""
+    for bit, and a decoder is reusable after both.  sub > 0: the scanners' private windows have that many frames and the
+    engine's windows are made of as many as are there ($PDMP3_BULK_SUB_FRAMES; by default 1024, i.e. the whole window at
+    these sizes): windows of every length up to `window`, the private windows' pools one behind the other"""
     from pdmp3_amd import api
     from test_split_scan import _regular_streams
     allst = dict(streams)
@@ -484,6 +486,8 @@ def test_split_scan_decodes_what_the_one_thread_scan_decodes(streams, monkeypatc
     monkeypatch.setenv("PDMP3_BULK_SCAN_THREADS", str(scanners))
     par = api.BulkDecoder(threads=2, window_frames=window)
     monkeypatch.delenv("PDMP3_BULK_SCAN_THREADS")
+    if sub:
+        monkeypatch.setenv("PDMP3_BULK_SUB_FRAMES", str(sub))      # (read per stream)
     try:
         for name, mp3 in allst.items():
             want = ref.decode(mp3)

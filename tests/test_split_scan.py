@@ -29,6 +29,11 @@ def split_scan(mp3, window, k, iso=0):
     return (n, frames.value, out[:max(n, 0)].tobytes())
 
 
+def api_frames(mp3):
+    from pdmp3_amd import api
+    return api.scan_buffer(mp3)[1]
+
+
 def _regular_streams():
     s = {
         "cbr_320": packer.generate(n_frames=700, seed=0x51, sfreq=0, mode=1, mode_ext=2, bitrate_index=14),
@@ -77,6 +82,21 @@ def test_k_scanners_give_the_one_scanners_windows(regular, window):
             assert blobk == blob1, (name, window, k)
 
 
+def test_private_windows_of_1024_frames(regular):
+    """the size the whole-stream decoder uses (par_drive: the engine's windows are made of several): every private window
+    but the stream's last has exactly that many frames -- no short first windows here, those are the one-thread scan's"""
+    mp3 = packer.generate(n_frames=9000, seed=0x5C, sfreq=0, mode=1, mode_ext=2, bitrate_index=9, block_pct=(40, 10, 40, 10))
+    n1, f1, blob1 = split_scan(mp3, 1024, 1)
+    assert n1 > 0 and f1 == api_frames(mp3)
+    first = np.frombuffer(blob1[:4], dtype=np.int32)[0]
+    assert first == 1024
+    for k in (2, 4, 8):
+        assert split_scan(mp3, 1024, k) == (n1, f1, blob1), k
+    short = mp3[:417 * 4500]                              # ends inside a window
+    a = split_scan(short, 1024, 1)
+    assert a[0] > 0 and split_scan(short, 1024, 3) == a
+
+
 def test_iso_switches_reach_every_scanner(regular):
     mp3 = regular["vbr_mixed_blocks"]
     a = split_scan(mp3, 32, 1, iso=0x1f)
@@ -100,3 +120,34 @@ def test_irregular_streams_are_turned_down():
         for k in (1, 3):
             n, _, _ = split_scan(mp3, 16, k)
             assert n in (NOT_TAKEN, GIVEN_UP), (name, k, n)
+
+
+@pytest.mark.parametrize("parts", [2, 3, 6, 8])
+def test_hop_threads_give_the_one_pre_pass(regular, parts, monkeypatch):
+    """the pre-pass in `parts` parts (hop threads from guessed places, $PDMP3_BULK_PREPASS_THREADS): same windows as the
+    pre-pass that walks the whole stream itself, on constant and variable bitrate (the guesses land inside frames), with
+    a change of the channel count, with corrupt main data (header-like bytes where a guess may land)"""
+    for name, mp3 in regular.items():
+        monkeypatch.setenv("PDMP3_BULK_PREPASS_THREADS", "1")
+        one = split_scan(mp3, 37, 4)
+        monkeypatch.setenv("PDMP3_BULK_PREPASS_THREADS", str(parts))
+        got = split_scan(mp3, 37, 4)
+        if got[0] == GIVEN_UP and one[0] > 0:
+            continue                                      # (a guess that chained but was no boundary: turned down, allowed)
+        assert got == one, (name, parts)
+
+
+def test_hop_threads_turn_down_what_the_pre_pass_turns_down(monkeypatch):
+    body = packer.generate(n_frames=900, seed=0x5C, bitrate_index=9)
+    at = 0
+    for _ in range(700):                                  # the 700th header (128 kbps at 44.1 kHz: 417 bytes + the padding bit)
+        at += 417 + ((body[at + 2] >> 1) & 1)
+    assert body[at] == 0xff and body[at + 1] == 0xfb
+    cases = {"junk_resync_late": body[:300000] + b"\x00" * 333 + body[300000:],          # inside a hop thread's part
+             "cut_mid_frame_late": body[:250000] + body[250400:],
+             "bad_header_late": body[:at] + b"\xff\xfb\xf0\x00" + body[at + 4:]}   # bitrate index 15
+    for parts in (1, 3, 5):
+        monkeypatch.setenv("PDMP3_BULK_PREPASS_THREADS", str(parts))
+        for name, mp3 in cases.items():
+            n, _, _ = split_scan(mp3, 16, 3)
+            assert n in (NOT_TAKEN, GIVEN_UP), (name, parts, n)

@@ -18,9 +18,12 @@ int main(int argc, char** argv) {
   const long long na = pdmp3_amd_test_split_scan(d, (size_t)n, 64, 1, 0, a, cap, &fa);
   int bad = 0;
   for (int k = 2; k <= 8; k += 2) {
+    char parts[8];
+    snprintf(parts, sizeof parts, "%d", k == 2 ? 1 : k);                /* the pre-pass in 1, 4, 6, 8 parts (hop threads) */
+    setenv("PDMP3_BULK_PREPASS_THREADS", parts, 1);
     const long long nb = pdmp3_amd_test_split_scan(d, (size_t)n, 64, k, 0, b, cap, &fb);
     const int same = na == nb && fa == fb && (na <= 0 || !memcmp(a, b, (size_t)na));
-    printf("K %d: %lld bytes, %lld frames, %s\n", k, nb, fb, same ? "same as one scanner" : "DIFFERENT");
+    printf("K %d, pre-pass in %s: %lld bytes, %lld frames, %s\n", k, parts, nb, fb, same ? "same as one scanner" : "DIFFERENT");
     bad += !same;
   }
   return bad;
