@@ -1309,6 +1309,9 @@ int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) 
 /* ------------------------------------------------------------------------ */
 #define BULK_SLOTS 6
 #define BULK_GATH_EXTRA 16             /* copy-list entries beyond one per frame: segment images of a split scan's windows */
+#define GATHER_MAX_HELPERS 8
+#define GATHER_QUEUE 512
+#define GATHER_TASK_ENTRIES 512          /* copy-list entries per task: half a megabyte of main data */
 #define PAR_MAX_BATCH 64               /* private windows of a split scan that go into one window of the engine, at most */
 #include <time.h>
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
@@ -1364,7 +1367,9 @@ struct par_scan;
 
 struct bulk {
   pdmp3_handle* id;
-  int cap;                            /* frames per window */
+  int cap;                            /* frames a window holds */
+  int target;                         /* frames the one-thread scan gives a window (<= cap) */
+  int trace2; double tr_t0;           /* $PDMP3_BULK_TRACE >= 2: per-window lines, times from the stream's start */
   int count_only;                     /* scan: stage A alone */
   int bits_mode;                      /* main data goes to the device undecoded (pdmp3_hip_stream_submit_bits) */
   pdmp3_frame_bits* bits_dst; uint8_t* res_dst;   /* where stage A writes the current window (bits mode) */
@@ -1428,9 +1433,15 @@ struct bulk {
   /* the submitter's helpers: a window's main data (1 KB per frame, out of the caller's stream into the slot's pinned pool)
    * is copied by several threads at once -- on one thread it is 9 ms of an hour of audio, which is what bounds the
    * pipeline once the scan is split */
-  pthread_t gh_th[4];
-  int gh_n, gh_quit, gh_parts, gh_next, gh_done;
-  uint8_t* gh_pool; const void* gh_list; int gh_count;
+  /* the main-data copies of the windows (pool_gather), as tasks: helper threads take them, and so does whoever waits for
+   * a slot's copies to be complete.  The one-thread scan's windows are cut into tasks when the submitter gets them; the
+   * split scan's as its private windows are put into the slot, so that the copies are under way while the window fills. */
+  pthread_t gh_th[GATHER_MAX_HELPERS];
+  int gh_n, gh_quit;
+  struct { uint8_t* pool; const void* list; int n, slot; } gq[GATHER_QUEUE];
+  unsigned gq_head, gq_tail;          /* pushed / taken */
+  int g_out[BULK_SLOTS];              /* tasks of the slot not finished yet */
+  int g_pushed[BULK_SLOTS];           /* the open window's copies have been handed out as it was filled */
   pthread_mutex_t gh_mu; pthread_cond_t gh_cv, gh_done_cv;
   int win_sink;
   struct pre_window* pw_cur;
@@ -1659,39 +1670,47 @@ static void fill_frame_bits(const pdmp3_handle* id, pdmp3_frame_bits* fb, int ne
 static void pool_gather(uint8_t* pool, const struct pool_copy* g, int n) {
   for (int i = 0; i < n; i++) if (g[i].n) memcpy(pool + g[i].dst, g[i].src, g[i].n);
 }
-static void gather_part(uint8_t* pool, const struct pool_copy* g, int n, int part, int parts) {
-  const int lo = (int)((long long)n * part / parts), hi = (int)((long long)n * (part + 1) / parts);
-  pool_gather(pool, g + lo, hi - lo);
+/* (gh_mu held) one task off the queue and done; 0: the queue is empty */
+static int gather_take_locked(struct bulk* b) {
+  if (b->gq_tail == b->gq_head) return 0;
+  const unsigned k = b->gq_tail++ % GATHER_QUEUE;
+  uint8_t* pool = b->gq[k].pool;
+  const struct pool_copy* list = (const struct pool_copy*)b->gq[k].list;
+  const int n = b->gq[k].n, slot = b->gq[k].slot;
+  pthread_mutex_unlock(&b->gh_mu);
+  pool_gather(pool, list, n);
+  pthread_mutex_lock(&b->gh_mu);
+  if (--b->g_out[slot] == 0) pthread_cond_broadcast(&b->gh_done_cv);
+  return 1;
 }
 static void* gather_helper(void* arg) {
   struct bulk* b = (struct bulk*)arg;
   pthread_mutex_lock(&b->gh_mu);
   for (;;) {
-    while (!b->gh_quit && b->gh_next >= b->gh_parts) pthread_cond_wait(&b->gh_cv, &b->gh_mu);
+    while (!b->gh_quit && b->gq_tail == b->gq_head) pthread_cond_wait(&b->gh_cv, &b->gh_mu);
     if (b->gh_quit) break;
-    const int part = b->gh_next++, parts = b->gh_parts, n = b->gh_count;
-    uint8_t* pool = b->gh_pool;
-    const struct pool_copy* list = (const struct pool_copy*)b->gh_list;
-    pthread_mutex_unlock(&b->gh_mu);
-    gather_part(pool, list, n, part, parts);
-    pthread_mutex_lock(&b->gh_mu);
-    if (++b->gh_done == parts) pthread_cond_signal(&b->gh_done_cv);
+    (void)gather_take_locked(b);
   }
   pthread_mutex_unlock(&b->gh_mu);
   return NULL;
 }
-/* pool_gather on the submitter and its helpers */
-static void pool_gather_par(struct bulk* b, uint8_t* pool, const struct pool_copy* g, int n) {
-  if (b->gh_n == 0 || n < 512) { pool_gather(pool, g, n); return; }
+/* the copies g[0, n) of `slot`'s window as tasks (a full queue: the caller does the copy itself) */
+static void gather_push(struct bulk* b, int slot, uint8_t* pool, const struct pool_copy* g, int n) {
+  for (int lo = 0; lo < n; lo += GATHER_TASK_ENTRIES) {
+    const int k = n - lo < GATHER_TASK_ENTRIES ? n - lo : GATHER_TASK_ENTRIES;
+    pthread_mutex_lock(&b->gh_mu);
+    if (b->gq_head - b->gq_tail >= GATHER_QUEUE) { pthread_mutex_unlock(&b->gh_mu); pool_gather(pool, g + lo, k); continue; }
+    const unsigned q = b->gq_head++ % GATHER_QUEUE;
+    b->gq[q].pool = pool; b->gq[q].list = g + lo; b->gq[q].n = k; b->gq[q].slot = slot;
+    b->g_out[slot]++;
+    pthread_cond_signal(&b->gh_cv);
+    pthread_mutex_unlock(&b->gh_mu);
+  }
+}
+/* until the slot's copies are complete; takes tasks (any slot's) while it waits */
+static void gather_wait(struct bulk* b, int slot) {
   pthread_mutex_lock(&b->gh_mu);
-  b->gh_pool = pool; b->gh_list = g; b->gh_count = n;
-  b->gh_parts = b->gh_n + 1; b->gh_next = 1; b->gh_done = 0;     /* part 0 is the submitter's own */
-  pthread_cond_broadcast(&b->gh_cv);
-  pthread_mutex_unlock(&b->gh_mu);
-  gather_part(pool, g, n, 0, b->gh_n + 1);
-  pthread_mutex_lock(&b->gh_mu);
-  b->gh_done++;
-  while (b->gh_done < b->gh_parts) pthread_cond_wait(&b->gh_done_cv, &b->gh_mu);
+  while (b->g_out[slot]) if (!gather_take_locked(b)) pthread_cond_wait(&b->gh_done_cv, &b->gh_mu);
   pthread_mutex_unlock(&b->gh_mu);
 }
 static void* bulk_submitter(void* arg) {
@@ -1706,12 +1725,17 @@ static void* bulk_submitter(void* arg) {
     const int gn = b->sub_gath[b->sub_tail & 7];
     pthread_mutex_unlock(&b->sub_mu);
     const double t0 = now_s();
-    if (pool) pool_gather_par(b, pdmp3_hip_stream_slot_pool(b->hs, slot), b->gath[slot], gn);
+    if (pool) {
+      if (gn > 0) gather_push(b, slot, pdmp3_hip_stream_slot_pool(b->hs, slot), b->gath[slot], gn);   /* (gn < 0: handed out while the window was filled) */
+      gather_wait(b, slot);
+    }
     const double t1 = now_s();
     const int rc = pool ? pdmp3_hip_stream_submit_pool_to(b->hs, slot, n, pool, dst, row)
                         : pdmp3_hip_stream_submit_bits_to(b->hs, slot, n, dst, row);
     if (rc != PDMP3_HIP_OK) fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
-    b->t_sub_gather += t1 - t0; b->t_sub_call += now_s() - t1;
+    const double t2 = now_s();
+    b->t_sub_gather += t1 - t0; b->t_sub_call += t2 - t1;
+    if (b->trace2) fprintf(stderr, "  submitter: %d frames to slot %d: taken at %.2f ms, copies %.0f us, engine call %.0f us\n", n, slot, (t0 - b->tr_t0) * 1e3, (t1 - t0) * 1e6, (t2 - t1) * 1e6);
     pthread_mutex_lock(&b->sub_mu);
     if (rc != PDMP3_HIP_OK) b->sub_rc = rc;
     b->sub_tail++;
@@ -1754,10 +1778,11 @@ static int bulk_at_limit(const struct bulk* b) { return b->limit_frames && b->fr
  * do after an eighth of a window's scan instead of a whole one (0.33 ms of a 7 ms decode at 4096 frames, twice that at
  * 8192), and the four together are exactly one full window, so every later window starts where it would have.  Device
  * Huffman with the compact upload only, and only for windows large enough to notice. */
-static int win_ramp(const struct bulk* b) { return b->bits_mode && b->pool_mode && !b->win_sink && b->cap >= 1024 && b->cap % 8 == 0; }
+static int win_ramp(const struct bulk* b) { return b->bits_mode && b->pool_mode && !b->win_sink && b->target >= 1024 && b->target % 8 == 0; }
 static int win_frames(const struct bulk* b, long long w) {
-  if (!win_ramp(b) || w >= 4) return b->cap;
-  return w < 2 ? b->cap / 8 : w == 2 ? b->cap / 4 : b->cap / 2;
+  if (b->win_sink) return b->cap;                 /* (a split scan's private window) */
+  if (!win_ramp(b) || w >= 4) return b->target;
+  return w < 2 ? b->target / 8 : w == 2 ? b->target / 4 : b->target / 2;
 }
 static pre_window* pw_new_in(struct par_cache* pc, int cap, long long index);
 static void pw_free(pre_window* w);
@@ -1809,6 +1834,7 @@ static int bits_open_window(struct bulk* b) {
   }
   if (bulk_collect(b, b->bits_slot, &src, &dst, &nbytes) != PDMP3_OK) return PDMP3_ERR;
   if (nbytes) bulk_start_b(b, NULL, src, dst, nbytes);
+  b->g_pushed[b->bits_slot] = 0;
   for (int i = 0; i < b->slot_arena_n[b->bits_slot]; i++) free(b->slot_arena[b->bits_slot][i]);       /* (its window was gathered long ago) */
   b->slot_arena_n[b->bits_slot] = 0;
   b->bits_dst = pdmp3_hip_stream_slot_bits(b->hs, b->bits_slot);
@@ -1916,7 +1942,7 @@ static int bits_close_window(struct bulk* b) {
     }
     const double t0 = now_s();
     flight_plan(b, f);
-    f->sub_seq = sub_enqueue(b, b->bits_slot, b->bits_n, f->direct ? f->dst : NULL, f->all_stereo == 1 ? 2304 : 4608, b->pool_mode ? b->pool_tail : 0, b->gath_n);
+    f->sub_seq = sub_enqueue(b, b->bits_slot, b->bits_n, f->direct ? f->dst : NULL, f->all_stereo == 1 ? 2304 : 4608, b->pool_mode ? b->pool_tail : 0, b->g_pushed[b->bits_slot] ? -1 : b->gath_n);
     b->t_submit += now_s() - t0;
     f->active = 1;
   }
@@ -2366,9 +2392,13 @@ static int par_prepass(struct par_scan* P) {
     main_top = top;
     while (sky_n && P->rec[sky[sky_n - 1]].top <= main_top) sky_n--;
     sky[sky_n++] = (int)f;
-    for (unsigned g = 0; g < 4; g++) {
-      if ((g & 1) >= nch) continue;
-      if ((q->ws >> g) & 1) ws1[g] = f; else ws0[g] = f;
+    {                                                   /* (no branches on the stream's bits: they do not predict) */
+      const unsigned wsb = q->ws, live = nch == 2 ? 0xfu : 0x5u;
+      for (unsigned g = 0; g < 4; g++) {
+        const long long on = -(long long)((wsb >> g) & (live >> g) & 1u), off = -(long long)((~wsb >> g) & (live >> g) & 1u);
+        ws1[g] = (ws1[g] & ~on) | (f & on);
+        ws0[g] = (ws0[g] & ~off) | (f & off);
+      }
     }
     h->istart = (h->istart + fb) % INBUF_SIZE;
     h->processed += fb;
@@ -2531,13 +2561,13 @@ done:
 
 /* Starts the hop threads, the pre-pass and the scanners for `mp3`; NULL when the stream is too short to bother or frame 0 is
  * not where a regular stream has it. */
-#define PAR_MIN_WINDOWS 4
+#define PAR_MIN_WINDOWS 4                /* private windows (tests, a forced split scan); 8 otherwise: shorter streams are not worth fifteen threads */
 #define PAR_MIN_PART_BYTES (1u << 20)
 static void par_free(struct par_scan* P) {          /* (the records and the hop threads' arrays are the cache's) */
   if (P->snap) for (long long w = 0; w < P->snap_cap; w++) free(P->snap[w].sky);
   free(P->win); free(P->snap); free(P->args); free(P);
 }
-static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size_t n, int K, int sub) {
+static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size_t n, int K, int sub, int min_windows) {
   if (K < 1 || n < 4096 || n > 0xfff00000u || (mp3[0] != 0xff) || (mp3[1] & 0xf0) != 0xf0) return NULL;
   frame_header H;
   header_fields(be32(mp3), &H);
@@ -2545,7 +2575,7 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
   const unsigned fb0 = frame_bytes(&H);
   if (sub < 1 || sub > b->cap) return NULL;
   const long long est = (long long)(n / fb0), est_windows = (est + sub - 1) / sub;
-  if (est_windows < PAR_MIN_WINDOWS) return NULL;
+  if (est_windows < min_windows) return NULL;
   if (K > PAR_MAX_SCANNERS) K = PAR_MAX_SCANNERS;
   if (K > est_windows) K = (int)est_windows;
   /* parts of the pre-pass: $PDMP3_BULK_PREPASS_THREADS, else by the host's cores; none shorter than a megabyte */
@@ -2556,7 +2586,10 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
   if (ev && atoi(ev) >= 1) { J = atoi(ev); min_part = 16384; }   /* (forced: tests split short streams) */
   if (K == 1) J = 1;                                    /* (one scanner: the sequential stage A, nothing to hurry for) */
   if (J > PAR_MAX_SEGS) J = PAR_MAX_SEGS;
-  while (J > 1 && n / (size_t)J < min_part) J--;
+  /* part 0 -- the pre-pass thread's own, where it reads the stream itself at a third of the speed -- is short: a 24th of
+   * the stream; the hop threads share the rest equally */
+  const size_t part0 = n / 24 > min_part ? n / 24 : min_part;
+  while (J > 1 && (n < part0 + min_part * (size_t)(J - 1))) J--;
   struct par_scan* P = (struct par_scan*)calloc(1, sizeof *P);
   if (!P) return NULL;
   P->b = b; P->mp3 = mp3; P->n = n; P->K = K; P->J = J; P->sub = sub; P->t0 = now_s();
@@ -2577,8 +2610,9 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
   int ok = P->rec && P->win && P->snap && P->args;
   for (int j = 1; ok && j < J; j++) {
     pre_seg* S = &P->seg[j];
-    S->P = P; S->j = j; S->guess = n / (size_t)J * (size_t)j; S->x_start = -2;
-    S->cap = (long long)((n / (size_t)J + 65536 + 4096) / 96) + 8;
+    const size_t share = (n - part0) / (size_t)(J - 1);
+    S->P = P; S->j = j; S->guess = part0 + share * (size_t)(j - 1); S->x_start = -2;
+    S->cap = (long long)((share + 65536 + 4096) / 96) + 8;
     if (pc->seg_cap[j] < S->cap) {
       free(pc->seg_rec[j]);
       pc->seg_rec[j] = (hop1*)malloc((size_t)S->cap * sizeof(hop1));
@@ -2685,6 +2719,8 @@ static void par_append(struct bulk* b, pre_window* pw) {
   struct pool_copy* g = b->gath_cur + b->gath_n;
   const struct pool_copy* gs = (const struct pool_copy*)pw->gath;
   for (int i = 0; i < pw->gath_n; i++) { g[i] = gs[i]; g[i].dst += base; }
+  gather_push(b, b->bits_slot, b->res_dst, g, pw->gath_n);       /* (under way while the window fills) */
+  b->g_pushed[b->bits_slot] = 1;
   b->bits_n += pw->n; b->gath_n += pw->gath_n; b->pool_tail += pw->pool_tail;
   b->slot_arena[b->bits_slot][b->slot_arena_n[b->bits_slot]++] = pw->arena; pw->arena = NULL;   /* (the copy list points into it until the submitter is through) */
 }
@@ -2706,13 +2742,14 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
   int sub = b->cap < 1024 ? b->cap : 1024;
   const char* se = getenv("PDMP3_BULK_SUB_FRAMES");
   if (se && atoi(se) >= 1) sub = atoi(se) < b->cap ? atoi(se) : b->cap;
-  struct par_scan* P = par_start(b, mp3, n, K, sub);
+  struct par_scan* P = par_start(b, mp3, n, K, sub, b->scan_forced ? PAR_MIN_WINDOWS : 2 * PAR_MIN_WINDOWS);
   if (!P) return PAR_NOT_TAKEN;
   long long total = 0, frames = 0, w = 0;
   int end = 0, engine_ok = 1, n_windows = 0;
   double t_win = 0, t_open = 0, t_fill = 0, t_more = 0;
   const char* tr = getenv("PDMP3_BULK_TRACE");
   const int trace2 = tr && atoi(tr) >= 2;
+  b->trace2 = trace2; b->tr_t0 = t_start;
   pre_window* held = NULL;                              /* taken from the scanners, did not fit the window before */
   for (;;) {
     const double t0 = now_s();
@@ -2797,11 +2834,11 @@ long long pdmp3_amd_test_split_scan(const unsigned char* mp3, size_t n, int wind
   pthread_once(&g_lut_once, build_luts);
   struct bulk* b = hook_get();
   if (!b) return -1;
-  b->cap = window_frames > 0 ? window_frames : 2048;
+  b->cap = b->target = window_frames > 0 ? window_frames : 2048;
   b->bits_mode = 1; b->pool_mode = 1;             /* (what the scanners' sinks are: the window schedule depends on it) */
   b->id->iso = iso;
   const double t_start = now_s();
-  struct par_scan* P = par_start(b, mp3, n, K, b->cap);
+  struct par_scan* P = par_start(b, mp3, n, K, b->cap, PAR_MIN_WINDOWS);
   if (!P) { hook_put(b); return PAR_NOT_TAKEN; }
   size_t o = 0;
   int end = 0, fit = 1;
@@ -2904,14 +2941,19 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
     threads = c > 64 ? 64 : c;
     if (bits_mode && threads > 4) threads = 4;   /* the pool only copies PCM out */
   }
-  /* frames per GPU batch.  Bits mode: 4096 -- k_unpack is bound by the length of one lane's chain, not by throughput, and
-   * two of its workgroups fit a CU: a window of 4096 frames costs little more than one of 2048 (72 -> ~78 us), larger ones
-   * make the first window late (measured: 2048 / 4096 / 8192 frames = 13.8 / 18.5 / 16.5 M frames/s end to end) */
-  if (window_frames <= 0) window_frames = bits_mode ? 4096 : 2048;
-  if (window_frames > 32768) window_frames = 32768;
+  /* frames per GPU batch.  Bits mode: k_unpack is bound by the length of one lane's chain, not by throughput, and two of
+   * its workgroups (16 frames each) fit a CU: 8192 frames fill the chip once, 68 -> 84 us against 4096.  The slots hold
+   * 8192; the split scan (PCM left on the device) fills them as far as its scanners have got when a slot is free, the
+   * one-thread scan (host destinations: the PCM's way home over PCIe is what bounds those, and a window's PCM leaves when
+   * the window is done) closes its windows at 4096 -- measured, pinned / pageable: 10.6 / 9.5 M frames/s against 9.6 / 8.1
+   * with windows of 8192.  A window size the caller names is both. */
+  int target = window_frames;
+  if (window_frames <= 0) { window_frames = bits_mode ? 8192 : 2048; target = bits_mode ? 4096 : 2048; }
+  if (window_frames > 32768) window_frames = target = 32768;
   struct bulk* b = (struct bulk*)calloc(1, sizeof *b);
   if (!b) return NULL;
   b->cap = window_frames;
+  b->target = target;
   {
     /* split scan (par_drive): 8 scanners where the process has 16 CPUs (they live for the few milliseconds of a stream's
      * scan), fewer on smaller quotas, none below 6 CPUs; PDMP3_BULK_SCAN_THREADS = 0 .. 8 overrides (0: one thread, as before) */
@@ -2952,9 +2994,9 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
       b->sub_started = 1;
       pthread_mutex_init(&b->gh_mu, NULL); pthread_cond_init(&b->gh_cv, NULL); pthread_cond_init(&b->gh_done_cv, NULL);
       {
-        const char* ge = getenv("PDMP3_BULK_GATHER_THREADS");      /* helpers of the submitter's main-data copy (0 .. 4) */
-        int want = ge ? atoi(ge) : (b->scan_threads > 0 ? 3 : 0);
-        if (want > 4) want = 4;
+        const char* ge = getenv("PDMP3_BULK_GATHER_THREADS");      /* helpers for the windows' main-data copies (0 .. 8) */
+        int want = ge ? atoi(ge) : (b->scan_threads >= 8 ? 6 : b->scan_threads > 0 ? 3 : 0);
+        if (want > GATHER_MAX_HELPERS) want = GATHER_MAX_HELPERS;
         for (b->gh_n = 0; b->gh_n < want; b->gh_n++)
           if (pthread_create(&b->gh_th[b->gh_n], NULL, gather_helper, b) != 0) break;
       }
