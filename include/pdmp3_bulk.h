@@ -41,17 +41,22 @@ typedef struct bulk pdmp3_amd_bulk;
 #define PDMP3_BULK_REPLAY (-2)
 
 /* threads <= 0: one worker per usable CPU (affinity and cgroup quota; at most 64; 4 with device Huffman, where the
- * pool only copies PCM out).  window_frames <= 0:
- * 4096 frames per GPU batch with device Huffman, 2048 with host Huffman (at most 32768).  Returns NULL when there is no transform engine
- * (no CPU fallback). */
+ * pool only copies PCM out).  window_frames <= 0: with device Huffman the engine's slots hold 8192 frames -- the split scan
+ * (below) fills them as far as its scanners have got when a slot is free, the one-thread scan closes its windows at 4096 --,
+ * with host Huffman 2048; a size given explicitly is both (at most 32768).  Returns NULL when there is no transform
+ * engine (no CPU fallback). */
 pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
 /* Environment: PDMP3_BULK_HOST_HUFFMAN=1 (below), PDMP3_BULK_SNAPSHOT_ROWS=1 (upload 2064-byte reservoir snapshots per frame
  * instead of the compact pool + row descriptors: tests), PDMP3_BULK_TRACE=1 (one summary of the pipeline's waits per decode on
- * stderr), PDMP3_BULK_SCAN_THREADS=n (0 .. 8: scanner threads of the split scan -- a pre-pass hops from header to header and
- * n threads run the scan from window boundaries, results identical to the one-thread scan; by default 8 / 4 / 2 with
+ * stderr; 2: a line per window as well), PDMP3_BULK_SCAN_THREADS=n (0 .. 16: scanner threads of the split scan -- a pre-pass
+ * hops from header to header and n threads run the scan from every 1024th frame into private windows that the calling
+ * thread puts into the engine's slots in stream order, results identical to the one-thread scan; by default 8 / 4 / 2 with
  * 16 / 12 / 6 usable CPUs and only when the PCM stays in device memory, where the scan is the bound; given explicitly: for
- * every destination; 0: never), PDMP3_BULK_GATHER_THREADS=n (0 .. 4 helpers of the thread that copies a window's main
- * data into the pinned upload buffer). */
+ * every destination and for streams from 4 private windows on instead of 8; 0: never), PDMP3_BULK_PREPASS_THREADS=n (1 .. 8
+ * parts of the pre-pass, all but the first with a thread of their own that hops from a guessed header; 6 / 3 / 1 by default
+ * with 16 / 12 / fewer usable CPUs), PDMP3_BULK_SUB_FRAMES=n (frames of a private window, default 1024),
+ * PDMP3_BULK_GATHER_THREADS=n (0 .. 8 helper threads for the copies of the windows' main data into the pinned upload
+ * buffers; 6 by default with 8 scanners, 3 with fewer, 0 without). */
 /* host_huffman = 0 (what pdmp3_amd_bulk_new gives unless PDMP3_BULK_HOST_HUFFMAN=1 is set): the host only runs
  * the sequential scan and ships side info + reservoir snapshots; scalefactors, Huffman and the frame-to-frame
  * merge run on the device (pdmp3_hip_stream_submit_bits) and the pool just copies PCM out.  host_huffman = 1:

@@ -2579,8 +2579,8 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
   if (K > PAR_MAX_SCANNERS) K = PAR_MAX_SCANNERS;
   if (K > est_windows) K = (int)est_windows;
   /* parts of the pre-pass: $PDMP3_BULK_PREPASS_THREADS, else by the host's cores; none shorter than a megabyte */
-  const long cores = sysconf(_SC_NPROCESSORS_ONLN);
-  int J = cores >= 32 ? 6 : cores >= 12 ? 3 : 1;
+  const int cores = usable_cpus();
+  int J = cores >= 16 ? 6 : cores >= 12 ? 3 : 1;
   const char* ev = getenv("PDMP3_BULK_PREPASS_THREADS");
   size_t min_part = PAR_MIN_PART_BYTES;
   if (ev && atoi(ev) >= 1) { J = atoi(ev); min_part = 16384; }   /* (forced: tests split short streams) */

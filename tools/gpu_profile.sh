@@ -35,6 +35,18 @@ timeout 300 python3 tools/phase_profile.py 131072 32 > $OUT/phase_profile.txt 2>
 timeout 300 python3 tools/ring_bench.py > $OUT/ring_bench.txt 2>&1; timeout 300 python3 tools/ring_profile.py 32768 > $OUT/ring_profile.txt 2>&1
 timeout 300 python3 tools/gran_profile.py 2048 > $OUT/gran_profile.txt 2>&1
 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 2> /dev/null > $OUT/bench_driver_flags.json; cat $OUT/bench_driver_flags.json | cut -c1-400
+# round 4, the whole-stream decoder's split scan: end to end with the PCM left in HBM (the pipeline's waits, a line per window),
+# its host side alone, the GPU's timeline of three decodes, a soak with short private windows
+{ PDMP3_BULK_TRACE=1 timeout 300 python3 tools/bulk_bench.py --frames 137813 --threads 4 --reps 8 --device-out 2>&1 | grep -E "split scan|submitter|frames_per_s" | tail -3
+  for w in 4096 16384; do echo "window $w:"; timeout 300 python3 tools/bulk_bench.py --frames 137813 --threads 4 --reps 8 --device-out --window $w 2> /dev/null | tail -1; done
+  for t in 4 12; do echo "scanners $t:"; PDMP3_BULK_SCAN_THREADS=$t timeout 300 python3 tools/bulk_bench.py --frames 137813 --threads 4 --reps 8 --device-out 2> /dev/null | tail -1; done
+  echo "pre-pass in one part:"; PDMP3_BULK_PREPASS_THREADS=1 timeout 300 python3 tools/bulk_bench.py --frames 137813 --threads 4 --reps 8 --device-out 2> /dev/null | tail -1
+  echo "pinned / pageable destination (one-thread scan):"; timeout 300 python3 tools/bulk_bench.py --frames 137813 --threads 4 --reps 6 --pinned 2> /dev/null | tail -1; timeout 300 python3 tools/bulk_bench.py --frames 137813 --threads 4 --reps 6 2> /dev/null | tail -1
+  echo "host side alone (tools/split_scan_bench.py):"; timeout 300 python3 tools/split_scan_bench.py --reps 6 --scanners 1,4,8 --windows 1024 2> /dev/null | tail -1
+} > $OUT/split_scan_runs.txt 2>&1; cat $OUT/split_scan_runs.txt | cut -c1-300
+PDMP3_BULK_TRACE=2 timeout 300 python3 tools/bulk_bench.py --frames 137813 --threads 4 --reps 3 --device-out 2>&1 > /dev/null | grep -E "^  ->|submitter:|split scan|pre-pass in" | tail -45 > $OUT/split_scan_trace.txt
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/bulk_tl -o tl -- python3 tools/bulk_bench.py --frames 137813 --threads 4 --reps 4 --device-out > /dev/null 2> $OUT/bulk_tl.log; python3 tools/bulk_timeline.py $OUT/bulk_tl/tl > $OUT/bulk_timeline.txt 2>&1; cat $OUT/bulk_timeline.txt | cut -c1-260
+{ PDMP3_BULK_SCAN_THREADS=8 PDMP3_BULK_SUB_FRAMES=64 timeout 900 python3 tools/soak_bulk.py 20; PDMP3_BULK_SCAN_THREADS=4 PDMP3_BULK_PREPASS_THREADS=5 timeout 900 python3 tools/soak_bulk.py 15; } > $OUT/soak_split.txt 2>&1; tail -3 $OUT/soak_split.txt
 # the same for a C5-shard-sized launch
 pmcb() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 tools/pmc_target.py 131072 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
 pmcb big_fetch FETCH_SIZE
