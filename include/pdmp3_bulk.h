@@ -52,9 +52,11 @@ pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
  * hops from header to header and n threads run the scan from every 1024th frame into private windows that the calling
  * thread puts into the engine's slots in stream order, results identical to the one-thread scan; by default 8 / 4 / 2 with
  * 16 / 12 / 6 usable CPUs and only when the PCM stays in device memory, where the scan is the bound; given explicitly: for
- * every destination and for streams from 4 private windows on instead of 8; 0: never), PDMP3_BULK_PREPASS_THREADS=n (1 .. 8
+ * every destination and for streams from 4 private windows on instead of 12; 0: never; decoders of one process that scan
+ * at the same time share: the second takes half the scanners, the third a third ...), PDMP3_BULK_PREPASS_THREADS=n (1 .. 8
  * parts of the pre-pass, all but the first with a thread of their own that hops from a guessed header; 6 / 3 / 1 by default
- * with 16 / 12 / fewer usable CPUs), PDMP3_BULK_SUB_FRAMES=n (frames of a private window, default 1024),
+ * with 16 / 12 / fewer usable CPUs), PDMP3_BULK_SUB_FRAMES=n (frames of a private window; by default 1024 for streams of
+ * 16384 frames and more, 512 from 8192, 256 below),
  * PDMP3_BULK_GATHER_THREADS=n (0 .. 8 helper threads for the copies of the windows' main data into the pinned upload
  * buffers; 6 by default with 8 scanners, 3 with fewer, 0 without). */
 /* host_huffman = 0 (what pdmp3_amd_bulk_new gives unless PDMP3_BULK_HOST_HUFFMAN=1 is set): the host only runs

@@ -2101,6 +2101,13 @@ typedef struct par_cache {
   hop1* seg_rec[PAR_MAX_SEGS]; long long seg_cap[PAR_MAX_SEGS];
   struct { struct bulk* wb; pdmp3_handle* id; uint8_t* pool; size_t pool_bytes; } scan[PAR_MAX_SCANNERS];
   pre_window* spare[2 * PAR_AHEAD]; int n_spare;
+  /* the threads of the scan (hop threads, pre-pass, scanners): started when a stream first needs them, kept for the next
+   * stream -- fourteen pthread_create / pthread_join per stream are 0.2 ms, as much as the scan of a five-minute file */
+  pthread_mutex_t crew_mu; pthread_cond_t crew_cv, crew_done_cv;
+  pthread_t crew[PAR_MAX_SCANNERS + PAR_MAX_SEGS];
+  int crew_n, crew_busy, crew_quit;               /* threads / jobs taken or waiting to be taken */
+  struct { void* (*fn)(void*); void* arg; int* left; } jobs[PAR_MAX_SCANNERS + PAR_MAX_SEGS];
+  unsigned job_head, job_tail;
 } par_cache;
 typedef struct hop_rec_s {
   uint32_t x;                 /* offset of the frame's header in the stream */
@@ -2143,7 +2150,7 @@ struct par_scan {
   double t_prepass, t_pre_part0, t_pre_wait, t0;
   int J;                      /* parts of the pre-pass: [0] is the pre-pass thread's own, the others have a hop thread each */
   pre_seg seg[PAR_MAX_SEGS];
-  pthread_t th_pre, th_hop[PAR_MAX_SEGS], th_scan[PAR_MAX_SCANNERS];
+  int jobs_left, hops_left;   /* pre-pass and scanners / hop threads that have not returned (under the crew's mutex) */
   struct scanner_arg* args;
 };
 
@@ -2190,11 +2197,59 @@ static void pw_free(pre_window* w) {
 }
 static par_cache* pc_new(void) {
   par_cache* pc = (par_cache*)calloc(1, sizeof *pc);
-  if (pc) pthread_mutex_init(&pc->mu, NULL);
+  if (pc) {
+    pthread_mutex_init(&pc->mu, NULL);
+    pthread_mutex_init(&pc->crew_mu, NULL); pthread_cond_init(&pc->crew_cv, NULL); pthread_cond_init(&pc->crew_done_cv, NULL);
+  }
   return pc;
+}
+#define CREW_MAX (PAR_MAX_SCANNERS + PAR_MAX_SEGS)
+static void* crew_main(void* arg) {
+  par_cache* pc = (par_cache*)arg;
+  pthread_mutex_lock(&pc->crew_mu);
+  for (;;) {
+    while (!pc->crew_quit && pc->job_tail == pc->job_head) pthread_cond_wait(&pc->crew_cv, &pc->crew_mu);
+    if (pc->job_tail == pc->job_head) break;            /* (quit, nothing left) */
+    const unsigned k = pc->job_tail++ % CREW_MAX;
+    void* (*fn)(void*) = pc->jobs[k].fn;
+    void* a = pc->jobs[k].arg;
+    int* left = pc->jobs[k].left;
+    pthread_mutex_unlock(&pc->crew_mu);
+    (void)fn(a);
+    pthread_mutex_lock(&pc->crew_mu);
+    pc->crew_busy--;
+    (*left)--;                                          /* (under crew_mu: whoever waits for 0 may free what `left` is part of) */
+    pthread_cond_broadcast(&pc->crew_done_cv);
+  }
+  pthread_mutex_unlock(&pc->crew_mu);
+  return NULL;
+}
+/* fn(arg) on a thread of its own, at once (the jobs of a stream wait for each other: each needs a thread); *left counts
+ * the stream's jobs that have not returned.  -1: no thread to be had. */
+static int crew_run(par_cache* pc, void* (*fn)(void*), void* arg, int* left) {
+  pthread_mutex_lock(&pc->crew_mu);
+  if (pc->crew_busy >= pc->crew_n) {
+    if (pc->crew_n >= CREW_MAX || pthread_create(&pc->crew[pc->crew_n], NULL, crew_main, pc) != 0) { pthread_mutex_unlock(&pc->crew_mu); return -1; }
+    pc->crew_n++;
+  }
+  const unsigned k = pc->job_head++ % CREW_MAX;
+  pc->jobs[k].fn = fn; pc->jobs[k].arg = arg; pc->jobs[k].left = left;
+  pc->crew_busy++;
+  (*left)++;
+  pthread_cond_signal(&pc->crew_cv);
+  pthread_mutex_unlock(&pc->crew_mu);
+  return 0;
+}
+static void crew_wait(par_cache* pc, int* left) {
+  pthread_mutex_lock(&pc->crew_mu);
+  while (*left) pthread_cond_wait(&pc->crew_done_cv, &pc->crew_mu);
+  pthread_mutex_unlock(&pc->crew_mu);
 }
 static void pc_free(par_cache* pc) {
   if (!pc) return;
+  pthread_mutex_lock(&pc->crew_mu); pc->crew_quit = 1; pthread_cond_broadcast(&pc->crew_cv); pthread_mutex_unlock(&pc->crew_mu);
+  for (int i = 0; i < pc->crew_n; i++) pthread_join(pc->crew[i], NULL);
+  pthread_mutex_destroy(&pc->crew_mu); pthread_cond_destroy(&pc->crew_cv); pthread_cond_destroy(&pc->crew_done_cv);
   for (int i = 0; i < pc->n_spare; i++) pw_destroy(pc->spare[i]);
   for (int j = 0; j < PAR_MAX_SEGS; j++) free(pc->seg_rec[j]);
   for (int k = 0; k < PAR_MAX_SCANNERS; k++) { free(pc->scan[k].wb); free(pc->scan[k].id); free(pc->scan[k].pool); }
@@ -2561,20 +2616,25 @@ done:
 
 /* Starts the hop threads, the pre-pass and the scanners for `mp3`; NULL when the stream is too short to bother or frame 0 is
  * not where a regular stream has it. */
-#define PAR_MIN_WINDOWS 4                /* private windows (tests, a forced split scan); 8 otherwise: shorter streams are not worth fifteen threads */
+#define PAR_MIN_WINDOWS 4                /* private windows (tests, a forced split scan); 12 otherwise */
 #define PAR_MIN_PART_BYTES (1u << 20)
 static void par_free(struct par_scan* P) {          /* (the records and the hop threads' arrays are the cache's) */
   if (P->snap) for (long long w = 0; w < P->snap_cap; w++) free(P->snap[w].sky);
   free(P->win); free(P->snap); free(P->args); free(P);
 }
-static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size_t n, int K, int sub, int min_windows) {
+static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size_t n, int K, int sub, int min_windows, int max_parts) {
   if (K < 1 || n < 4096 || n > 0xfff00000u || (mp3[0] != 0xff) || (mp3[1] & 0xf0) != 0xf0) return NULL;
   frame_header H;
   header_fields(be32(mp3), &H);
   if (H.id != 1 || H.bitrate_index == 0 || H.bitrate_index == 15 || H.sfreq == 3 || H.layer != 3) return NULL;
   const unsigned fb0 = frame_bytes(&H);
-  if (sub < 1 || sub > b->cap) return NULL;
-  const long long est = (long long)(n / fb0), est_windows = (est + sub - 1) / sub;
+  const long long est = (long long)(n / fb0);
+  /* sub = 0: the caller leaves the private windows' size to the stream's length -- 1024 frames for long streams, 512 and
+   * 256 for files of a few minutes (C4: 4096 frames and up), so that every scanner has two windows or more */
+  if (sub == 0) sub = est >= 16384 ? 1024 : est >= 8192 ? 512 : 256;
+  if (sub > b->cap) sub = b->cap;
+  if (sub < 1) return NULL;
+  const long long est_windows = (est + sub - 1) / sub;
   if (est_windows < min_windows) return NULL;
   if (K > PAR_MAX_SCANNERS) K = PAR_MAX_SCANNERS;
   if (K > est_windows) K = (int)est_windows;
@@ -2586,6 +2646,7 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
   if (ev && atoi(ev) >= 1) { J = atoi(ev); min_part = 16384; }   /* (forced: tests split short streams) */
   if (K == 1) J = 1;                                    /* (one scanner: the sequential stage A, nothing to hurry for) */
   if (J > PAR_MAX_SEGS) J = PAR_MAX_SEGS;
+  if (J > max_parts) J = max_parts;
   /* part 0 -- the pre-pass thread's own, where it reads the stream itself at a third of the speed -- is short: a 24th of
    * the stream; the hop threads share the rest equally */
   const size_t part0 = n / 24 > min_part ? n / 24 : min_part;
@@ -2623,20 +2684,17 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
   }
   if (!ok) { par_free(P); return NULL; }
   pthread_mutex_init(&P->mu, NULL); pthread_cond_init(&P->cv, NULL);
-  /* (a thread that cannot be started: the ones that run are told to stop, joined, and the stream goes the one-thread way) */
-  int n_hop = 0, n_scan = 0, pre = 0;
-  for (int j = 1; j < J; j++) { if (pthread_create(&P->th_hop[j], NULL, par_hop_thread, &P->seg[j]) != 0) break; n_hop++; }
-  if (n_hop == J - 1 && pthread_create(&P->th_pre, NULL, par_prepass_thread, P) == 0) pre = 1;
-  for (int k = 0; pre && k < K; k++) {
+  /* (a thread that cannot be had: the ones that run are told to stop and waited for, and the stream goes the one-thread way) */
+  int started = 1;
+  for (int j = 1; started && j < J; j++) started = crew_run(pc, par_hop_thread, &P->seg[j], &P->hops_left) == 0;
+  if (started) started = crew_run(pc, par_prepass_thread, P, &P->jobs_left) == 0;
+  for (int k = 0; started && k < K; k++) {
     P->args[k].P = P; P->args[k].k = k; P->args[k].rc = -1;
-    if (pthread_create(&P->th_scan[k], NULL, par_scanner, &P->args[k]) != 0) break;
-    n_scan++;
+    started = crew_run(pc, par_scanner, &P->args[k], &P->jobs_left) == 0;
   }
-  if (n_hop != J - 1 || !pre || n_scan != K) {
+  if (!started) {
     pthread_mutex_lock(&P->mu); P->abort = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
-    for (int j = 1; j <= n_hop; j++) pthread_join(P->th_hop[j], NULL);
-    if (pre) pthread_join(P->th_pre, NULL);
-    for (int k = 0; k < n_scan; k++) pthread_join(P->th_scan[k], NULL);
+    crew_wait(pc, &P->jobs_left); crew_wait(pc, &P->hops_left);
     pthread_mutex_destroy(&P->mu); pthread_cond_destroy(&P->cv);
     par_free(P);
     return NULL;
@@ -2645,12 +2703,13 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
 }
 /* joins the threads and frees everything; returns the pre-pass's verdict: 0 = the stream was regular and complete */
 static int par_finish(struct par_scan* P) {
+  par_cache* pc = P->b->pc;
   pthread_mutex_lock(&P->mu); P->quit = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
-  pthread_join(P->th_pre, NULL);
-  for (int k = 0; k < P->K; k++) pthread_join(P->th_scan[k], NULL);
-  /* (the hop threads look at abort only: they are through before the pre-pass unless it gave up early) */
-  pthread_mutex_lock(&P->mu); const int ok = !P->irregular && !P->abort; P->abort = 1; pthread_mutex_unlock(&P->mu);
-  for (int j = 1; j < P->J; j++) pthread_join(P->th_hop[j], NULL);
+  /* (the pre-pass and the scanners leave on `quit`; the hop threads look at abort only -- they are through long before
+   * unless the stitcher gave up early: told to stop once the verdict is taken, which the others' end no longer changes) */
+  crew_wait(pc, &P->jobs_left);
+  pthread_mutex_lock(&P->mu); const int ok = !P->irregular && !P->abort; P->abort = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
+  crew_wait(pc, &P->hops_left);
   for (long long w = 0; w < P->win_cap; w++) pw_free(P->win[w]);
   pthread_mutex_destroy(&P->mu); pthread_cond_destroy(&P->cv);
   par_free(P);
@@ -2737,13 +2796,22 @@ static void par_append(struct bulk* b, pre_window* pw) {
  * GPU's, a window that is not full waits for more. */
 #define PAR_NOT_TAKEN (-3)
 #define PAR_GIVEN_UP (-4)
+static atomic_int g_par_active;                    /* split scans under way in this process */
 static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, int K) {
   const double t_start = now_s();
-  int sub = b->cap < 1024 ? b->cap : 1024;
+  int sub = 0;                                          /* (by the stream's length: par_start) */
   const char* se = getenv("PDMP3_BULK_SUB_FRAMES");
   if (se && atoi(se) >= 1) sub = atoi(se) < b->cap ? atoi(se) : b->cap;
-  struct par_scan* P = par_start(b, mp3, n, K, sub, b->scan_forced ? PAR_MIN_WINDOWS : 2 * PAR_MIN_WINDOWS);
-  if (!P) return PAR_NOT_TAKEN;
+  /* streams from 12 private windows on (3072 frames: a scan of 0.25 ms on one thread); a forced split scan: from 4 */
+  /* several decoders of one process at it at once (a corpus, a decoder per few files): they share the host's cores --
+   * the second takes half the scanners, the third and fourth a third and a quarter (two at least), and only the first
+   * has hop threads */
+  const int others = atomic_fetch_add(&g_par_active, 1);
+  if (others > 0) { K = K / (others + 1); if (K < 2) K = 2; }
+  struct par_scan* P = par_start(b, mp3, n, K, sub, b->scan_forced ? PAR_MIN_WINDOWS : 3 * PAR_MIN_WINDOWS, others > 0 ? 1 : PAR_MAX_SEGS);
+  if (!P) { atomic_fetch_sub(&g_par_active, 1); return PAR_NOT_TAKEN; }
+  sub = P->sub;
+  K = P->K;
   long long total = 0, frames = 0, w = 0;
   int end = 0, engine_ok = 1, n_windows = 0;
   double t_win = 0, t_open = 0, t_fill = 0, t_more = 0;
@@ -2800,6 +2868,7 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
   uint32_t last_hw = 0;
   if (end == 1 && nf > 0) last_hw = be32(mp3 + P->rec[nf - 1].x);
   const int ok = par_finish(P) == 0 && end == 1 && engine_ok && frames == nf;
+  atomic_fetch_sub(&g_par_active, 1);
   if (!engine_ok) { b->failed = 1; return -1; }
   if (!ok) return PAR_GIVEN_UP;
   if (nf > 0) { header_fields(last_hw, &b->id->hdr); b->id->l_hdr = b->id->hdr; }
@@ -2838,7 +2907,7 @@ long long pdmp3_amd_test_split_scan(const unsigned char* mp3, size_t n, int wind
   b->bits_mode = 1; b->pool_mode = 1;             /* (what the scanners' sinks are: the window schedule depends on it) */
   b->id->iso = iso;
   const double t_start = now_s();
-  struct par_scan* P = par_start(b, mp3, n, K, b->cap, PAR_MIN_WINDOWS);
+  struct par_scan* P = par_start(b, mp3, n, K, b->cap, PAR_MIN_WINDOWS, PAR_MAX_SEGS);
   if (!P) { hook_put(b); return PAR_NOT_TAKEN; }
   size_t o = 0;
   int end = 0, fit = 1;
