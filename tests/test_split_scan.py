@@ -151,3 +151,38 @@ def test_hop_threads_turn_down_what_the_pre_pass_turns_down(monkeypatch):
         for name, mp3 in cases.items():
             n, _, _ = split_scan(mp3, 16, 3)
             assert n in (NOT_TAKEN, GIVEN_UP), (name, parts, n)
+
+
+def test_random_streams_random_splits(monkeypatch):
+    """40 streams with the packer's parameters drawn at random (rate, bitrate or VBR range, mode, CRC, reservoir on / off,
+    block mix, fill), each cut at random: private windows of 5 .. 70 frames, 2 .. 8 scanners, the pre-pass in 1 .. 5 parts --
+    the windows are the one scanner's, byte for byte"""
+    rs = np.random.RandomState(0x5ca9)
+    taken = 0
+    for i in range(40):
+        blocks = rs.randint(0, 100, 4) + 1
+        mode = int(rs.choice([0, 1, 1, 2, 3]))
+        kw = dict(n_frames=int(rs.randint(250, 900)), seed=1000 + i, sfreq=int(rs.randint(0, 3)), mode=mode, mode_ext=int(rs.randint(0, 4)),
+                  crc=bool(rs.randint(0, 2)), reservoir=bool(rs.randint(0, 4)), block_pct=tuple(int(x) for x in blocks),
+                  mixed_pct=int(rs.randint(0, 101)), fill_pct=int(rs.randint(60, 100)), big_pct=int(rs.randint(0, 12)))
+        if rs.randint(0, 2):
+            lo = int(rs.randint(2, 10))
+            kw.update(vbr=True, vbr_lo=lo, vbr_hi=int(rs.randint(lo, 15)))
+        else:
+            kw.update(bitrate_index=int(rs.randint(4, 15)))
+        mp3 = packer.generate(**kw)
+        window = int(rs.randint(5, 71))
+        monkeypatch.setenv("PDMP3_BULK_PREPASS_THREADS", "1")
+        one = split_scan(mp3, window, 1)
+        if one[0] in (NOT_TAKEN, GIVEN_UP):
+            continue                                      # (e.g. the first frames underflow without a reservoir to start from)
+        assert one[1] == api_frames(mp3), kw
+        taken += 1
+        for _ in range(2):
+            k, parts = int(rs.randint(2, 9)), int(rs.randint(1, 6))
+            monkeypatch.setenv("PDMP3_BULK_PREPASS_THREADS", str(parts))
+            got = split_scan(mp3, window, k)
+            if got[0] == GIVEN_UP and parts > 1:
+                continue                                  # (a guess that chained but was no boundary)
+            assert got == one, (kw, window, k, parts)
+    assert taken >= 30
