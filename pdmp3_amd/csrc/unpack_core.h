@@ -132,6 +132,20 @@ PD_HD uint32_t row_word(const pdmp3_row_desc* d, const uint8_t* pool, unsigned j
   return v;
 }
 
+// bytes j .. j + 15 (j a multiple of 16) as four little-endian words: one 16-byte read where they come from one place --
+// nearly always: a row changes its source at the tops of the frames on its skyline, a handful of places in 2064 bytes
+PD_HD void row_chunk16(const pdmp3_row_desc* d, const uint8_t* pool, unsigned j, uint32_t out[4]) {
+  const pdmp3_row_desc* e = d;
+  const uint8_t* src = nullptr;
+  for (;;) {
+    if (e->top > j) { if (e->top >= j + 16) src = pool + e->row_off + j; break; }
+    if (!e->up) { src = pool + e->s_off + j; break; }   // (the image is 2064 = 129 x 16 bytes: j + 15 is inside)
+    e -= e->up;
+  }
+  if (src) { __builtin_memcpy(out, src, 16); return; }
+  for (int q = 0; q < 4; q++) out[q] = row_word(d, pool, j + 4u * (unsigned)q);
+}
+
 // ---------------------------------------------------------------------------
 // bit reader over one reservoir row (same windows as pdmp3_host.c peek32 / peek64)
 // ---------------------------------------------------------------------------

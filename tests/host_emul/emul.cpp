@@ -173,8 +173,17 @@ extern "C" int emul_unpack_frames(const pdmp3_frame_bits* bits, const uint8_t* r
 }
 
 
-// reservoir rows from the pool (unpack_core.h row_word: what k_rows runs per frame)
+// reservoir rows from the pool (unpack_core.h row_chunk16: what k_rows runs per frame), and word by word (row_word: the
+// rule itself; the tests ask for both and want them equal)
 extern "C" void emul_rows(const pdmp3_row_desc* desc, const uint8_t* pool, int n_frames, uint8_t* rows) {
+  for (int f = 0; f < n_frames; ++f)
+    for (unsigned c = 0; c < PDMP3_RESERVOIR_BYTES / 16; ++c) {
+      uint32_t v[4];
+      row_chunk16(desc + f, pool, 16 * c, v);
+      memcpy(rows + (size_t)f * PDMP3_RESERVOIR_BYTES + 16 * c, v, 16);
+    }
+}
+extern "C" void emul_rows_by_word(const pdmp3_row_desc* desc, const uint8_t* pool, int n_frames, uint8_t* rows) {
   for (int f = 0; f < n_frames; ++f)
     for (unsigned w = 0; w < PDMP3_RESERVOIR_BYTES / 4; ++w) {
       const uint32_t v = row_word(desc + f, pool, 4 * w);

@@ -177,6 +177,9 @@ def test_pool_rows_are_the_snapshot_rows(emul):
             continue
         rows = np.zeros((len(bits), 2064), dtype=np.uint8)
         emul.emul_rows(desc.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p), len(bits), rows.ctypes.data_as(C.c_void_p))
+        rows_w = np.zeros_like(rows)                        # (the rule word by word: what k_rows' 16-byte chunks must equal)
+        emul.emul_rows_by_word(desc.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p), len(bits), rows_w.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(rows, rows_w)
         bad = np.nonzero((rows != res).any(axis=1))[0]
         assert bad.size == 0, (len(bits), bad[:5], desc[bad[:2]])
         checked += len(bits)
