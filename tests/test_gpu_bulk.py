@@ -516,3 +516,62 @@ def test_split_scan_is_the_default_for_device_destinations(monkeypatch):
     finally:
         ref.close()
         dev.close()
+
+
+def test_decoders_side_by_side_into_device_memory():
+    """four decoders on their own threads, each with a queue of files of a few minutes (4096-frame files: the split scan
+    with 256-frame private windows, its threads kept from file to file and shared between the decoders that scan at the
+    same time), PCM left in device memory, files queued back to back with one wait at the end: every file's PCM is the
+    one-thread decoder's"""
+    import threading
+    import torch
+    from pdmp3_amd import api
+    rs = np.random.RandomState(77)
+    files, sizes = [], []
+    i = 0
+    while len(files) < 16:
+        i += 1
+        kw = dict(n_frames=int(rs.randint(3500, 5000)), seed=400 + i, sfreq=int(rs.randint(0, 3)), mode=int(rs.choice([0, 1, 3])),
+                  block_pct=(40, 10, 40, 10), mixed_pct=30, gain=(128, 140))
+        if i % 2:
+            kw.update(vbr=True, vbr_lo=5, vbr_hi=14)
+        else:
+            kw.update(bitrate_index=int(rs.randint(7, 15)))
+        f = np.frombuffer(packer.generate(**kw), dtype=np.uint8)
+        try:
+            sizes.append(api.scan_buffer(f)[0])
+        except api.RingReplay:                              # (1152-byte frames: the reference has no finite output, DESIGN 7)
+            continue
+        files.append(f)
+    os.environ["PDMP3_BULK_SCAN_THREADS"] = "0"
+    try:
+        ref = api.BulkDecoder(threads=2)
+    finally:
+        del os.environ["PDMP3_BULK_SCAN_THREADS"]
+    want = [ref.decode(f) for f in files]
+    ref.close()
+    outs = [torch.zeros(max(s, 2) // 2, dtype=torch.int16, device="cuda:0") for s in sizes]
+    errs = []
+
+    def work(j):
+        b = api.BulkDecoder(threads=2)
+        try:
+            for _ in range(2):                              # (twice: the second pass runs on the kept threads and memory)
+                for i in range(j, len(files), 4):
+                    got, _, _ = b.decode_into_device(files[i], outs[i], wait=False)
+                    if got != sizes[i]:
+                        errs.append((i, got))
+                b.wait()
+        except Exception as e:                              # noqa: BLE001
+            errs.append(repr(e))
+        finally:
+            b.close()
+    ts = [threading.Thread(target=work, args=(j,)) for j in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(len(files)):
+        assert np.array_equal(outs[i].cpu().numpy(), want[i]), i
