@@ -2142,8 +2142,9 @@ struct par_scan {
   span_snap* snap; long long snap_cap;   /* by window index; [0] unused (a fresh handle) */
   hop_rec* rec; long long rec_cap;
   long long n_frames;         /* valid once prepass_done */
-  int prepass_done, irregular, abort;
-  int quit;                   /* the stitcher has left: nobody wants further windows (not an error) */
+  int prepass_done, irregular;
+  atomic_int abort;           /* (set under the mutex, so that waiters wake; also looked at in loops that hold no lock) */
+  atomic_int quit;            /* the stitcher has left: nobody wants further windows (not an error) */
   pre_window** win; long long win_cap;    /* finished windows by stream index */
   int scanners_done;
   pthread_mutex_t mu; pthread_cond_t cv;
