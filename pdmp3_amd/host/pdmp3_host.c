@@ -1369,6 +1369,7 @@ struct bulk {
   pdmp3_handle* id;
   int cap;                            /* frames a window holds */
   int target;                         /* frames the one-thread scan gives a window (<= cap) */
+  int ramp_on;                        /* this stream's first windows are short (win_ramp): long streams only */
   int trace2; double tr_t0;           /* $PDMP3_BULK_TRACE >= 2: per-window lines, times from the stream's start */
   int count_only;                     /* scan: stage A alone */
   int bits_mode;                      /* main data goes to the device undecoded (pdmp3_hip_stream_submit_bits) */
@@ -1778,7 +1779,7 @@ static int bulk_at_limit(const struct bulk* b) { return b->limit_frames && b->fr
  * do after an eighth of a window's scan instead of a whole one (0.33 ms of a 7 ms decode at 4096 frames, twice that at
  * 8192), and the four together are exactly one full window, so every later window starts where it would have.  Device
  * Huffman with the compact upload only, and only for windows large enough to notice. */
-static int win_ramp(const struct bulk* b) { return b->bits_mode && b->pool_mode && !b->win_sink && b->target >= 1024 && b->target % 8 == 0; }
+static int win_ramp(const struct bulk* b) { return b->ramp_on && b->bits_mode && b->pool_mode && !b->win_sink && b->target >= 1024 && b->target % 8 == 0; }
 static int win_frames(const struct bulk* b, long long w) {
   if (b->win_sink) return b->cap;                 /* (a split scan's private window) */
   if (!win_ramp(b) || w >= 4) return b->target;
@@ -3160,6 +3161,16 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
   b->pcm_pinned = pcm_cap ? pdmp3_hip_host_is_pinned(pcm, pcm_cap) : 0;      /* 1 pinned host memory, 2 device memory */
   const double t_in = now_s();
   long long total = PAR_NOT_TAKEN;
+  /* short first windows (win_ramp) only for streams long enough to gain from them: a file of a few minutes would go up
+   * in five windows instead of two, and a window costs the GPU 150 us whatever its size (C4 corpus to pageable memory:
+   * 5.2 -> 4.0 M frames/s with the ramp on every file) */
+  b->ramp_on = 0;
+  if (n >= 4 && mp3[0] == 0xff && (mp3[1] & 0xf0) == 0xf0) {
+    frame_header H0;
+    header_fields(((uint32_t)mp3[0] << 24) | ((uint32_t)mp3[1] << 16) | ((uint32_t)mp3[2] << 8) | mp3[3], &H0);
+    if (H0.id == 1 && H0.layer == 3 && H0.bitrate_index != 0 && H0.bitrate_index != 15 && H0.sfreq != 3)
+      b->ramp_on = (long long)(n / frame_bytes(&H0)) >= 8LL * b->target;
+  }
   /* The split scan pays where the scan is the bound: with the PCM left in device memory (13 -> 18 M frames/s).  Towards host
    * memory the PCIe link bounds the pipeline and the extra threads only take memory bandwidth from the DMA engines
    * (measured: pinned 10.4 -> 8.3 M frames/s, pageable 9.1 -> 7.9 M) -- there the one-thread scan stays, unless
