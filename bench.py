@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--cpu-all-seconds", type=float, default=6.0, help="all-host-cores leg of the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bitstream-to-PCM extra")
+    ap.add_argument("--from-idle", action="store_true", help="N = 1: also time the W + K launches once before any other GPU work (from_idle_gpu)")
     ap.add_argument("--shard", type=int, default=SHARD_FRAMES, help="N = 1: frames of the extra C5-shard figure (0 = skip)")
     ap.add_argument("--big", type=int, default=131072, help="frames of the extra large-batch roofline probe (0 = skip)")
     args = ap.parse_args()
@@ -244,6 +245,106 @@ def main():
 
     def step():
         eng.decode(spectra, side, pcm, chunk_frames=args.chunk)
+
+    def larger_launches():
+        """the legs on launches of the C5-shard size.  They run BEFORE the warm-up and the timed region of the headline (one
+        GPU only): a decoder that is kept busy runs at the clocks these 60 ms of launches bring the GPU to, and the W + K
+        launches of the headline -- 0.5 ms with the driver's W = 5, K = 20 -- do not get there by themselves (the same 25
+        launches measured first, from an idle GPU: 21.4-21.9 us each; after these legs: see `clocks` in the line)."""
+        extra = {}
+        if args.shard and world == 1:
+            # what ONE rank of an N > 1 run does, on this GPU alone: the C5 shard of rank 1 -- 125 000 frames from a 2-frame
+            # halo, same seed, same engine call, hence the same kernel -- so that the driver's 1 -> N curve compares like
+            # with like (the N = 1 headline is C2, another workload and another kernel).  Outside the timed region (before it: see larger_launches).
+            ns = args.shard
+            sp3, sd3, pcm3 = eng.alloc_frames(ns + 2)
+            eng.generate(SEED_C5, ns - 2, ns + 2, sp3, sd3)
+            for _ in range(5):
+                eng.decode(sp3, sd3, pcm3, chunk_frames=args.chunk)
+            torch.cuda.synchronize()
+            reps = 20
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w0 = time.perf_counter()
+            a.record()
+            for _ in range(reps):
+                eng.decode(sp3, sd3, pcm3, chunk_frames=args.chunk)
+            b.record()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - w0) / reps
+            ms = a.elapsed_time(b) / reps
+            ach = (ns + 2) * ALGO_BYTES_PER_FRAME / (ms * 1e-3) / 1e9
+            extra["c5_shard_1gpu"] = {
+                "workload": "C5 shard of rank 1 (BASELINE configs[4]): frames [%d, %d) of the 1M-frame stream decoded from a 2-frame "
+                            "halo, one GPU, what each rank of an N > 1 run does per step" % (ns, 2 * ns),
+                "frames": ns, "halo_frames": 2, "kernel": eng.last_launch_kernel(), "avg_launch_ms": round(ms, 4),
+                "ms_per_step": round(wall * 1e3, 4), "frames_per_s": round(ns / wall, 1),
+                "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
+            del sp3, sd3, pcm3
+
+        if args.big and world == 1:
+            # kernel quality at throughput size (SURVEY 8d C5 shard scale), outside the timed region (before it)
+            nb = args.big
+            sp2, sd2, pcm2 = eng.alloc_frames(nb)
+            eng.generate(0x5EED0000C5, 0, nb, sp2, sd2)
+            for _ in range(10):                             # (sustained-throughput figure: the first launches after the 28 us
+                eng.decode(sp2, sd2, pcm2, chunk_frames=args.chunk)   #  C2 launches run 5 % slower than the steady state)
+            torch.cuda.synchronize()
+            reps = 20
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                eng.decode(sp2, sd2, pcm2, chunk_frames=args.chunk)
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / reps
+            ach = nb * ALGO_BYTES_PER_FRAME / (ms * 1e-3) / 1e9
+            extra["roofline_large_batch"] = {
+                "frames": nb, "avg_launch_ms": round(ms, 4), "frames_per_s": round(nb / (ms * 1e-3), 1),
+                "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                "fp32_tflops": round(nb * ALGO_FLOP_PER_FRAME / (ms * 1e-3) / 1e12, 2),
+                "fp32_frac": round(nb * ALGO_FLOP_PER_FRAME / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
+            }
+            # float PCM (pdmp3_hip_decode_frames_f32, SURVEY 8f #4): 3584 algorithmic bytes per granule-channel
+            # (1152 spectra + 128 side + 2304 float PCM) = 14336 per stereo frame
+            pcmf = torch.empty((nb, 2304), dtype=torch.float32, device=eng.tdev)
+            for _ in range(2):
+                eng.decode_f32(sp2, sd2, pcmf, chunk_frames=args.chunk)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                eng.decode_f32(sp2, sd2, pcmf, chunk_frames=args.chunk)
+            b.record()
+            torch.cuda.synchronize()
+            msf = a.elapsed_time(b) / reps
+            achf = nb * 14336 / (msf * 1e-3) / 1e9
+            extra["roofline_float_pcm"] = {"frames": nb, "avg_launch_ms": round(msf, 4), "frames_per_s": round(nb / (msf * 1e-3), 1),
+                                         "algorithmic_bytes_per_frame": 14336, "achieved": round(achf, 2), "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": round(achf / HBM_PEAK_GBS, 5), "kernel": "k_decode<false, true, 1>"}
+            del sp2, sd2, pcm2, pcmf
+
+
+        return extra
+
+    # --from-idle: the same W + K launches once from an idle GPU, reported beside the headline (`from_idle_gpu`): what the
+    # clocks are worth (off by default: the rocprofv3 summary of the default command should hold the headline's launches only)
+    from_idle = None
+    if world == 1 and args.from_idle and (args.shard or args.big):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - w0
+        from_idle = {"avg_launch_ms": round(e0.elapsed_time(e1) / args.steps, 5), "ms_per_step": round(wall / args.steps * 1e3, 5),
+                     "frames_per_s": round(n * args.steps / wall, 1),
+                     "what": "the same %d warm-up + %d timed launches as the headline, run first, before any other GPU work of this process" % (args.warmup, args.steps)}
+    extra_legs = larger_launches() if world == 1 else {}
 
     for _ in range(args.warmup):
         step()
@@ -378,76 +479,12 @@ def main():
         out["gather_GBps"] = round(gather_bytes / (gather_ms * 1e-3) / 1e9, 2)
         out["gather_backend"] = "rccl" if backend == "nccl" else backend
 
-    if args.shard and world == 1:
-        # what ONE rank of an N > 1 run does, on this GPU alone: the C5 shard of rank 1 -- 125 000 frames from a 2-frame
-        # halo, same seed, same engine call, hence the same kernel -- so that the driver's 1 -> N curve compares like
-        # with like (the N = 1 headline is C2, another workload and another kernel).  Outside the timed region.
-        ns = args.shard
-        sp3, sd3, pcm3 = eng.alloc_frames(ns + 2)
-        eng.generate(SEED_C5, ns - 2, ns + 2, sp3, sd3)
-        for _ in range(5):
-            eng.decode(sp3, sd3, pcm3, chunk_frames=args.chunk)
-        torch.cuda.synchronize()
-        reps = 20
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        w0 = time.perf_counter()
-        a.record()
-        for _ in range(reps):
-            eng.decode(sp3, sd3, pcm3, chunk_frames=args.chunk)
-        b.record()
-        torch.cuda.synchronize()
-        wall = (time.perf_counter() - w0) / reps
-        ms = a.elapsed_time(b) / reps
-        ach = (ns + 2) * ALGO_BYTES_PER_FRAME / (ms * 1e-3) / 1e9
-        out["c5_shard_1gpu"] = {
-            "workload": "C5 shard of rank 1 (BASELINE configs[4]): frames [%d, %d) of the 1M-frame stream decoded from a 2-frame "
-                        "halo, one GPU, what each rank of an N > 1 run does per step" % (ns, 2 * ns),
-            "frames": ns, "halo_frames": 2, "kernel": eng.last_launch_kernel(), "avg_launch_ms": round(ms, 4),
-            "ms_per_step": round(wall * 1e3, 4), "frames_per_s": round(ns / wall, 1),
-            "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
-        del sp3, sd3, pcm3
-
-    if args.big and world == 1:
-        # kernel quality at throughput size (SURVEY 8d C5 shard scale), outside the timed region
-        nb = args.big
-        sp2, sd2, pcm2 = eng.alloc_frames(nb)
-        eng.generate(0x5EED0000C5, 0, nb, sp2, sd2)
-        for _ in range(10):                             # (sustained-throughput figure: the first launches after the 28 us
-            eng.decode(sp2, sd2, pcm2, chunk_frames=args.chunk)   #  C2 launches run 5 % slower than the steady state)
-        torch.cuda.synchronize()
-        reps = 20
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            eng.decode(sp2, sd2, pcm2, chunk_frames=args.chunk)
-        b.record()
-        torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / reps
-        ach = nb * ALGO_BYTES_PER_FRAME / (ms * 1e-3) / 1e9
-        out["roofline_large_batch"] = {
-            "frames": nb, "avg_launch_ms": round(ms, 4), "frames_per_s": round(nb / (ms * 1e-3), 1),
-            "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-            "fp32_tflops": round(nb * ALGO_FLOP_PER_FRAME / (ms * 1e-3) / 1e12, 2),
-            "fp32_frac": round(nb * ALGO_FLOP_PER_FRAME / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
-        }
-        # float PCM (pdmp3_hip_decode_frames_f32): 3584 algorithmic bytes per granule-channel
-        # (1152 spectra + 128 side + 2304 float PCM) = 14336 per stereo frame
-        pcmf = torch.empty((nb, 2304), dtype=torch.float32, device=eng.tdev)
-        for _ in range(2):
-            eng.decode_f32(sp2, sd2, pcmf, chunk_frames=args.chunk)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            eng.decode_f32(sp2, sd2, pcmf, chunk_frames=args.chunk)
-        b.record()
-        torch.cuda.synchronize()
-        msf = a.elapsed_time(b) / reps
-        achf = nb * 14336 / (msf * 1e-3) / 1e9
-        out["roofline_float_pcm"] = {"frames": nb, "avg_launch_ms": round(msf, 4), "frames_per_s": round(nb / (msf * 1e-3), 1),
-                                     "algorithmic_bytes_per_frame": 14336, "achieved": round(achf, 2), "peak": HBM_PEAK_GBS,
-                                     "unit": "GB/s", "frac": round(achf / HBM_PEAK_GBS, 5), "kernel": "k_decode<false, true, 1>"}
-        del sp2, sd2, pcm2, pcmf
+    out.update(extra_legs)
+    if from_idle:
+        out["from_idle_gpu"] = from_idle
+    if extra_legs:
+        out["clocks"] = ("busy: the legs on launches of 125 000 / 131 072 frames (c5_shard_1gpu, roofline_large_batch, roofline_float_pcm: "
+                         "about 60 ms of launches) ran before the warm-up and the timed region; --shard 0 --big 0 times the headline from an idle GPU")
 
     if world == 1 and not args.no_e2e:
         # beside the hot-path metric: the same path fed from a bitstream in host memory to PCM in host memory (host scan ->
