@@ -90,7 +90,11 @@ long long pdmp3_amd_bulk_decode(pdmp3_amd_bulk* b, const unsigned char* mp3, siz
 /* Optional: PCM buffers in pinned host memory.  When the `pcm` given to the decode calls lies in such a buffer the
  * GPU downloads every window straight into it (mono frames packed on the way) and the host never touches the
  * samples; any other memory works too, through a staging buffer and a copy by the pool.  A DEVICE pointer (hipMalloc,
- * a torch tensor) is accepted as `pcm` as well: the PCM then never leaves the GPU. */
+ * a torch tensor) is accepted as `pcm` as well: the PCM then never leaves the GPU -- the decode kernel stores it there
+ * itself when the destination is memory of the decoder's device and takes whole frames (copies otherwise).  The decoder
+ * works on HIP streams of its own, which do NOT wait for the caller's: whatever the caller still has in flight on the
+ * buffer (a fill, an earlier consumer) must be complete before the decode call, and a consumer on another stream starts
+ * after pdmp3_amd_bulk_decode / pdmp3_amd_bulk_wait has returned. */
 void* pdmp3_amd_pcm_alloc(size_t bytes);
 void pdmp3_amd_pcm_free(void* p);
 

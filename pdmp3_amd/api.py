@@ -290,7 +290,9 @@ class BulkDecoder:
     def decode_into_device(self, mp3, out_tensor, wait=True):
         """PCM into a torch int16 tensor on the GPU.  Windows of one channel count go from the engine's buffer to the
         tensor without leaving the device; a window that mixes mono and stereo frames, or the one the tensor ends in,
-        is staged in pinned host memory and copied from there."""
+        is staged in pinned host memory and copied from there.  The decoder writes from its own HIP streams, which do not
+        wait for torch's: work of the caller's that is still pending on the tensor (a fill, say) must be through first
+        (torch.cuda.synchronize()), and with wait=False the tensor is the decoder's until wait() has returned."""
         a = _as_u8(mp3)
         rate, ch = C.c_long(0), C.c_int(0)
         f = self.lib.pdmp3_amd_bulk_decode if wait else self.lib.pdmp3_amd_bulk_decode_async

@@ -336,6 +336,7 @@ def test_pcm_stays_on_the_device(streams, host_huffman):
         for k in ("cbr128_js_441", "js_32k_256"):          # queued back to back
             want = ref.decode(streams[k])
             o = torch.zeros(want.size, dtype=torch.int16, device="cuda")
+            torch.cuda.synchronize()                        # (the fill must be through: the decoder's streams do not wait for torch's)
             b.decode_into_device(streams[k], o, wait=False)
             outs.append((k, o, want))
         b.wait()
@@ -510,6 +511,7 @@ def test_split_scan_is_the_default_for_device_destinations(monkeypatch):
     try:
         want = ref.decode(mp3)
         out = torch.zeros(total // 2, dtype=torch.int16, device="cuda:0")
+        torch.cuda.synchronize()                            # (the decoder's streams do not wait for torch's: the fill must be through)
         dev.decode_into_device(mp3, out)
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), want)
@@ -551,6 +553,7 @@ def test_decoders_side_by_side_into_device_memory():
     want = [ref.decode(f) for f in files]
     ref.close()
     outs = [torch.zeros(max(s, 2) // 2, dtype=torch.int16, device="cuda:0") for s in sizes]
+    torch.cuda.synchronize()                                # (the decoders' streams do not wait for torch's: the fills must be through)
     errs = []
 
     def work(j):
