@@ -49,7 +49,7 @@ timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 2> /dev/null > $OUT/
 } > $OUT/split_scan_runs.txt 2>&1; cat $OUT/split_scan_runs.txt | cut -c1-300
 PDMP3_BULK_TRACE=2 timeout 300 python3 tools/bulk_bench.py --frames 137813 --threads 4 --reps 3 --device-out 2>&1 > /dev/null | grep -E "^  ->|submitter:|split scan|pre-pass in" | tail -45 > $OUT/split_scan_trace.txt
 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/bulk_tl -o tl -- python3 tools/bulk_bench.py --frames 137813 --threads 4 --reps 4 --device-out > /dev/null 2> $OUT/bulk_tl.log; python3 tools/bulk_timeline.py $OUT/bulk_tl/tl > $OUT/bulk_timeline.txt 2>&1; cat $OUT/bulk_timeline.txt | cut -c1-260
-{ PDMP3_BULK_SCAN_THREADS=8 PDMP3_BULK_SUB_FRAMES=64 timeout 900 python3 tools/soak_bulk.py 20; PDMP3_BULK_SCAN_THREADS=4 PDMP3_BULK_PREPASS_THREADS=5 timeout 900 python3 tools/soak_bulk.py 15; } > $OUT/soak_split.txt 2>&1; tail -3 $OUT/soak_split.txt
+{ PDMP3_BULK_SCAN_THREADS=8 PDMP3_BULK_SUB_FRAMES=64 timeout 900 python3 tools/soak_bulk.py 20; PDMP3_BULK_SCAN_THREADS=4 PDMP3_BULK_PREPASS_THREADS=5 timeout 900 python3 tools/soak_bulk.py 15; timeout 300 python3 tools/soak_device.py 40; } > $OUT/soak_split.txt 2>&1; tail -3 $OUT/soak_split.txt
 # the same for a C5-shard-sized launch
 pmcb() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 tools/pmc_target.py 131072 0 > /dev/null 2> $OUT/$name.log; echo "$name rc=$?"; }
 pmcb big_fetch FETCH_SIZE
