@@ -2138,6 +2138,7 @@ struct par_scan {
    * scanner produces windows at half the rate the GPU takes them.  Window by window, w is ready at
    * w x [pre-pass time per window] + [scan time of one window], always ahead of the GPU's w x 157 us.) */
   int sub;                    /* frames of a private window (the engine's windows are made of several: par_drive) */
+  int one_window;             /* by its first frame's size the stream fits one window of the engine */
   long long next_win;         /* the next window nobody has taken yet */
   long long stitched;         /* windows the stitcher has taken */
   span_snap* snap; long long snap_cap;   /* by window index; [0] unused (a fresh handle) */
@@ -2656,6 +2657,7 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
   struct par_scan* P = (struct par_scan*)calloc(1, sizeof *P);
   if (!P) return NULL;
   P->b = b; P->mp3 = mp3; P->n = n; P->K = K; P->J = J; P->sub = sub; P->t0 = now_s();
+  P->one_window = est + est / 16 <= b->cap;
   if (!b->pc && !(b->pc = pc_new())) { free(P); return NULL; }
   par_cache* pc = b->pc;
   P->rec_cap = (long long)(n / 96) + 8;                 /* (no Layer III frame is shorter than 96 bytes) */
@@ -2843,8 +2845,11 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
       while (b->bits_n < b->cap) {                      /* what else is there, or worth waiting for */
         int e2;
         pre_window* more = par_next_window_wait(P, w, &e2, 0);
-        if (!more && e2 == 0 && bulk_in_flight(b) >= 2) more = par_next_window_wait(P, w, &e2, 50e-6);
-        if (!more) { if (e2 == 0 && bulk_in_flight(b) >= 2) continue; break; }
+        /* (a stream that fits one slot goes up as ONE window -- a file of a few minutes: every window costs the GPU its
+         *  150 us whatever it holds, and in a corpus the GPU has the file before to work on meanwhile) */
+        const int hold = e2 == 0 && !more && (P->one_window || bulk_in_flight(b) >= 2);
+        if (hold) more = par_next_window_wait(P, w, &e2, 50e-6);
+        if (!more) { if (e2 == 0 && (P->one_window || bulk_in_flight(b) >= 2)) continue; break; }
         if (trace2) pw_trace(more, w, t_start, t3, now_s());
         w++;
         if (!par_fits(b, more)) { held = more; break; }
