@@ -1370,6 +1370,7 @@ struct bulk {
   int cap;                            /* frames a window holds */
   int target;                         /* frames the one-thread scan gives a window (<= cap) */
   int ramp_on;                        /* this stream's first windows are short (win_ramp): long streams only */
+  int cur_target;                     /* this stream's window size: the slot's capacity for a stream that fits one slot, else `target` */
   int trace2; double tr_t0;           /* $PDMP3_BULK_TRACE >= 2: per-window lines, times from the stream's start */
   int count_only;                     /* scan: stage A alone */
   int bits_mode;                      /* main data goes to the device undecoded (pdmp3_hip_stream_submit_bits) */
@@ -1782,7 +1783,7 @@ static int bulk_at_limit(const struct bulk* b) { return b->limit_frames && b->fr
 static int win_ramp(const struct bulk* b) { return b->ramp_on && b->bits_mode && b->pool_mode && !b->win_sink && b->target >= 1024 && b->target % 8 == 0; }
 static int win_frames(const struct bulk* b, long long w) {
   if (b->win_sink) return b->cap;                 /* (a split scan's private window) */
-  if (!win_ramp(b) || w >= 4) return b->target;
+  if (!win_ramp(b) || w >= 4) return b->cur_target > 0 ? b->cur_target : b->target;
   return w < 2 ? b->target / 8 : w == 2 ? b->target / 4 : b->target / 2;
 }
 static pre_window* pw_new_in(struct par_cache* pc, int cap, long long index);
@@ -3170,11 +3171,18 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
    * in five windows instead of two, and a window costs the GPU 150 us whatever its size (C4 corpus to pageable memory:
    * 5.2 -> 4.0 M frames/s with the ramp on every file) */
   b->ramp_on = 0;
+  b->cur_target = b->target;
   if (n >= 4 && mp3[0] == 0xff && (mp3[1] & 0xf0) == 0xf0) {
     frame_header H0;
     header_fields(((uint32_t)mp3[0] << 24) | ((uint32_t)mp3[1] << 16) | ((uint32_t)mp3[2] << 8) | mp3[3], &H0);
     if (H0.id == 1 && H0.layer == 3 && H0.bitrate_index != 0 && H0.bitrate_index != 15 && H0.sfreq != 3)
-      b->ramp_on = (long long)(n / frame_bytes(&H0)) >= 8LL * b->target;
+    {
+      const long long est0 = (long long)(n / frame_bytes(&H0));
+      b->ramp_on = est0 >= 8LL * b->target;
+      /* a file of a few minutes that fits one slot goes up as one window instead of a full one and a remainder (4096 + 32
+       * frames, say: the remainder costs the GPU as much as the full one) */
+      if (b->bits_mode && est0 > b->target && est0 + est0 / 16 <= b->cap) b->cur_target = b->cap;
+    }
   }
   /* The split scan pays where the scan is the bound: with the PCM left in device memory (13 -> 18 M frames/s).  Towards host
    * memory the PCIe link bounds the pipeline and the extra threads only take memory bandwidth from the DMA engines
