@@ -2,7 +2,8 @@
 """bench.py -- throughput of the Layer-III transform hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU)
+  (N > 1: one rank per GPU -- either launched by torch.distributed.run, or, as the plain command, bench.py starts
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...` itself as a child and relays its line)
 
 A "step" is one pass of the hot path (pdmp3_hip_decode_frames: requantize ->
 reorder -> stereo -> antialias -> IMDCT/overlap -> frequency inversion ->
@@ -186,6 +187,34 @@ def measured_traffic(frames, n_halo):
         return None, None
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher around it: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N bench.py <the same arguments>` as a child process (one rank per GPU, rendezvous on 127.0.0.1 at a
+    free port) and relay what it prints.  Called before anything of this process has imported torch or initialised HIP:
+    the children are ordinary fresh processes, nothing is exec'ed from a process that holds the GPU."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in r.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)                              # the launcher's chatter, kept off the one-line contract
+    if lines:
+        print(lines[-1])
+    sys.stdout.flush()
+    sys.exit(r.returncode if r.returncode else (0 if lines else 1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,10 +227,18 @@ def main():
     ap.add_argument("--cpu-all-seconds", type=float, default=6.0, help="all-host-cores leg of the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bitstream-to-PCM extra")
-    ap.add_argument("--from-idle", action="store_true", help="N = 1: also time the W + K launches once before any other GPU work (from_idle_gpu)")
+    ap.add_argument("--from-idle", dest="from_idle", action="store_true", default=True,
+                    help="N = 1: also time the W + K launches once before any other GPU work (from_idle_gpu; the default)")
+    ap.add_argument("--no-from-idle", dest="from_idle", action="store_false",
+                    help="skip from_idle_gpu (a rocprofv3 summary of the command then holds the headline's launches only)")
     ap.add_argument("--shard", type=int, default=SHARD_FRAMES, help="N = 1: frames of the extra C5-shard figure (0 = skip)")
     ap.add_argument("--big", type=int, default=131072, help="frames of the extra large-batch roofline probe (0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the plain command (`python bench.py --gpus N ...`): start the N ranks here, as a FRESH child -- this process has
+        # not imported torch nor touched the GPU, and never will -- and hand on its one JSON line and its exit code
+        return self_launch(args.gpus)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -215,10 +252,8 @@ def main():
     import pdmp3_amd
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d under a launcher with WORLD_SIZE=%d: running %d ranks" % (args.gpus, world, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # PDMP3_BENCH_BACKEND=gloo + several ranks on one GPU is only for exercising this code path on a
@@ -279,6 +314,9 @@ def main():
                 "frames": ns, "halo_frames": 2, "kernel": eng.last_launch_kernel(), "avg_launch_ms": round(ms, 4),
                 "ms_per_step": round(wall * 1e3, 4), "frames_per_s": round(ns / wall, 1),
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
+            # kept for the parity check that runs after the headline's timed region: the PCM of the shard's first 256 frames
+            # (the 2 halo frames in front of them are decode-and-discard) and of its last 2
+            extra["_c5_pcm"] = (ns, pcm3[2:2 + min(256, ns)].cpu().numpy(), pcm3[-2:].cpu().numpy())
             del sp3, sd3, pcm3
 
         if args.big and world == 1:
@@ -326,8 +364,9 @@ def main():
 
         return extra
 
-    # --from-idle: the same W + K launches once from an idle GPU, reported beside the headline (`from_idle_gpu`): what the
-    # clocks are worth (off by default: the rocprofv3 summary of the default command should hold the headline's launches only)
+    # from_idle_gpu: the same W + K launches once from an idle GPU, reported beside the headline -- the figure that compares
+    # like with like across rounds (rounds 1-3 timed the headline this way); --no-from-idle leaves it out, so that a
+    # rocprofv3 summary of the command holds the headline's launches only
     from_idle = None
     if world == 1 and args.from_idle and (args.shard or args.big):
         for _ in range(args.warmup):
@@ -341,8 +380,11 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         wall = time.perf_counter() - w0
-        from_idle = {"avg_launch_ms": round(e0.elapsed_time(e1) / args.steps, 5), "ms_per_step": round(wall / args.steps * 1e3, 5),
+        ms_i = e0.elapsed_time(e1) / args.steps
+        ach_i = n * ALGO_BYTES_PER_FRAME / (ms_i * 1e-3) / 1e9
+        from_idle = {"avg_launch_ms": round(ms_i, 5), "ms_per_step": round(wall / args.steps * 1e3, 5),
                      "frames_per_s": round(n * args.steps / wall, 1),
+                     "achieved": round(ach_i, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_i / HBM_PEAK_GBS, 5),
                      "what": "the same %d warm-up + %d timed launches as the headline, run first, before any other GPU work of this process" % (args.warmup, args.steps)}
     extra_legs = larger_launches() if world == 1 else {}
 
@@ -469,6 +511,26 @@ def main():
         except Exception as e:
             parity = {"error": repr(e)}
     out["parity"] = parity
+    c5_pcm = extra_legs.pop("_c5_pcm", None)
+    if c5_pcm is not None:
+        # the C5 shard's own parity (after every timed region): its first 256 frames -- the shard boundary, decoded from the
+        # 2-frame halo -- and its last 2 against the CPU decoder started cold 8 frames earlier (the state is 2 deep)
+        try:
+            import numpy as np
+            dec, against, o = parity_checker()
+            ns, head, tail = c5_pcm
+            got, want = [], []
+            for a, b, g in ((ns, ns + head.shape[0], head), (2 * ns - 2, 2 * ns, tail)):
+                w0 = max(0, a - 8)
+                sp_h, sd_h = o.generate(SEED_C5, w0, b - w0)
+                sd_h["frame"][0] |= 0x40                            # PDMP3_FR_RESET
+                want.append(dec.decode(sp_h, sd_h)[a - w0:])
+                got.append(g)
+            extra_legs["c5_shard_1gpu"]["parity"] = parity_of(
+                np.concatenate(got), np.concatenate(want), head.shape[0] + 2, against,
+                "the shard's first %d frames (behind the 2-frame halo) and its last 2" % head.shape[0])
+        except Exception as e:
+            extra_legs["c5_shard_1gpu"]["parity"] = {"error": repr(e)}
     if per_rank is not None:
         out["ranks"] = per_rank
         out["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0
@@ -484,7 +546,8 @@ def main():
         out["from_idle_gpu"] = from_idle
     if extra_legs:
         out["clocks"] = ("busy: the legs on launches of 125 000 / 131 072 frames (c5_shard_1gpu, roofline_large_batch, roofline_float_pcm: "
-                         "about 60 ms of launches) ran before the warm-up and the timed region; --shard 0 --big 0 times the headline from an idle GPU")
+                         "about 60 ms of launches) ran before the warm-up and the timed region; `from_idle_gpu` = the same W + K launches measured first, "
+                         "from an idle GPU: the figure to compare across rounds")
 
     if world == 1 and not args.no_e2e:
         # beside the hot-path metric: the same path fed from a bitstream in host memory to PCM in host memory (host scan ->

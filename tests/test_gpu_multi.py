@@ -46,6 +46,21 @@ def test_bench_two_ranks_gathered_pcm_equals_unsharded(engine, tmp_path):
     assert np.array_equal(got, pcm.cpu().numpy()), "sharded + gathered PCM differs from the unsharded decode"
 
 
+def test_bench_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher around it (the driver's N = 1 command with another N): bench.py
+    starts the ranks itself as a fresh child torch.distributed.run and relays the one JSON line and the exit code"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PDMP3_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "3000"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["config"]["frames_per_gpu"] == 3000
+    assert [x["rank"] for x in d["ranks"]] == [0, 1] and d["parity"]["ok"] and d["value"] > 0
+
+
 def test_corpus_dealt_over_devices(oracle):
     """C4's partitioning (whole files per GPU, largest first) through per-device decoders"""
     import torch

@@ -164,33 +164,47 @@ def test_gpu_large_synthetic_properties(engine):
 
 
 def test_gpu_c5_shards(engine, oracle):
-    """BASELINE configs[4] (C5) at reduced scale on one GPU: the 1M-frame synthetic stream is cut into 8
-    frame-range shards (pdmp3_amd.sharding), each generated on device from its counter-based generator and
-    decoded from a 2-frame halo; parity against the oracle on every frame within +-2 of a shard boundary and
-    on a prefix of each shard (the oracle warms up on 8 frames before the window it checks).
-    PDMP3_FULL_C5=1 uses the full 125 000 frames per shard."""
+    """BASELINE configs[4] (C5) at its stated size on one GPU: the 1 000 000-frame synthetic stream is cut into 8
+    frame-range shards of 125 000 frames (pdmp3_amd.sharding), each generated on device from its counter-based
+    generator and decoded from a 2-frame halo; parity against the oracle on every frame within +-2 of
+    a shard boundary and on a 4096-frame prefix of each shard.  The oracle decodes the prefixes in pieces of 512
+    frames on a thread pool, each started cold 8 frames in front of the frames it is compared on (the synthesis
+    state reaches 2 granules back)."""
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     from pdmp3_amd.sharding import shard_with_halo, frame_range
     seed = 0x5EED0000C5
-    per = 125000 if os.environ.get("PDMP3_FULL_C5") else 20000
+    per, prefix, piece = 125000, 4096, 512
     world, total = 8, 8 * per
-    for rank in range(world):
-        first, count, halo = shard_with_halo(total, rank, world)
-        lo, hi = frame_range(total, rank, world)
-        spectra, side, pcm = engine.alloc_frames(count)
-        engine.generate(seed, first, count, spectra, side)
-        engine.decode(spectra, side, pcm)
-        torch.cuda.synchronize()
-        got = pcm[halo:].cpu().numpy()                      # frames lo .. hi-1
-        assert got.shape[0] == hi - lo == per
-        for a, b in ((lo, lo + 48), (hi - 4, hi)):          # shard start (incl. prefix) and shard end
-            w0 = max(0, a - 8)
-            sp, sd = oracle.generate(seed, w0, b - w0)
-            if w0 > 0:
-                sd["frame"][0] |= 0x40                      # oracle starts cold; its first 8 frames are discarded
-            want = oracle.decode(sp, sd)[a - w0:]
-            assert_pcm_close(got[a - lo:b - lo], want, 1, "shard %d frames %d..%d" % (rank, a, b))
-        del spectra, side, pcm
+    oracle.decode(*oracle.generate(seed, 0, 1))            # the oracle's lazily built tables, once, on this thread
+
+    def want_of(ab):
+        a, b = ab
+        w0 = max(0, a - 8)
+        sp, sd = oracle.generate(seed, w0, b - w0)
+        if w0 > 0:
+            sd["frame"][0] |= 0x40                          # oracle starts cold; its first 8 frames are discarded
+        return oracle.decode(sp, sd)[a - w0:]
+
+    checked = 0
+    with ThreadPoolExecutor(max(1, min(16, len(os.sched_getaffinity(0))))) as pool:
+        for rank in range(world):
+            first, count, halo = shard_with_halo(total, rank, world)
+            lo, hi = frame_range(total, rank, world)
+            assert (count, halo) == ((per + 2, 2) if rank else (per, 0))
+            spectra, side, pcm = engine.alloc_frames(count)
+            engine.generate(seed, first, count, spectra, side)
+            engine.decode(spectra, side, pcm)
+            torch.cuda.synchronize()
+            assert pcm.shape[0] - halo == hi - lo == per
+            # shard start (the boundary's +2 side and the 4096-frame prefix) and shard end (the next boundary's -2 side)
+            wins = [(a, min(a + piece, lo + prefix)) for a in range(lo, lo + prefix, piece)] + [(hi - 4, hi)]
+            got = [pcm[halo + a - lo:halo + b - lo].cpu().numpy() for a, b in wins]
+            del spectra, side, pcm
+            for (a, b), g, w in zip(wins, got, pool.map(want_of, wins)):
+                assert_pcm_close(g, w, 1, "shard %d frames %d..%d" % (rank, a, b))
+                checked += b - a
+    assert checked == world * (prefix + 4)
 
 
 @pytest.mark.parametrize("chunk", [0, 1, 2, 3, 7])
