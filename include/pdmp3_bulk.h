@@ -58,7 +58,14 @@ pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
  * with 16 / 12 / fewer usable CPUs), PDMP3_BULK_SUB_FRAMES=n (frames of a private window; by default 1024 for streams of
  * 16384 frames and more, 512 from 8192, 256 below),
  * PDMP3_BULK_GATHER_THREADS=n (0 .. 8 helper threads for the copies of the windows' main data into the pinned upload
- * buffers; 6 by default with 8 scanners, 3 with fewer, 0 without). */
+ * buffers; 6 by default with 8 scanners, 3 with fewer, 0 without).
+ * Thread footprint of ONE decoder with a device destination on a host with 16 usable CPUs or more, for its lifetime
+ * (the threads are started when a stream first needs them and then sleep on a job queue between streams): 8 scanners,
+ * 5 hop threads + the pre-pass, 6 gather helpers, the submitter and the copy-out pool (`threads`) -- about 25.  Only
+ * the scanners are shared out between decoders of one process that scan at the same time (above); gather helpers,
+ * hop threads and the pre-pass are per decoder, and their waits yield the CPU (sched_yield) rather than sleep.  A
+ * process that keeps many decoders (one per GPU and more) should size them with the variables above --
+ * PDMP3_BULK_SCAN_THREADS=2 PDMP3_BULK_PREPASS_THREADS=1 PDMP3_BULK_GATHER_THREADS=1 is 6 threads per decoder. */
 /* host_huffman = 0 (what pdmp3_amd_bulk_new gives unless PDMP3_BULK_HOST_HUFFMAN=1 is set): the host only runs
  * the sequential scan and ships side info + reservoir snapshots; scalefactors, Huffman and the frame-to-frame
  * merge run on the device (pdmp3_hip_stream_submit_bits) and the pool just copies PCM out.  host_huffman = 1:

@@ -110,7 +110,8 @@ void pdmp3_hip_destroy(pdmp3_hip_ctx* ctx);
 /* Environment read by pdmp3_hip_create() (none of them changes a result):
  *   PDMP3_HIP_CHAIN=0             every launch takes the chunk kernel (a chunk of frames per wave, halo)
  *   PDMP3_HIP_GRAN_MAX=n          largest launch, in frames, that takes the granule kernel (default 12288 on an MI355X)
- *   PDMP3_HIP_RING_MIN=n          launches of at least n frames take the persistent granule kernel k_decode_p (default 0 = never)
+ *   PDMP3_HIP_RING_MIN=n          launches of at least n frames take the persistent granule kernel k_decode_p (default 0 = never;
+ *                                 only in a library built with -DPDMP3_WITH_RING_KERNEL: the default build does not carry the kernel)
  *   PDMP3_HIP_DIRECT_MAX=n        largest batch of a stream object that runs on the pinned host buffers directly (default 32; 0: never)
  *   PDMP3_HIP_SF_HINT=0|1|2       sampling frequency whose line table the granule kernel keeps in LDS (default 0 = 44.1 kHz;
  *                                 granules of another one read the table from memory)
@@ -153,7 +154,8 @@ size_t pdmp3_hip_state_bytes(void);
  *
  * Asynchronous on `stream`.
  */
-#define PDMP3_HIP_CHUNK_PERSISTENT (-3)   /* chunk_frames: take the persistent granule kernel whatever the launch size (tests, tools) */
+#define PDMP3_HIP_CHUNK_PERSISTENT (-3)   /* chunk_frames: take the persistent granule kernel whatever the launch size (tests, tools);
+                                             PDMP3_HIP_EINVAL from a library built without -DPDMP3_WITH_RING_KERNEL (the default) */
 int pdmp3_hip_decode_frames(pdmp3_hip_ctx* ctx,
                             const int16_t* d_spectra,
                             const pdmp3_gc_side* d_side,

@@ -97,6 +97,19 @@ class Oracle:
         n = spectra.shape[0]
         return self.lib.orc_time_decode(_ptr(spectra), _ptr(side), n, reps)
 
+    def huffman_quad(self, iso, bits, nbits):
+        """one count1 quadruple through the restatement's huffman_decode with the quirk mask `iso` (table number 33):
+        ((v, w, x, y), bits consumed, status)"""
+        out = (C.c_int * 5)()
+        res = self.lib.orc_huffman_quad(C.c_uint(iso), C.c_uint(bits), C.c_int(nbits), out)
+        return tuple(out[:4]), out[4], res
+
+    def huffman_nodes(self):
+        n = C.c_uint(0)
+        self.lib.orc_huffman_nodes.restype = C.POINTER(C.c_uint16)
+        p = self.lib.orc_huffman_nodes(C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
     def pow43(self):
         return np.ctypeslib.as_array(self.lib.orc_table_pow43(), shape=(8207,)).copy()
 
@@ -249,6 +262,20 @@ class Reference:
 
     def time_decode(self, spectra, side, reps=1):
         return self.lib.ref_time_decode(self.h, _ptr(spectra), _ptr(side), spectra.shape[0], reps)
+
+    def huffman_table_words(self, first, n):
+        """words [first, first + n) of the reference's g_huffman_table (P:235-515), from its memory"""
+        out = np.zeros(n, dtype=np.uint16)
+        self.lib.ref_huffman_table_words.restype = C.c_uint
+        total = self.lib.ref_huffman_table_words(C.c_uint(first), C.c_uint(n), _ptr(out))
+        return out, int(total)
+
+    def huffman_quad_at(self, offset, bits, nbits):
+        """the reference's own Huffman_Decode (P:1593-1643) on table number 33 with its tree pointer set `offset`
+        words into g_huffman_table: ((v, w, x, y), bits consumed, status)"""
+        out = (C.c_int * 5)()
+        res = self.lib.ref_huffman_quad_at(C.c_uint(offset), C.c_uint(bits), C.c_int(nbits), out)
+        return tuple(out[:4]), out[4], res
 
     def decode_buffer_like_cli(self, mp3: bytes, tap_frames=0):
         buf = np.frombuffer(mp3, dtype=np.uint8)

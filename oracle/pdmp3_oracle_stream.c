@@ -556,3 +556,23 @@ size_t orc_decode_buffer_like_cli(const unsigned char* mp3, size_t n, unsigned c
   orc_stream_delete(s);
   return total;
 }
+
+/* One count1 quadruple decoded by the restatement's own huffman_decode (P:1593-1643) with the quirk mask `iso`
+ * (ORC_ISO_TABLE33 selects the last 31 nodes of the table, the reference's + 2261 otherwise: H1), from the `nbits`
+ * (<= 32) bits of `bits`, msb first, then zeroes.  out = {v, w, x, y, bits consumed}.  Lets the tests compare the
+ * switch with the reference's own tree walk over its own array (oracle/ref_harness.c: ref_huffman_quad_at). */
+int orc_huffman_quad(unsigned iso, unsigned bits, int nbits, int* out) {
+  orc_stream* s = orc_stream_new();
+  if (!s) return ORC_ERR;
+  s->iso = iso;
+  for (int i = 0; i < 8; i++) s->main_vec[i] = 0;
+  for (int i = 0; i < nbits && i < 32; i++)
+    if ((bits >> (nbits - 1 - i)) & 1u) s->main_vec[i >> 3] |= 0x80u >> (i & 7);
+  set_main_pos(s, 0);
+  int x = 0, y = 0, v = 0, w = 0;
+  const int res = huffman_decode(s, 33, &x, &y, &v, &w);
+  out[0] = v; out[1] = w; out[2] = x; out[3] = y; out[4] = (int)main_pos(s);
+  orc_stream_delete(s);
+  return res;
+}
+const uint16_t* orc_huffman_nodes(unsigned* n) { *n = (unsigned)(sizeof ot_huff_nodes / sizeof ot_huff_nodes[0]); return ot_huff_nodes; }

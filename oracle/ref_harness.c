@@ -214,3 +214,35 @@ size_t ref_decode_buffer_like_cli(const unsigned char* mp3, size_t n, unsigned c
   ref_delete(id);
   return total;
 }
+
+/* --- the tree the standard means by table 33 sits in the reference's own array, 31 words
+ * from g_huffman_table + 2773 (P:512-515), where g_huffman_main[33] fails to point (P:569 says + 2261).  The two
+ * accessors below let the tests pin the PDMP3_ISO_TABLE33 code book on the reference's memory and on the
+ * reference's own tree walk. --- */
+
+/* words [first, first + n) of g_huffman_table (P:235-515) as they sit in this library's memory; returns the
+ * number of words in the array */
+unsigned ref_huffman_table_words(unsigned first, unsigned n, unsigned short* out) {
+  const unsigned total = (unsigned)(sizeof g_huffman_table / sizeof g_huffman_table[0]);
+  for (unsigned i = 0; i < n && first + i < total; i++) out[i] = g_huffman_table[first + i];
+  return total;
+}
+
+/* the reference's Huffman_Decode (P:1593-1643) for table number 33 with g_huffman_main[33] pointed, for the length
+ * of this call, `offset` words into g_huffman_table; the bit stream is the `nbits` (<= 32) bits of `bits`, msb
+ * first, then zeroes.  out = {v, w, x, y, bits consumed}; returns Huffman_Decode's status */
+int ref_huffman_quad_at(unsigned offset, unsigned bits, int nbits, int* out) {
+  pdmp3_handle* id = ref_new();
+  for (int i = 0; i < 8; i++) id->g_main_data_vec[i] = 0;
+  for (int i = 0; i < nbits && i < 32; i++)
+    if ((bits >> (nbits - 1 - i)) & 1u) id->g_main_data_vec[i >> 3] |= 0x80u >> (i & 7);
+  Set_Main_Pos(id, 0);
+  const hufftables saved = g_huffman_main[33];
+  g_huffman_main[33].hufftable = g_huffman_table + offset;
+  int32_t x = 0, y = 0, v = 0, w = 0;
+  const int res = Huffman_Decode(id, 33, &x, &y, &v, &w);
+  g_huffman_main[33] = saved;
+  out[0] = v; out[1] = w; out[2] = x; out[3] = y; out[4] = (int)Get_Main_Pos(id);
+  ref_delete(id);
+  return res;
+}

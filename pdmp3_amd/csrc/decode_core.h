@@ -31,6 +31,16 @@
 #include <string.h>
 #include "../../include/pdmp3_hip.h"
 
+namespace pdmp3 {
+struct ConstBank;
+}
+
+// ---------------------------------------------------------------------------
+// THE ONE PLACE where the device build (hipcc) and the host test build (g++, tests/host_emul) differ: function
+// attributes, the cross-lane primitives, the matrix instruction, vector types, the address-space-typed pointers and the
+// three spots where the device form is an instruction the host has to spell out (RTZ multiplies, v_med3, readfirstlane of
+// a pointer).  Everything below this block is one text for both.
+// ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
 #define PD_FN __device__ __forceinline__
 #define PD_SLOW_FN __device__ __attribute__((noinline))      /* a real call: its registers and spills are its own */
@@ -74,6 +84,50 @@
 // a flag word that is KNOWN to be in LDS, read / written as such (through a struct handed to a called function the
 // compiler loses the address space and falls back to flat accesses, which wait for every counter)
 #define PD_LDS_FLAG(p) (*(volatile __attribute__((address_space(3))) unsigned*)(p))
+#define PD_BALLOT(c) ((unsigned long long)__builtin_amdgcn_ballot_w64(c))
+// Pointer to the constant bank: address-space-4 (constant) typed so that wave-uniform reads are scalar loads, and
+// "laundered" through an empty asm once per granule so that the compiler cannot hoist the ~800 loop-invariant scalar
+// loads out of the granule loop (which spills hundreds of SGPRs into VGPR lanes).  PD_LAUNDER does the same for any
+// scalar-register value.
+namespace pdmp3 {
+typedef const __attribute__((address_space(4))) ConstBank* BankPtr;
+}
+#define PD_LAUNDER(p) asm volatile("" : "+s"(p))
+// a pointer argument of a CALLED function arrives in vector registers: back into scalar ones
+#define PD_UNIFORM_PTR(T, p) ((T)(((unsigned long long)(unsigned)PD_UNIFORM((int)((unsigned long long)(p) >> 32)) << 32) | (unsigned)PD_UNIFORM((int)(unsigned long long)(p))))
+// index into a table whose out-of-range reads are harmless on the device (somewhere in LDS) and replaced by the caller
+#define PD_UNCHECKED_INDEX(v, lo, n) (v)
+#define PD_FMED3(x, lo, hi) __builtin_amdgcn_fmed3f((x), (lo), (hi))
+namespace pdmp3 {
+// two / four binary32 values in consecutive registers: element-wise + - * on the pairs are the packed VALU forms
+// (v_pk_add_f32, v_pk_mul_f32: one issue slot for two results; each element rounded exactly like the scalar operation)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x4_f32 (layout: "MFMA formulation" below)
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// v_permlane32_swap_b32: lanes 32..63 of a exchange with lanes 0..31 of b
+__device__ __forceinline__ void permlane32_swap(int& a, int& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+  a = (int)r[0];
+  b = (int)r[1];
+}
+// p[t] = p[t] * 32767 rounded TOWARD ZERO, t = 0..17: the FP32 rounding mode is switched to RTZ and back inside one
+// asm statement, the compiler never sees another mode (see pcm_convert18)
+__device__ __forceinline__ void mul18_rtz_32767(float* p) {
+#define PD_M(n) "v_mul_f32 %" #n ", 0x46fffe00, %" #n "\n\t"
+  asm volatile(
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "s_nop 1\n\t"
+      PD_M(0) PD_M(1) PD_M(2) PD_M(3) PD_M(4) PD_M(5) PD_M(6) PD_M(7) PD_M(8)
+      PD_M(9) PD_M(10) PD_M(11) PD_M(12) PD_M(13) PD_M(14) PD_M(15) PD_M(16) PD_M(17)
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t"
+      "s_nop 1"
+      : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]),
+        "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15]), "+v"(p[16]), "+v"(p[17]));
+#undef PD_M
+}
+}  // namespace pdmp3
 #else
 namespace pdmp3 {
 namespace emu {   // provided by tests/host_emul/wave_emul.h: one wave = 64 fibers
@@ -82,6 +136,7 @@ void wave_sync();                             // returns when all 64 lanes have 
 void wave_yield();                            // all 64 lanes arrive, the other live waves run
 float shfl_xor(float v, int mask);
 bool any(bool c);
+unsigned long long ballot(bool c);
 void mfma16(float a, float b, float* cd);     // v_mfma_f32_16x16x4_f32: cd[4] in and out
 void permlane32_swap(int* a, int* b);         // v_permlane32_swap_b32 vdst = a, src = b
 }  // namespace emu
@@ -108,6 +163,41 @@ void permlane32_swap(int* a, int* b);         // v_permlane32_swap_b32 vdst = a,
 #define PD_SLEEP() ::pdmp3::emu::wave_yield()    /* the other live waves of the workgroup run (a lone wave comes straight back) */
 #define PD_SETPRIO(x) ((void)0)
 #define PD_LDS_FLAG(p) (*(volatile unsigned*)(p))
+#define PD_BALLOT(c) (::pdmp3::emu::ballot(c))
+namespace pdmp3 {
+typedef const ConstBank* BankPtr;
+}
+#define PD_LAUNDER(p) ((void)0)
+#define PD_UNIFORM_PTR(T, p) (p)
+#define PD_UNCHECKED_INDEX(v, lo, n) ((unsigned)((v) - (lo)) < (unsigned)(n) ? (v) : 0)
+namespace pdmp3 {
+typedef float f32x2 __attribute__((vector_size(8)));
+typedef unsigned short u16x2 __attribute__((vector_size(4)));
+typedef float f32x4 __attribute__((vector_size(16)));
+static inline f32x4 mfma16(float a, float b, f32x4 c) {
+  float cd[4] = {c[0], c[1], c[2], c[3]};
+  emu::mfma16(a, b, cd);
+  return (f32x4){cd[0], cd[1], cd[2], cd[3]};
+}
+static inline void permlane32_swap(int& a, int& b) { emu::permlane32_swap(&a, &b); }
+// v_med3_f32 with the hardware's NaN rule: any NaN among the operands -> min3 of the others
+static inline float pd_fmed3_host(float x, float lo, float hi) {
+  if (x != x) return lo < hi ? lo : hi;
+  return x < lo ? lo : (x > hi ? hi : x);
+}
+// the binary32 product x * 32767 rounded toward zero: the binary64 product is exact; round it to nearest and step back
+// when that went away from zero
+static inline void mul18_rtz_32767(float* p) {
+  for (int t = 0; t < 18; t++) {
+    const double d = (double)p[t] * 32767.0;
+    float f = (float)d;
+    if (f == f && !__builtin_isinf(f) && __builtin_fabs((double)f) > __builtin_fabs(d)) f = __builtin_nextafterf(f, 0.0f);
+    else if (__builtin_isinf(f) && !__builtin_isinf(p[t])) f = __builtin_copysignf(0x1.fffffep+127f, f);   // RTZ never rounds up to infinity
+    p[t] = f;
+  }
+}
+}  // namespace pdmp3
+#define PD_FMED3(x, lo, hi) (::pdmp3::pd_fmed3_host((x), (lo), (hi)))
 #endif
 
 // development only (tools/ab_pmc.sh): phases switched off for instruction-count / timing experiments -- results are wrong
@@ -138,18 +228,7 @@ struct ConstBank {
   uint16_t sfb_s[3][16];  // g_sf_band_indices[].s
 };
 
-// Pointer to the bank.  On the device it is address-space-4 (constant) typed so
-// that wave-uniform reads are scalar loads, and it is "laundered" through an
-// empty asm once per granule so that the compiler cannot hoist the ~800
-// loop-invariant scalar loads out of the granule loop (which spills hundreds of
-// SGPRs into VGPR lanes).
-#if defined(__HIPCC__)
-typedef const __attribute__((address_space(4))) ConstBank* BankPtr;
-#define PD_LAUNDER(p) asm volatile("" : "+s"(p))
-#else
-typedef const ConstBank* BankPtr;
-#define PD_LAUNDER(p) ((void)0)
-#endif
+// (BankPtr, the pointer to the bank, and PD_LAUNDER: top of the file)
 
 // Large tables in global memory (L2-resident; copied to LDS per chunk where hot).
 struct GlobalTables {
@@ -246,15 +325,6 @@ PD_FN GranuleInfo granule_info(const WaveData& L) {
 PD_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 PD_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-// two binary32 values in a register pair: element-wise + - * on them are the packed VALU forms (v_pk_add_f32,
-// v_pk_mul_f32: one issue slot for two results; each element rounded exactly like the scalar operation)
-#if defined(__HIPCC__)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-#else
-typedef float f32x2 __attribute__((vector_size(8)));
-typedef unsigned short u16x2 __attribute__((vector_size(4)));
-#endif
 
 // ---------------------------------------------------------------------------
 // chunk prologue: per-lane constants, LDS copies of hot tables
@@ -560,12 +630,8 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
 // Same arithmetic per line as ph_requant: (t1 t2) (+-t3), P:2132; MS in binary64 like P:1923-1926.
 // ---------------------------------------------------------------------------
 PD_FN float pow43z_at(const TabLds& S, int v) {
-#if defined(__HIPCC__)
-  // |v| >= 128 reads past the table (somewhere in LDS or beyond it: harmless); such values are replaced by the caller
-  return S.pow43z[kPow43Small + v];
-#else
-  return S.pow43z[kPow43Small + ((unsigned)(v + kPow43Small) < 2u * kPow43Small ? v : 0)];
-#endif
+  // |v| >= 128 reads past the table on the device (somewhere in LDS or beyond it: harmless); such values are replaced by the caller
+  return S.pow43z[kPow43Small + PD_UNCHECKED_INDEX(v, -kPow43Small, 2 * kPow43Small)];
 }
 // the full table for the values outside -128 .. 127 (rare): every lane issues its loads unconditionally (entry 0 when
 // its value is small -- one shared line), so that all of a group's gathers are in flight together
@@ -684,17 +750,7 @@ PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalT
 //              registers ARE the A fragments (row = t = j, k = 4 kq + r arrives as k-step r) -- the hybrid output
 //              never goes through LDS and the matrixing costs 8 instead of 16 MFMAs per row tile.
 // ---------------------------------------------------------------------------
-#if defined(__HIPCC__)
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-PD_FN f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-#else
-typedef float f32x4 __attribute__((vector_size(16)));
-PD_FN f32x4 mfma16(float a, float b, f32x4 c) {
-  float cd[4] = {c[0], c[1], c[2], c[3]};
-  emu::mfma16(a, b, cd);
-  return (f32x4){cd[0], cd[1], cd[2], cd[3]};
-}
-#endif
+// (mfma16(a, b, c) and f32x4: top of the file)
 
 // alias reduction in place (P:1706-1732): lane (ch, sb) owns the boundary below subband sb
 PD_FN void ph_antialias(int lane, WaveData& L, BankPtr cb, bool only_first = false) {   // only_first: boundary sb 0 | 1 alone
@@ -902,48 +958,35 @@ PD_FN int pcm_from_sum(float sum) {
 // one asm statement, the compiler never sees another mode.  Then: clamp to +-32767 in binary32 (exact), convert,
 // and the reference's wrap-around: a product at or beyond 2^31 (sum > 65538, the largest binary32 whose product
 // is still below 2^31) or a NaN comes out of cvttsd2si as INT32_MIN and is then clipped to -32767.
-PD_FN void pcm_convert18(const float* sum, int* out) {
-#if defined(__HIPCC__)
+// `wrap` (wave-uniform): some lane of the wave holds a sum beyond 65538 or a NaN -- the per-sample form of the wrap-around.
+// Pure per lane: the host build tests it by itself against pcm_from_sum (tests/test_pipeline_emul.py).
+PD_FN void pcm_convert18_lane(const float* sum, int* out, bool wrap) {
   float p[18];
   PD_UNROLL for (int t = 0; t < 18; t++) p[t] = sum[t];
-#define PD_M(n) "v_mul_f32 %" #n ", 0x46fffe00, %" #n "\n\t"
-  asm volatile(
-      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-      "s_nop 1\n\t"
-      PD_M(0) PD_M(1) PD_M(2) PD_M(3) PD_M(4) PD_M(5) PD_M(6) PD_M(7) PD_M(8)
-      PD_M(9) PD_M(10) PD_M(11) PD_M(12) PD_M(13) PD_M(14) PD_M(15) PD_M(16) PD_M(17)
-      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t"
-      "s_nop 1"
-      : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]),
-        "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15]), "+v"(p[16]), "+v"(p[17]));
-#undef PD_M
-  // The wrap-around is a property of signals driven 65 000 x past full scale: one test for the wave (the largest of the
-  // 18 sums of every lane; fmax passes over NaNs, which v_med3 turns into -32767 by itself -- its NaN rule is min3)
-  // instead of a compare and a select per sample.
-  float mx = sum[0];
-  PD_UNROLL for (int t = 1; t < 18; t++) mx = __builtin_fmaxf(mx, sum[t]);
-  if (PD_ANY(!(mx <= 65538.0f))) {
+  mul18_rtz_32767(p);
+  if (wrap) {
     PD_UNROLL for (int t = 0; t < 18; t++) {
-      const int n = (int)__builtin_amdgcn_fmed3f(p[t], -32767.0f, 32767.0f);
+      const int n = (int)PD_FMED3(p[t], -32767.0f, 32767.0f);
       out[t] = (sum[t] <= 65538.0f) ? n : -32767;
     }
   } else {
-    PD_UNROLL for (int t = 0; t < 18; t++) out[t] = (int)__builtin_amdgcn_fmed3f(p[t], -32767.0f, 32767.0f);
+    // (a NaN sum gives a NaN product, which v_med3 turns into -32767 by itself -- its NaN rule is min3: the same result
+    //  as the branch above, whatever the wave-wide test saw)
+    PD_UNROLL for (int t = 0; t < 18; t++) out[t] = (int)PD_FMED3(p[t], -32767.0f, 32767.0f);
   }
-#else
-  for (int t = 0; t < 18; t++) out[t] = pcm_from_sum(sum[t]);
-#endif
 }
-
-// v_permlane32_swap_b32: lanes 32..63 of a exchange with lanes 0..31 of b
-PD_FN void permlane32_swap(int& a, int& b) {
-#if defined(__HIPCC__)
-  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
-  a = (int)r[0];
-  b = (int)r[1];
-#else
-  emu::permlane32_swap(&a, &b);
-#endif
+// The wrap-around is a property of signals driven 65 000 x past full scale: one test for the wave (the largest of the
+// 18 sums of every lane) instead of a compare and a select per sample.  fmax passes over NaNs: a NaN among finite sums
+// does not raise `wrap` -- and need not: both forms of pcm_convert18_lane give -32767 for it (the host test checks
+// exactly that, lane by lane, against pcm_from_sum).  Called by every lane of the wave (idle ones: act = false).
+PD_FN bool pcm_wave_wraps(const float* sum, bool act) {
+  bool big = false;
+  if (act) {
+    float mx = sum[0];
+    PD_UNROLL for (int t = 1; t < 18; t++) mx = __builtin_fmaxf(mx, sum[t]);
+    big = !(mx <= 65538.0f);
+  }
+  return PD_ANY(big);
 }
 
 // the 18 sums of a lane (P:2028) -> PCM of the granule: conversion, channel pairing, stores
@@ -951,11 +994,12 @@ template <bool F32>
 PD_FN void pcm_emit(int lane, WaveData& L, int nch, bool act, const float* sum, int16_t* pcm_g, float* pcmf_g) {
   const int i = lane & 31;
   int out[18];
+  const bool wrap = F32 ? false : pcm_wave_wraps(sum, act);
   if (act) {
     if (F32) {
       // float PCM: the binary32 `sum` of P:2028 itself, before the scaling to int16
       PD_UNROLL for (int t = 0; t < 18; t++) out[t] = (int)f2u(sum[t]);
-    } else pcm_convert18(sum, out);
+    } else pcm_convert18_lane(sum, out, wrap);
   }
   if (F32) {
     if (nch == 2) {
@@ -1041,10 +1085,9 @@ PD_FN void ph_store(int lane, WaveData& L, int nch, int16_t* pcm_g, bool emit) {
 
 // Highest frame in [f_lo, f_hi) that has two channels or carries the RESET flag, or -1.  Wave-uniform.
 PD_FN int last_stereo_or_reset(const pdmp3_gc_side* side, int f_lo, int f_hi) {
-#if defined(__HIPCC__)
   // 256 frames per step: four independent byte loads per lane in flight (a step costs one memory round trip; an
   // all-mono batch makes its last chunk walk the whole batch, so the steps had better be few)
-  const int lane = threadIdx.x & 63;
+  const int lane = PD_LANE();
   for (int base = f_hi - 256;; base -= 256) {
     bool hit[4];
     PD_UNROLL for (int q = 0; q < 4; q++) {
@@ -1056,18 +1099,11 @@ PD_FN int last_stereo_or_reset(const pdmp3_gc_side* side, int f_lo, int f_hi) {
       }
     }
     PD_UNROLL for (int q = 3; q >= 0; q--) {
-      const unsigned long long m = __ballot(hit[q]);
+      const unsigned long long m = PD_BALLOT(hit[q]);
       if (m) return base + 64 * q + 63 - __builtin_clzll(m);
     }
     if (base <= f_lo) return -1;
   }
-#else
-  for (int f = f_hi - 1; f >= f_lo; --f) {
-    const uint8_t b = reinterpret_cast<const uint8_t*>(side + (size_t)f * 4)[7];
-    if (((b & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 || (b & PDMP3_FR_RESET)) return f;
-  }
-  return -1;
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1645,12 +1681,9 @@ PD_FN void ph_window_hist(int lane, WaveData& L, const LaneRegs& R, const float*
 template <bool F32>
 PD_SLOW_FN void gran_slow_chunk(DecodeArgs a, GlobalTables T, BankPtr cb, int f, WaveData* L, TabLds* S, GranPos second, bool publish,
                                 LaneRegs* state_only) {
-#if defined(__HIPCC__)
   // (arguments of a called function arrive in vector registers; the constant bank's address has to be scalar again)
-  const unsigned long long u = (unsigned long long)cb;
-  cb = (BankPtr)(((unsigned long long)(unsigned)PD_UNIFORM((int)(u >> 32)) << 32) | (unsigned)PD_UNIFORM((int)u));
+  cb = PD_UNIFORM_PTR(BankPtr, cb);
   f = PD_UNIFORM(f);
-#endif
   gran_tabs_wait(second);
   run_chunk<false, false, F32, false>(a, T, cb, f, *L, *S, publish ? &second : nullptr, state_only);
 }
@@ -1928,9 +1961,7 @@ PD_FN void run_granule_ring(const DecodeArgs& a, const GlobalTables& T, BankPtr 
     // (a turn is run_granule's straight-line body as it is: the per-lane constants are asked for again every turn -- they
     //  come from the L1 / L2 -- because held across the loop they cost what the chunk kernel pays: spills and moves; the
     //  table pointers are laundered so that the compiler does not hoist those loads out of the loop)
-#if defined(__HIPCC__)
-    asm volatile("" : "+s"(Tl.taps), "+s"(Tl.frag_long), "+s"(Tl.frag_mat));
-#endif
+    PD_LAUNDER(Tl.taps); PD_LAUNDER(Tl.frag_long); PD_LAUNDER(Tl.frag_mat);
     if (a.prof) { const unsigned long long t_ = PD_CLOCK(); if (lane == 0) a.prof[(size_t)g * kProfSlots] = t_; }
     LaneRegs pf;
     ph_prefetch(lane, pf, a.spectra + (size_t)g * 1152, a.side + (size_t)g * 2);

@@ -89,9 +89,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   run_granule_wave<F32>(a, T, (BankPtr)&c_bank, g, L[w], S, gp, pf);
 }
 
+// OPT-IN BUILD (make EXTRA=-DPDMP3_WITH_RING_KERNEL): measured 1.66 x slower than the engine's own choice at every size
+// (profiles/r04_ring_bench.txt), so the default library does not carry its two 7 k-instruction kernels.
 // Persistent form (decode_core.h run_granule_ring): a workgroup of 16 waves goes round a contiguous range of
 // `frames_per_wg` frames, one granule per wave and turn; constants and tables once per wave / workgroup, hand-over through
 // the LDS mailboxes as a ring, one halo per range.  One workgroup per CU (158 KB of LDS), four waves per SIMD.
+#if defined(PDMP3_WITH_RING_KERNEL)
 template <bool F32>
 __global__ __launch_bounds__(64 * 16) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_decode_p(DecodeArgs a, GlobalTables T, int frames_per_wg) {
   constexpr int W = 16;
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(64 * 16) __attribute__((amdgpu_waves_per_eu(4, 4)))
   const GranPos gp{L, mb, w, W, &tabs_ready, 1, 2 * f0, 2 * f1};
   run_granule_ring<F32>(a, T, (BankPtr)&c_bank, L[w], S, gp, f0, f1);
 }
+#endif
 
 // same kernel with shader-clock stamps after every phase (tools/phase_profile.py)
 __global__ __launch_bounds__(64, PDMP3_WAVES_PER_EU) void k_decode_prof(DecodeArgs a, GlobalTables T) {
@@ -669,6 +673,13 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   if ((plain || ring_prof) && c->chain_mode != 0 && n_frames >= 16 &&
       (chunk_frames_arg == PDMP3_HIP_CHUNK_PERSISTENT || ring_prof || (chunk_frames_arg <= 1 && chunk_frames_arg >= 0 && c->ring_min_frames > 0 && n_frames >= c->ring_min_frames)))
     ring = true;
+#if !defined(PDMP3_WITH_RING_KERNEL)
+  if (ring && (chunk_frames_arg == PDMP3_HIP_CHUNK_PERSISTENT || ring_prof)) {
+    if (own_tmp) (void)hipFreeAsync(d_state_tmp, s);
+    return fail(PDMP3_HIP_EINVAL, "this build of libpdmp3_hip.so does not carry the persistent kernel (make -C pdmp3_amd/csrc EXTRA=-DPDMP3_WITH_RING_KERNEL)", hipSuccess);
+  }
+  ring = false;
+#endif
   const bool gran_prof = d_prof && chunk_frames_arg == -2;          // (development: the granule kernel with per-wave stamps)
   if (!ring && (plain || gran_prof) && c->chain_mode != 0 && chunk_frames_arg <= 1 && n_frames <= c->gran_max_frames) {
     // one granule per wave (run_granule): tails and matrixing rows are handed from wave to wave, no halo.  Waits for
@@ -683,6 +694,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   }
   GlobalTables T{c->d_pow43, c->d_linetab, c->d_win, c->d_frag, c->d_frag + 10 * 64, c->d_frag + 20 * 64, c->d_frag + 28 * 64, c->d_tab_image};
   const int nchunks = (n_frames + a.chunk_frames - 1) / a.chunk_frames;
+#if defined(PDMP3_WITH_RING_KERNEL)
   if (ring) {
     // one workgroup per CU while a range keeps at least 8 frames (= one turn of the 16 waves)
     const int cus = c->cus > 0 ? c->cus : 256;
@@ -693,7 +705,9 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
     c->last_kind = PDMP3_HIP_LAUNCH_PERSISTENT;
     if (d_pcm_f32) hipLaunchKernelGGL((k_decode_p<true>), dim3(n_wgs), dim3(64 * 16), 0, s, a, T, per);
     else hipLaunchKernelGGL((k_decode_p<false>), dim3(n_wgs), dim3(64 * 16), 0, s, a, T, per);
-  } else if (gran) {
+  } else
+#endif
+  if (gran) {
     // (workgroups of 8 waves while that gives every CU at most one of them)
     const bool small = 2 * n_frames <= c->wave_slots_gran / 2;
     const int W = small ? 8 : 16;

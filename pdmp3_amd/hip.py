@@ -156,6 +156,16 @@ class Engine:
             self.h, spectra.data_ptr(), side.data_ptr(), n,
             state.data_ptr() if state is not None else None, pcm.data_ptr(), int(chunk_frames), self._stream()))
 
+    def has_persistent_kernel(self):
+        """was the library built with -DPDMP3_WITH_RING_KERNEL (k_decode_p, an opt-in since round 5)?  Asked by trying:
+        a launch with chunk_frames = PDMP3_HIP_CHUNK_PERSISTENT fails cleanly in a build without it."""
+        import torch
+        sp, sd, pcm = self.alloc_frames(16)
+        sp.zero_(); sd.zero_()
+        rc = self.lib.pdmp3_hip_decode_frames(self.h, sp.data_ptr(), sd.data_ptr(), 16, None, pcm.data_ptr(), -3, self._stream())
+        torch.cuda.synchronize()
+        return rc == 0
+
     def decode_f32(self, spectra, side, pcm_f32, n_frames=None, state=None, chunk_frames=0):
         """float PCM (pdmp3_hip_decode_frames_f32): pcm_f32 = float32 tensor, 2304 floats per frame"""
         n = int(spectra.shape[0]) if n_frames is None else int(n_frames)

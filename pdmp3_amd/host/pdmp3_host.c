@@ -1390,7 +1390,7 @@ struct bulk {
    * submitter thread copies them just before the window goes up (pool_gather).  What the scanner itself needs from
    * the pool before that -- a few KB per window, pool_materialize -- it copies early (pool_ensure). */
   struct pool_copy { const uint8_t* src; uint32_t dst, n; } *gath[BULK_SLOTS], *gath_cur;
-  int gath_n;
+  int gath_n, gath_cap;                           /* entries written / entries gath_cur has room for */
   int sky[RESERVOIR_BYTES + 1], sky_n;            /* frames of the segment no later frame has topped yet (pdmp3_row_desc.up) */
   pdmp3_row_desc* rec_desc; size_t rec_pool_cap;  /* parse-only pool mode (host tests): caller memory, one window */
   bulk_window win[2];
@@ -1794,7 +1794,7 @@ static int pool_literal(struct bulk* b, size_t dst, const uint8_t* src, size_t n
   memcpy(b->res_dst + dst, src, n);
   if (!b->win_sink) return PDMP3_OK;
   pre_window* w = b->pw_cur;
-  if (w->arena_len + n > PW_ARENA_BYTES || b->gath_n >= b->cap + BULK_GATH_EXTRA - 1) return PDMP3_ERR;
+  if (w->arena_len + n > PW_ARENA_BYTES || b->gath_n >= b->gath_cap - 1) return PDMP3_ERR;
   memcpy(w->arena + w->arena_len, src, n);
   struct pool_copy* g = &b->gath_cur[b->gath_n++];
   g->src = w->arena + w->arena_len; g->dst = (uint32_t)dst; g->n = (uint32_t)n;
@@ -1810,7 +1810,7 @@ static int bits_open_window(struct bulk* b) {
     b->pw_cur = pw_new_in(b->pc, b->cap, b->stream_win);
     if (!b->pw_cur) return PDMP3_ERR;
     b->bits_dst = b->pw_cur->bits; b->desc_dst = b->pw_cur->desc;
-    b->gath_cur = (struct pool_copy*)b->pw_cur->gath;
+    b->gath_cur = (struct pool_copy*)b->pw_cur->gath; b->gath_cap = b->cap + BULK_GATH_EXTRA;
     b->res_dst = b->priv_pool;
     b->pool_cap = (size_t)b->cap * RESERVOIR_BYTES + PDMP3_POOL_SLACK_BYTES;
     return PDMP3_OK;
@@ -1823,6 +1823,7 @@ static int bits_open_window(struct bulk* b) {
       free(b->gath[0]);
       b->gath_cur = b->gath[0] = (struct pool_copy*)malloc((b->rec_cap + 1) * sizeof(struct pool_copy));
       if (!b->gath_cur) return PDMP3_ERR;
+      b->gath_cap = b->rec_cap + 1;
     }
     return PDMP3_OK;
   }
@@ -1844,7 +1845,7 @@ static int bits_open_window(struct bulk* b) {
   if (b->pool_mode) {
     b->desc_dst = pdmp3_hip_stream_slot_rowdesc(b->hs, b->bits_slot);
     b->pool_cap = pdmp3_hip_stream_pool_bytes(b->hs);
-    b->gath_cur = b->gath[b->bits_slot];
+    b->gath_cur = b->gath[b->bits_slot]; b->gath_cap = b->cap + BULK_GATH_EXTRA * (PAR_MAX_BATCH + 1);
     if (!b->desc_dst || !b->gath_cur) return PDMP3_ERR;
   }
   return b->bits_dst && b->res_dst ? PDMP3_OK : PDMP3_ERR;
@@ -1916,6 +1917,10 @@ static int fill_reservoir_pool(pdmp3_handle* id, unsigned size, unsigned begin) 
   b->cur_explicit = 0;
   b->cur_staged = 1;
   if (id->vsrc) {                                 /* the bytes stay where they are for now (pool_gather) */
+    /* the copy list holds one entry per frame and BULK_GATH_EXTRA literals (a split scan's private window; an engine
+     * window that private windows are stitched into: that many per private window): never write past it, whatever
+     * PW_ARENA_BYTES / RESERVOIR_BYTES let through (the window fails; the stream then takes the one-thread scan) */
+    if (b->gath_n >= b->gath_cap) { b->failed = 1; return PDMP3_ERR; }
     struct pool_copy* g = &b->gath_cur[b->gath_n++];
     g->src = id->vsrc + id->vfed - ring_filled(id); g->dst = (uint32_t)b->pool_tail; g->n = size;
     id->istart = (id->istart + size) % INBUF_SIZE;
@@ -2326,7 +2331,7 @@ static inline void hop_prefetch(const unsigned char* mp3, size_t x, unsigned fb)
 static long long seg_wait_start(pre_seg* S) {           /* (found within microseconds of the thread's start) */
   long long v;
   while ((v = __atomic_load_n(&S->x_start, __ATOMIC_ACQUIRE)) == -2) {
-    if (S->P->abort) return -1;
+    if (S->P->abort || S->P->quit) return -1;
     sched_yield();
   }
   return v;
@@ -2394,7 +2399,7 @@ static int par_prepass(struct par_scan* P) {
   long long part_end = P->J > 1 ? seg_wait_start(&P->seg[1]) : -3;     /* where part 0 ends */
   if (part_end == -1) goto out;
   for (;;) {
-    if (P->abort) goto out;
+    if (P->abort || P->quit) goto out;                  /* (given up, or the stitcher has left: rc stays "not regular") */
     if (next < P->snap_cap && f == (long long)next * P->sub) {        /* window `next` starts here */
       span_snap* S = &P->snap[next];
       S->frame = f; S->istart = h->istart; S->iend = h->iend; S->processed = h->processed; S->vfed = h->vfed; S->fed = fed;
@@ -2433,7 +2438,7 @@ static int par_prepass(struct par_scan* P) {
         pre_seg* G = &P->seg[part];
         if (part_i < __atomic_load_n(&G->count, __ATOMIC_ACQUIRE)) { q = &G->rec[part_i++]; break; }
         const int st = __atomic_load_n(&G->state, __ATOMIC_ACQUIRE);
-        if (st == SEG_RUNNING) { if (P->abort) goto out; const double tw = now_s(); sched_yield(); P->t_pre_wait += now_s() - tw; continue; }
+        if (st == SEG_RUNNING) { if (P->abort || P->quit) goto out; const double tw = now_s(); sched_yield(); P->t_pre_wait += now_s() - tw; continue; }
         if (part_i < __atomic_load_n(&G->count, __ATOMIC_ACQUIRE)) continue;   /* (its last records came with the state) */
         if (st != SEG_AT_NEXT || part + 1 >= P->J) goto out;           /* a header the regular path does not take, or a guess that was none */
         part++; part_i = 0;
@@ -2479,7 +2484,8 @@ static void* par_prepass_thread(void* arg) {
   struct par_scan* P = (struct par_scan*)arg;
   const double t0 = now_s();
   (void)par_prepass(P);
-  P->t_prepass = now_s() - t0;
+  const double dt = now_s() - t0;
+  pthread_mutex_lock(&P->mu); P->t_prepass = dt; pthread_mutex_unlock(&P->mu);     /* (read by the stitcher's trace) */
   return NULL;
 }
 
@@ -2710,8 +2716,10 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
 static int par_finish(struct par_scan* P) {
   par_cache* pc = P->b->pc;
   pthread_mutex_lock(&P->mu); P->quit = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
-  /* (the pre-pass and the scanners leave on `quit`; the hop threads look at abort only -- they are through long before
-   * unless the stitcher gave up early: told to stop once the verdict is taken, which the others' end no longer changes) */
+  /* (the pre-pass -- its loop and its waits for the hop threads -- and the scanners leave on `quit` or `abort`; the hop
+   * threads look at abort only -- they are through long before unless the stitcher gave up early: told to stop once the
+   * verdict is taken, which the others' end no longer changes.  A pre-pass that left on `quit` before its end reports
+   * "not regular": the verdict below is then -1, as for any stream the stitcher did not see to its end) */
   crew_wait(pc, &P->jobs_left);
   pthread_mutex_lock(&P->mu); const int ok = !P->irregular && !P->abort; P->abort = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
   crew_wait(pc, &P->hops_left);
@@ -2870,7 +2878,7 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
     if (!engine_ok) { pthread_mutex_lock(&P->mu); P->abort = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu); break; }
   }
   pw_free(held);
-  const double t_pre = P->t_prepass;
+  pthread_mutex_lock(&P->mu); const double t_pre = P->t_prepass; pthread_mutex_unlock(&P->mu);
   const long long nf = P->n_frames;
   if (trace2) par_trace_prepass(P);
   uint32_t last_hw = 0;
@@ -3033,7 +3041,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
   b->target = target;
   {
     /* split scan (par_drive): 8 scanners where the process has 16 CPUs (they live for the few milliseconds of a stream's
-     * scan), fewer on smaller quotas, none below 6 CPUs; PDMP3_BULK_SCAN_THREADS = 0 .. 8 overrides (0: one thread, as before) */
+     * scan), fewer on smaller quotas, none below 6 CPUs; PDMP3_BULK_SCAN_THREADS = 0 .. PAR_MAX_SCANNERS (16) overrides (0: one thread, as before) */
     const int c = usable_cpus();
     const char* e = getenv("PDMP3_BULK_SCAN_THREADS");
     b->scan_threads = e ? atoi(e) : (c >= 16 ? 8 : c >= 12 ? 4 : c >= 6 ? 2 : 0);

@@ -190,3 +190,14 @@ extern "C" void emul_rows_by_word(const pdmp3_row_desc* desc, const uint8_t* poo
       memcpy(rows + (size_t)f * PDMP3_RESERVOIR_BYTES + 4 * w, &v, 4);
     }
 }
+
+// pcm_convert18_lane (the device's int16 conversion: RTZ product, v_med3 clamp, the reference's wrap-around) for n groups
+// of 18 sums, both forms (`wrap` = what the wave-wide test would have said), beside pcm_from_sum (P:2028-2031 restated
+// with the binary64 product): the test compares the three, NaNs, infinities and sums beyond the wrap point included
+extern "C" void emul_pcm_convert18(const float* sums, int n_groups, int* out_fast, int* out_wrap, int* out_exact) {
+  for (int g = 0; g < n_groups; ++g) {
+    pcm_convert18_lane(sums + 18 * g, out_fast + 18 * g, false);
+    pcm_convert18_lane(sums + 18 * g, out_wrap + 18 * g, true);
+    for (int t = 0; t < 18; ++t) out_exact[18 * g + t] = pcm_from_sum(sums[18 * g + t]);
+  }
+}

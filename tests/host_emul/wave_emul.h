@@ -168,6 +168,16 @@ inline bool any(bool c) {
   return r;
 }
 
+inline unsigned long long ballot(bool c) {
+  Wave& w = g_wave;
+  w.flag[w.cur] = c;
+  wave_sync();
+  unsigned long long r = 0;
+  for (int l = 0; l < kLanes; l++) r |= (unsigned long long)(w.flag[l] ? 1 : 0) << l;
+  wave_sync();
+  return r;
+}
+
 // v_permlane32_swap_b32 vdst = a, src = b: lanes 32..63 of a exchange with lanes 0..31 of b
 inline void permlane32_swap(int* a, int* b) {
   Wave& w = g_wave;

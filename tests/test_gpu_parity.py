@@ -335,6 +335,8 @@ def test_gpu_persistent_granule_kernel_equals_independent_chunks(engine, name):
     engine makes ranges of >= 8 frames, so 64-frame corpora are 8 workgroups"""
     import torch
     from test_pipeline_emul import _mode_switch_records
+    if not engine.has_persistent_kernel():
+        pytest.skip("libpdmp3_hip.so built without -DPDMP3_WITH_RING_KERNEL (the default since round 5: the kernel lost its benchmark)")
     for sp, sd in (corpus.case(name), _mode_switch_records()):
         dsp, dsd = engine.upload(sp, sd)
         n = sp.shape[0]

@@ -267,3 +267,32 @@ def test_emul_persistent_granule_kernel_states_and_mode_switches(emul, oracle):
     sp4 = np.concatenate([a, b, a]); sd4 = np.concatenate([sa, sb, sa])
     for hint in (0, 1):
         assert np.array_equal(emul_decode_ring(emul, sp4, sd4, 8, sf_hint=hint), emul_decode(emul, sp4, sd4, 0)), hint
+
+
+def test_emul_int16_conversion_lane_form_equals_the_reference_conversion(emul):
+    """pcm_convert18_lane -- binary32 product rounded toward zero, v_med3 clamp (NaN -> min3), the wrap-around beyond
+    65538 -- against pcm_from_sum (P:2028-2031: binary64 product, cvttsd2si, clip to +-32767), per sample: the
+    per-sample form (`wrap`) everywhere, the fast form wherever no sample of the wave is beyond the wrap point -- NaNs
+    included, which the wave-wide test (an fmax) does not see: both forms give -32767 for them"""
+    rng = np.random.default_rng(7)
+    n = 18 * 4000
+    s = np.concatenate([
+        rng.standard_normal(n).astype(np.float32),                              # around full scale
+        (rng.standard_normal(n) * 1e-3).astype(np.float32),
+        (rng.integers(-40000, 40000, n) / np.float32(32767.0)).astype(np.float32),   # products next to integers
+        np.nextafter((rng.integers(-40000, 40000, n) / np.float32(32767.0)).astype(np.float32), np.float32(0)),
+        (rng.standard_normal(n) * 3e4).astype(np.float32),                      # up to and beyond the wrap point
+        rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32),  # any bit pattern: NaNs, infinities, denormals
+    ])
+    special = np.array([np.nan, np.inf, -np.inf, 65538.0, np.nextafter(np.float32(65538.0), np.float32(1e9)), -65538.0, -70000.0,
+                        1.0, -1.0, 0.0, -0.0, 32767.0 / 32767.0, 3.4e38, -3.4e38, 1e-45, 65537.99, 2.0, -2.0], np.float32)
+    s = np.concatenate([s, special]).astype(np.float32)
+    assert s.size % 18 == 0
+    g = s.size // 18
+    fast = np.zeros(s.size, np.int32); wrap = np.zeros(s.size, np.int32); exact = np.zeros(s.size, np.int32)
+    with np.errstate(all="ignore"):
+        emul.emul_pcm_convert18(_p(s), g, _p(fast), _p(wrap), _p(exact))
+    assert np.array_equal(wrap, exact)
+    ok = ~(s > np.float32(65538.0))                     # NaNs stay in: the fast form must get them right by itself
+    assert np.array_equal(fast[ok], exact[ok])
+    assert (exact[np.isnan(s)] == -32767).all() and (fast[np.isnan(s)] == -32767).all()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box round: smoke, GPU parity tests, bench.
 # Usage (from the repo root): gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tag]'
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

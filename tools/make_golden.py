@@ -55,6 +55,22 @@ def main():
     np.savez_compressed(os.path.join(gold, "c2_prefix.npz"), pcm_head=pcm[:32],
                         pcm_sha_2048=np.array([sha(pcm)]), input_sha=np.array([sha(sp), sha(sd)]))
     print("c2 2048-frame pcm sha", sha(pcm)[:16])
+    # the tree of the REAL table 33 -- the last 31 words of the reference's g_huffman_table, read
+    # out of the compiled reference's memory -- and what the reference's own Huffman_Decode makes of every 8-bit pattern
+    # (4-bit code word + up to 4 sign bits) when its table-33 pointer is set there
+    import json
+    words, total = ref.huffman_table_words(2773, 31)
+    assert total == 2804
+    quads = {}
+    for bits in range(256):
+        (v, w, x, y), used, res = ref.huffman_quad_at(2773, bits, 8)
+        assert res == 0
+        quads["%02x" % bits] = [v, w, x, y, used]
+    json.dump({"what": "g_huffman_table[2773..2804) of /root/reference/pdmp3.c as compiled into oracle/_ref, and the reference's "
+                       "Huffman_Decode over that tree for every 8-bit input: [v, w, x, y, bits consumed]",
+               "first": 2773, "total_words": total, "words": [int(t) for t in words], "quads": quads},
+              open(os.path.join(gold, "huff_table33.json"), "w"), indent=0)
+    print("table 33 tree:", " ".join("%04x" % t for t in words))
 
 
 if __name__ == "__main__":
