@@ -104,6 +104,8 @@ namespace pdmp3 {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// element-wise fused multiply-add of two pairs: v_pk_fma_f32 (each element = fmaf)
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 // v_mfma_f32_16x16x4_f32 (layout: "MFMA formulation" below)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // v_permlane32_swap_b32: lanes 32..63 of a exchange with lanes 0..31 of b
@@ -112,20 +114,25 @@ __device__ __forceinline__ void permlane32_swap(int& a, int& b) {
   a = (int)r[0];
   b = (int)r[1];
 }
-// p[t] = p[t] * 32767 rounded TOWARD ZERO, t = 0..17: the FP32 rounding mode is switched to RTZ and back inside one
-// asm statement, the compiler never sees another mode (see pcm_convert18)
-__device__ __forceinline__ void mul18_rtz_32767(float* p) {
-#define PD_M(n) "v_mul_f32 %" #n ", 0x46fffe00, %" #n "\n\t"
+// p[t] = x[t] * 32767 rounded TOWARD ZERO, t = 0..17: the FP32 rounding mode is switched to RTZ and back inside one asm
+// statement (two of them, nine products each: an asm statement takes 30 operands), the compiler never sees another mode
+// (see pcm_convert18).  Out of place -- the products land in registers of their own (early-clobber), so that the compiler
+// is free to let the sums die where they were accumulated: in place it copied all eighteen first.
+__device__ __forceinline__ void mul9_rtz_32767(const float* x, float* p) {
+#define PD_M(n, m) "v_mul_f32 %" #n ", 0x46fffe00, %" #m "\n\t"
   asm volatile(
       "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
       "s_nop 1\n\t"
-      PD_M(0) PD_M(1) PD_M(2) PD_M(3) PD_M(4) PD_M(5) PD_M(6) PD_M(7) PD_M(8)
-      PD_M(9) PD_M(10) PD_M(11) PD_M(12) PD_M(13) PD_M(14) PD_M(15) PD_M(16) PD_M(17)
+      PD_M(0, 9) PD_M(1, 10) PD_M(2, 11) PD_M(3, 12) PD_M(4, 13) PD_M(5, 14) PD_M(6, 15) PD_M(7, 16) PD_M(8, 17)
       "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t"
       "s_nop 1"
-      : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]),
-        "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15]), "+v"(p[16]), "+v"(p[17]));
+      : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]), "=&v"(p[8])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]));
 #undef PD_M
+}
+__device__ __forceinline__ void mul18_rtz_32767(const float* x, float* p) {
+  mul9_rtz_32767(x, p);
+  mul9_rtz_32767(x + 9, p + 9);
 }
 }  // namespace pdmp3
 #else
@@ -174,6 +181,7 @@ namespace pdmp3 {
 typedef float f32x2 __attribute__((vector_size(8)));
 typedef unsigned short u16x2 __attribute__((vector_size(4)));
 typedef float f32x4 __attribute__((vector_size(16)));
+static inline f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return (f32x2){__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])}; }
 static inline f32x4 mfma16(float a, float b, f32x4 c) {
   float cd[4] = {c[0], c[1], c[2], c[3]};
   emu::mfma16(a, b, cd);
@@ -187,12 +195,12 @@ static inline float pd_fmed3_host(float x, float lo, float hi) {
 }
 // the binary32 product x * 32767 rounded toward zero: the binary64 product is exact; round it to nearest and step back
 // when that went away from zero
-static inline void mul18_rtz_32767(float* p) {
+static inline void mul18_rtz_32767(const float* x, float* p) {
   for (int t = 0; t < 18; t++) {
-    const double d = (double)p[t] * 32767.0;
+    const double d = (double)x[t] * 32767.0;
     float f = (float)d;
     if (f == f && !__builtin_isinf(f) && __builtin_fabs((double)f) > __builtin_fabs(d)) f = __builtin_nextafterf(f, 0.0f);
-    else if (__builtin_isinf(f) && !__builtin_isinf(p[t])) f = __builtin_copysignf(0x1.fffffep+127f, f);   // RTZ never rounds up to infinity
+    else if (__builtin_isinf(f) && !__builtin_isinf(x[t])) f = __builtin_copysignf(0x1.fffffep+127f, f);   // RTZ never rounds up to infinity
     p[t] = f;
   }
 }
@@ -204,6 +212,21 @@ static inline void mul18_rtz_32767(float* p) {
 #ifndef PD_EXP_SKIP
 #define PD_EXP_SKIP 0
 #endif
+// the VALU columns' coefficients as [m][q] (q fastest): the pair (q, q + 1) of one m is an aligned scalar-register pair, a
+// v_pk_fma_f32 operand as it comes out of the s_load -- as [q][m] every packed FMA needed one or two s_mov_b32 in front of
+// it and the block two more scalar loads (131072 frames 1.037 -> 1.005 ms, round 5; 0 = the old layout, for A/B)
+#ifndef PD_C36_MQ
+#define PD_C36_MQ 1
+#endif
+// A/B switches of round 5 (tools/build_variants.sh): the chunk kernel's requantisation with the long-block fast path;
+// the band scales of the next granule in ONE phase with the window (their LDS round trips side by side)
+#ifndef PD_CHUNK_FAST_REQUANT
+#define PD_CHUNK_FAST_REQUANT 0
+#endif
+#ifndef PD_SCALES_WITH_WINDOW
+#define PD_SCALES_WITH_WINDOW 0
+#endif
+
 
 namespace pdmp3 {
 
@@ -218,8 +241,15 @@ constexpr int kPow43Small = 128;      // |is| below this come from the LDS copy 
 // Small tables; lives in __constant__ memory on the device so that
 // wave-uniform indices become scalar loads.
 struct ConstBank {
+#if PD_C36_MQ
+  float c36x[18][4];      // cos_N36 (P:620-729) columns p = 16, 17, 34, 35 as [m][q]: the columns left to the VALU; q fastest, so
+  float s36x[18][4];      //   that the pair (q, q + 1) of one m is an aligned pair of scalar registers (v_pk_fma_f32 operand)
+#define PD_C36(cb, t, q, m) ((cb)->t[m][q])
+#else
   float c36x[4][18];      // cos_N36 (P:620-729) columns p = 16, 17, 34, 35 as [q][m]: the columns left to the VALU
   float s36x[4][18];      // the same columns of the short-block matrix (3 x 12-point IMDCT, win[2] folded in)
+#define PD_C36(cb, t, q, m) ((cb)->t[q][m])
+#endif
   float cs[8], ca[8];     // P:573-574
   float isr_l[16];        // is_ratio_l for is_pos 0..6 (P:2166-2172); [7] unused;
   float isr_r[16];        // [8..15]: the reference reads past is_ratios[] (H3) -> defined as t = 0
@@ -290,6 +320,7 @@ struct LaneRegs {
 
 // Uniform per-granule facts, decoded from the side records in LDS.
 struct GranuleInfo {
+  int fr;                  // the frame's flag byte (PDMP3_FR_*)
   int nch, sfreq, mode, mode_ext;
   int iso;                 // PDMP3_GC_ISO_* of the frame's records (0: the reference's behaviour)
   int count1_0, count1_1, flags0, flags1;
@@ -309,6 +340,7 @@ PD_FN GranuleInfo granule_info(const WaveData& L) {
   const uint32_t w0 = (uint32_t)PD_UNIFORM(*reinterpret_cast<const uint32_t*>(&L.side[0][0]));
   const uint32_t w1 = (uint32_t)PD_UNIFORM(*reinterpret_cast<const uint32_t*>(&L.side[1][0]));
   const int fr = PD_UNIFORM(L.side[0][7]);
+  g.fr = fr;
   g.iso = PD_UNIFORM(L.side[0][offsetof(pdmp3_gc_side, iso)]);
   g.sfreq = fr & PDMP3_FR_SFREQ_MASK;
   if (g.sfreq > 2) g.sfreq = 2;
@@ -486,8 +518,11 @@ PD_FN void ph_scales(int lane, WaveData& L);
 // SCALES: the band scales (ph_scales) are computed in here -- in the fast path while the loads from the full |is|^(4/3)
 // table are in flight (straight-line callers, which have nothing else to put there).
 template <bool DUMP, int NI = 9, bool FAST = false, bool TG = false, bool SCALES = false>
-PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const GlobalTables& T, float* dump0, float* dump1) {
-  const GranuleInfo g = granule_info(L);
+PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const GlobalTables& T, float* dump0, float* dump1,
+                      const GranuleInfo* gi = nullptr) {
+  // (gi: the granule's facts, read once by the caller -- every granule_info() is an LDS round trip and four
+  //  v_readfirstlane at the head of a phase, and the phase fences keep the compiler from sharing one between phases)
+  const GranuleInfo g = gi ? *gi : granule_info(L);
   const bool tg = TG && (g.sfreq != S.sfreq);                       // wave-uniform
   const uint16_t* gtab = T.linetab + (size_t)g.sfreq * 3 * 576;
   const bool joint = (g.nch == 2) && (g.mode == 1) && (g.mode_ext != 0);
@@ -506,13 +541,17 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
 #define PD_LINE(i) (lane + 64 * (i))
   {
     unsigned e0[NI], e1[NI];
-    // (the values are pinned inside each branch: merged, the two would become one FLAT load of a selected address)
+    // (the values are pinned inside each branch: merged, the two would become one FLAT load of a selected address.
+    //  ALL the loads first, then the pins: a pin is an asm statement that reads the value, so a pin right behind its load
+    //  is a wait for that load -- eighteen LDS round trips one after the other, which is what this was until round 5)
     if (tg) {
-      PD_UNROLL for (int i = 0; i < NI; i++) { e0[i] = gtab[kind0 * 576 + PD_LINE(i)]; PD_PIN(e0[i]); }
-      PD_UNROLL for (int i = 0; i < NI; i++) { e1[i] = gtab[kind1 * 576 + PD_LINE(i)]; PD_PIN(e1[i]); }
+      PD_UNROLL for (int i = 0; i < NI; i++) e0[i] = gtab[kind0 * 576 + PD_LINE(i)];
+      PD_UNROLL for (int i = 0; i < NI; i++) e1[i] = gtab[kind1 * 576 + PD_LINE(i)];
+      PD_UNROLL for (int i = 0; i < NI; i++) { PD_PIN(e0[i]); PD_PIN(e1[i]); }
     } else {
-      PD_UNROLL for (int i = 0; i < NI; i++) { e0[i] = S.ltab[kind0][PD_LINE(i)]; PD_PIN(e0[i]); }
-      PD_UNROLL for (int i = 0; i < NI; i++) { e1[i] = S.ltab[kind1][PD_LINE(i)]; PD_PIN(e1[i]); }
+      PD_UNROLL for (int i = 0; i < NI; i++) e0[i] = S.ltab[kind0][PD_LINE(i)];
+      PD_UNROLL for (int i = 0; i < NI; i++) e1[i] = S.ltab[kind1][PD_LINE(i)];
+      PD_UNROLL for (int i = 0; i < NI; i++) { PD_PIN(e0[i]); PD_PIN(e1[i]); }
     }
     int v0[NI], v1[NI];
     float s0[NI], s1[NI];
@@ -753,8 +792,8 @@ PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalT
 // (mfma16(a, b, c) and f32x4: top of the file)
 
 // alias reduction in place (P:1706-1732): lane (ch, sb) owns the boundary below subband sb
-PD_FN void ph_antialias(int lane, WaveData& L, BankPtr cb, bool only_first = false) {   // only_first: boundary sb 0 | 1 alone
-  const GranuleInfo g = granule_info(L);
+PD_FN void ph_antialias(int lane, WaveData& L, BankPtr cb, bool only_first = false, const GranuleInfo* gi = nullptr) {   // only_first: boundary sb 0 | 1 alone
+  const GranuleInfo g = gi ? *gi : granule_info(L);
   const int ch = lane >> 5, sb = lane & 31;
   if (ch >= g.nch || sb == 0) return;
   if (only_first && sb != 1) return;
@@ -803,8 +842,8 @@ PD_FN float ph_peek_head(int lane, const WaveData& L, const TabLds& S, const Glo
 
 template <bool DUMP>
 PD_FN void ph_mfma(int lane, WaveData& L, const TabLds& S, LaneRegs& R, BankPtr cb, const GlobalTables& T, float* dump2, float* dump3,
-                   bool do_matrix) {   // do_matrix (wave-uniform) = false: a halo granule whose polyphase input nobody reads
-  const GranuleInfo g = granule_info(L);
+                   bool do_matrix, const GranuleInfo* gi = nullptr) {   // do_matrix (wave-uniform) = false: a halo granule whose polyphase input nobody reads
+  const GranuleInfo g = gi ? *gi : granule_info(L);
   const int j = lane & 15, kq = lane >> 4;
   if (DUMP) {   // stage 2 = lines after alias reduction
     PD_UNROLL for (int i = 0; i < 9; i++) {
@@ -828,13 +867,13 @@ PD_FN void ph_mfma(int lane, WaveData& L, const TabLds& S, LaneRegs& R, BankPtr 
     PD_UNROLL for (int m = 0; m < 18; m++) in[m] = x[m];
     float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     PD_UNROLL for (int m = 0; m < 18; m++)
-      PD_UNROLL for (int q = 0; q < 4; q++) y[q] = PD_FMA(in[m], cb->c36x[q][m], y[q]);
+      PD_UNROLL for (int q = 0; q < 4; q++) y[q] = PD_FMA(in[m], PD_C36(cb, c36x, q, m), y[q]);
     const float* w = S.win[llow ? 0 : g.block_type(cl)];
     y[0] = y[0] * w[16]; y[1] = y[1] * w[17]; y[2] = y[2] * w[34]; y[3] = y[3] * w[35];
     if (any_short) {                      // wave-uniform
       float ys[4] = {0.0f, 0.0f, 0.0f, 0.0f};
       PD_UNROLL for (int m = 0; m < 18; m++)
-        PD_UNROLL for (int q = 0; q < 4; q++) ys[q] = PD_FMA(in[m], cb->s36x[q][m], ys[q]);
+        PD_UNROLL for (int q = 0; q < 4; q++) ys[q] = PD_FMA(in[m], PD_C36(cb, s36x, q, m), ys[q]);
       PD_UNROLL for (int q = 0; q < 4; q++) y[q] = lshort ? ys[q] : y[q];
     }
     o16 = y[0] + R.ovl[16]; o17 = y[1] + R.ovl[17];                       // P:1775
@@ -962,8 +1001,7 @@ PD_FN int pcm_from_sum(float sum) {
 // Pure per lane: the host build tests it by itself against pcm_from_sum (tests/test_pipeline_emul.py).
 PD_FN void pcm_convert18_lane(const float* sum, int* out, bool wrap) {
   float p[18];
-  PD_UNROLL for (int t = 0; t < 18; t++) p[t] = sum[t];
-  mul18_rtz_32767(p);
+  mul18_rtz_32767(sum, p);
   if (wrap) {
     PD_UNROLL for (int t = 0; t < 18; t++) {
       const int n = (int)PD_FMED3(p[t], -32767.0f, 32767.0f);
@@ -990,9 +1028,12 @@ PD_FN bool pcm_wave_wraps(const float* sum, bool act) {
 }
 
 // the 18 sums of a lane (P:2028) -> PCM of the granule: conversion, channel pairing, stores
-template <bool F32>
-PD_FN void pcm_emit(int lane, WaveData& L, int nch, bool act, const float* sum, int16_t* pcm_g, float* pcmf_g) {
+// ALL: a stereo granule -- every lane active, nch = 2: no execution masks anywhere
+template <bool F32, bool ALL = false>
+PD_FN void pcm_emit(int lane, WaveData& L, int nch_arg, bool act_arg, const float* sum, int16_t* pcm_g, float* pcmf_g) {
   const int i = lane & 31;
+  const int nch = ALL ? 2 : nch_arg;
+  const bool act = ALL ? true : act_arg;
   int out[18];
   const bool wrap = F32 ? false : pcm_wave_wraps(sum, act);
   if (act) {
@@ -1034,14 +1075,70 @@ PD_FN void pcm_emit(int lane, WaveData& L, int nch, bool act, const float* sum, 
   }
 }
 
+// The window sums of a granule (P:2015-2026) and its PCM.  sum[t] = sum_k we[k] E[15 + t - 2 k] + wo[k] O[14 + t - 2 k], the 16
+// FMAs in this order (k ascending, we before wo), where E[s], O[s] are the lane's two DCT coefficients of slot s: s = 0..14
+// the history (slots 3..17 of the granule before), s = 15..32 this granule's slots t = 0..17.  Two consecutive sums share
+// every coefficient and read neighbouring slots, so the phase is written on PAIRS: Ep[j] = (E[2 j + 1], E[2 j + 2]),
+// Op[j] = (O[2 j], O[2 j + 1]), sum pair q = (sum[2 q], sum[2 q + 1]) = sum_k we[k] Ep[7 + q - k] + wo[k] Op[7 + q - k] --
+// one v_pk_fma_f32 per two FMAs, every operand an aligned register pair BY CONSTRUCTION: the pairs of this granule's slots are
+// loaded as pairs (ds_read2_b32), and the history of the next granule is pairs 9..15 as they are (E[18 + s] = next E[s]: the
+// pairing survives the shift by 18), so nothing is moved to form an operand.  (Left to the SLP vectoriser the same FMAs came
+// out packed too, but with ~40 register moves per granule to re-pair O, whose natural load pairs (t, t + 1) start at the
+// wrong parity.)  E[0] is never read (the oldest slot enters with wo only); it stays in the state for its layout's sake.
+// ALL: a stereo granule (every lane active).
+template <bool F32, bool ALL>
+PD_FN void ph_window_emit(int lane, WaveData& L, LaneRegs& R, int nch, int16_t* pcm_g, float* pcmf_g) {
+  const int ch = lane >> 5;
+  const bool act = ALL || ch < nch;            // (mono: lanes 32..63 idle, their history is channel 1's and stays)
+  float sum[18];
+  if (act) {
+    const float* he = &L.hyb[ch][0][R.idx_e];  // slot t at he[33 t]
+    const float* ho = &L.hyb[ch][0][R.idx_o];
+    f32x2 Ep[16], Op[16];
+    PD_UNROLL for (int j = 0; j < 7; j++) { Ep[j] = (f32x2){R.he[2 * j + 1], R.he[2 * j + 2]}; Op[j] = (f32x2){R.ho[2 * j], R.ho[2 * j + 1]}; }
+    // (the compiler merges loads off one base register into ds_read2_b32 in the order of their offsets: (0, 1), (2, 3), ...
+    //  O's pairs start at an odd slot, so its slot 0 is read through a base of its own -- else every register of O is moved)
+    int io0 = R.idx_o;
+    PD_PIN(io0);
+    // three sums pairs at a time: a v_pk_fma_f32 that reads the result of the one before it costs a wait state
+#define PD_WIN_LOAD(j0, j1) \
+    PD_UNROLL for (int j = (j0); j < (j1); j++) { \
+      Ep[j] = (f32x2){he[33 * (2 * j - 14)], he[33 * (2 * j - 13)]}; \
+      if (j >= 8) Op[j] = (f32x2){ho[33 * (2 * j - 15)], ho[33 * (2 * j - 14)]}; \
+    }
+#define PD_WIN_SUMS(q0) { \
+      f32x2 acc[3] = {(f32x2){0.0f, 0.0f}, (f32x2){0.0f, 0.0f}, (f32x2){0.0f, 0.0f}}; \
+      PD_UNROLL for (int k = 0; k < 8; k++) { \
+        PD_UNROLL for (int u = 0; u < 3; u++) acc[u] = fma2((f32x2){R.we[k], R.we[k]}, Ep[7 + (q0) + u - k], acc[u]); \
+        PD_UNROLL for (int u = 0; u < 3; u++) acc[u] = fma2((f32x2){R.wo[k], R.wo[k]}, Op[7 + (q0) + u - k], acc[u]); \
+      } \
+      PD_UNROLL for (int u = 0; u < 3; u++) { sum[2 * ((q0) + u)] = acc[u][0]; sum[2 * ((q0) + u) + 1] = acc[u][1]; } \
+    }
+    PD_WIN_LOAD(7, 16)
+    const float o17 = ho[33 * 17];
+    Op[7] = (f32x2){R.ho[14], L.hyb[ch][0][io0]};
+    PD_WIN_SUMS(0)
+    PD_WIN_SUMS(3)
+    PD_WIN_SUMS(6)
+#undef PD_WIN_LOAD
+#undef PD_WIN_SUMS
+    R.he[0] = Ep[8][1];
+    PD_UNROLL for (int j = 0; j < 7; j++) {
+      R.he[2 * j + 1] = Ep[j + 9][0]; R.he[2 * j + 2] = Ep[j + 9][1];
+      R.ho[2 * j] = Op[j + 9][0]; R.ho[2 * j + 1] = Op[j + 9][1];
+    }
+    R.ho[14] = o17;
+  }
+  pcm_emit<F32, ALL>(lane, L, nch, act, sum, pcm_g, pcmf_g);
+}
+
 // full = false (wave-uniform): the last halo granule -- only its slots 3..17 are wanted, as the next granule's history
 template <bool F32>
 PD_FN void ph_window(int lane, WaveData& L, LaneRegs& R, bool full, int nch, int16_t* pcm_g, float* pcmf_g) {
   // (nch is a parameter: by now the side records in LDS are the NEXT granule's, see run_chunk)
-  const int ch = lane >> 5;
-  const bool act = ch < nch;                   // (mono: lanes 32..63 idle, their history is channel 1's and stays)
   if (!full) {
-    if (act) {
+    const int ch = lane >> 5;
+    if (ch < nch) {
       PD_UNROLL for (int s = 0; s < kHistSlots; s++) {
         R.he[s] = L.hyb[ch][3 + s][R.idx_e];
         R.ho[s] = L.hyb[ch][3 + s][R.idx_o];
@@ -1049,27 +1146,8 @@ PD_FN void ph_window(int lane, WaveData& L, LaneRegs& R, bool full, int nch, int
     }
     return;
   }
-  float sum[18];
-  if (act) {
-    // E[s], O[s]: the lane's two coefficients of slot s; s = 0..14 history, 15..32 this granule
-    float E[kHistSlots + 18], O[kHistSlots + 18];
-    PD_UNROLL for (int s = 0; s < kHistSlots; s++) { E[s] = R.he[s]; O[s] = R.ho[s]; }
-    PD_UNROLL for (int t = 0; t < 18; t++) {
-      E[kHistSlots + t] = L.hyb[ch][t][R.idx_e];
-      O[kHistSlots + t] = L.hyb[ch][t][R.idx_o];
-    }
-    const float* we = R.we; const float* wo = R.wo;
-    PD_UNROLL for (int t = 0; t < 18; t++) {
-      float acc = 0.0f;
-      PD_UNROLL for (int k = 0; k < 8; k++) {     // P:2021-2026: u[32j+i], j = 2k (age 2k), 2k+1 (age 2k+1)
-        acc = PD_FMA(we[k], E[kHistSlots + t - 2 * k], acc);
-        acc = PD_FMA(wo[k], O[kHistSlots + t - 2 * k - 1], acc);
-      }
-      sum[t] = acc;
-    }
-    PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = E[18 + s]; R.ho[s] = O[18 + s]; }
-  }
-  pcm_emit<F32>(lane, L, nch, act, sum, pcm_g, pcmf_g);
+  if (nch == 2) ph_window_emit<F32, true>(lane, L, R, 2, pcm_g, pcmf_g);      // wave-uniform
+  else ph_window_emit<F32, false>(lane, L, R, nch, pcm_g, pcmf_g);
 }
 
 // PCM of a mono granule (576 samples = 1152 bytes) from the LDS staging buffer; stereo granules were stored by
@@ -1235,41 +1313,38 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     const bool emit = (k >= 0) && (g >= g_begin);
     const bool feeds_next = (k == -1) || (k >= 0 && (g == g_begin - 1 || g == g_keep));
     PD_LAUNDER(cb);
-    {
-      int sf = L.side[0][7] & PDMP3_FR_SFREQ_MASK;
-      if (sf > 2) sf = 2;
-      if (OWN_TABS && sf != cur_sfreq) {          // wave-uniform: first granule, or the stream changed sampling rate
-        PD_PHASE(load_linetab(lane, S, T, sf))
-        cur_sfreq = sf;
-      }
+    // the granule's facts (wave-uniform, scalar registers), read ONCE here for all its phases; the commit phase below
+    // overwrites the side records with the next granule's
+    const GranuleInfo gi = granule_info(L);
+    if (OWN_TABS && gi.sfreq != cur_sfreq) {      // wave-uniform: first granule, or the stream changed sampling rate
+      PD_PHASE(load_linetab(lane, S, T, gi.sfreq))
+      cur_sfreq = gi.sfreq;
     }
     PD_TICK(0)
-    const int fr_here = PD_UNIFORM(L.side[0][7]);
-    const bool reset_here = gr == 0 && (fr_here & PDMP3_FR_RESET);
-    // (read here, not next to its use: the commit phase below overwrites the side records with the next granule's)
-    const int nch_g = ((fr_here & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
+    const bool reset_here = gr == 0 && (gi.fr & PDMP3_FR_RESET);
+    const int nch_g = gi.nch;
     PD_TICK(1)
     float* dmp = DUMP ? a.stages + ((size_t)f * 16 + gr * 8) * 576 : nullptr;
     if (g == g_peek) {                     // wave-uniform: lines 0..63, boundary sb 0 | 1, three IMDCT outputs
-      PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<false, 1, false, !OWN_TABS>(lane, L, S, cb, T, nullptr, nullptr))
+      PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<false, 1, false, !OWN_TABS>(lane, L, S, cb, T, nullptr, nullptr, &gi))
       PD_TICK(2)
       PD_PHASE(
         if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
-        ph_antialias(lane, L, cb, true);
+        ph_antialias(lane, L, cb, true, &gi);
       )
       PD_TICK(3)
       PD_PHASE(ph_peek_tail(lane, L, S, R, T))
       PD_TICK(4)
     } else {
-      PD_PHASE(if (reset_here) state_zero(lane, R); if (!(PD_EXP_SKIP & 1)) ph_requant<DUMP, 9, false, !OWN_TABS>(lane, L, S, cb, T, dmp, dmp + 576))
+      PD_PHASE(if (reset_here) state_zero(lane, R); if (!(PD_EXP_SKIP & 1)) ph_requant<DUMP, 9, PD_CHUNK_FAST_REQUANT != 0, !OWN_TABS>(lane, L, S, cb, T, dmp, dmp + 576, &gi))
       PD_TICK(2)
       PD_PHASE(
         // the next granule's HBM reads fly during this granule's transforms
         if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
-        if (!(PD_EXP_SKIP & 2)) ph_antialias(lane, L, cb);
+        if (!(PD_EXP_SKIP & 2)) ph_antialias(lane, L, cb, false, &gi);
       )
       PD_TICK(3)
-      PD_PHASE(if (!(PD_EXP_SKIP & 4)) ph_mfma<DUMP>(lane, L, S, R, cb, T, dmp + 2 * 576, dmp + 3 * 576, emit || feeds_next))
+      PD_PHASE(if (!(PD_EXP_SKIP & 4)) ph_mfma<DUMP>(lane, L, S, R, cb, T, dmp + 2 * 576, dmp + 3 * 576, emit || feeds_next, &gi))
       PD_TICK(4)
     }
     PD_TICK(5)
@@ -1278,12 +1353,17 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     // the window the wave sat through the acknowledgement of its nine stores every granule: 10 % of the loop.)
     if (g_next < g_end) {
       PD_PHASE(ph_commit(lane, L, R))
-      PD_PHASE(if (!(PD_EXP_SKIP & 8)) ph_scales(lane, L))                   // next granule's (its side info was committed just above)
+      if (!PD_SCALES_WITH_WINDOW) { PD_PHASE(if (!(PD_EXP_SKIP & 8)) ph_scales(lane, L)) }    // next granule's (its side info was committed just above)
     }
     PD_TICK(6)
+    // (PD_SCALES_WITH_WINDOW: the scales read the side records, the window reads hyb and writes PCM -- nothing of one is
+    //  the other's, so they share a phase and their LDS round trips run side by side)
     if ((emit || feeds_next) && !(PD_EXP_SKIP & 16)) {
-      PD_PHASE(ph_window<F32>(lane, L, R, emit, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g,
+      PD_PHASE(if (PD_SCALES_WITH_WINDOW && g_next < g_end) ph_scales(lane, L);
+               ph_window<F32>(lane, L, R, emit, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g,
                                 F32 ? a.pcm_f32 + (size_t)f * 2304 + gr * 576 * nch_g : nullptr))
+    } else if (PD_SCALES_WITH_WINDOW && g_next < g_end) {
+      PD_PHASE(ph_scales(lane, L))
     }
     PD_PHASE(if (!F32) ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, emit))
     PD_TICK(7)
@@ -1419,7 +1499,11 @@ PD_FN void gran_send_rows(int lane, const WaveData& L, const DecodeArgs& a, int 
   const int ch = lane >> 5, i = lane & 31;
   if (gp.w == gp.wpw - 1) {
     float* st = a.chain_state + (size_t)g * kGranFloats + kOvlRegs * 64;
-    for (int s = 0; s < kHistSlots; s++) PD_STORE_DEVICE(&st[s * 64 + lane], L.hyb[ch][3 + s][i]);
+    // (all fifteen out of LDS first: a device-scope store is ordered after the load of its value, and load by load that is
+    //  fifteen LDS round trips in a row in the workgroup's last wave -- the wave a launch ends with)
+    float v[kHistSlots];
+    PD_UNROLL for (int s = 0; s < kHistSlots; s++) v[s] = L.hyb[ch][3 + s][i];
+    PD_UNROLL for (int s = 0; s < kHistSlots; s++) PD_STORE_DEVICE(&st[s * 64 + lane], v[s]);
     gran_far_signal(lane, a, g, 1);
   } else {
     GranMb& mb = gp.mb[gp.w + 1];
@@ -1518,8 +1602,9 @@ PD_FN bool gran_far_wait(const DecodeArgs& a, int g, int k, bool bounded) {
 
 // ---- ph_mfma in two stages (stereo granules).  ph_imdct: everything up to the windowed IMDCT outputs, indexed like
 // R.ovl: y1 = first halves (what the overlap is added to), y2 = tails (the next granule's overlap).  xr is dead after it.
-PD_FN void ph_imdct(int lane, const WaveData& L, const TabLds& S, const LaneRegs& R, BankPtr cb, const GlobalTables& T, float* y1, float* y2) {
-  const GranuleInfo g = granule_info(L);
+PD_FN void ph_imdct(int lane, const WaveData& L, const TabLds& S, const LaneRegs& R, BankPtr cb, const GlobalTables& T, float* y1, float* y2,
+                    const GranuleInfo* gi = nullptr) {
+  const GranuleInfo g = gi ? *gi : granule_info(L);
   const int j = lane & 15, kq = lane >> 4;
   const bool any_short = g.is_short(0) || g.is_short(1);
   {   // IMDCT outputs p = 16, 17, 34, 35 on the VALU: lane = (cl, sb), scalar-broadcast coefficients
@@ -1532,13 +1617,13 @@ PD_FN void ph_imdct(int lane, const WaveData& L, const TabLds& S, const LaneRegs
     PD_UNROLL for (int m = 0; m < 18; m++) in[m] = x[m];
     float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     PD_UNROLL for (int m = 0; m < 18; m++)
-      PD_UNROLL for (int q = 0; q < 4; q++) y[q] = PD_FMA(in[m], cb->c36x[q][m], y[q]);
+      PD_UNROLL for (int q = 0; q < 4; q++) y[q] = PD_FMA(in[m], PD_C36(cb, c36x, q, m), y[q]);
     const float* w = S.win[llow ? 0 : g.block_type(cl)];
     y[0] = y[0] * w[16]; y[1] = y[1] * w[17]; y[2] = y[2] * w[34]; y[3] = y[3] * w[35];
     if (any_short) {                      // wave-uniform
       float ys[4] = {0.0f, 0.0f, 0.0f, 0.0f};
       PD_UNROLL for (int m = 0; m < 18; m++)
-        PD_UNROLL for (int q = 0; q < 4; q++) ys[q] = PD_FMA(in[m], cb->s36x[q][m], ys[q]);
+        PD_UNROLL for (int q = 0; q < 4; q++) ys[q] = PD_FMA(in[m], PD_C36(cb, s36x, q, m), ys[q]);
       PD_UNROLL for (int q = 0; q < 4; q++) y[q] = lshort ? ys[q] : y[q];
     }
     y1[16] = y[0]; y1[17] = y[1]; y2[16] = y[2]; y2[17] = y[3];
@@ -1671,7 +1756,7 @@ PD_FN void ph_window_hist(int lane, WaveData& L, const LaneRegs& R, const float*
     }
     sum[t] = s;
   }
-  pcm_emit<F32>(lane, L, 2, true, sum, pcm_g, pcmf_g);
+  pcm_emit<F32, true>(lane, L, 2, true, sum, pcm_g, pcmf_g);
 }
 
 // run_chunk as a CALLED function, for the granule kernel's rare paths (frames that do not go the granule way; the state
@@ -1777,7 +1862,8 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   PD_GT(2)
   gran_tabs_wait(gp);
   PD_LAUNDER(cb);
-  if (!(PD_EXP_SKIP & 1)) { PD_PHASE((ph_requant<false, 9, true, true, true>(lane, L, S, cb, T, nullptr, nullptr))) }
+  const GranuleInfo gi = granule_info(L);         // (the granule's facts, read once for the three phases that want them)
+  if (!(PD_EXP_SKIP & 1)) { PD_PHASE((ph_requant<false, 9, true, true, true>(lane, L, S, cb, T, nullptr, nullptr, &gi))) }
   PD_GT(3)
   // A SIMD issues from its OLDEST wave first: of the four waves that share one -- places w, w + 4, w + 8, w + 12 of the
   // workgroup -- the first gets through requantisation in 5 k ticks and the last in 12 k (profiles/r04_gran_profile.txt),
@@ -1789,10 +1875,10 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
     const int q = gp.w >> 2;
     if (q == 1) PD_SETPRIO(1); else if (q == 2) PD_SETPRIO(2); else if (q == 3) PD_SETPRIO(3); else PD_SETPRIO(0);
   }
-  if (!(PD_EXP_SKIP & 2)) { PD_PHASE(ph_antialias(lane, L, cb)) }
+  if (!(PD_EXP_SKIP & 2)) { PD_PHASE(ph_antialias(lane, L, cb, false, &gi)) }
   float y1[kOvlRegs], y2[kOvlRegs];
   if (PD_EXP_SKIP & 4) { PD_UNROLL for (int m = 0; m < kOvlRegs; m++) { y1[m] = L.xr[0][m * 64 + lane]; y2[m] = L.xr[1][m * 64 + lane]; } }
-  else { PD_PHASE(ph_imdct(lane, L, S, R, cb, T, y1, y2)) }
+  else { PD_PHASE(ph_imdct(lane, L, S, R, cb, T, y1, y2, &gi)) }
   PD_GT(4)
   // from here on the wave reads nothing of spec / side / scale / xr any more: its mailboxes are free
   if (RING) gran_lds_flag_tag(lane, &gp.mb[gp.w].free, tag);

@@ -57,9 +57,11 @@ __global__ __launch_bounds__(64 * WPW, PDMP3_WAVES_PER_EU) void k_decode(DecodeA
 // chain is its blockIdx.  128 VGPRs and 9.3 KB of LDS per wave + one table block per workgroup: two workgroups = 16 waves
 // per CU, four per SIMD.
 // W = 16: one workgroup per CU holds the CU's sixteen waves (a launch of 2048 frames is one workgroup on every CU of
-// an MI355X); W = 8 for the smaller launches: twice as many CUs share the work, two waves per SIMD.
+// an MI355X); W = 8 for the smaller launches: twice as many CUs share the work, two waves per SIMD -- which is also all
+// the occupancy that form is compiled for (a workgroup of 8 waves is one per CU in the launches that take it; asked for
+// four waves per SIMD the compiler could not get there and said so: 217 registers, occupancy 2).
 template <bool F32, int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_decode_g(DecodeArgs a, GlobalTables T) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W / 4, W / 4))) void k_decode_g(DecodeArgs a, GlobalTables T) {
   __shared__ WaveData L[W];
   __shared__ TabLds S;
   __shared__ GranMb mb[W];
@@ -725,7 +727,12 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
     if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
     else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
     else if (d_pcm_f32) hipLaunchKernelGGL((k_decode<false, true>), dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
-    else hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
+    else {
+      // (development: PDMP3_HIP_DEBUG_LDS_PAD = bytes of dynamic LDS added to every workgroup of the chunk kernel, which
+      //  lowers the number of waves a CU holds -- 24576: one wave per SIMD instead of two; tools/occupancy_scaling.py)
+      static const int lds_pad = [] { const char* e = getenv("PDMP3_HIP_DEBUG_LDS_PAD"); return e ? atoi(e) : 0; }();
+      hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), (size_t)lds_pad, s, a, T, nchunks);
+    }
   }
   hipError_t e = hipGetLastError();
   const char* what = "launch k_decode";

@@ -120,8 +120,8 @@ inline void build_host_tables(HostTables& H) {
   static const int xcol[4] = {16, 17, 34, 35};
   for (int q = 0; q < 4; q++)
     for (int m = 0; m < 18; m++) {
-      cb.c36x[q][m] = kCosN36[m * 36 + xcol[q]];
-      cb.s36x[q][m] = bs[m][xcol[q]];
+      PD_C36(&cb, c36x, q, m) = kCosN36[m * 36 + xcol[q]];
+      PD_C36(&cb, s36x, q, m) = bs[m][xcol[q]];
     }
   // matrixing: C[n] = sum_sb s[sb] cos((2 sb + 1) n pi / 64), n = 0..31, taken from the reference's own matrix
   // N[i][sb] = (float)cos((float)((16 + i) (2 sb + 1)) * (pi / 64)) (pdmp3.c:1992):  C[n] = v[n - 16] (n >= 16),

@@ -9,6 +9,7 @@ run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 run sq3 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_F32 SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC
+run grbm GRBM_GUI_ACTIVE GRBM_COUNT SQ_WAVES SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_IFETCH
 run tcc1 FETCH_SIZE
 run tcc2 WRITE_SIZE
 python3 - <<'PY'
