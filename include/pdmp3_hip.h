@@ -181,6 +181,10 @@ int pdmp3_hip_release_stream_scratch(pdmp3_hip_ctx* ctx, void* stream);
 #define PDMP3_HIP_LAUNCH_GRANULES16 16
 #define PDMP3_HIP_LAUNCH_PERSISTENT 32   /* k_decode_p: workgroups of 16 wavefronts going round a range of frames each */
 int pdmp3_hip_last_launch_kind(const pdmp3_hip_ctx* ctx);
+/* The device's PCI address ("0000:c1:00.0") into buf (len >= 16): what a host stage needs to find the CPUs and the
+ * memory next to the GPU (/sys/bus/pci/devices/<address>/local_cpulist, numa_node) -- the whole-stream decoder keeps
+ * its helper threads and its pinned buffers there (include/pdmp3_bulk.h).  No reference counterpart. */
+int pdmp3_hip_pci_bus_id(const pdmp3_hip_ctx* ctx, char* buf, int len);
 
 /* Float PCM (not in the reference, whose only output is int16): the same decode, but what is stored is
  * the binary32 synthesis sum that P:2028-2031 scale by 32767, truncate and clip -- full scale is +-1.0, nothing is

@@ -473,6 +473,12 @@ static int fail(int code, const char* what, hipError_t e) {
 extern "C" const char* pdmp3_hip_last_error(void) { return g_err; }
 
 extern "C" size_t pdmp3_hip_state_bytes(void) { return (size_t)kStateFloats * sizeof(float); }
+extern "C" int pdmp3_hip_pci_bus_id(const pdmp3_hip_ctx* c, char* buf, int len) {
+  if (!c || !buf || len < 16) return PDMP3_HIP_EINVAL;
+  if (hipDeviceGetPCIBusId(buf, len, c->device) != hipSuccess) { buf[0] = 0; return PDMP3_HIP_EDEVICE; }
+  return PDMP3_HIP_OK;
+}
+
 extern "C" int pdmp3_hip_last_launch_kind(const pdmp3_hip_ctx* c) { return c ? c->last_kind.load(std::memory_order_relaxed) : PDMP3_HIP_LAUNCH_NONE; }
 
 extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {

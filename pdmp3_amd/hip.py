@@ -24,7 +24,7 @@ FRAME_PCM_INT16 = 2304
 FRAME_SIDE_BYTES = 512
 
 EXPORTS = [
-    "pdmp3_hip_create", "pdmp3_hip_destroy", "pdmp3_hip_last_error", "pdmp3_hip_state_bytes", "pdmp3_hip_last_launch_kind",
+    "pdmp3_hip_create", "pdmp3_hip_destroy", "pdmp3_hip_last_error", "pdmp3_hip_state_bytes", "pdmp3_hip_last_launch_kind", "pdmp3_hip_pci_bus_id",
     "pdmp3_hip_decode_frames", "pdmp3_hip_decode_frames_f32", "pdmp3_hip_decode_frames_stages", "pdmp3_hip_generate_frames",
     "pdmp3_host_generate_frames",
     "pdmp3_hip_stream_create", "pdmp3_hip_stream_destroy", "pdmp3_hip_stream_reset", "pdmp3_hip_stream_spectra",

@@ -1319,6 +1319,38 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 #define BULK_GRAB 8                   /* frames a worker takes per trip to the counter */
 #define BULK_COPY_PIECE ((size_t)256 << 10)
 
+/* PCM out of a pinned slot into the caller's (pageable) memory.  The destination is written once and not read here
+ * again, the source was written by the DMA engine and is in no cache: on x86-64 the copy goes through non-temporal
+ * stores -- no read-for-ownership of the destination lines, a third less memory traffic per byte than memcpy below
+ * glibc's own non-temporal threshold (tens of megabytes; the pieces here are 256 KB) -- with the source prefetched a
+ * few lines ahead.  With four copy threads a window's 19 MB have to leave at 11 GB/s per thread to keep up with
+ * PCIe; a host whose cores do 7 GB/s with plain memcpy was the 6.4 M frames/s of the round-4 driver run (the same
+ * build did 9.7 M elsewhere).  PDMP3_BULK_PLAIN_COPY=1: memcpy. */
+#if defined(__x86_64__)
+#include <emmintrin.h>
+static int g_plain_copy = -1;
+static void copy_out(unsigned char* dst, const unsigned char* src, size_t n) {
+  int plain = __atomic_load_n(&g_plain_copy, __ATOMIC_RELAXED);
+  if (plain < 0) { const char* e = getenv("PDMP3_BULK_PLAIN_COPY"); plain = (e && *e == '1') ? 1 : 0; __atomic_store_n(&g_plain_copy, plain, __ATOMIC_RELAXED); }
+  if (plain || n < 4096) { memcpy(dst, src, n); return; }
+  const size_t head = (size_t)(-(uintptr_t)dst & 63);          /* up to the destination's next cache line */
+  if (head) { memcpy(dst, src, head); dst += head; src += head; n -= head; }
+  size_t lines = n >> 6;
+  while (lines--) {
+    _mm_prefetch((const char*)src + 512, _MM_HINT_NTA);
+    const __m128i a = _mm_loadu_si128((const __m128i*)src), b = _mm_loadu_si128((const __m128i*)src + 1);
+    const __m128i c = _mm_loadu_si128((const __m128i*)src + 2), d = _mm_loadu_si128((const __m128i*)src + 3);
+    _mm_stream_si128((__m128i*)dst, a); _mm_stream_si128((__m128i*)dst + 1, b);
+    _mm_stream_si128((__m128i*)dst + 2, c); _mm_stream_si128((__m128i*)dst + 3, d);
+    src += 64; dst += 64;
+  }
+  _mm_sfence();
+  if (n & 63) memcpy(dst, src, n & 63);
+}
+#else
+static void copy_out(unsigned char* dst, const unsigned char* src, size_t n) { memcpy(dst, src, n); }
+#endif
+
 typedef struct {
   frame_header hdr;
   side_info si;
@@ -1391,6 +1423,7 @@ struct bulk {
    * the pool before that -- a few KB per window, pool_materialize -- it copies early (pool_ensure). */
   struct pool_copy { const uint8_t* src; uint32_t dst, n; } *gath[BULK_SLOTS], *gath_cur;
   int gath_n, gath_cap;                           /* entries written / entries gath_cur has room for */
+  cpu_set_t near_gpu;                             /* the CPUs of the GPU's NUMA node this process may use (empty: no binding) */
   int sky[RESERVOIR_BYTES + 1], sky_n;            /* frames of the segment no later frame has topped yet (pdmp3_row_desc.up) */
   pdmp3_row_desc* rec_desc; size_t rec_pool_cap;  /* parse-only pool mode (host tests): caller memory, one window */
   bulk_window win[2];
@@ -1485,7 +1518,7 @@ static void* bulk_worker(void* arg) {
       const size_t c0 = __atomic_fetch_add(&b->copy_next, BULK_COPY_PIECE, __ATOMIC_RELAXED);
       if (c0 >= cbytes) break;
       const size_t c1 = cbytes - c0 < BULK_COPY_PIECE ? cbytes : c0 + BULK_COPY_PIECE;
-      if (crow == 4608) memcpy(cdst + c0, csrc + c0, c1 - c0);
+      if (crow == 4608) copy_out(cdst + c0, csrc + c0, c1 - c0);
       else {                                       /* mono: 2304-byte frames out of 4608-byte slots */
         for (size_t off = c0; off < c1;) {
           const size_t r = off / 2304, w = off % 2304;
@@ -2113,6 +2146,7 @@ typedef struct par_cache {
   pthread_mutex_t crew_mu; pthread_cond_t crew_cv, crew_done_cv;
   pthread_t crew[PAR_MAX_SCANNERS + PAR_MAX_SEGS];
   int crew_n, crew_busy, crew_quit;               /* threads / jobs taken or waiting to be taken */
+  cpu_set_t near_gpu;                             /* where they run (struct bulk::near_gpu; empty: anywhere) */
   struct { void* (*fn)(void*); void* arg; int* left; } jobs[PAR_MAX_SCANNERS + PAR_MAX_SEGS];
   unsigned job_head, job_tail;
 } par_cache;
@@ -2239,6 +2273,7 @@ static int crew_run(par_cache* pc, void* (*fn)(void*), void* arg, int* left) {
   pthread_mutex_lock(&pc->crew_mu);
   if (pc->crew_busy >= pc->crew_n) {
     if (pc->crew_n >= CREW_MAX || pthread_create(&pc->crew[pc->crew_n], NULL, crew_main, pc) != 0) { pthread_mutex_unlock(&pc->crew_mu); return -1; }
+    if (CPU_COUNT(&pc->near_gpu) > 0) (void)pthread_setaffinity_np(pc->crew[pc->crew_n], sizeof pc->near_gpu, &pc->near_gpu);
     pc->crew_n++;
   }
   const unsigned k = pc->job_head++ % CREW_MAX;
@@ -2665,7 +2700,10 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
   if (!P) return NULL;
   P->b = b; P->mp3 = mp3; P->n = n; P->K = K; P->J = J; P->sub = sub; P->t0 = now_s();
   P->one_window = est + est / 16 <= b->cap;
-  if (!b->pc && !(b->pc = pc_new())) { free(P); return NULL; }
+  if (!b->pc) {
+    if (!(b->pc = pc_new())) { free(P); return NULL; }
+    b->pc->near_gpu = b->near_gpu;
+  }
   par_cache* pc = b->pc;
   P->rec_cap = (long long)(n / 96) + 8;                 /* (no Layer III frame is shorter than 96 bytes) */
   if (pc->rec_cap < P->rec_cap) {
@@ -3017,6 +3055,44 @@ static int usable_cpus(void) {
   return n < 1 ? 1 : (int)n;
 }
 
+/* The CPUs next to the GPU (/sys/bus/pci/devices/<address>/local_cpulist), as far as this process may run on them.
+ * The GPU boxes are two-socket machines: the decoder's pinned buffers sit behind one socket's memory controllers and
+ * the GPU behind one socket's PCIe root; helper threads that wander to the other socket copy every PCM byte across the
+ * socket link and back (measured on such a box, PCM to pageable memory, the same build run after run: 6.1 .. 9.1 M
+ * frames/s; the round-4 driver run's 6.4 M against 9.7 M elsewhere).  So the decoder's own threads -- copy pool,
+ * submitter, gather helpers, the split scan's crew -- are kept on the GPU's node, and its pinned buffers are allocated
+ * from a thread that is there.  PDMP3_BULK_NUMA=0: leave everything to the scheduler.  Returns the number of CPUs. */
+static int gpu_local_cpus(pdmp3_hip_ctx* ctx, cpu_set_t* out) {
+  CPU_ZERO(out);
+  const char* e = getenv("PDMP3_BULK_NUMA");
+  if (e && *e == '0') return 0;
+  char bdf[64], path[160], list[1024];
+  if (pdmp3_hip_pci_bus_id(ctx, bdf, (int)sizeof bdf) != PDMP3_HIP_OK || !bdf[0]) return 0;
+  for (char* p = bdf; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return 0;
+  const int ok = fgets(list, sizeof list, f) != NULL;
+  fclose(f);
+  if (!ok) return 0;
+  cpu_set_t mine;
+  if (sched_getaffinity(0, sizeof mine, &mine) != 0) return 0;
+  for (const char* p = list; *p;) {                     /* "0-63,128-191" */
+    char* end;
+    const long a = strtol(p, &end, 10);
+    if (end == p) break;
+    long b = a;
+    p = end;
+    if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0 && CPU_ISSET((int)c, &mine)) CPU_SET((int)c, out);
+    while (*p == ',' || *p == ' ' || *p == '\n') p++;
+  }
+  const int n = CPU_COUNT(out);
+  if (n == CPU_COUNT(&mine)) { CPU_ZERO(out); return 0; }           /* one node, or already bound: nothing to do */
+  return n;
+}
+static void bind_thread(pthread_t t, const cpu_set_t* set) { if (CPU_COUNT(set) > 0) (void)pthread_setaffinity_np(t, sizeof *set, set); }
+
 /* threads <= 0: one per usable CPU (at most 64); window_frames <= 0: 2048.  with_engine = 0 gives a
  * parse-only decoder (host tests on machines without a GPU). */
 static struct bulk* bulk_new(int threads, int window_frames, int with_engine, int bits_mode, int device) {
@@ -3024,7 +3100,9 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
   if (threads <= 0) {
     const int c = usable_cpus();
     threads = c > 64 ? 64 : c;
-    if (bits_mode && threads > 4) threads = 4;   /* the pool only copies PCM out */
+    /* (the pool only copies PCM out: at most 6 threads, 4 below 16 usable CPUs -- the scan, the submitter and on a
+     *  device destination the split scan's threads want cores too) */
+    if (bits_mode && threads > (c >= 16 ? 6 : 4)) threads = c >= 16 ? 6 : 4;
   }
   /* frames per GPU batch.  Bits mode: k_unpack is bound by the length of one lane's chain, not by throughput, and two of
    * its workgroups (16 frames each) fit a CU: 8192 frames fill the chip once, 68 -> 84 us against 4096.  The slots hold
@@ -3060,7 +3138,16 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
   }
   if (with_engine) {
     pdmp3_hip_ctx* ctx = shared_ctx_on(device);
-    if (!ctx || pdmp3_hip_stream_create_slots(ctx, b->cap, BULK_SLOTS, &b->hs) != PDMP3_HIP_OK) {
+    int made = PDMP3_HIP_EINVAL;
+    if (ctx) {
+      /* the slots' pinned buffers: allocated (and first touched, by the pinning) from a thread on the GPU's node */
+      cpu_set_t before;
+      const int rebind = gpu_local_cpus(ctx, &b->near_gpu) > 0 && sched_getaffinity(0, sizeof before, &before) == 0;
+      if (rebind) (void)sched_setaffinity(0, sizeof b->near_gpu, &b->near_gpu);
+      made = pdmp3_hip_stream_create_slots(ctx, b->cap, BULK_SLOTS, &b->hs);
+      if (rebind) (void)sched_setaffinity(0, sizeof before, &before);
+    }
+    if (made != PDMP3_HIP_OK) {
       fprintf(stderr, "pdmp3: no MI355X transform engine: %s\n", pdmp3_hip_last_error());
       b->hs = NULL;
       pdmp3_amd_bulk_delete(b);
@@ -3077,6 +3164,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
       pthread_mutex_init(&b->sub_mu, NULL); pthread_cond_init(&b->sub_cv, NULL); pthread_cond_init(&b->sub_done_cv, NULL);
       if (pthread_create(&b->sub_th, NULL, bulk_submitter, b) != 0) { pdmp3_amd_bulk_delete(b); return NULL; }
       b->sub_started = 1;
+      bind_thread(b->sub_th, &b->near_gpu);
       pthread_mutex_init(&b->gh_mu, NULL); pthread_cond_init(&b->gh_cv, NULL); pthread_cond_init(&b->gh_done_cv, NULL);
       {
         const char* ge = getenv("PDMP3_BULK_GATHER_THREADS");      /* helpers for the windows' main-data copies (0 .. 8) */
@@ -3084,6 +3172,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
         if (want > GATHER_MAX_HELPERS) want = GATHER_MAX_HELPERS;
         for (b->gh_n = 0; b->gh_n < want; b->gh_n++)
           if (pthread_create(&b->gh_th[b->gh_n], NULL, gather_helper, b) != 0) break;
+          else bind_thread(b->gh_th[b->gh_n], &b->near_gpu);
       }
     }
   }
@@ -3092,6 +3181,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
   if (!b->th) { pdmp3_amd_bulk_delete(b); return NULL; }
   for (b->nth = 0; b->nth < threads; b->nth++)
     if (pthread_create(&b->th[b->nth], NULL, bulk_worker, b) != 0) break;
+    else bind_thread(b->th[b->nth], &b->near_gpu);
   if (b->nth == 0) { pdmp3_amd_bulk_delete(b); return NULL; }
   return b;
 }
