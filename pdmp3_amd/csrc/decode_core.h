@@ -901,7 +901,13 @@ PD_FN void ph_mfma(int lane, WaveData& L, const TabLds& S, LaneRegs& R, BankPtr 
       const bool mixrows = wsf && g.is_mixed(ch);        // subbands 0, 1 use window/transform 0 (P:1769-1771)
       const int bt = g.block_type(ch);
       float bfr[10];
-      if (shrt) { PD_UNROLL for (int k = 0; k < 10; k++) bfr[k] = T.frag_short[k * 64 + lane]; }
+      if (shrt) {
+        // (pinned = waited for INSIDE this branch: the wait counters are per wave, not per path -- with the short blocks' loads
+        //  still in flight where the paths meet, the long-block path too sat through `s_waitcnt vmcnt(9) .. vmcnt(0)` between
+        //  its matrix instructions, i.e. waited for the prefetch of the next granule, asked for a moment before, every granule)
+        PD_UNROLL for (int k = 0; k < 10; k++) bfr[k] = T.frag_short[k * 64 + lane];
+        PD_UNROLL for (int k = 0; k < 10; k++) PD_PIN(bfr[k]);
+      }
       else { PD_UNROLL for (int k = 0; k < 10; k++) bfr[k] = R.bi[k]; }
       f32x4 acc[2][2];
       float afr[2][5];
@@ -1635,7 +1641,13 @@ PD_FN void ph_imdct(int lane, const WaveData& L, const TabLds& S, const LaneRegs
     const bool mixrows = wsf && g.is_mixed(ch);        // subbands 0, 1 use window/transform 0 (P:1769-1771)
     const int bt = g.block_type(ch);
     float bfr[10];
-    if (shrt) { PD_UNROLL for (int k = 0; k < 10; k++) bfr[k] = T.frag_short[k * 64 + lane]; }
+    if (shrt) {
+        // (pinned = waited for INSIDE this branch: the wait counters are per wave, not per path -- with the short blocks' loads
+        //  still in flight where the paths meet, the long-block path too sat through `s_waitcnt vmcnt(9) .. vmcnt(0)` between
+        //  its matrix instructions, i.e. waited for the prefetch of the next granule, asked for a moment before, every granule)
+        PD_UNROLL for (int k = 0; k < 10; k++) bfr[k] = T.frag_short[k * 64 + lane];
+        PD_UNROLL for (int k = 0; k < 10; k++) PD_PIN(bfr[k]);
+      }
     else { PD_UNROLL for (int k = 0; k < 10; k++) bfr[k] = R.bi[k]; }
     f32x4 acc[2][2];
     float afr[2][5];
