@@ -297,6 +297,11 @@ struct alignas(16) TabLds {
   alignas(16) uint16_t ltab[3][576];
   uint8_t bandaddr[3][5][64];      // long blocks (ph_requant_long): [sfreq] 4 x scale index of the lane's lines, see fast_line()
   int sfreq;                       // the sampling frequency ltab is for
+  int pad_[3];
+  // the window taps of lane i = lane & 31 (GlobalTables::taps holds them per lane; both channels' are alike): the granule
+  // kernel reads them from here -- its sixteen waves took 16 x 256 B each through the CU's L1 at their entry, 64 KB per
+  // workgroup; as part of the table image that is 2 KB per workgroup
+  alignas(16) float taps[16][32];
 };
 static_assert(sizeof(TabLds) % 16 == 0, "copied in 16-byte pieces");
 struct WaveLds : WaveData {
@@ -368,6 +373,7 @@ PD_FN void state_zero(int lane, LaneRegs& R) {
 }
 
 // the per-lane constants of a wave
+template <bool TAPS = true>          // TAPS = false: the caller takes we / wo from the workgroup's table block (TabLds::taps)
 PD_FN void lane_init(int lane, WaveData& L, LaneRegs& R, BankPtr cb, const GlobalTables& T) {
   const int i = lane & 31;
   // v[i] = C[16+i] (i<16), 0 (i==16), -C[48-i] (i>16);  v[32+i] = -C[16-i] (i<=16), -C[i-16] (i>16)
@@ -376,9 +382,11 @@ PD_FN void lane_init(int lane, WaveData& L, LaneRegs& R, BankPtr cb, const Globa
   (void)cb;
   R.idx_e = (i < 16) ? 16 + i : ((i == 16) ? 0 : 48 - i);
   R.idx_o = (i <= 16) ? 16 - i : i - 16;
-  for (int k = 0; k < 8; k++) {
-    R.we[k] = T.taps[k * 64 + lane];
-    R.wo[k] = T.taps[(8 + k) * 64 + lane];
+  if (TAPS) {
+    for (int k = 0; k < 8; k++) {
+      R.we[k] = T.taps[k * 64 + lane];
+      R.wo[k] = T.taps[(8 + k) * 64 + lane];
+    }
   }
   state_zero(lane, R);
   if (lane < 4) L.peek[lane] = 1.0f;
@@ -1743,8 +1751,9 @@ PD_FN void ph_overlap_matrix(int lane, WaveData& L, const LaneRegs& R, const flo
 }
 // the window sums of a stereo granule in two parts (same chain of 16 FMAs per sum as ph_window, newest slot first):
 // the terms that read the granule's own slots ...
-PD_FN void ph_window_own(int lane, const WaveData& L, const LaneRegs& R, float* acc) {
+PD_FN void ph_window_own(int lane, const WaveData& L, const TabLds& S, LaneRegs& R, float* acc) {
   const int ch = lane >> 5;
+  PD_UNROLL for (int k = 0; k < 8; k++) { R.we[k] = S.taps[k][lane & 31]; R.wo[k] = S.taps[8 + k][lane & 31]; }
   float E[18], O[18];
   PD_UNROLL for (int t = 0; t < 18; t++) { E[t] = L.hyb[ch][t][R.idx_e]; O[t] = L.hyb[ch][t][R.idx_o]; }
   PD_UNROLL for (int t = 0; t < 18; t++) {
@@ -1820,7 +1829,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   // runs ahead of the other three of its SIMD until it has published, the first one catches up after it has taken
   const bool far_sender = !RING && gp.w == gp.wpw - 1 && next_takes;
   if (far_sender) PD_SETPRIO(2);
-  PD_PHASE(lane_init(lane, L, R, cb, T))
+  PD_PHASE(lane_init<false>(lane, L, R, cb, T))
   if (h5 && (gr == 1 || !fresh)) {
     if (!RING) PD_SETPRIO(3);     // (these waves have an eighth more to do than the others of their SIMDs, and a launch ends with its last wave)
     // (wave-uniform) granule 1 / channel 1 of this frame is a short block: its scales read three hybrid outputs of granule 0
@@ -1952,7 +1961,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
     return;
   }
   float acc[18];
-  if (PD_EXP_SKIP & 16) { PD_UNROLL for (int t = 0; t < 18; t++) acc[t] = L.hyb[0][t][lane & 31]; } else { PD_PHASE(ph_window_own(lane, L, R, acc)) }
+  if (PD_EXP_SKIP & 16) { PD_UNROLL for (int t = 0; t < 18; t++) acc[t] = L.hyb[0][t][lane & 31]; } else { PD_PHASE(ph_window_own(lane, L, S, R, acc)) }
   PD_GT(9)
   if (have_halo) { PD_UNROLL for (int s = 0; s < kHistSlots; s++) { R.he[s] = H.he[s]; R.ho[s] = H.ho[s]; } }
   else if (from_caller) {

@@ -168,6 +168,8 @@ inline void build_tab_images(HostTables& H) {
         for (int lane = 0; lane < 64; lane++)
           S.bandaddr[f][i][lane] = (uint8_t)((H.linetab[(size_t)f * 3 * 576 + fast_line(lane, i)] >> 10) << 2);
     S.sfreq = sf;
+    for (int k = 0; k < 16; k++)
+      for (int i = 0; i < 32; i++) S.taps[k][i] = H.taps[k * 64 + i];
   }
 }
 
