@@ -7,7 +7,7 @@ torch tensors: plumbing for device memory, streams and torch.distributed) into
 the library.  There is NO CPU fallback here: if the library is missing or
 there is no GPU, calls raise.
 """
-from .hip import (Engine, SIDE_DTYPE, FRAME_PCM_INT16, FRAME_SPECTRA_INT16,  # noqa: F401
+from .hip import (Engine, NodeDecoder, SIDE_DTYPE, FRAME_PCM_INT16, FRAME_SPECTRA_INT16,  # noqa: F401
                   library_path, load_library, build_library)
 
-__all__ = ["Engine", "SIDE_DTYPE", "library_path", "load_library", "build_library"]
+__all__ = ["Engine", "NodeDecoder", "SIDE_DTYPE", "library_path", "load_library", "build_library"]

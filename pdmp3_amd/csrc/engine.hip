@@ -471,6 +471,8 @@ static int fail(int code, const char* what, hipError_t e) {
   } while (0)
 
 extern "C" const char* pdmp3_hip_last_error(void) { return g_err; }
+// (for the library's other translation unit, node.hip: the calling thread's error text)
+extern "C" void pdmp3_hip_set_error_(const char* text) { snprintf(g_err, sizeof g_err, "%s", text ? text : ""); }
 
 extern "C" size_t pdmp3_hip_state_bytes(void) { return (size_t)kStateFloats * sizeof(float); }
 extern "C" int pdmp3_hip_pci_bus_id(const pdmp3_hip_ctx* c, char* buf, int len) {

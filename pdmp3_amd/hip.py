@@ -75,6 +75,95 @@ def load_library():
     return lib
 
 
+NODE_EXPORTS = ["pdmp3_node_create", "pdmp3_node_destroy", "pdmp3_node_ranks", "pdmp3_node_shard",
+                "pdmp3_node_decode_records", "pdmp3_node_decode_generated"]
+NODE_RCCL, NODE_COPY = 0, 1
+
+
+class NodeTiming(C.Structure):
+    _fields_ = [("prepare_ms", C.c_double), ("decode_ms", C.c_double), ("gather_ms", C.c_double),
+                ("gather_bytes", C.c_longlong), ("rccl_ranks", C.c_int)]
+
+
+def node_shard(n_frames, rank, world, frame_flags=None):
+    """pdmp3_node_shard (include/pdmp3_node.h): (first frame to decode, frames to decode, frames to discard) -- the C side of
+    pdmp3_amd.sharding.shard_with_halo; a pure function, no GPU needed"""
+    lib = load_library()
+    lib.pdmp3_node_shard.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_void_p] + [C.POINTER(C.c_longlong)] * 3
+    lib.pdmp3_node_shard.restype = None
+    a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+    fl = None
+    if frame_flags is not None:
+        fl = np.ascontiguousarray(frame_flags, dtype=np.uint8)
+    lib.pdmp3_node_shard(n_frames, rank, world, fl.ctypes.data_as(C.c_void_p) if fl is not None else None,
+                         C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+class NodeDecoder:
+    """include/pdmp3_node.h: one stream decoded by several GPUs of this node from ONE process -- frame-range shards with
+    halos, no collective inside the decode, the PCM gathered to devices[0] over RCCL (transport = NODE_RCCL) or, for tests
+    that list one GPU several times, by device copies (NODE_COPY)."""
+
+    def __init__(self, devices, transport=NODE_RCCL):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("pdmp3_amd.NodeDecoder needs HIP devices; there is no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        L = self.lib
+        L.pdmp3_node_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.pdmp3_node_destroy.argtypes = [C.c_void_p]
+        L.pdmp3_node_ranks.argtypes = [C.c_void_p]
+        L.pdmp3_node_decode_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.POINTER(NodeTiming)]
+        L.pdmp3_node_decode_generated.argtypes = [C.c_void_p, C.c_uint64, C.c_longlong, C.c_void_p, C.POINTER(NodeTiming)]
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        rc = L.pdmp3_node_create(arr, len(self.devices), int(transport), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("pdmp3_node_create: error %d: %s" % (rc, L.pdmp3_hip_last_error().decode()))
+        self.h = h
+        self.tdev = torch.device("cuda", self.devices[0])
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s: error %d: %s" % (what, rc, self.lib.pdmp3_hip_last_error().decode()))
+
+    def decode_generated(self, seed, n_frames):
+        """-> (int16 tensor [n_frames, 2304] on devices[0], NodeTiming)"""
+        t = self.torch
+        pcm = t.empty((n_frames, FRAME_PCM_INT16), dtype=t.int16, device=self.tdev)
+        tm = NodeTiming()
+        t.cuda.synchronize(self.tdev)
+        self._check(self.lib.pdmp3_node_decode_generated(self.h, seed, n_frames, pcm.data_ptr(), C.byref(tm)), "pdmp3_node_decode_generated")
+        return pcm, tm
+
+    def decode_records(self, spectra, side):
+        """spectra / side: numpy arrays in host memory (the layout of Engine.upload) -> (PCM tensor on devices[0], NodeTiming)"""
+        t = self.torch
+        sp = np.ascontiguousarray(spectra, dtype=np.int16)
+        sd = np.ascontiguousarray(side)
+        n = sp.shape[0]
+        pcm = t.empty((n, FRAME_PCM_INT16), dtype=t.int16, device=self.tdev)
+        tm = NodeTiming()
+        t.cuda.synchronize(self.tdev)
+        self._check(self.lib.pdmp3_node_decode_records(self.h, sp.ctypes.data_as(C.c_void_p), sd.ctypes.data_as(C.c_void_p), n,
+                                                       pcm.data_ptr(), C.byref(tm)), "pdmp3_node_decode_records")
+        return pcm, tm
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pdmp3_node_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def host_generate(seed, first_frame, n_frames):
     """pdmp3_host_generate_frames: the SURVEY 8d generator on the host (no GPU needed)."""
     lib = load_library()

@@ -26,6 +26,38 @@ def test_hip_library_exports():
     assert lib.pdmp3_hip_state_bytes() > 0
 
 
+def test_node_library_exports_and_shard_arithmetic():
+    """include/pdmp3_node.h: every declared symbol is in libpdmp3_hip.so (RCCL itself is looked up at run time: the
+    library must load without it), and pdmp3_node_shard -- a pure function -- is pdmp3_amd.sharding.shard_with_halo:
+    even and uneven splits, and cuts after runs of mono frames, RESET frames included"""
+    import pdmp3_amd
+    from pdmp3_amd import hip, sharding
+    lib = pdmp3_amd.load_library()
+    names = _declared("pdmp3_node.h")
+    assert set(hip.NODE_EXPORTS) == set(n for n in names if n.startswith("pdmp3_node_"))
+    for n in names:
+        assert hasattr(lib, n), "include/pdmp3_node.h declares %s but the library lacks it" % n
+    deps = os.popen("ldd %s" % pdmp3_amd.library_path()).read()
+    assert "rccl" not in deps and "nccl" not in deps, "the engine library must not link against RCCL"
+    rng = np.random.default_rng(5)
+    for n, world in ((1000000, 8), (10, 3), (7, 8), (1, 1), (125000, 2), (4097, 5)):
+        for rank in range(world):
+            assert hip.node_shard(n, rank, world) == sharding.shard_with_halo(n, rank, world), (n, rank, world)
+    for trial in range(300):
+        n = int(rng.integers(1, 120))
+        world = int(rng.integers(1, 9))
+        # runs of stereo (mode 1) and mono (mode 3) frames, RESET flags sprinkled in
+        flags = np.zeros(n, np.uint8)
+        f = 0
+        while f < n:
+            run = int(rng.integers(1, 12))
+            flags[f:f + run] = (3 if rng.integers(0, 2) else 1) << 2
+            f += run
+        flags[rng.random(n) < 0.06] |= 0x40
+        for rank in range(world):
+            assert hip.node_shard(n, rank, world, flags) == sharding.shard_with_halo(n, rank, world, frame_flags=flags), (trial, rank, world)
+
+
 def test_api_library_exports():
     """libpdmp3.so: every function include/pdmp3.h (the reference's API) and include/pdmp3_bulk.h declare"""
     from pdmp3_amd import api

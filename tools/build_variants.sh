@@ -15,7 +15,7 @@ for spec in "$@"; do
     rm -rf /tmp/pdmp3_variant_$name; mkdir -p $src /tmp/pdmp3_variant_$name/include
     for f in $(git -C $ROOT ls-tree --name-only $rev pdmp3_amd/csrc/ include/); do git -C $ROOT show $rev:$f > /tmp/pdmp3_variant_$name/$f; done
   fi
-  ( cd $src && hipcc $FLAGS $extra -shared -o $ROOT/pdmp3_amd/variants/$name.so engine.hip ) &
+  ( cd $src && hipcc $FLAGS $extra -shared -o $ROOT/pdmp3_amd/variants/$name.so engine.hip $( [ -f node.hip ] && echo node.hip ) -ldl ) &
 done
 wait
 ls -la $ROOT/pdmp3_amd/variants/
