@@ -223,6 +223,26 @@ static inline void mul18_rtz_32767(const float* x, float* p) {
 #ifndef PD_CHUNK_FAST_REQUANT
 #define PD_CHUNK_FAST_REQUANT 0
 #endif
+// issue priorities of the chunk kernel's phases (s_setprio 0..3; A/B in profiles/r05_kernel_experiments.txt)
+#ifndef PD_PRIO_MFMA
+#define PD_PRIO_MFMA 2
+#endif
+#ifndef PD_PRIO_WINDOW
+#define PD_PRIO_WINDOW 0
+#endif
+#ifndef PD_PRIO_REQUANT
+#define PD_PRIO_REQUANT 1
+#endif
+#ifndef PD_PRIO_REST
+#define PD_PRIO_REST 0
+#endif
+#ifndef PD_PRIO_AA
+#define PD_PRIO_AA 1
+#endif
+
+#ifndef PD_PRIO_SCALES
+#define PD_PRIO_SCALES PD_PRIO_REST
+#endif
 #ifndef PD_SCALES_WITH_WINDOW
 #define PD_SCALES_WITH_WINDOW 0
 #endif
@@ -1350,14 +1370,17 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       PD_PHASE(ph_peek_tail(lane, L, S, R, T))
       PD_TICK(4)
     } else {
+      PD_SETPRIO(PD_PRIO_REQUANT);
       PD_PHASE(if (reset_here) state_zero(lane, R); if (!(PD_EXP_SKIP & 1)) ph_requant<DUMP, 9, PD_CHUNK_FAST_REQUANT != 0, !OWN_TABS>(lane, L, S, cb, T, dmp, dmp + 576, &gi))
       PD_TICK(2)
+      PD_SETPRIO(PD_PRIO_AA);
       PD_PHASE(
         // the next granule's HBM reads fly during this granule's transforms
         if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
         if (!(PD_EXP_SKIP & 2)) ph_antialias(lane, L, cb, false, &gi);
       )
       PD_TICK(3)
+      PD_SETPRIO(PD_PRIO_MFMA);
       PD_PHASE(if (!(PD_EXP_SKIP & 4)) ph_mfma<DUMP>(lane, L, S, R, cb, T, dmp + 2 * 576, dmp + 3 * 576, emit || feeds_next, &gi))
       PD_TICK(4)
     }
@@ -1365,6 +1388,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     // The next granule is committed to LDS BEFORE this granule's PCM stores are issued (ph_window issues them): its
     // prefetch loads are older than those stores, so waiting for them never waits for a store.  (With the commit after
     // the window the wave sat through the acknowledgement of its nine stores every granule: 10 % of the loop.)
+    PD_SETPRIO(PD_PRIO_SCALES);
     if (g_next < g_end) {
       PD_PHASE(ph_commit(lane, L, R))
       if (!PD_SCALES_WITH_WINDOW) { PD_PHASE(if (!(PD_EXP_SKIP & 8)) ph_scales(lane, L)) }    // next granule's (its side info was committed just above)
@@ -1373,12 +1397,14 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     // (PD_SCALES_WITH_WINDOW: the scales read the side records, the window reads hyb and writes PCM -- nothing of one is
     //  the other's, so they share a phase and their LDS round trips run side by side)
     if ((emit || feeds_next) && !(PD_EXP_SKIP & 16)) {
+      PD_SETPRIO(PD_PRIO_WINDOW);
       PD_PHASE(if (PD_SCALES_WITH_WINDOW && g_next < g_end) ph_scales(lane, L);
                ph_window<F32>(lane, L, R, emit, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g,
                                 F32 ? a.pcm_f32 + (size_t)f * 2304 + gr * 576 * nch_g : nullptr))
     } else if (PD_SCALES_WITH_WINDOW && g_next < g_end) {
       PD_PHASE(ph_scales(lane, L))
     }
+    PD_SETPRIO(PD_PRIO_REST);
     PD_PHASE(if (!F32) ph_store(lane, L, nch_g, a.pcm + (size_t)f * 2304 + gr * 576 * nch_g, emit))
     PD_TICK(7)
   }
@@ -1892,6 +1918,8 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   // priority: the late ones catch up (same box, three runs each: C2 19.9-20.3 -> 19.4-19.8 us, 8192 frames 70.0 -> 68.7,
   // 12288 frames 102.4 -> 100.8; every other schedule tried -- from the start, mirrored, back to equal after the IMDCT --
   // was worse or the same).
+  // (round 5: priorities by STAGE instead -- the further a wave has got, the lower, which is what paid in the chunk kernel --
+  //  or stage + age class: C2 18.4-18.6 us as it is, 18.5-19.7 with every such schedule, profiles/r05_kernel_experiments.txt)
   if (!RING && !(h5 && (gr == 1 || !fresh))) {
     const int q = gp.w >> 2;
     if (q == 1) PD_SETPRIO(1); else if (q == 2) PD_SETPRIO(2); else if (q == 3) PD_SETPRIO(3); else PD_SETPRIO(0);

@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu --no-e2e > $OUT/bench_under_rocprof.json 2> $OUT/stats.log; echo "stats rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu --no-e2e --no-from-idle > $OUT/bench_under_rocprof.json 2> $OUT/stats.log; echo "stats rc=$?"
 cat $OUT/stats/bench_kernel_stats.csv
 # the same from an idle GPU (no larger launches before the timed region): the clocks' share of the headline
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_idle -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu --no-e2e --big 0 --shard 0 > $OUT/bench_idle_under_rocprof.json 2> $OUT/stats_idle.log; echo "idle stats rc=$?"
@@ -21,7 +21,7 @@ pmc sq3 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bulk_stats -o bulk -- python3 tools/bulk_bench.py --frames 40000 --threads 2 --reps 2 > $OUT/bulk_under_rocprof.json 2> $OUT/bulk_stats.log; echo "bulk stats rc=$?"
 cat $OUT/bulk_stats/bulk_kernel_stats.csv | cut -c1-160
 # un-profiled lines
-timeout 600 python3 bench.py --from-idle 2> /dev/null > $OUT/bench.json; echo "bench rc=$?"; cat $OUT/bench.json
+timeout 600 python3 bench.py 2> /dev/null > $OUT/bench.json; echo "bench rc=$?"; cat $OUT/bench.json
 timeout 600 python3 tools/bulk_bench.py --frames 137813 --threads 2 2> /dev/null | tail -1 > $OUT/bulk_decode.json; cat $OUT/bulk_decode.json
 timeout 600 python3 tools/bulk_bench.py --frames 137813 --threads 1,8,16,32 --host-huffman 2> /dev/null | tail -1 > $OUT/bulk_decode_host_huffman.json; cat $OUT/bulk_decode_host_huffman.json
 for j in 1 4 6; do timeout 600 python3 tools/bulk_bench.py --c4 $j 2> /dev/null | tail -1; done > $OUT/bulk_c4.json; cat $OUT/bulk_c4.json
@@ -35,7 +35,6 @@ PDMP3_HIP_UNPACK_PROF=1 timeout 300 python3 tools/bulk_bench.py --frames 20000 -
 timeout 300 python3 tools/phase_profile.py 131072 32 > $OUT/phase_profile.txt 2>&1; timeout 300 python3 tools/phase_profile.py 2048 1 >> $OUT/phase_profile.txt 2>&1
 # round 4: the persistent granule kernel against the engine's own choice, its per-turn stamps, the granule kernel's per-wave stamps,
 # the driver's short invocation of the bench
-timeout 300 python3 tools/ring_bench.py > $OUT/ring_bench.txt 2>&1; timeout 300 python3 tools/ring_profile.py 32768 > $OUT/ring_profile.txt 2>&1
 timeout 300 python3 tools/gran_profile.py 2048 > $OUT/gran_profile.txt 2>&1
 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 2> /dev/null > $OUT/bench_driver_flags.json; cat $OUT/bench_driver_flags.json | cut -c1-400
 # round 4, the whole-stream decoder's split scan: end to end with the PCM left in HBM (the pipeline's waits, a line per window),
