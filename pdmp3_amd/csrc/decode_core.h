@@ -1083,9 +1083,7 @@ PD_FN void pcm_emit(int lane, WaveData& L, int nch_arg, bool act_arg, const floa
       PD_UNROLL for (int q = 0; q < 9; q++) {
         int a = out[2 * q], b = out[2 * q + 1];
         permlane32_swap(a, b);
-        float* d = pcmf_g + 2 * (64 * q + lane);
-        d[0] = u2f((uint32_t)a);
-        d[1] = u2f((uint32_t)b);
+        reinterpret_cast<f32x2*>(pcmf_g)[lane + 64 * q] = (f32x2){u2f((uint32_t)a), u2f((uint32_t)b)};
       }
     } else if (act) {
       PD_UNROLL for (int t = 0; t < 18; t++) pcmf_g[32 * t + i] = u2f((uint32_t)out[t]);
@@ -1146,7 +1144,16 @@ PD_FN void ph_window_emit(int lane, WaveData& L, LaneRegs& R, int nch, int16_t* 
         PD_UNROLL for (int u = 0; u < 3; u++) acc[u] = fma2((f32x2){R.we[k], R.we[k]}, Ep[7 + (q0) + u - k], acc[u]); \
         PD_UNROLL for (int u = 0; u < 3; u++) acc[u] = fma2((f32x2){R.wo[k], R.wo[k]}, Op[7 + (q0) + u - k], acc[u]); \
       } \
-      PD_UNROLL for (int u = 0; u < 3; u++) { sum[2 * ((q0) + u)] = acc[u][0]; sum[2 * ((q0) + u) + 1] = acc[u][1]; } \
+      PD_UNROLL for (int u = 0; u < 3; u++) { \
+        if (F32 && ALL) { \
+          /* float PCM of a stereo granule: a pair of sums is a pair of time slots -- stored as soon as it is there (the \
+             eighteen sums held until the end were 20 spilled registers in this kernel) */ \
+          int a_ = (int)f2u(acc[u][0]), b_ = (int)f2u(acc[u][1]); \
+          permlane32_swap(a_, b_); \
+          /* (one base + a constant offset per pair, one 8-byte store: the granule's PCM is 16-byte aligned by contract) */ \
+          reinterpret_cast<f32x2*>(pcmf_g)[lane + 64 * ((q0) + u)] = (f32x2){u2f((uint32_t)a_), u2f((uint32_t)b_)}; \
+        } else { sum[2 * ((q0) + u)] = acc[u][0]; sum[2 * ((q0) + u) + 1] = acc[u][1]; } \
+      } \
     }
     PD_WIN_LOAD(7, 16)
     const float o17 = ho[33 * 17];
@@ -1163,7 +1170,7 @@ PD_FN void ph_window_emit(int lane, WaveData& L, LaneRegs& R, int nch, int16_t* 
     }
     R.ho[14] = o17;
   }
-  pcm_emit<F32, ALL>(lane, L, nch, act, sum, pcm_g, pcmf_g);
+  if (!(F32 && ALL)) pcm_emit<F32, ALL>(lane, L, nch, act, sum, pcm_g, pcmf_g);
 }
 
 // full = false (wave-uniform): the last halo granule -- only its slots 3..17 are wanted, as the next granule's history
