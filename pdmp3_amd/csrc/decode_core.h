@@ -51,6 +51,8 @@ struct ConstBank;
 #define PD_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 #define PD_CLOCK() __builtin_amdgcn_s_memtime()
 #define PD_UNROLL _Pragma("unroll")
+#define PD_UNROLL_N(n) _Pragma(PD_STR_(unroll n))
+#define PD_STR_(x) #x
 #define PD_NOUNROLL _Pragma("nounroll")
 #define PD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // pins a VGPR value at this program point (keeps IR passes from sinking the
@@ -155,6 +157,7 @@ void permlane32_swap(int* a, int* b);         // v_permlane32_swap_b32 vdst = a,
 #define PD_FMA(a, b, c) __builtin_fmaf((a), (b), (c))   /* a true fused multiply-add, as on the device */
 #define PD_CLOCK() 0ull
 #define PD_UNROLL
+#define PD_UNROLL_N(n)
 #define PD_NOUNROLL
 #define PD_SCHED_FENCE() ((void)0)
 #define PD_PIN(x) ((void)0)

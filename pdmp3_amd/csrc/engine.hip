@@ -178,7 +178,7 @@ __device__ __forceinline__ void ring_store(SymRec* p, uint32_t x, uint32_t y) {
 
 __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* tabs, const pdmp3_frame_bits* bits,
                                                             const uint8_t* res, int n_frames, int16_t* spectra,
-                                                            pdmp3_gc_side* side, GcRaw* raw, int tab_n16, unsigned long long* prof) {
+                                                            GcRaw* raw, int tab_n16, unsigned long long* prof) {
   __shared__ UnpackTables U;
   __shared__ uint32_t rows[kUnpackRows * kRowStrideW + 4];
   __shared__ uint32_t fbits[kUnpackRows * kFrameBitsW];
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kUnpackThreads) void k_unpack(const UnpackTables* t
       // the walker's first trips instead of in front of them
       if (wave == 1) {
         if (fl < nrows)
-          unpack_records(U, row, *reinterpret_cast<const pdmp3_frame_bits*>(fbits + fl * kFrameBitsW), g, side + idx, raw + idx);
+          unpack_scalefactors(U, row, *reinterpret_cast<const pdmp3_frame_bits*>(fbits + fl * kFrameBitsW), g, raw + idx);
       } else {
         uint4* z = reinterpret_cast<uint4*>(spectra + (size_t)f0 * 4 * 576);
         for (int i = (int)threadIdx.x - 128; i < nrows * 4 * 72; i += 128) z[i] = make_uint4(0, 0, 0, 0);
@@ -318,101 +318,115 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_rows(const pdmp3_row_desc* 
   }
 }
 
-// inclusive "last lane that has a value" scan over the wave, (has << 16 | 16-bit value) in one register: Hillis-Steele
-// inside each row of 16 lanes with DPP row shifts, then the two row broadcasts of the classic GCN wave scan -- 6
-// cross-lane moves at VALU rate.  (With __shfl_up = ds_bpermute the 24 dependent LDS round trips of a step were most of
-// round 1's 43 us per window.)
-constexpr unsigned kHas = 0x10000u;
-__device__ __forceinline__ unsigned scan_packed(unsigned r) {
-#define PD_SCAN_STEP(ctrl, row_mask)                                                                     \
-  {                                                                                                      \
-    const unsigned s_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r, ctrl, row_mask, 0xf, false);    \
-    r = (r & kHas) ? r : s_;                                                                             \
+// The merge (unpack_core.h "The same merge by BLOCKS"): a workgroup per block of 32 frames, a lane per surviving value.
+// k_merge_outcome: the block's 10 KB of merge input into LDS with 16-byte loads, every lane walks the 32 frames for its
+// slot, a row of outcomes goes out; the workgroup that is through last among the eight of a super-block (a counter that
+// wraps back to zero by itself) composes the eight rows into the super-block's.  What the eight exchange travels as the
+// granule kernel's hand-overs do: device-scope relaxed atomic accesses, ordered by the wait for the stores and the counter.
+constexpr int kMergeRaw16 = kMergeBlk * 4 * (int)sizeof(GcRaw) / 16;              // 640
+constexpr int kMergeBits16 = kMergeBlk * (int)sizeof(pdmp3_frame_bits) / 16;      // 160
+constexpr int kMergeSide16 = kMergeBlk * PDMP3_FRAME_SIDE_BYTES / 16;             // 1024
+constexpr int kMergeRow16 = kMergeLanes * 4 / 16;                                 // a row of outcomes: 64
+constexpr int kMergeStageRows = 40;                                               // rows of outcomes a block looks at in one go (a window of 8192 frames: 38 at most)
+constexpr int kMergeRawPer = (kMergeRaw16 + kMergeLanes - 1) / kMergeLanes, kMergeBitsPer = (kMergeBits16 + kMergeLanes - 1) / kMergeLanes;
+static_assert(sizeof(GcRaw) % 16 == 0 && sizeof(pdmp3_frame_bits) % 16 == 0 && kMergeSlots <= kMergeLanes, "the merge copies 16 bytes at a time");
+__global__ __launch_bounds__(kMergeLanes) void k_merge_outcome(const GcRaw* raw, const pdmp3_frame_bits* bits, int n_frames, uint32_t* outc,
+                                                                uint32_t* sup, unsigned* counters) {
+  __shared__ uint4 raw_s[kMergeRaw16];
+  __shared__ uint8_t fr_s[kMergeBlk];
+  __shared__ unsigned last_s;
+  const int b = blockIdx.x, f0 = b * kMergeBlk, t = threadIdx.x;
+  const int nb = n_frames - f0 < kMergeBlk ? n_frames - f0 : kMergeBlk;
+  const uint4* src = reinterpret_cast<const uint4*>(raw + (size_t)f0 * 4);
+  for (int i = t; i < nb * 20; i += kMergeLanes) raw_s[i] = src[i];
+  if (t < nb) fr_s[t] = bits[f0 + t].frame;
+  __syncthreads();
+  unsigned o = 0;
+  if (t < kMergeSlots) o = merge_block_outcome(t, reinterpret_cast<const GcRaw*>(raw_s), fr_s, nb, PD_UNIFORM(merge_wave_kind(t & ~63)));
+  const int sb = b / kMergeSuper, b0 = sb * kMergeSuper;
+  const int n_in = (int)gridDim.x - b0 < kMergeSuper ? (int)gridDim.x - b0 : kMergeSuper;
+  if (n_in == 1) {                                         // (a super-block of one block: its outcome is the block's)
+    outc[(size_t)b * kMergeLanes + t] = o;
+    sup[(size_t)sb * kMergeLanes + t] = o;
+    return;
   }
-  PD_SCAN_STEP(0x111, 0xf)     // row_shr:1
-  PD_SCAN_STEP(0x112, 0xf)     // row_shr:2
-  PD_SCAN_STEP(0x114, 0xf)     // row_shr:4
-  PD_SCAN_STEP(0x118, 0xf)     // row_shr:8   -> prefix within each row
-  PD_SCAN_STEP(0x142, 0xa)     // row_bcast:15 into rows 1, 3
-  PD_SCAN_STEP(0x143, 0xc)     // row_bcast:31 into rows 2, 3
-#undef PD_SCAN_STEP
-  return r;
+  __hip_atomic_store(outc + (size_t)b * kMergeLanes + t, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  PD_VMEM_DRAIN();
+  __syncthreads();
+  if (t == 0) last_s = atomicInc(counters + sb, (unsigned)n_in - 1u) == (unsigned)n_in - 1u;
+  __syncthreads();
+  if (!last_s) return;
+  const int tw = t < kMergeSlots ? merge_twin(t) : -1;
+  unsigned oj[kMergeSuper], o0j[kMergeSuper];
+  PD_UNROLL for (int j = 0; j < kMergeSuper; j++) {
+    const int jj = j < n_in ? j : n_in - 1;
+    oj[j] = PD_LOAD_DEVICE(outc + (size_t)(b0 + jj) * kMergeLanes + t);
+    o0j[j] = tw >= 0 ? PD_LOAD_DEVICE(outc + (size_t)(b0 + jj) * kMergeLanes + tw) : 0u;
+  }
+  unsigned acc = 0, acc0 = 0;
+  PD_UNROLL for (int j = 0; j < kMergeSuper; j++)
+    if (j < n_in) merge_compose_step(oj[j], o0j[j], acc, acc0);
+  sup[(size_t)sb * kMergeLanes + t] = acc;
 }
-__device__ __forceinline__ unsigned pack_has(bool has, unsigned val) { return (has ? kHas : 0u) | (val & 0xffffu); }
 
-// One workgroup of eight waves per surviving value (unpack_core.h merge_slot).  A step is 2048 frames = 32 blocks of 64,
-// four blocks per wave: every wave asks for its four blocks' inputs at once (one round trip to memory for the whole
-// step), scans each block by itself, leaves the block's outcome -- "a frame of mine wrote the value: this one" -- in
-// LDS, and after a barrier finds what reaches its blocks from the left with one more scan over those 32 outcomes.
-// A slot of granule 1 that may copy granule 0's value (scfsi) does this twice: the twin's chain first, then its own.
-// (Round 2: one wave per value walking 256 frames per trip on its carry chain, 33 us per window.)
-constexpr int kMergeWaves = 8, kMergeBlocks = 4 * kMergeWaves, kMergeStep = 64 * kMergeBlocks;
-__device__ __forceinline__ unsigned merge_carry_in(const unsigned* sums, unsigned carry, int blk, int lane, unsigned* carry_out) {
-  // lane i < 32: outcome of block i; inclusive scan; block blk takes what block blk - 1 ends with
-  const unsigned inc = scan_packed(lane < kMergeBlocks ? sums[lane] : 0u);
-  const unsigned left = (unsigned)__shfl((int)inc, blk > 0 ? blk - 1 : 0);
-  const unsigned last = (unsigned)__shfl((int)inc, kMergeBlocks - 1);
-  *carry_out = (last & kHas) ? (last & 0xffffu) : carry;
-  return (blk > 0 && (left & kHas)) ? (left & 0xffffu) : carry;
-}
-__global__ __launch_bounds__(64 * kMergeWaves) void k_merge(const GcRaw* raw, const pdmp3_frame_bits* bits, int n_frames,
-                                                             const uint16_t* state_in, uint16_t* state_out, pdmp3_gc_side* side) {
-  __shared__ unsigned sum0[kMergeBlocks], sum1[kMergeBlocks];
-  const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tw = merge_twin(t);
-  unsigned carry = state_in[t], carry0 = tw >= 0 ? state_in[tw] : 0;
-  for (int base = 0; base < n_frames; base += kMergeStep) {
-    MergeIn m[4];
-    uint8_t fr[4], iso[4];
-    PD_UNROLL for (int q = 0; q < 4; q++) {
-      const int f = base + 64 * (4 * wave + q) + lane;
-      m[q] = MergeIn{false, false, false, 0, 0};
-      fr[q] = 0; iso[q] = 0;
-      if (f < n_frames) {
-        fr[q] = bits[f].frame;
-        iso[q] = bits[f].iso;
-        m[q] = merge_load(t, raw + (size_t)f * 4, (fr[q] & PDMP3_FR_NEWSTREAM) != 0);
-      }
-    }
-    if (base) __syncthreads();                       // (the step before is done with the outcomes)
-    unsigned v0[4] = {0, 0, 0, 0};
-    if (tw >= 0) {                                   // uniform for the workgroup
-      unsigned loc[4];
-      PD_UNROLL for (int q = 0; q < 4; q++) {
-        loc[q] = scan_packed(pack_has(m[q].set0, m[q].val0));
-        const unsigned end = (unsigned)__shfl((int)loc[q], 63);
-        if (lane == 0) sum0[4 * wave + q] = end;
-      }
-      __syncthreads();
-      unsigned next0 = carry0;
-      PD_UNROLL for (int q = 0; q < 4; q++) {
-        const unsigned in = merge_carry_in(sum0, carry0, 4 * wave + q, lane, &next0);
-        v0[q] = (loc[q] & kHas) ? (loc[q] & 0xffffu) : in;
-      }
-      carry0 = next0;
-    }
-    unsigned loc[4];
-    PD_UNROLL for (int q = 0; q < 4; q++) {
-      loc[q] = scan_packed(pack_has(m[q].set || m[q].copy, m[q].copy ? v0[q] : m[q].val));
-      const unsigned end = (unsigned)__shfl((int)loc[q], 63);
-      if (lane == 0) sum1[4 * wave + q] = end;
+// k_merge_apply: block b asks for its frames' inputs, walks the rows of outcomes in front of it -- super-blocks 0 .. b / 8 - 1,
+// then the blocks of its own super-block -- from the values the window before left, then its own frames; the records are
+// built in LDS -- zeroes, the frame's own side fields (a thread per granule-channel), scalefactors and count1 (a thread per
+// slot: byte stores) -- and leave with 16-byte stores: the whole of `side` is written here, once.  The last block leaves
+// the values for the next window.
+__global__ __launch_bounds__(kMergeLanes) void k_merge_apply(const GcRaw* raw, const pdmp3_frame_bits* bits, int n_frames, const uint32_t* outc,
+                                                              const uint32_t* sup, const uint16_t* state_in, uint16_t* state_out, pdmp3_gc_side* side) {
+  __shared__ uint4 raw_s[kMergeRaw16];
+  __shared__ uint4 bits_s[kMergeBits16];
+  __shared__ uint4 img_s[kMergeSide16];
+  __shared__ uint4 stage_s[kMergeStageRows * kMergeRow16];
+  __shared__ uint32_t meta_s[kMergeBlk];
+  __shared__ uint8_t trash_s[kMergeLanes];
+  const int b = blockIdx.x, f0 = b * kMergeBlk, t = threadIdx.x;
+  const int nb = n_frames - f0 < kMergeBlk ? n_frames - f0 : kMergeBlk;
+  uint4 rv[kMergeRawPer], bv[kMergeBitsPer];
+  uint32_t hw = 0;
+  {
+    if (t < nb) hw = *reinterpret_cast<const uint32_t*>(bits + f0 + t);      // frame | scfsi | iso
+    const uint4* src = reinterpret_cast<const uint4*>(raw + (size_t)f0 * 4);
+    // (values, not arrays in memory: every element is assigned on every path)
+    PD_UNROLL for (int k = 0; k < kMergeRawPer; k++) { const int i = t + k * kMergeLanes; rv[k] = make_uint4(0, 0, 0, 0); if (i < nb * 20) rv[k] = src[i]; }
+    const uint4* bsrc = reinterpret_cast<const uint4*>(bits + f0);
+    PD_UNROLL for (int k = 0; k < kMergeBitsPer; k++) { const int i = t + k * kMergeLanes; bv[k] = make_uint4(0, 0, 0, 0); if (i < nb * 5) bv[k] = bsrc[i]; }
+  }
+  const int tw = t < kMergeSlots ? merge_twin(t) : -1;
+  const unsigned kind = PD_UNIFORM(merge_wave_kind(t & ~63));
+  unsigned val = t < kMergeSlots ? state_in[t] : 0u, val0 = tw >= 0 ? state_in[tw] : 0u;
+  const int nsup = b / kMergeSuper, total = nsup + b % kMergeSuper;
+  for (int c0 = 0; c0 < total; c0 += kMergeStageRows) {
+    const int nc = total - c0 < kMergeStageRows ? total - c0 : kMergeStageRows;
+    if (c0) __syncthreads();
+    for (int i = t; i < nc * kMergeRow16; i += kMergeLanes) {
+      const int r = c0 + i / kMergeRow16;
+      const uint32_t* row = r < nsup ? sup + (size_t)r * kMergeLanes : outc + (size_t)(nsup * kMergeSuper + r - nsup) * kMergeLanes;
+      stage_s[i] = reinterpret_cast<const uint4*>(row)[i % kMergeRow16];
     }
     __syncthreads();
-    unsigned next = carry;
-    PD_UNROLL for (int q = 0; q < 4; q++) {
-      const int f = base + 64 * (4 * wave + q) + lane;
-      const unsigned in = merge_carry_in(sum1, carry, 4 * wave + q, lane, &next);
-      const unsigned v = (loc[q] & kHas) ? (loc[q] & 0xffffu) : in;
-      if (f < n_frames) {
-        pdmp3_frame_bits F;
-        F.frame = fr[q];
-        F.iso = iso[q];                              // (PDMP3_ISO_SF21 / SF12: the one-past-the-end slots stay zero)
-        merge_store(t, F, side + (size_t)f * 4, v);
-      }
+    if (t < kMergeSlots) {
+      if (kind & 1u) merge_carry_rows<true>(reinterpret_cast<const uint32_t*>(stage_s), nc, t, tw, val, val0);
+      else merge_carry_rows<false>(reinterpret_cast<const uint32_t*>(stage_s), nc, t, tw, val, val0);
     }
-    carry = next;
   }
-  if (threadIdx.x == 0) state_out[t] = (uint16_t)carry;
+  PD_UNROLL for (int k = 0; k < kMergeRawPer; k++) { const int i = t + k * kMergeLanes; if (i < nb * 20) raw_s[i] = rv[k]; }
+  PD_UNROLL for (int k = 0; k < kMergeBitsPer; k++) { const int i = t + k * kMergeLanes; if (i < nb * 5) bits_s[i] = bv[k]; }
+  for (int i = t; i < kMergeSide16; i += kMergeLanes) img_s[i] = make_uint4(0, 0, 0, 0);
+  if (t < nb) meta_s[t] = merge_frame_meta(hw & 0xffu, hw >> 24);
+  __syncthreads();
+  const pdmp3_frame_bits* F = reinterpret_cast<const pdmp3_frame_bits*>(bits_s);
+  pdmp3_gc_side* img = reinterpret_cast<pdmp3_gc_side*>(img_s);
+  if ((t >> 2) < nb) side_fields(F[t >> 2], t & 3, img + t);
+  if (t < kMergeSlots) {
+    val = merge_block_apply(t, val, val0, reinterpret_cast<const GcRaw*>(raw_s), meta_s, nb, img, trash_s + t, kind);
+    if (f0 + nb == n_frames) state_out[t] = (uint16_t)val;
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(side + (size_t)f0 * 4);
+  for (int i = t; i < nb * (PDMP3_FRAME_SIDE_BYTES / 16); i += kMergeLanes) dst[i] = img_s[i];
 }
 
 // Scratch of a chained launch (DecodeArgs::chain_*): launches that are ordered one after the other share a buffer --
@@ -799,7 +813,7 @@ struct StreamSlot {
   int16_t* d_spectra; pdmp3_gc_side* d_side; int16_t* d_pcm;
   // bitstream-level input (allocated on first use)
   pdmp3_frame_bits* h_bits; uint8_t* h_res;                       // pinned
-  pdmp3_frame_bits* d_bits; uint8_t* d_res; GcRaw* d_raw;
+  pdmp3_frame_bits* d_bits; uint8_t* d_res; GcRaw* d_raw; uint32_t* d_outc; unsigned* d_mcnt;
   pdmp3_row_desc* h_desc; pdmp3_row_desc* d_desc; uint8_t* d_pool;   // compact bits input: pinned descriptors; the pool is h_res
   uint8_t* h_in; uint8_t* d_in;   // the blocks h_desc | h_bits | h_res and d_desc | d_bits | d_pool point into
   int busy;
@@ -830,7 +844,7 @@ extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
     (void)hipHostFree(t.h_spectra); (void)hipHostFree(t.h_side); (void)hipHostFree(t.h_pcm);
     (void)hipFree(t.d_spectra); (void)hipFree(t.d_side); (void)hipFree(t.d_pcm);
     (void)hipHostFree(t.h_in);
-    (void)hipFree(t.d_in); (void)hipFree(t.d_res); (void)hipFree(t.d_raw);
+    (void)hipFree(t.d_in); (void)hipFree(t.d_res); (void)hipFree(t.d_raw); (void)hipFree(t.d_outc); (void)hipFree(t.d_mcnt);
   }
   (void)hipFree(hs->d_sfstate);
   if (hs->ev_state) (void)hipEventDestroy(hs->ev_state);
@@ -1116,6 +1130,11 @@ static int ensure_bits(pdmp3_hip_stream* hs) {
     t.d_pool = t.d_in + desc_bytes + bits_bytes;
     HIP_TRY(hipMalloc((void**)&t.d_res, n * PDMP3_RESERVOIR_BYTES + 16), "hipMalloc reservoir");
     HIP_TRY(hipMalloc((void**)&t.d_raw, n * 4 * sizeof(GcRaw)), "hipMalloc raw");
+    // rows of outcomes: one per block of kMergeBlk frames, then one per super-block; the super-blocks' counters (zero between launches)
+    const size_t mblk = (n + kMergeBlk - 1) / kMergeBlk, msup = (mblk + kMergeSuper - 1) / kMergeSuper;
+    HIP_TRY(hipMalloc((void**)&t.d_outc, (mblk + msup) * kMergeLanes * sizeof(uint32_t)), "hipMalloc merge outcomes");
+    HIP_TRY(hipMalloc((void**)&t.d_mcnt, (msup + 1) * sizeof(unsigned)), "hipMalloc merge counters");
+    HIP_TRY(hipMemset(t.d_mcnt, 0, (msup + 1) * sizeof(unsigned)), "memset merge counters");
   }
   HIP_TRY(hipMalloc((void**)&hs->d_sfstate, 2 * 256 * sizeof(uint16_t)), "hipMalloc sfstate");
   HIP_TRY(hipMemset(hs->d_sfstate, 0, 2 * 256 * sizeof(uint16_t)), "memset sfstate");
@@ -1181,7 +1200,7 @@ static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_
     int blocks = (n_frames + kUnpackRows - 1) / kUnpackRows;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(kUnpackThreads), 0, t.stream, hs->ctx->d_unpack, t.d_bits, t.d_res,
-                       n_frames, t.d_spectra, t.d_side, t.d_raw, hs->ctx->unpack_n16, hs->ctx->d_uprof);
+                       n_frames, t.d_spectra, t.d_raw, hs->ctx->unpack_n16, hs->ctx->d_uprof);
     HIP_TRY(hipGetLastError(), "launch k_unpack");
     if (hs->ctx->d_uprof) {                            // development only: serialises, prints one line per launch
       static std::vector<unsigned long long> hp(2048 * 8);
@@ -1199,11 +1218,16 @@ static int submit_bits(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_
               trips > 0 ? d[2] / trips : 0.0, tmax);
     }
   }
-  // everything from here on continues the previous batch (scalefactor / count1 carry, synthesis state)
+  // what each block of 64 frames does to the values that survive frames needs nothing of the batch before ...
+  const unsigned merge_blocks_n = (unsigned)((n_frames + kMergeBlk - 1) / kMergeBlk);
+  uint32_t* d_sup = t.d_outc + (size_t)merge_blocks_n * kMergeLanes;
+  hipLaunchKernelGGL(k_merge_outcome, dim3(merge_blocks_n), dim3(kMergeLanes), 0, t.stream, t.d_raw, t.d_bits, n_frames, t.d_outc, d_sup, t.d_mcnt);
+  HIP_TRY(hipGetLastError(), "launch k_merge_outcome");
+  // ... everything from here on continues it (scalefactor / count1 carry, synthesis state)
   if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
-  hipLaunchKernelGGL(k_merge, dim3(kMergeSlots), dim3(64 * kMergeWaves), 0, t.stream, t.d_raw, t.d_bits, n_frames,
+  hipLaunchKernelGGL(k_merge_apply, dim3(merge_blocks_n), dim3(kMergeLanes), 0, t.stream, t.d_raw, t.d_bits, n_frames, t.d_outc, d_sup,
                      hs->d_sfstate + 256 * hs->sf_cur, hs->d_sfstate + 256 * (hs->sf_cur ^ 1), t.d_side);
-  HIP_TRY(hipGetLastError(), "launch k_merge");
+  HIP_TRY(hipGetLastError(), "launch k_merge_apply");
   hs->sf_cur ^= 1;
   // A destination in THIS device's memory that takes whole 4608-byte rows: the kernel stores the PCM there itself (the
   // copy from the slot's buffer was 11 us of a window's 235 -- 75 MB through HBM for 8192 frames; end to end, A/B on one

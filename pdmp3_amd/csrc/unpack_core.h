@@ -475,16 +475,11 @@ PD_HD unsigned part2_start_of(const UnpackTables& U, const pdmp3_frame_bits& F, 
   return pos;
 }
 
-PD_HD void unpack_records(const UnpackTables& U, const uint8_t* res, const pdmp3_frame_bits& F, int g, pdmp3_gc_side* rec,
-                          GcRaw* raw) {
-  const int gr = g >> 1, ch = g & 1;
+// The fields of a gc record that are the frame's own side info, into a record that is ZERO: everything but the
+// scalefactors and count1, which the merge fills in (the values that survive frames).
+PD_HD void side_fields(const pdmp3_frame_bits& F, int g, pdmp3_gc_side* rec) {
+  const int ch = g & 1;
   const int nch = ((F.frame & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
-  {
-    uint32_t* r32 = reinterpret_cast<uint32_t*>(rec);
-    for (int i = 0; i < 32; i++) r32[i] = 0;
-    uint32_t* w32 = reinterpret_cast<uint32_t*>(raw);
-    for (int i = 0; i < 20; i++) w32[i] = 0;
-  }
   rec->frame = F.frame & (uint8_t)~PDMP3_FR_NEWSTREAM;
   // the ISO switches of the frame (include/pdmp3.h PDMP3_ISO_*: MS_BOUND = 2, IS_SHORT = 4) as the records' PDMP3_GC_ISO_* bits
   rec->iso = (uint8_t)(((F.iso & 0x02u) ? PDMP3_GC_ISO_MS_ALL : 0u) | ((F.iso & 0x04u) ? PDMP3_GC_ISO_IS_SHORT : 0u));
@@ -494,8 +489,18 @@ PD_HD void unpack_records(const UnpackTables& U, const uint8_t* res, const pdmp3
   rec->flags = s.flags;
   rec->subblock_gain[0] = s.subblock_gain[0]; rec->subblock_gain[1] = s.subblock_gain[1]; rec->subblock_gain[2] = s.subblock_gain[2];
   if (g == 3 && !(F.iso & 0x10u)) rec->scalefac_s[12][0] = rec->scalefac_s[12][1] = rec->scalefac_s[12][2] = PDMP3_SF_PEEK;   // (PDMP3_ISO_SF12: stays 0)
+}
 
-  // ---- scalefactors (P:1383-1430)
+// the scalefactors the stream carries for this granule-channel (P:1383-1430), as the merge's input
+PD_HD void unpack_scalefactors(const UnpackTables& U, const uint8_t* res, const pdmp3_frame_bits& F, int g, GcRaw* raw) {
+  const int gr = g >> 1, ch = g & 1;
+  const int nch = ((F.frame & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
+  {
+    uint32_t* w32 = reinterpret_cast<uint32_t*>(raw);
+    for (int i = 0; i < 20; i++) w32[i] = 0;
+  }
+  if (ch >= nch) return;
+  const pdmp3_gc_bits& s = F.gc[g];
   BitPos b{res, part2_start_of(U, F, g, nch)};
   const unsigned slen1 = U.slen[s.scalefac_compress * 2], slen2 = U.slen[s.scalefac_compress * 2 + 1];
   const bool wsf = (s.flags & PDMP3_GC_WIN_SWITCH) != 0;
@@ -525,6 +530,15 @@ PD_HD void unpack_records(const UnpackTables& U, const uint8_t* res, const pdmp3
     raw->sf_l_set = set;
     raw->sf_l_copy = (uint8_t)copy;
   }
+}
+
+// both (the sequential form; k_unpack writes the merge's input only and k_merge_apply builds the whole record)
+PD_HD void unpack_records(const UnpackTables& U, const uint8_t* res, const pdmp3_frame_bits& F, int g, pdmp3_gc_side* rec,
+                          GcRaw* raw) {
+  uint32_t* r32 = reinterpret_cast<uint32_t*>(rec);
+  for (int i = 0; i < 32; i++) r32[i] = 0;
+  side_fields(F, g, rec);
+  unpack_scalefactors(U, res, F, g, raw);
 }
 
 // false: no Huffman data (channel absent, or part2_3_length == 0: spectra stay zero, count1 keeps its old value, H6)
@@ -690,6 +704,270 @@ PD_HD void merge_slot(int t, const GcRaw* raw, const pdmp3_frame_bits* F, int n,
     merge_store(t, F[f], rec + (size_t)f * 4, val);
   }
   state[t] = (uint16_t)val;
+}
+
+// ---------------------------------------------------------------------------
+// The same merge by BLOCKS of 32 frames (engine.hip: k_merge_outcome, k_merge_apply).  A slot's chain through a window
+// is cut where the blocks meet: a first kernel finds what each block does to each slot without knowing what reaches it
+// -- nothing, a value, or (granule-1 scalefac_l slots, scfsi) "the twin's value as it reached this block" -- and, per
+// eight blocks, what the eight do together; the second walks those outcomes from the window's start up to its own
+// block (a lane per slot: at most 31 super-blocks and 7 blocks in a window of 8192 frames), then through its 32 frames
+// with the frames' inputs and the records under construction in LDS.  Round 1-4's kernel had a
+// workgroup per slot read one byte out of every frame's 320 and write one into every frame's 512: 47 us a window of
+// 8192 frames, all of it the texture path's one-lane-per-line accesses.
+// ---------------------------------------------------------------------------
+constexpr int kMergeBlk = 32;                     // frames of a block
+constexpr int kMergeSuper = 8;                    // blocks whose outcomes are composed into one (a "super-block": 256 frames)
+constexpr int kMergeLanes = 256;                  // threads of a workgroup and entries of a row of outcomes; lane t < kMergeSlots is slot t
+constexpr int kMergeBatch = 8;                    // frames (rows of outcomes) whose LDS reads are under way together
+constexpr unsigned kOutValue = 1u << 14, kOutTwin = 2u << 14, kOutKind = 3u << 14, kOutVal = 0x3fffu;
+
+// merge_load / merge_store for one slot with everything that depends on the slot alone worked out once: where in a
+// frame's 320 bytes of merge input (GcRaw [4]) its "set" bit, its value, its twin's and its copy bit are, where in the
+// frame's 512 bytes of records its value goes and where the reference's one-past-the-end read of a neighbour finds it.
+// The per-frame loop is then five 32-bit reads, shifts and selects, no branch on the slot.
+struct MergeLane {
+  uint16_t set_w, set0_w, val_w, val0_w, copy_w;     // byte offsets of aligned 32-bit words in the frame's merge input
+  uint8_t set_bit, set0_bit, val_sh, val0_sh;
+  uint32_t val_mask, copy_mask;                      // copy_mask 0: no twin (set0 / val0 then read the slot's own words, unused)
+  uint16_t own_off, alias_off;                       // byte offsets in the frame's records; alias_off 0xffff: none
+  uint8_t own_g, alias_g, alias_iso, own16;          // stores happen when gc own_g / alias_g is active and (iso & alias_iso) == 0
+};
+// per frame: bit 0 PDMP3_FR_NEWSTREAM, bits 8-11 gc g is active, bits 16-23 the frame's PDMP3_ISO_* switches
+PD_HD uint32_t merge_frame_meta(unsigned frame, unsigned iso) {
+  const bool mono = ((frame & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3;
+  return ((frame & PDMP3_FR_NEWSTREAM) ? 1u : 0u) | (mono ? 0x500u : 0xf00u) | (iso & 0xffu) << 16;
+}
+PD_HD uint32_t merge_frame_meta(const pdmp3_frame_bits& F) { return merge_frame_meta(F.frame, F.iso); }
+static_assert(offsetof(pdmp3_frame_bits, frame) == 0 && offsetof(pdmp3_frame_bits, iso) == 3, "k_merge_apply reads both with the record's first word");
+PD_HD MergeLane merge_lane(int t) {
+  MergeLane L{};
+  const unsigned kRaw = (unsigned)sizeof(GcRaw), kRec = (unsigned)sizeof(pdmp3_gc_side);
+  const unsigned o_set_l = (unsigned)offsetof(GcRaw, sf_l_set), o_set_s = (unsigned)offsetof(GcRaw, sf_s_set);
+  const unsigned o_sf_l = (unsigned)offsetof(GcRaw, sf_l), o_sf_s = (unsigned)offsetof(GcRaw, sf_s);
+  const unsigned r_sf_l = (unsigned)offsetof(pdmp3_gc_side, scalefac_l), r_sf_s = (unsigned)offsetof(pdmp3_gc_side, scalefac_s);
+  L.alias_off = 0xffff; L.val_mask = 0xffu;
+  unsigned set_byte, val_byte, set0_byte, val0_byte;
+  if (t < 84) {
+    const unsigned g = (unsigned)t / 21, sfb = (unsigned)t - 21 * g;
+    set_byte = g * kRaw + o_set_l; L.set_bit = (uint8_t)sfb;
+    val_byte = g * kRaw + o_sf_l + sfb;
+    set0_byte = set_byte; val0_byte = val_byte; L.set0_bit = L.set_bit;
+    if (g >= 2) {
+      const unsigned grp = sfb < 6 ? 0 : sfb < 11 ? 1 : sfb < 16 ? 2 : 3;
+      set0_byte = (g & 1) * kRaw + o_set_l;
+      val0_byte = (g & 1) * kRaw + o_sf_l + sfb;
+      L.copy_w = (uint16_t)(g * kRaw + ((unsigned)offsetof(GcRaw, sf_l_copy) & ~3u));
+      L.copy_mask = 1u << (8 * ((unsigned)offsetof(GcRaw, sf_l_copy) & 3u) + grp);
+    }
+    L.own_off = (uint16_t)(g * kRec + r_sf_l + sfb); L.own_g = (uint8_t)g;
+    if (sfb == 0 && g >= 1) { L.alias_off = (uint16_t)((g - 1) * kRec + r_sf_l + 21); L.alias_g = (uint8_t)(g - 1); L.alias_iso = 0x08; }
+  } else if (t < 228) {
+    const unsigned u = (unsigned)t - 84, g = u / 36, k = u - 36 * g, sfb = k / 3, w = k - 3 * sfb;
+    set_byte = g * kRaw + o_set_s; L.set_bit = (uint8_t)sfb;
+    val_byte = g * kRaw + o_sf_s + k;
+    set0_byte = set_byte; val0_byte = val_byte; L.set0_bit = L.set_bit;
+    L.own_off = (uint16_t)(g * kRec + r_sf_s + k); L.own_g = (uint8_t)g;
+    if (sfb == 0 && g >= 1) { L.alias_off = (uint16_t)((g - 1) * kRec + r_sf_s + 36 + w); L.alias_g = (uint8_t)(g - 1); L.alias_iso = 0x10; }
+    if (k == 0 && g == 0) { L.alias_off = (uint16_t)(3 * kRec + r_sf_l + 21); L.alias_g = 3; L.alias_iso = 0x08; }   // last block: scalefac_s follows
+  } else {
+    const unsigned g = (unsigned)t - 228;
+    set_byte = g * kRaw + (unsigned)offsetof(GcRaw, count1_set); L.set_bit = 0;      // (count1_set is 0 or 1)
+    val_byte = g * kRaw + (unsigned)offsetof(GcRaw, count1); L.val_mask = 0xffffu;
+    set0_byte = set_byte; val0_byte = val_byte; L.set0_bit = 0;
+    L.own_off = (uint16_t)(g * kRec + (unsigned)offsetof(pdmp3_gc_side, count1)); L.own_g = (uint8_t)g; L.own16 = 1;
+  }
+  L.set_w = (uint16_t)(set_byte & ~3u); L.set_bit = (uint8_t)(L.set_bit + 8 * (set_byte & 3u));
+  L.set0_w = (uint16_t)(set0_byte & ~3u); L.set0_bit = (uint8_t)(L.set0_bit + 8 * (set0_byte & 3u));
+  L.val_w = (uint16_t)(val_byte & ~3u); L.val_sh = (uint8_t)(8 * (val_byte & 3u));
+  L.val0_w = (uint16_t)(val0_byte & ~3u); L.val0_sh = (uint8_t)(8 * (val0_byte & 3u));
+  return L;
+}
+static_assert(offsetof(GcRaw, count1) % 4 == 0 && offsetof(GcRaw, sf_l_set) % 4 == 0 && offsetof(GcRaw, sf_s_set) % 4 == 0 &&
+              sizeof(GcRaw) % 4 == 0, "merge_lane reads aligned words");
+// frame i of a block: rawf = its 320 bytes of merge input as words.  TWIN = false: a slot known to have no twin (set0 /
+// val0 / copy are not looked at; what a wave's slots are is known per wave: merge_wave_kind)
+template <bool TWIN>
+PD_HD MergeIn merge_lane_load(const MergeLane& L, const uint32_t* rawf, bool newstream) {
+  MergeIn m{false, false, false, 0, 0};
+  const bool w = (rawf[L.set_w >> 2] >> L.set_bit & 1u) != 0;
+  const unsigned v = (rawf[L.val_w >> 2] >> L.val_sh) & L.val_mask;
+  m.val = w ? v : 0u; m.set = w || newstream;
+  if (TWIN) {
+    const bool w0 = (rawf[L.set0_w >> 2] >> L.set0_bit & 1u) != 0;
+    const unsigned v0 = (rawf[L.val0_w >> 2] >> L.val0_sh) & 0xffu;
+    m.val0 = w0 ? v0 : 0u; m.set0 = w0 || newstream;
+    m.copy = (rawf[L.copy_w >> 2] & L.copy_mask) != 0;
+  }
+  return m;
+}
+// (no branches: a store that is not to happen goes to `trash`, a byte of the lane's own -- the loop over a block's frames
+//  stays one basic block and the reads of the frames ahead are under way while these are issued.  WIDE = false: no slot
+//  of the wave is count1's, the only 16-bit value)
+template <bool WIDE>
+PD_HD void merge_lane_store(const MergeLane& L, uint32_t meta, uint8_t* recf, unsigned val, uint8_t* trash) {
+  const bool own = (meta >> (8 + L.own_g) & 1u) != 0;
+  const bool alias = L.alias_off != 0xffff && (meta >> (8 + L.alias_g) & 1u) && !((meta >> 16) & L.alias_iso);
+  *(own ? recf + L.own_off : trash) = (uint8_t)val;
+  if (WIDE) *(own && L.own16 ? recf + L.own_off + 1 : trash) = (uint8_t)(val >> 8);
+  *(alias ? recf + L.alias_off : trash) = (uint8_t)val;
+}
+// slots [t0, t0 + 64) of a wave: bit 0 = some have twins (granule-1 scalefac_l: 42 .. 83), bit 1 = count1's are among them
+PD_HD unsigned merge_wave_kind(int t0) { return (t0 < 84 && t0 + 64 > 42 ? 1u : 0u) | (t0 + 64 > 228 ? 2u : 0u); }
+
+// what the nb frames of a block do to slot t: 0 (nothing), kOutValue | v, or kOutTwin.  frame_flags: pdmp3_frame_bits.frame
+// (Eight frames at a time, reads first: a lane's walk is a chain of LDS round trips otherwise.  TAIL: fewer than eight
+//  are left -- past the last one it is read again and ignored.)
+struct MergeOut { bool has, has0, twin; unsigned val, val0; };
+template <bool TWIN, bool TAIL>
+PD_HD void merge_outcome_batch(const MergeLane& L, const uint32_t* rw, const uint8_t* frame_flags, int i0, int nb, MergeOut& o) {
+  MergeIn m[kMergeBatch];
+  PD_UNROLL for (int k = 0; k < kMergeBatch; k++) {
+    const int i = !TAIL || i0 + k < nb ? i0 + k : nb - 1;
+    m[k] = merge_lane_load<TWIN>(L, rw + (size_t)i * (4 * sizeof(GcRaw) / 4), (frame_flags[i] & PDMP3_FR_NEWSTREAM) != 0);
+  }
+  PD_UNROLL for (int k = 0; k < kMergeBatch; k++) {
+    const bool valid = !TAIL || i0 + k < nb, set = valid && m[k].set;
+    o.val = set ? m[k].val : o.val; o.has = o.has || set;
+    if (TWIN) {
+      const bool set0 = valid && m[k].set0, copy = valid && m[k].copy;
+      o.val0 = set0 ? m[k].val0 : o.val0; o.has0 = o.has0 || set0;
+      o.twin = o.twin && !set;
+      o.twin = copy ? !o.has0 : o.twin; o.has = o.has || copy; o.val = copy ? o.val0 : o.val;
+    }
+  }
+}
+template <bool TWIN>
+PD_HD unsigned merge_block_outcome_t(int t, const GcRaw* raw_blk, const uint8_t* frame_flags, int nb) {
+  const MergeLane L = merge_lane(t);
+  const uint32_t* rw = reinterpret_cast<const uint32_t*>(raw_blk);
+  MergeOut o{false, false, false, 0, 0};
+  int i0 = 0;
+  for (; i0 + kMergeBatch <= nb; i0 += kMergeBatch) merge_outcome_batch<TWIN, false>(L, rw, frame_flags, i0, nb, o);
+  if (i0 < nb) merge_outcome_batch<TWIN, true>(L, rw, frame_flags, i0, nb, o);
+  return !o.has ? 0u : o.twin ? kOutTwin : (kOutValue | (o.val & kOutVal));
+}
+// kind: merge_wave_kind of the wave the slot is in (the same for all its lanes), or 3 where that is not known
+PD_HD unsigned merge_block_outcome(int t, const GcRaw* raw_blk, const uint8_t* frame_flags, int nb, unsigned kind = 3) {
+  return (kind & 1u) ? merge_block_outcome_t<true>(t, raw_blk, frame_flags, nb) : merge_block_outcome_t<false>(t, raw_blk, frame_flags, nb);
+}
+
+// one block (or super-block) further: o / o0 = the outcomes of the slot and of its twin (0 for slots that have none)
+PD_HD void merge_carry_step(unsigned o, unsigned o0, unsigned& val, unsigned& val0) {
+  val = (o & kOutKind) == kOutValue ? (o & kOutVal) : (o & kOutKind) == kOutTwin ? val0 : val;      // (the twin's value in FRONT of the block)
+  val0 = (o0 & kOutKind) == kOutValue ? (o0 & kOutVal) : val0;
+}
+// nr rows of outcomes (kMergeLanes entries each) in a row: eight at a time, reads first
+template <bool TWIN>
+PD_HD void merge_carry_rows(const uint32_t* rows, int nr, int t, int tw, unsigned& val, unsigned& val0) {
+  for (int j0 = 0; j0 < nr; j0 += kMergeBatch) {
+    unsigned o[kMergeBatch], o0[kMergeBatch];
+    PD_UNROLL for (int k = 0; k < kMergeBatch; k++) {
+      const int j = j0 + k < nr ? j0 + k : nr - 1;
+      o[k] = rows[(size_t)j * kMergeLanes + t];
+      o0[k] = TWIN && tw >= 0 ? rows[(size_t)j * kMergeLanes + tw] : 0u;
+    }
+    PD_UNROLL for (int k = 0; k < kMergeBatch; k++)
+      if (j0 + k < nr) merge_carry_step(o[k], o0[k], val, val0);
+  }
+}
+// the same on outcomes instead of values: acc / acc0 = what the blocks so far do together (0, kOutValue | v, kOutTwin = "the
+// twin's value in front of the FIRST of them")
+PD_HD void merge_compose_step(unsigned o, unsigned o0, unsigned& acc, unsigned& acc0) {
+  const unsigned k = o & kOutKind;
+  acc = k == kOutValue ? o : k == kOutTwin ? ((acc0 & kOutKind) == kOutValue ? acc0 : kOutTwin) : acc;
+  acc0 = (o0 & kOutKind) == kOutValue ? o0 : acc0;
+}
+
+// the block's frames with what reaches it: merge_slot's loop; meta[i] = merge_frame_meta of frame i; returns the slot's
+// value behind the block
+template <bool TWIN, bool WIDE, bool TAIL>
+PD_HD void merge_apply_batch(const MergeLane& L, const uint32_t* rw, const uint32_t* meta, int i0, int nb, uint8_t* rec, uint8_t* trash,
+                             unsigned& val, unsigned& val0) {
+  MergeIn m[kMergeBatch];
+  uint32_t mt[kMergeBatch];
+  PD_UNROLL for (int k = 0; k < kMergeBatch; k++) {
+    const int i = !TAIL || i0 + k < nb ? i0 + k : nb - 1;
+    mt[k] = meta[i];
+    m[k] = merge_lane_load<TWIN>(L, rw + (size_t)i * (4 * sizeof(GcRaw) / 4), (mt[k] & 1u) != 0);
+  }
+  PD_UNROLL for (int k = 0; k < kMergeBatch; k++) {
+    const bool valid = !TAIL || i0 + k < nb;
+    val = valid && m[k].set ? m[k].val : val;
+    if (TWIN) {
+      val0 = valid && m[k].set0 ? m[k].val0 : val0;
+      val = valid && m[k].copy ? val0 : val;
+    }
+    const int i = valid ? i0 + k : nb - 1;                     // (an ignored frame: every store to `trash`)
+    merge_lane_store<WIDE>(L, valid ? mt[k] : 0u, rec + (size_t)i * (4 * sizeof(pdmp3_gc_side)), val, trash);
+  }
+}
+template <bool TWIN, bool WIDE>
+PD_HD unsigned merge_block_apply_t(int t, unsigned val, unsigned val0, const GcRaw* raw_blk, const uint32_t* meta, int nb,
+                                   pdmp3_gc_side* rec_blk, uint8_t* trash) {
+  const MergeLane L = merge_lane(t);
+  const uint32_t* rw = reinterpret_cast<const uint32_t*>(raw_blk);
+  uint8_t* rec = reinterpret_cast<uint8_t*>(rec_blk);
+  int i0 = 0;
+  for (; i0 + kMergeBatch <= nb; i0 += kMergeBatch) merge_apply_batch<TWIN, WIDE, false>(L, rw, meta, i0, nb, rec, trash, val, val0);
+  if (i0 < nb) merge_apply_batch<TWIN, WIDE, true>(L, rw, meta, i0, nb, rec, trash, val, val0);
+  return val;
+}
+PD_HD unsigned merge_block_apply(int t, unsigned val, unsigned val0, const GcRaw* raw_blk, const uint32_t* meta, int nb,
+                                 pdmp3_gc_side* rec_blk, uint8_t* trash, unsigned kind = 3) {
+  switch (kind & 3u) {
+    case 0: return merge_block_apply_t<false, false>(t, val, val0, raw_blk, meta, nb, rec_blk, trash);
+    case 1: return merge_block_apply_t<true, false>(t, val, val0, raw_blk, meta, nb, rec_blk, trash);
+    case 2: return merge_block_apply_t<false, true>(t, val, val0, raw_blk, meta, nb, rec_blk, trash);
+    default: return merge_block_apply_t<true, true>(t, val, val0, raw_blk, meta, nb, rec_blk, trash);
+  }
+}
+
+// the two kernels one after the other on the host (test build): side must hold the records' side fields already
+// (unpack_records); outc: merge_outcome_rows(n) x kMergeLanes entries of scratch -- a row per block, then a row per super-block
+PD_HD int merge_outcome_rows(int n_frames) {
+  const int nblk = (n_frames + kMergeBlk - 1) / kMergeBlk;
+  return nblk + (nblk + kMergeSuper - 1) / kMergeSuper;
+}
+PD_HD void merge_blocks(const GcRaw* raw, const pdmp3_frame_bits* F, int n, const uint16_t* state_in, uint16_t* state,
+                        pdmp3_gc_side* rec, uint32_t* outc) {
+  const int nblk = (n + kMergeBlk - 1) / kMergeBlk;
+  uint32_t* sup = outc + (size_t)nblk * kMergeLanes;
+  for (int b = 0; b < nblk; b++) {
+    const int f0 = b * kMergeBlk, nb = n - f0 < kMergeBlk ? n - f0 : kMergeBlk;
+    uint8_t fl[kMergeBlk];
+    for (int i = 0; i < nb; i++) fl[i] = F[f0 + i].frame;
+    for (int t = 0; t < kMergeSlots; t++)
+      outc[(size_t)b * kMergeLanes + t] = merge_block_outcome(t, raw + (size_t)f0 * 4, fl, nb, merge_wave_kind(t & ~63));
+    if (b % kMergeSuper == kMergeSuper - 1 || b == nblk - 1)              // (the device: whichever of the eight workgroups is through last)
+      for (int t = 0; t < kMergeSlots; t++) {
+        const int tw = merge_twin(t), b0 = b - b % kMergeSuper;
+        unsigned acc = 0, acc0 = 0;
+        for (int j = b0; j <= b; j++) merge_compose_step(outc[(size_t)j * kMergeLanes + t], tw >= 0 ? outc[(size_t)j * kMergeLanes + tw] : 0u, acc, acc0);
+        sup[(size_t)(b / kMergeSuper) * kMergeLanes + t] = acc;
+      }
+  }
+  for (int t = 0; t < kMergeSlots; t++) state[t] = state_in[t];        // (a window without frames)
+  for (int b = 0; b < nblk; b++) {
+    const int f0 = b * kMergeBlk, nb = n - f0 < kMergeBlk ? n - f0 : kMergeBlk;
+    uint32_t meta[kMergeBlk];
+    for (int i = 0; i < nb; i++) meta[i] = merge_frame_meta(F[f0 + i]);
+    for (int t = 0; t < kMergeSlots; t++) {
+      const int tw = merge_twin(t);
+      unsigned val = state_in[t], val0 = tw >= 0 ? state_in[tw] : 0;
+      const uint32_t* own = outc + (size_t)(b - b % kMergeSuper) * kMergeLanes;
+      if (merge_wave_kind(t & ~63) & 1u) {
+        merge_carry_rows<true>(sup, b / kMergeSuper, t, tw, val, val0);
+        merge_carry_rows<true>(own, b % kMergeSuper, t, tw, val, val0);
+      } else {
+        merge_carry_rows<false>(sup, b / kMergeSuper, t, tw, val, val0);
+        merge_carry_rows<false>(own, b % kMergeSuper, t, tw, val, val0);
+      }
+      uint8_t trash;
+      val = merge_block_apply(t, val, val0, raw + (size_t)f0 * 4, meta, nb, rec + (size_t)f0 * 4, &trash, merge_wave_kind(t & ~63));
+      if (b == nblk - 1) state[t] = (uint16_t)val;
+    }
+  }
 }
 
 }  // namespace pdmp3

@@ -2122,10 +2122,12 @@ typedef struct pre_seg {
   struct par_scan* P; int j;
   size_t guess;
   hop1* rec; long long cap;
-  long long count;            /* records written (atomic, release) */
-  int state;                  /* SEG_* (atomic, release; final once not SEG_RUNNING) */
   long long x_start;          /* where its first header is: -2 not known yet, -1 none found (atomic) */
+  char pad0[64];              /* (what the hop thread keeps writing has cache lines of its own: its neighbours write theirs as often) */
+  long long count;            /* records written (atomic, release; moved on every 8 frames and at the end) */
+  int state;                  /* SEG_* (atomic, release; final once not SEG_RUNNING) */
   double t_sync, t_done;      /* trace */
+  char pad1[64];
 } pre_seg;
 #define PAR_MAX_SCANNERS 16
 #define PAR_MAX_SEGS 8
@@ -2170,6 +2172,8 @@ typedef struct {              /* the scanner's state in front of frame `frame` (
 } span_snap;
 
 struct par_scan {
+  /* ---- set before the threads start, read by all of them (the pre-pass looks at abort / quit once per frame: none of this
+   *      shares a cache line with what the scanners and the stitcher write) */
   struct bulk* b;
   const unsigned char* mp3; size_t n;
   int K;
@@ -2178,23 +2182,33 @@ struct par_scan {
    * scanner produces windows at half the rate the GPU takes them.  Window by window, w is ready at
    * w x [pre-pass time per window] + [scan time of one window], always ahead of the GPU's w x 157 us.) */
   int sub;                    /* frames of a private window (the engine's windows are made of several: par_drive) */
+  int spin;                   /* a scanner whose snapshot is the next or the one after spins for it (hosts with cores to spare); else it yields */
   int one_window;             /* by its first frame's size the stream fits one window of the engine */
-  long long next_win;         /* the next window nobody has taken yet */
-  long long stitched;         /* windows the stitcher has taken */
   span_snap* snap; long long snap_cap;   /* by window index; [0] unused (a fresh handle) */
   hop_rec* rec; long long rec_cap;
-  long long n_frames;         /* valid once prepass_done */
-  int prepass_done, irregular;
+  pre_window** win; long long win_cap;    /* finished windows by stream index (entries: under the mutex) */
+  int J;                      /* parts of the pre-pass: [0] is the pre-pass thread's own, the others have a hop thread each */
+  struct scanner_arg* args;
+  double t0;
   atomic_int abort;           /* (set under the mutex, so that waiters wake; also looked at in loops that hold no lock) */
   atomic_int quit;            /* the stitcher has left: nobody wants further windows (not an error) */
-  pre_window** win; long long win_cap;    /* finished windows by stream index */
+  char pad0[64];
+  /* ---- the pre-pass's: how far it is.  The scanners do not sleep on a condition for their snapshots -- with a dozen of them
+   *      waiting, every broadcast (a snapshot, a finished window, a window taken) woke them all and the mutex they then queued
+   *      for was the pre-pass's too: 2.7 ms of pre-pass with 8 scanners, 5.8 ms with 16 -- they watch this counter */
+  long long published;        /* windows < this have their snapshot (atomic, release; 1 from the start: window 0 needs none) */
+  long long n_frames;         /* valid once prepass_done */
+  int prepass_done, irregular;   /* (prepass_done: atomic, release; set under the mutex as well: the stitcher sleeps on the condition) */
+  double t_prepass, t_pre_part0, t_pre_wait;
+  char pad1[64];
+  /* ---- the scanners' and the stitcher's */
+  long long next_win;         /* the next window nobody has taken yet (atomic) */
+  long long stitched;         /* windows the stitcher has taken (atomic; written under the mutex) */
   int scanners_done;
   pthread_mutex_t mu; pthread_cond_t cv;
-  double t_prepass, t_pre_part0, t_pre_wait, t0;
-  int J;                      /* parts of the pre-pass: [0] is the pre-pass thread's own, the others have a hop thread each */
-  pre_seg seg[PAR_MAX_SEGS];
   int jobs_left, hops_left;   /* pre-pass and scanners / hop threads that have not returned (under the crew's mutex) */
-  struct scanner_arg* args;
+  char pad2[64];
+  pre_seg seg[PAR_MAX_SEGS];
 };
 
 static void pw_destroy(pre_window* w) {
@@ -2407,8 +2421,9 @@ static void* par_hop_thread(void* arg) {
       hop_prefetch(mp3, x, S->rec[c].fb);
       x += S->rec[c].fb;
       c++;
-      __atomic_store_n(&S->count, c, __ATOMIC_RELEASE);
+      if (!(c & 7)) __atomic_store_n(&S->count, c, __ATOMIC_RELEASE);
     }
+    __atomic_store_n(&S->count, c, __ATOMIC_RELEASE);
   }
   S->t_done = now_s() - P->t0;
   __atomic_store_n(&S->state, state, __ATOMIC_RELEASE);
@@ -2443,10 +2458,8 @@ static int par_prepass(struct par_scan* P) {
       if (!S->sky) goto out;
       memcpy(S->sky, sky, (size_t)sky_n * sizeof(int));
       memcpy(S->last_ws0, ws0, sizeof ws0); memcpy(S->last_ws1, ws1, sizeof ws1);
-      pthread_mutex_lock(&P->mu);
       S->ready = 1;
-      pthread_cond_broadcast(&P->cv);
-      pthread_mutex_unlock(&P->mu);
+      __atomic_store_n(&P->published, (long long)next + 1, __ATOMIC_RELEASE);
       next++;
     }
     while (ring_filled(h) < HOP_END_BYTES) {            /* H10 + the CLI's feeds (bulk_drive) */
@@ -2471,7 +2484,9 @@ static int par_prepass(struct par_scan* P) {
     } else {
       for (;;) {
         pre_seg* G = &P->seg[part];
-        if (part_i < __atomic_load_n(&G->count, __ATOMIC_ACQUIRE)) { q = &G->rec[part_i++]; break; }
+        /* (the records were written by another core, most of them a while ago: they come from its cache or from memory,
+         *  a line per four frames -- asked for well ahead, or the loop runs at one such miss per line) */
+        if (part_i < __atomic_load_n(&G->count, __ATOMIC_ACQUIRE)) { __builtin_prefetch(&G->rec[part_i + 64], 0, 3); q = &G->rec[part_i++]; break; }
         const int st = __atomic_load_n(&G->state, __ATOMIC_ACQUIRE);
         if (st == SEG_RUNNING) { if (P->abort || P->quit) goto out; const double tw = now_s(); sched_yield(); P->t_pre_wait += now_s() - tw; continue; }
         if (part_i < __atomic_load_n(&G->count, __ATOMIC_ACQUIRE)) continue;   /* (its last records came with the state) */
@@ -2510,7 +2525,7 @@ out:
   pthread_mutex_lock(&P->mu);
   P->n_frames = f;
   P->irregular = rc != 0;
-  P->prepass_done = 1;
+  __atomic_store_n(&P->prepass_done, 1, __ATOMIC_RELEASE);
   pthread_cond_broadcast(&P->cv);
   pthread_mutex_unlock(&P->mu);
   return rc;
@@ -2598,19 +2613,30 @@ static void* par_scanner(void* arg) {
   if (!wb || !id || !pool) goto done;
   const int whole = P->K == 1;                          /* one scanner: the sequential stage A, from frame 0 to the end */
   for (;;) {
-    pthread_mutex_lock(&P->mu);
-    const long long w = P->next_win++;
+    const long long w = __atomic_fetch_add(&P->next_win, 1, __ATOMIC_RELAXED);
     const double t_take = now_s();
-    /* (not further than PAR_AHEAD windows in front of the stitcher: finished windows are memory) */
+    /* its snapshot: a few tens of microseconds away as a rule (the pre-pass leaves one every 10-25 us and the scanners take
+     * them in turn).  The scanner that is next, or next but one, keeps looking; those further ahead sleep 20 us at a time.
+     * (Not further than PAR_AHEAD windows in front of the stitcher either: finished windows are memory.) */
     int ready = 0;
     while (!P->abort && !P->quit) {
-      const int known = w == 0 || (w < P->snap_cap && P->snap[w].ready);
-      if (!known && (P->prepass_done || w >= P->snap_cap)) break;      /* the stream ended (or went irregular) before this window */
-      if (known && w < P->stitched + PAR_AHEAD) { ready = 1; break; }
-      pthread_cond_wait(&P->cv, &P->mu);
+      const long long pub = __atomic_load_n(&P->published, __ATOMIC_ACQUIRE);
+      if (w < pub) {
+        if (w < __atomic_load_n(&P->stitched, __ATOMIC_RELAXED) + PAR_AHEAD) { ready = 1; break; }
+      } else if (w >= P->snap_cap) break;
+      else if (__atomic_load_n(&P->prepass_done, __ATOMIC_ACQUIRE)) {
+        /* the stream ended (or went irregular) before this window -- unless its snapshot came with the end */
+        if (w < __atomic_load_n(&P->published, __ATOMIC_ACQUIRE)) continue;
+        break;
+      }
+      if (w >= pub && w < pub + 2) {
+        if (P->spin) for (int i = 0; i < 64; i++) __builtin_ia32_pause(); else sched_yield();
+      } else {
+        const struct timespec nap = {0, 20000};
+        (void)nanosleep(&nap, NULL);
+      }
     }
     const int stop = P->abort;
-    pthread_mutex_unlock(&P->mu);
     if (stop) break;
     if (!ready || (whole && w > 0)) { A->rc = 0; break; }
     memset(id, 0, sizeof *id);
@@ -2699,6 +2725,8 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
   struct par_scan* P = (struct par_scan*)calloc(1, sizeof *P);
   if (!P) return NULL;
   P->b = b; P->mp3 = mp3; P->n = n; P->K = K; P->J = J; P->sub = sub; P->t0 = now_s();
+  { const char* sp = getenv("PDMP3_BULK_SCAN_SPIN"); P->spin = sp ? atoi(sp) != 0 : cores >= 2 * K + 8; }
+  P->published = 1;
   P->one_window = est + est / 16 <= b->cap;
   if (!b->pc) {
     if (!(b->pc = pc_new())) { free(P); return NULL; }
@@ -2773,7 +2801,7 @@ static pre_window* par_next_window_wait(struct par_scan* P, long long w, int* en
   pthread_mutex_lock(&P->mu);
   for (;;) {
     if (P->abort || (P->prepass_done && P->irregular)) { *end = -1; break; }
-    if (w < P->win_cap && P->win[w]) { pw = P->win[w]; P->win[w] = NULL; P->stitched = w + 1; pthread_cond_broadcast(&P->cv); break; }
+    if (w < P->win_cap && P->win[w]) { pw = P->win[w]; P->win[w] = NULL; __atomic_store_n(&P->stitched, w + 1, __ATOMIC_RELAXED); break; }
     if (P->prepass_done && w >= (P->n_frames + P->sub - 1) / P->sub) { *end = 1; break; }
     if (P->scanners_done == P->K && P->prepass_done) { *end = -1; break; }      /* (a window is missing: should not happen) */
     if (wait_s < 0) { pthread_cond_wait(&P->cv, &P->mu); continue; }

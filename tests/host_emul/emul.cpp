@@ -168,7 +168,16 @@ extern "C" int emul_unpack_frames(const pdmp3_frame_bits* bits, const uint8_t* r
                 side + (size_t)f * 4 + g, &raw[(size_t)f * 4 + g]);
   uint16_t st_in[256];
   memcpy(st_in, state, sizeof st_in);
+  // the merge by blocks of 32 frames (what k_merge_outcome + k_merge_apply run) on a copy of the records, beside the rule
+  // itself (merge_slot: one slot through all the frames in order): the two must agree in every byte and in the state
+  std::vector<pdmp3_gc_side> side_b(side, side + (size_t)n_frames * 4);
+  std::vector<uint32_t> outc((size_t)merge_outcome_rows(n_frames) * kMergeLanes + 1, 0);
+  uint16_t state_b[256];
+  memcpy(state_b, state, sizeof state_b);
+  merge_blocks(raw.data(), bits, n_frames, st_in, state_b, side_b.data(), outc.data());
   for (int t = 0; t < kMergeSlots; ++t) merge_slot(t, raw.data(), bits, n_frames, st_in, state, side);
+  if (n_frames > 0 && memcmp(side_b.data(), side, (size_t)n_frames * 4 * sizeof(pdmp3_gc_side)) != 0) return -2;
+  if (memcmp(state_b, state, kMergeSlots * sizeof(uint16_t)) != 0) return -3;
   return (int)U->n_lut;
 }
 

@@ -204,3 +204,28 @@ def test_pool_window_longer_than_the_link_fields(emul):
     rows = np.zeros((len(bits), 2064), dtype=np.uint8)
     emul.emul_rows(desc.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p), len(bits), rows.ctypes.data_as(C.c_void_p))
     assert np.array_equal(rows, res)
+
+
+def test_merge_by_blocks_over_long_windows(emul):
+    """k_merge_outcome / k_merge_apply cut a window into blocks of 32 frames, compose the outcomes of eight blocks and chain both (unpack_core.h
+    merge_blocks; emul_unpack_frames runs it beside merge_slot and returns -2 / -3 when a record byte or the carried state
+    differs): windows of a dozen blocks with scfsi copies, short and mixed blocks, a mono part (channel 1's slots keep
+    their values through it) and a second stream behind the first (PDMP3_FR_NEWSTREAM in the middle of a block)"""
+    from pdmp3_amd import api
+    a = packer.generate(n_frames=420, seed=61, vbr=True, block_pct=(55, 10, 25, 10), mixed_pct=40, mode=1, mode_ext=2)
+    m = packer.generate(n_frames=150, seed=62, mode=3, bitrate_index=7)
+    c = packer.generate(n_frames=333, seed=63, bitrate_index=11, block_pct=(97, 1, 1, 1))
+    parts = [api.parse_bits(x)[:2] for x in (a + m, c)]
+    bits = np.concatenate([b for b, _ in parts])
+    res = np.concatenate([r for _, r in parts])
+    n = bits.shape[0]
+    assert n > 850 and int(((bits["frame"] & 0x80) != 0).sum()) == 2
+    whole = emul_unpack(emul, bits, res)
+    b = api.BulkDecoder(threads=2, window_frames=256, parse_only=True)
+    try:
+        sd_h = np.concatenate([b.parse(x)[1] for x in (a + m, c)])
+    finally:
+        b.close()
+    assert np.array_equal(whole[1].view(np.uint8), sd_h.view(np.uint8))
+    for cuts in ([0, 64, 128, n], [0, 63, 129, 500, n], [0, 1, n - 1, n]):
+        assert _records_equal(emul_unpack(emul, bits, res, cuts), whole), cuts

@@ -38,14 +38,21 @@ def c4(args, api):
 
     douts = [torch.empty(max(b, 2) // 2, dtype=torch.int16, device="cuda:%d" % (0)) for b, _ in sizes] if args.device_out else None
 
+    calls = {}
+
     def work(j):
+        t_calls = []
         for i in plan[j]:                                  # back to back, one wait at the end
+            t0 = time.perf_counter()
             if douts is not None:
                 got, _, _ = decs[j].decode_into_device(files[i], douts[i], wait=False)
             else:
                 got, _, _ = decs[j].decode_into_async(files[i], outs[i])
+            t_calls.append(time.perf_counter() - t0)
             assert got == sizes[i][0]
+        t0 = time.perf_counter()
         decs[j].wait()
+        calls[j] = (t_calls, time.perf_counter() - t0)
     best = None
     for _ in range(args.reps + 1):                      # first pass = warm-up
         ts = [threading.Thread(target=work, args=(j,)) for j in range(args.c4)]
@@ -58,6 +65,10 @@ def c4(args, api):
         best = dt if best is None else min(best, dt)
     for d in decs:
         d.close()
+    if os.environ.get("BULK_BENCH_VERBOSE"):               # the last pass: where a decoder's time went
+        for j, (tc, tw) in sorted(calls.items()):
+            print("decoder %d: %d files, calls %.2f ms in all (median %.0f us, longest %.0f us), final wait %.2f ms" %
+                  (j, len(tc), sum(tc) * 1e3, sorted(tc)[len(tc) // 2] * 1e6, max(tc) * 1e6, tw * 1e3), file=sys.stderr)
     frames = sum(fr for _, fr in sizes)
     print(json.dumps({"workload": "C4: %d files, %d frames, mono/stereo/joint x 32/44.1/48 kHz x CBR/VBR x block mixes" % (len(files), frames),
                       "decoders": args.c4, "gpus": ngpu, "seconds": round(best, 4), "frames_per_s": round(frames / best, 1),
