@@ -1460,6 +1460,7 @@ struct bulk {
   int sub_gath[8];                    /* entries of the slot's copy list */
   void* sub_dst[8];
   long long sub_head, sub_tail;       /* jobs enqueued / completed */
+  long long sub_copied;               /* jobs whose main data is out of the caller's stream (<= sub_tail + 1) */
   size_t next_copy_row;               /* row size of the copy job bulk_collect last handed out */
   /* split scan (par_scan below): a scanner that fills private windows (struct pre_window) instead of engine slots */
   int scan_threads;                   /* scanners of the split scan (0: stage A on the calling thread alone) */
@@ -1765,6 +1766,10 @@ static void* bulk_submitter(void* arg) {
       gather_wait(b, slot);
     }
     const double t1 = now_s();
+    pthread_mutex_lock(&b->sub_mu);                /* (whoever only waits for the stream's bytes to be free need not sit through the engine call) */
+    b->sub_copied = b->sub_tail + 1;
+    pthread_cond_broadcast(&b->sub_done_cv);
+    pthread_mutex_unlock(&b->sub_mu);
     const int rc = pool ? pdmp3_hip_stream_submit_pool_to(b->hs, slot, n, pool, dst, row)
                         : pdmp3_hip_stream_submit_bits_to(b->hs, slot, n, dst, row);
     if (rc != PDMP3_HIP_OK) fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
@@ -1793,6 +1798,16 @@ static int sub_wait_seq(struct bulk* b, long long seq) {   /* window number `seq
   if (!b->sub_started) return PDMP3_OK;
   pthread_mutex_lock(&b->sub_mu);
   while (b->sub_tail <= seq) pthread_cond_wait(&b->sub_done_cv, &b->sub_mu);
+  const int rc = b->sub_rc;
+  pthread_mutex_unlock(&b->sub_mu);
+  return rc == PDMP3_HIP_OK ? PDMP3_OK : PDMP3_ERR;
+}
+/* every enqueued window's main data has been copied out of the caller's stream (the windows themselves may still be on
+ * their way to the GPU: a failure there shows at the next call or at the wait) */
+static int sub_drain_copied(struct bulk* b) {
+  if (!b->sub_started) return PDMP3_OK;
+  pthread_mutex_lock(&b->sub_mu);
+  while (b->sub_copied < b->sub_head) pthread_cond_wait(&b->sub_done_cv, &b->sub_mu);
   const int rc = b->sub_rc;
   pthread_mutex_unlock(&b->sub_mu);
   return rc == PDMP3_HIP_OK ? PDMP3_OK : PDMP3_ERR;
@@ -2222,7 +2237,7 @@ static pre_window* pw_new_in(par_cache* pc, int cap, long long index) {
     pthread_mutex_lock(&pc->mu);
     while (pc->n_spare && !w) {
       w = pc->spare[--pc->n_spare];
-      if (w->cap != cap) { pw_destroy(w); w = NULL; }   /* (the decoder's window size has changed) */
+      if (w->cap < cap) { pw_destroy(w); w = NULL; }    /* (too small for this stream's private windows; a larger one does) */
     }
     pthread_mutex_unlock(&pc->mu);
   }
@@ -2294,9 +2309,15 @@ static int crew_run(par_cache* pc, void* (*fn)(void*), void* arg, int* left) {
   pc->jobs[k].fn = fn; pc->jobs[k].arg = arg; pc->jobs[k].left = left;
   pc->crew_busy++;
   (*left)++;
-  pthread_cond_signal(&pc->crew_cv);
   pthread_mutex_unlock(&pc->crew_mu);
   return 0;
+}
+/* the jobs queued so far may start: ONE wake-up for all of them (a signal per job is a system call per job on the calling
+ * thread -- eleven of them in front of a file of a few minutes that is scanned in 0.2 ms) */
+static void crew_kick(par_cache* pc) {
+  pthread_mutex_lock(&pc->crew_mu);
+  pthread_cond_broadcast(&pc->crew_cv);
+  pthread_mutex_unlock(&pc->crew_mu);
 }
 static void crew_wait(par_cache* pc, int* left) {
   pthread_mutex_lock(&pc->crew_mu);
@@ -2688,7 +2709,7 @@ done:
 /* Starts the hop threads, the pre-pass and the scanners for `mp3`; NULL when the stream is too short to bother or frame 0 is
  * not where a regular stream has it. */
 #define PAR_MIN_WINDOWS 4                /* private windows (tests, a forced split scan); 12 otherwise */
-#define PAR_MIN_PART_BYTES (1u << 20)
+#define PAR_MIN_PART_BYTES (1u << 18)   /* (a file of a few minutes -- 2 to 4 MB -- in six parts: the hop is a chain of cache misses, 0.1 us a frame on a stream that is not in the caches) */
 static void par_free(struct par_scan* P) {          /* (the records and the hop threads' arrays are the cache's) */
   if (P->snap) for (long long w = 0; w < P->snap_cap; w++) free(P->snap[w].sky);
   free(P->win); free(P->snap); free(P->args); free(P);
@@ -2769,6 +2790,7 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
     P->args[k].P = P; P->args[k].k = k; P->args[k].rc = -1;
     started = crew_run(pc, par_scanner, &P->args[k], &P->jobs_left) == 0;
   }
+  crew_kick(pc);
   if (!started) {
     pthread_mutex_lock(&P->mu); P->abort = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
     crew_wait(pc, &P->jobs_left); crew_wait(pc, &P->hops_left);
@@ -3334,7 +3356,7 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
     ok = ok && bulk_finish_b(b) == PDMP3_OK;
   }
   if (drain || !b->bits_mode || !ok) ok = bulk_drain(b) == PDMP3_OK && ok;
-  else if (b->pool_mode) ok = sub_drain(b) == PDMP3_OK && ok;      /* the submitter has taken the main data out of `mp3` */
+  else if (b->pool_mode) ok = sub_drain_copied(b) == PDMP3_OK && ok;      /* the submitter has taken the main data out of `mp3` */
   b->t_tail += now_s() - t_driven;
   if (rate) *rate = (long)kSampleRates[b->id->hdr.sfreq];
   if (channels) *channels = b->id->hdr.mode == 3 ? 1 : 2;
