@@ -77,6 +77,10 @@ pdmp3_amd_bulk* pdmp3_amd_bulk_new_ex(int threads, int window_frames, int host_h
 pdmp3_amd_bulk* pdmp3_amd_bulk_new_on(int threads, int window_frames, int host_huffman, int device);
 void pdmp3_amd_bulk_delete(pdmp3_amd_bulk* b);
 int pdmp3_amd_bulk_threads(const pdmp3_amd_bulk* b);
+/* Streams the decoder's split scan (several scanner threads; taken for device destinations, or with
+ * PDMP3_BULK_SCAN_THREADS) decoded to their end, and streams it gave up half way -- irregular ones: resync, tags, a
+ * truncation the ring's feed cadence shows -- and decoded again with the one-thread scan.  Same PCM either way. */
+void pdmp3_amd_bulk_split_scans(const pdmp3_amd_bulk* b, long long* taken, long long* given_up);
 /* ISO-correct switches (include/pdmp3.h: PDMP3_ISO_*, pdmp3_amd_set_quirks) for the streams decoded from now on;
  * 0 (the default) = the reference's behaviour, bit for bit.  The CLI driver reads the mask from $PDMP3_CLI_ISO. */
 int pdmp3_amd_bulk_set_quirks(pdmp3_amd_bulk* b, unsigned iso_mask);

@@ -13,7 +13,7 @@ PDMP3_OK, PDMP3_ERR, PDMP3_NEED_MORE, PDMP3_NEW_FORMAT, PDMP3_NO_SPACE = 0, -1, 
 PDMP3_ENC_SIGNED_16 = 0xD0
 _LIB = None
 
-BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads", "pdmp3_amd_bulk_set_quirks",
+BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads", "pdmp3_amd_bulk_split_scans", "pdmp3_amd_bulk_set_quirks",
                 "pdmp3_amd_scan_buffer", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_decode_async", "pdmp3_amd_bulk_wait", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
                 "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits", "pdmp3_amd_bulk_parse_pool", "pdmp3_amd_pcm_alloc", "pdmp3_amd_pcm_free", "pdmp3_amd_stream_loop", "pdmp3_amd_write_wav"]
 
@@ -64,6 +64,8 @@ def load_library():
     lib.pdmp3_amd_bulk_new_parse_only.argtypes = [C.c_int, C.c_int]
     lib.pdmp3_amd_bulk_delete.argtypes = [vp]
     lib.pdmp3_amd_bulk_threads.argtypes = [vp]
+    lib.pdmp3_amd_bulk_split_scans.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    lib.pdmp3_amd_bulk_split_scans.restype = None
     lib.pdmp3_amd_scan_buffer.restype = C.c_longlong
     lib.pdmp3_amd_scan_buffer.argtypes = [vp, C.c_size_t, C.POINTER(C.c_longlong)]
     lib.pdmp3_amd_bulk_decode.restype = C.c_longlong
@@ -303,6 +305,12 @@ class BulkDecoder:
         if total < 0:
             raise RuntimeError("pdmp3_amd_bulk_decode: engine failure")
         return total, rate.value, ch.value
+
+    def split_scans(self):
+        """-> (streams the split scan decoded to their end, streams it gave up half way and handed to the one-thread scan)"""
+        a, g = C.c_longlong(0), C.c_longlong(0)
+        self.lib.pdmp3_amd_bulk_split_scans(self.h, C.byref(a), C.byref(g))
+        return a.value, g.value
 
     def wait(self):
         if self.lib.pdmp3_amd_bulk_wait(self.h) != 0:

@@ -1461,6 +1461,7 @@ struct bulk {
   void* sub_dst[8];
   long long sub_head, sub_tail;       /* jobs enqueued / completed */
   long long sub_copied;               /* jobs whose main data is out of the caller's stream (<= sub_tail + 1) */
+  long long par_taken, par_given_up;  /* streams the split scan took to their end / gave up half way (pdmp3_amd_bulk_split_scans) */
   size_t next_copy_row;               /* row size of the copy job bulk_collect last handed out */
   /* split scan (par_scan below): a scanner that fills private windows (struct pre_window) instead of engine slots */
   int scan_threads;                   /* scanners of the split scan (0: stage A on the calling thread alone) */
@@ -2721,9 +2722,11 @@ static struct par_scan* par_start(struct bulk* b, const unsigned char* mp3, size
   if (H.id != 1 || H.bitrate_index == 0 || H.bitrate_index == 15 || H.sfreq == 3 || H.layer != 3) return NULL;
   const unsigned fb0 = frame_bytes(&H);
   const long long est = (long long)(n / fb0);
-  /* sub = 0: the caller leaves the private windows' size to the stream's length -- 1024 frames for long streams, 512 and
-   * 256 for files of a few minutes (C4: 4096 frames and up), so that every scanner has two windows or more */
-  if (sub == 0) sub = est >= 16384 ? 1024 : est >= 8192 ? 512 : 256;
+  /* sub = 0: the caller leaves the private windows' size to the decoder: 256 frames.  (Until round 5: 1024 for long streams, 512
+   * and 256 for files of a few minutes.  The host side takes as long either way; what the shorter ones buy is at the stream's
+   * start -- the first window is with the stitcher after 0.05 ms instead of 0.13 -- and in how evenly the engine's windows fill:
+   * 137812 frames with the PCM left in HBM, five runs each, interleaved: 31.6 M frames/s with 1024, 32.8 with 512, 34.2 with 256.) */
+  if (sub == 0) sub = 256;
   if (sub > b->cap) sub = b->cap;
   if (sub < 1) return NULL;
   const long long est_windows = (est + sub - 1) / sub;
@@ -2865,8 +2868,8 @@ static int bulk_in_flight(struct bulk* b) {
   return n;
 }
 /* a private window onto the end of the engine's open window: its pool behind what is there, offsets moved accordingly */
-static int par_fits(const struct bulk* b, const pre_window* pw) {
-  return b->bits_n + pw->n <= b->cap && b->pool_tail + pw->pool_tail + POOL_ROOM <= b->pool_cap &&
+static int par_fits(const struct bulk* b, const pre_window* pw, int lim) {
+  return (b->bits_n + pw->n <= lim || (!b->bits_n && pw->n <= b->cap)) && b->pool_tail + pw->pool_tail + POOL_ROOM <= b->pool_cap &&
          b->gath_n + pw->gath_n <= b->cap + BULK_GATH_EXTRA * (PAR_MAX_BATCH + 1) && b->slot_arena_n[b->bits_slot] < PAR_MAX_BATCH;
 }
 static void par_append(struct bulk* b, pre_window* pw) {
@@ -2922,24 +2925,32 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
   pre_window* held = NULL;                              /* taken from the scanners, did not fit the window before */
   for (;;) {
     const double t0 = now_s();
+    const int was_held = held != NULL;                  /* (taken from the scanners -- and counted -- when it did not fit the window before) */
     pre_window* pw = held ? held : par_next_window(P, w, &end);
     held = NULL;
     const double t1 = now_s();
     t_win += t1 - t0;
     if (!pw) break;
-    if (trace2) pw_trace(pw, w, t_start, t0, t1);
-    w++;
+    if (!was_held) {
+      if (trace2) pw_trace(pw, w, t_start, t0, t1);
+      w++;
+    }
     const int opened = engine_ok && bits_open_window(b) == PDMP3_OK;
     const double t2 = now_s();
     t_open += t2 - t1;
-    if (opened && par_fits(b, pw)) {
+    /* (Tried in round 5: a short LAST window -- the stream's end known from the pre-pass, the window that would leave less than
+     *  2048 frames behind stopping that far short of it -- so that the caller waits for a shorter chain of kernels at the end:
+     *  32.2 against 33.8 M frames/s without, five interleaved runs.  The GPU is the bound by then, and two windows cost it more
+     *  than one.) */
+    const int lim = b->cap;
+    if (opened && par_fits(b, pw, lim)) {
       par_append(b, pw);
       for (int i = 0; i < pw->n; i++) total += 2304 * pw->nch[i];
       frames += pw->n;
       pw_free(pw);
       const double t3 = now_s();
       t_fill += t3 - t2;
-      while (b->bits_n < b->cap) {                      /* what else is there, or worth waiting for */
+      while (b->bits_n < lim) {                         /* what else is there, or worth waiting for */
         int e2;
         pre_window* more = par_next_window_wait(P, w, &e2, 0);
         /* (a stream that fits one slot goes up as ONE window -- a file of a few minutes: every window costs the GPU its
@@ -2949,7 +2960,7 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
         if (!more) { if (e2 == 0 && (P->one_window || bulk_in_flight(b) >= 2)) continue; break; }
         if (trace2) pw_trace(more, w, t_start, t3, now_s());
         w++;
-        if (!par_fits(b, more)) { held = more; break; }
+        if (!par_fits(b, more, lim)) { held = more; break; }
         par_append(b, more);
         for (int i = 0; i < more->n; i++) total += 2304 * more->nch[i];
         frames += more->n;
@@ -2971,10 +2982,13 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
   if (trace2) par_trace_prepass(P);
   uint32_t last_hw = 0;
   if (end == 1 && nf > 0) last_hw = be32(mp3 + P->rec[nf - 1].x);
-  const int ok = par_finish(P) == 0 && end == 1 && engine_ok && frames == nf;
+  const int fin = par_finish(P);
+  const int ok = fin == 0 && end == 1 && engine_ok && frames == nf;
   atomic_fetch_sub(&g_par_active, 1);
+  if (!ok && tr) fprintf(stderr, "bulk trace: split scan given up: pre-pass verdict %d, end %d, engine %d, frames %lld of %lld, %d windows\n", fin, end, engine_ok, frames, nf, n_windows);
   if (!engine_ok) { b->failed = 1; return -1; }
-  if (!ok) return PAR_GIVEN_UP;
+  if (!ok) { b->par_given_up++; return PAR_GIVEN_UP; }
+  b->par_taken++;
   if (nf > 0) { header_fields(last_hw, &b->id->hdr); b->id->l_hdr = b->id->hdr; }
   if (getenv("PDMP3_BULK_TRACE"))
     fprintf(stderr, "bulk trace: split scan, %d scanners, %lld frames in private windows of %d, %d windows to the engine, pre-pass %.2f ms; stitch %.2f ms = "
@@ -3250,6 +3264,13 @@ struct bulk* pdmp3_amd_bulk_new(int threads, int window_frames) {
 struct bulk* pdmp3_amd_bulk_new_parse_only(int threads, int window_frames) { return bulk_new(threads, window_frames, 0, 0, 0); }
 struct bulk* pdmp3_amd_bulk_new_parse_bits(void) { return bulk_new(1, 1, 0, 1, 0); }
 int pdmp3_amd_bulk_threads(const struct bulk* b) { return b ? b->nth : 0; }
+/* streams this decoder's split scan (several scanner threads: device destinations, or PDMP3_BULK_SCAN_THREADS) decoded to
+ * their end, and streams it gave up half way and decoded again with the one-thread scan (irregular ones: resync, tags,
+ * truncation in the middle of the ring's cadence) -- same PCM either way; for tests and for whoever wonders about the rate */
+void pdmp3_amd_bulk_split_scans(const struct bulk* b, long long* taken, long long* given_up) {
+  if (taken) *taken = b ? b->par_taken : 0;
+  if (given_up) *given_up = b ? b->par_given_up : 0;
+}
 /* the ISO-correct switches (include/pdmp3.h: pdmp3_amd_set_quirks) for the streams this decoder is given from now on */
 int pdmp3_amd_bulk_set_quirks(struct bulk* b, unsigned iso_mask) { return b ? pdmp3_amd_set_quirks(b->id, iso_mask) : PDMP3_ERR; }
 

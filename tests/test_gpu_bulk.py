@@ -476,7 +476,7 @@ def test_split_scan_decodes_what_the_one_thread_scan_decodes(streams, monkeypatc
     ones (resync, tags, truncation) are turned down before or half way -- then the windows that have gone up are let
     through and the stream is decoded again by the one-thread scan: either way the PCM is the one-thread decoder's, bit
     for bit, and a decoder is reusable after both.  sub > 0: the scanners' private windows have that many frames and the
-    engine's windows are made of as many as are there ($PDMP3_BULK_SUB_FRAMES; by default 1024, i.e. the whole window at
+    engine's windows are made of as many as are there ($PDMP3_BULK_SUB_FRAMES; by default 256, i.e. the whole window at
     these sizes): windows of every length up to `window`, the private windows' pools one behind the other"""
     from pdmp3_amd import api
     from test_split_scan import _regular_streams
@@ -494,6 +494,15 @@ def test_split_scan_decodes_what_the_one_thread_scan_decodes(streams, monkeypatc
             want = ref.decode(mp3)
             got = par.decode(mp3)
             assert got.shape == want.shape and np.array_equal(got, want), name
+        # ... and the regular ones really went the split way (a private window that does not fit the engine's open window
+        # is held for the next one: until round 5 the stitcher then skipped the window behind it, the frame count came out
+        # short and the stream was decoded again the one-thread way -- right PCM, a quarter of the rate)
+        taken0, given0 = par.split_scans()
+        regular = {k: v for k, v in _regular_streams().items() if k != "main_data_flipped"}
+        for name, mp3 in regular.items():
+            par.decode(mp3)
+        taken, given = par.split_scans()
+        assert given == given0 and taken - taken0 >= 5, (taken0, given0, taken, given)      # (the five constant-bitrate ones at least: 400-700 frames each)
     finally:
         ref.close()
         par.close()
