@@ -465,6 +465,7 @@ struct pdmp3_hip_ctx {
   unsigned debug_flags;     // PDMP3_HIP_DEBUG_FAR_TIMEOUT=1: every wait for another workgroup gives up at once (tests)
   std::atomic<int> last_kind;   // PDMP3_HIP_LAUNCH_* of the latest decode launch, any thread (reports only)
   int direct_max_frames;    // record batches of a stream up to this size run on the pinned host buffers directly (PDMP3_HIP_DIRECT_MAX)
+  int gran_w8;              // development: PDMP3_HIP_GRAN_W=8 -- every launch of the granule kernel in workgroups of 8 waves
   int sf_hint;              // sampling-frequency index the granule kernel's line tables are loaded for (PDMP3_HIP_SF_HINT; 0 = 44.1 kHz)
   std::mutex chain_mu;
   unsigned long long chain_clock;
@@ -533,6 +534,7 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     c->wave_slots_gran = cus * 4 * 4;
     const char* dm = getenv("PDMP3_HIP_DIRECT_MAX");
     c->direct_max_frames = dm ? atoi(dm) : 32;
+    { const char* gw = getenv("PDMP3_HIP_GRAN_W"); c->gran_w8 = gw && atoi(gw) == 8; }
     const char* h = getenv("PDMP3_HIP_SF_HINT");
     c->sf_hint = (h && *h >= '0' && *h <= '2') ? *h - '0' : 0;
     const char* d = getenv("PDMP3_HIP_DEBUG_FAR_TIMEOUT");
@@ -733,7 +735,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
 #endif
   if (gran) {
     // (workgroups of 8 waves while that gives every CU at most one of them)
-    const bool small = 2 * n_frames <= c->wave_slots_gran / 2;
+    const bool small = 2 * n_frames <= c->wave_slots_gran / 2 || c->gran_w8;
     const int W = small ? 8 : 16;
     c->last_kind = W;
     const int n_wgs = (2 * n_frames + W - 1) / W;

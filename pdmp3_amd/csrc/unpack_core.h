@@ -50,7 +50,7 @@
 namespace pdmp3 {
 
 constexpr int kHuffFirstBits = 8;
-constexpr int kHuffLutMax = 9728;                 // entries: 19 first levels, the second levels and a leaf per short code word (host_tables.h checks)
+constexpr int kHuffLutMax = 9024;                 // entries: 19 first levels, the second levels and a leaf per short code word (host_tables.h checks)
 constexpr unsigned kResBytes = PDMP3_RESERVOIR_BYTES;
 constexpr unsigned kFastLimit = (kResBytes - 8) * 8u;   // bit positions from which an 8-byte load stays inside the row
 
