@@ -31,7 +31,8 @@ PDMP3_ENC_SIGNED_16, PDMP3_ENC_FLOAT_32 = 0xD0, 0x200
 
 
 def library_path():
-    return os.path.join(_HERE, "libpdmp3.so")
+    # PDMP3_HOST_LIB: alternative build of the host library (A/B experiments; it brings the engine library it was linked with)
+    return os.environ.get("PDMP3_HOST_LIB") or os.path.join(_HERE, "libpdmp3.so")
 
 
 def load_library():
@@ -64,8 +65,9 @@ def load_library():
     lib.pdmp3_amd_bulk_new_parse_only.argtypes = [C.c_int, C.c_int]
     lib.pdmp3_amd_bulk_delete.argtypes = [vp]
     lib.pdmp3_amd_bulk_threads.argtypes = [vp]
-    lib.pdmp3_amd_bulk_split_scans.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
-    lib.pdmp3_amd_bulk_split_scans.restype = None
+    if hasattr(lib, "pdmp3_amd_bulk_split_scans"):          # (absent from builds before round 5's end: PDMP3_HOST_LIB A/B runs)
+        lib.pdmp3_amd_bulk_split_scans.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        lib.pdmp3_amd_bulk_split_scans.restype = None
     lib.pdmp3_amd_scan_buffer.restype = C.c_longlong
     lib.pdmp3_amd_scan_buffer.argtypes = [vp, C.c_size_t, C.POINTER(C.c_longlong)]
     lib.pdmp3_amd_bulk_decode.restype = C.c_longlong

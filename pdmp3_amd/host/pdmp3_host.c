@@ -3233,7 +3233,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
       pthread_mutex_init(&b->gh_mu, NULL); pthread_cond_init(&b->gh_cv, NULL); pthread_cond_init(&b->gh_done_cv, NULL);
       {
         const char* ge = getenv("PDMP3_BULK_GATHER_THREADS");      /* helpers for the windows' main-data copies (0 .. 8) */
-        int want = ge ? atoi(ge) : (b->scan_threads >= 8 ? 4 : b->scan_threads > 0 ? 3 : 0);
+        int want = ge ? atoi(ge) : (b->scan_threads >= 8 ? 6 : b->scan_threads > 0 ? 3 : 0);   /* (4 instead of 6: the same with the PCM left in HBM, 9.0 against 9.7 M frames/s to pinned memory) */
         if (want > GATHER_MAX_HELPERS) want = GATHER_MAX_HELPERS;
         for (b->gh_n = 0; b->gh_n < want; b->gh_n++)
           if (pthread_create(&b->gh_th[b->gh_n], NULL, gather_helper, b) != 0) break;
