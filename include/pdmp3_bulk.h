@@ -49,21 +49,24 @@ pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
 /* Environment: PDMP3_BULK_HOST_HUFFMAN=1 (below), PDMP3_BULK_SNAPSHOT_ROWS=1 (upload 2064-byte reservoir snapshots per frame
  * instead of the compact pool + row descriptors: tests), PDMP3_BULK_TRACE=1 (one summary of the pipeline's waits per decode on
  * stderr; 2: a line per window as well), PDMP3_BULK_SCAN_THREADS=n (0 .. 16: scanner threads of the split scan -- a pre-pass
- * hops from header to header and n threads run the scan from every 1024th frame into private windows that the calling
- * thread puts into the engine's slots in stream order, results identical to the one-thread scan; by default 8 / 4 / 2 with
- * 16 / 12 / 6 usable CPUs and only when the PCM stays in device memory, where the scan is the bound; given explicitly: for
+ * hops from header to header and n threads run the scan from every 256th frame into private windows that the calling
+ * thread puts into the engine's slots in stream order, results identical to the one-thread scan; by default 12 / 8 / 4 / 2 with
+ * 32 / 16 / 12 / 6 usable CPUs and only when the PCM stays in device memory, where the scan is the bound; given explicitly: for
  * every destination and for streams from 4 private windows on instead of 12; 0: never; decoders of one process that scan
  * at the same time share: the second takes half the scanners, the third a third ...), PDMP3_BULK_PREPASS_THREADS=n (1 .. 8
  * parts of the pre-pass, all but the first with a thread of their own that hops from a guessed header; 6 / 3 / 1 by default
- * with 16 / 12 / fewer usable CPUs), PDMP3_BULK_SUB_FRAMES=n (frames of a private window; by default 1024 for streams of
- * 16384 frames and more, 512 from 8192, 256 below),
+ * with 16 / 12 / fewer usable CPUs; no part shorter than 256 KB), PDMP3_BULK_SUB_FRAMES=n (frames of a private window; 256 by
+ * default), PDMP3_BULK_SCAN_SPIN=0 / 1 (a scanner whose snapshot is the next or the one after yields / spins while it waits; by
+ * default it spins where the process has 2 x scanners + 8 CPUs),
  * PDMP3_BULK_GATHER_THREADS=n (0 .. 8 helper threads for the copies of the windows' main data into the pinned upload
  * buffers; 6 by default with 8 scanners, 3 with fewer, 0 without).
  * Thread footprint of ONE decoder with a device destination on a host with 16 usable CPUs or more, for its lifetime
  * (the threads are started when a stream first needs them and then sleep on a job queue between streams): 8 scanners,
  * 5 hop threads + the pre-pass, 6 gather helpers, the submitter and the copy-out pool (`threads`) -- about 25.  Only
  * the scanners are shared out between decoders of one process that scan at the same time (above); gather helpers,
- * hop threads and the pre-pass are per decoder, and their waits yield the CPU (sched_yield) rather than sleep.  A
+ * hop threads and the pre-pass are per decoder, and their waits yield the CPU (sched_yield) or nap 20 us at a time rather
+ * than sleep on a condition (the scanners' wait for their snapshots: a broadcast per snapshot to a dozen sleepers was
+ * the split scan's bottleneck until round 5).  A
  * process that keeps many decoders (one per GPU and more) should size them with the variables above --
  * PDMP3_BULK_SCAN_THREADS=2 PDMP3_BULK_PREPASS_THREADS=1 PDMP3_BULK_GATHER_THREADS=1 is 6 threads per decoder. */
 /* host_huffman = 0 (what pdmp3_amd_bulk_new gives unless PDMP3_BULK_HOST_HUFFMAN=1 is set): the host only runs

@@ -117,6 +117,9 @@ void pdmp3_hip_destroy(pdmp3_hip_ctx* ctx);
  *                                 granules of another one read the table from memory)
  *   PDMP3_HIP_DEBUG_FAR_TIMEOUT=1 tests: every wait for another workgroup gives up at once (the independent way is taken)
  *   PDMP3_HIP_UNPACK_PROF=1       development: shader-clock stamps of k_unpack's steps, one line per launch on stderr
+ *   PDMP3_HIP_GRAN_W=8            development: every launch of the granule kernel in workgroups of 8 waves (84 KB of LDS: one fits a
+ *                                 CU beside a workgroup of k_unpack; by default launches that fill the chip take 16 -- measured with the
+ *                                 whole-stream decoder: 30.7 against 32.8 M frames/s)
  * and by the host library (libpdmp3.so): PDMP3_DEVICE, PDMP3_STREAM_THREADS, PDMP3_NO_READAHEAD (include/pdmp3.h),
  * PDMP3_BULK_HOST_HUFFMAN, PDMP3_BULK_SNAPSHOT_ROWS, PDMP3_BULK_TRACE (include/pdmp3_bulk.h), PDMP3_CLI_STREAMING, PDMP3_CLI_WAV. */
 const char* pdmp3_hip_last_error(void);
