@@ -61,12 +61,14 @@ def test_bulk_long_vbr_stream(oracle):
 
 
 def test_windows_larger_than_a_merge_step():
-    """windows of 5000 and 7001 frames: k_merge walks a window in steps of 2048 frames with a carry between them, k_unpack
-    gets 313 / 438 workgroups -- same PCM, bit for bit, as with the default window and as with host Huffman"""
+    """windows of 5000, 7001 and 14999 frames: k_merge_apply walks the rows of outcomes in front of a block 40 at a time (a
+    window of 14999 frames has 58 super-blocks: two goes for its last blocks; 31 + 7 rows at most up to 8192 frames), the last
+    block of a window is a partial one (7001 = 218 x 32 + 25), k_unpack gets 313 / 438 / 938 workgroups -- same PCM, bit for
+    bit, as with the default window and as with host Huffman"""
     from pdmp3_amd import api
     mp3 = packer.generate(n_frames=15000, seed=79, vbr=True, block_pct=(40, 10, 40, 10), mixed_pct=30)
     outs = []
-    for window, hh in ((2048, False), (5000, False), (7001, False), (4096, True)):
+    for window, hh in ((2048, False), (5000, False), (7001, False), (14999, False), (4096, True)):
         b = api.BulkDecoder(threads=4, window_frames=window, host_huffman=hh)
         try:
             outs.append(b.decode(mp3))
