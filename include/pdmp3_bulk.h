@@ -59,7 +59,8 @@ pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
  * default), PDMP3_BULK_SCAN_SPIN=0 / 1 (a scanner whose snapshot is the next or the one after yields / spins while it waits; by
  * default it spins where the process has 2 x scanners + 8 CPUs),
  * PDMP3_BULK_GATHER_THREADS=n (0 .. 8 helper threads for the copies of the windows' main data into the pinned upload
- * buffers; 6 by default with 8 scanners, 3 with fewer, 0 without).
+ * buffers; 6 by default with 8 scanners, 3 with fewer, 0 without), PDMP3_BULK_GATHER_NT=0 (those copies with memcpy instead
+ * of non-temporal stores).
  * Thread footprint of ONE decoder with a device destination on a host with 16 usable CPUs or more, for its lifetime
  * (the threads are started when a stream first needs them and then sleep on a job queue between streams): 8 scanners,
  * 5 hop threads + the pre-pass, 6 gather helpers, the submitter and the copy-out pool (`threads`) -- about 25.  Only

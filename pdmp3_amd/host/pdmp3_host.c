@@ -1001,7 +1001,7 @@ static struct {
 } g_hp = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, {{0, 0, 0, 0}}, 0, 0};
 
 static inline void hp_pause(void) {
-#if defined(__x86_64__) || defined(__i386__)
+#if defined(__x86_64__)
   __builtin_ia32_pause();
 #else
   sched_yield();
@@ -1704,7 +1704,36 @@ static void fill_frame_bits(const pdmp3_handle* id, pdmp3_frame_bits* fb, int ne
 }
 
 /* the main data a window's frames left in the caller's stream, into its pool (entries the scanner needed early have n = 0) */
+/* (The pool is written once and read by the copy engine: non-temporal stores for the whole cache lines of an entry -- no
+ *  read-for-ownership of 9 MB per window, nothing of it in the caches the scanners work in.  A frame's main data is about a
+ *  kilobyte, its first and last partial line go the ordinary way.  PDMP3_BULK_GATHER_NT=0: memcpy.) */
+static int g_gather_nt = -1;
 static void pool_gather(uint8_t* pool, const struct pool_copy* g, int n) {
+#if defined(__x86_64__)
+  int nt = __atomic_load_n(&g_gather_nt, __ATOMIC_RELAXED);
+  if (nt < 0) { const char* e = getenv("PDMP3_BULK_GATHER_NT"); nt = !(e && *e == '0'); __atomic_store_n(&g_gather_nt, nt, __ATOMIC_RELAXED); }
+  if (nt) {
+    for (int i = 0; i < n; i++) {
+      size_t len = g[i].n;
+      if (!len) continue;
+      unsigned char* dst = pool + g[i].dst;
+      const unsigned char* src = g[i].src;
+      if (len < 256) { memcpy(dst, src, len); continue; }
+      const size_t head = (size_t)(-(uintptr_t)dst & 63);
+      if (head) { memcpy(dst, src, head); dst += head; src += head; len -= head; }
+      for (size_t lines = len >> 6; lines; lines--) {
+        const __m128i a = _mm_loadu_si128((const __m128i*)src), b = _mm_loadu_si128((const __m128i*)src + 1);
+        const __m128i c = _mm_loadu_si128((const __m128i*)src + 2), d = _mm_loadu_si128((const __m128i*)src + 3);
+        _mm_stream_si128((__m128i*)dst, a); _mm_stream_si128((__m128i*)dst + 1, b);
+        _mm_stream_si128((__m128i*)dst + 2, c); _mm_stream_si128((__m128i*)dst + 3, d);
+        src += 64; dst += 64;
+      }
+      if (len & 63) memcpy(dst, src, len & 63);
+    }
+    _mm_sfence();
+    return;
+  }
+#endif
   for (int i = 0; i < n; i++) if (g[i].n) memcpy(pool + g[i].dst, g[i].src, g[i].n);
 }
 /* (gh_mu held) one task off the queue and done; 0: the queue is empty */
