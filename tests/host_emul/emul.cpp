@@ -182,6 +182,56 @@ extern "C" int emul_unpack_frames(const pdmp3_frame_bits* bits, const uint8_t* r
 }
 
 
+// the merge alone on RANDOM merge input (every combination of set / copy bits, mono frames, new streams in the middle of a
+// block, the two ISO switches that keep the one-past-the-end slots zero): merge_blocks -- the form of the two kernels --
+// against merge_slot, records and carried state.  Returns 0, or 1 + the index of the first frame whose records differ,
+// or -1 when only the state differs.
+extern "C" int emul_merge_fuzz(uint64_t seed, int n_frames, int p_set, int p_copy, int p_mono, int p_new) {
+  auto rnd = [&seed]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(seed >> 33); };
+  std::vector<GcRaw> raw((size_t)n_frames * 4);
+  std::vector<pdmp3_frame_bits> bits((size_t)n_frames);
+  memset(raw.data(), 0, raw.size() * sizeof(GcRaw));
+  memset(bits.data(), 0, bits.size() * sizeof(pdmp3_frame_bits));
+  for (int f = 0; f < n_frames; f++) {
+    const bool mono = (int)(rnd() % 100) < p_mono;
+    bits[f].frame = (uint8_t)((mono ? 3u : rnd() % 3u) << PDMP3_FR_MODE_SHIFT);
+    if (f == 0 || (int)(rnd() % 1000) < p_new) bits[f].frame |= PDMP3_FR_NEWSTREAM;
+    bits[f].iso = (uint8_t)((rnd() % 8 == 0 ? 0x08u : 0u) | (rnd() % 8 == 0 ? 0x10u : 0u));
+    for (int g = 0; g < 4; g++) {
+      GcRaw& r = raw[(size_t)f * 4 + g];
+      if (mono && (g & 1)) continue;                          // (what unpack_scalefactors leaves for a channel that is not there: zeroes)
+      if ((int)(rnd() % 100) < p_set) { r.count1 = (uint16_t)(rnd() % 577); r.count1_set = 1; }
+      const bool shrt = rnd() % 4 == 0, mixed = shrt && rnd() % 2;
+      if (shrt) {
+        if (mixed) { r.sf_l_set = 0xffu; for (int b = 0; b < 8; b++) r.sf_l[b] = (uint8_t)(rnd() % 16); }
+        unsigned set = 0;
+        for (int b = mixed ? 3 : 0; b < 12; b++) { set |= 1u << b; for (int w = 0; w < 3; w++) r.sf_s[b * 3 + w] = (uint8_t)(rnd() % 16); }
+        r.sf_s_set = (uint16_t)set;
+      } else if ((int)(rnd() % 100) < p_set) {
+        unsigned set = 0, copy = 0;
+        for (int g4 = 0; g4 < 4; g4++) {
+          const int lo = g4 ? 1 + 5 * g4 : 0, hi = 6 + 5 * g4;
+          if (g >= 2 && (int)(rnd() % 100) < p_copy) copy |= 1u << g4;
+          else for (int b = lo; b < hi; b++) { r.sf_l[b] = (uint8_t)(rnd() % 16); set |= 1u << b; }
+        }
+        r.sf_l_set = set; r.sf_l_copy = (uint8_t)copy;
+      }
+    }
+  }
+  uint16_t st_in[256], st_a[256], st_b[256];
+  for (int i = 0; i < 256; i++) st_in[i] = st_a[i] = st_b[i] = (uint16_t)(rnd() % (i >= 228 ? 577 : 16));
+  std::vector<pdmp3_gc_side> side_a((size_t)n_frames * 4), side_b((size_t)n_frames * 4);
+  memset(side_a.data(), 0, side_a.size() * sizeof(pdmp3_gc_side));
+  for (int f = 0; f < n_frames; f++) for (int g = 0; g < 4; g++) side_fields(bits[f], g, &side_a[(size_t)f * 4 + g]);
+  side_b = side_a;
+  std::vector<uint32_t> outc((size_t)merge_outcome_rows(n_frames) * kMergeLanes + 1, 0);
+  for (int t = 0; t < kMergeSlots; ++t) merge_slot(t, raw.data(), bits.data(), n_frames, st_in, st_a, side_a.data());
+  merge_blocks(raw.data(), bits.data(), n_frames, st_in, st_b, side_b.data(), outc.data());
+  for (int f = 0; f < n_frames; f++)
+    if (memcmp(&side_a[(size_t)f * 4], &side_b[(size_t)f * 4], 4 * sizeof(pdmp3_gc_side)) != 0) return 1 + f;
+  return memcmp(st_a, st_b, kMergeSlots * sizeof(uint16_t)) != 0 ? -1 : 0;
+}
+
 // reservoir rows from the pool (unpack_core.h row_chunk16: what k_rows runs per frame), and word by word (row_word: the
 // rule itself; the tests ask for both and want them equal)
 extern "C" void emul_rows(const pdmp3_row_desc* desc, const uint8_t* pool, int n_frames, uint8_t* rows) {

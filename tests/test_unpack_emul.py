@@ -229,3 +229,16 @@ def test_merge_by_blocks_over_long_windows(emul):
     assert np.array_equal(whole[1].view(np.uint8), sd_h.view(np.uint8))
     for cuts in ([0, 64, 128, n], [0, 63, 129, 500, n], [0, 1, n - 1, n]):
         assert _records_equal(emul_unpack(emul, bits, res, cuts), whole), cuts
+
+
+@pytest.mark.parametrize("p_set,p_copy,p_mono,p_new", [(90, 30, 0, 0), (50, 60, 10, 5), (10, 90, 30, 20), (3, 50, 0, 1), (100, 0, 100, 0)])
+def test_merge_by_blocks_on_random_merge_input(emul, p_set, p_copy, p_mono, p_new):
+    """the two merge kernels' host form (merge_blocks: per-lane descriptors, batched walks, outcomes of blocks and super-blocks,
+    specialised per wave) against the rule (merge_slot) on random merge input -- set and copy bits at every density (a slot that
+    is written in 3 % of the frames is carried over dozens of blocks, one whose twin is never written before a copy takes the
+    incoming twin's value), mono frames, new streams in the middle of a block, the ISO switches -- for windows of every
+    length around the block and super-block sizes"""
+    emul.emul_merge_fuzz.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    for k, n in enumerate([1, 31, 32, 33, 63, 64, 255, 256, 257, 300, 511, 1024, 1400, 2500]):
+        rc = emul.emul_merge_fuzz(0xA5A5 + 977 * k + p_set, n, p_set, p_copy, p_mono, p_new)
+        assert rc == 0, (n, rc)
