@@ -1297,6 +1297,47 @@ extern "C" int pdmp3_host_generate_frames(uint64_t seed, int64_t first_frame, in
   return PDMP3_HIP_OK;
 }
 
+// Test entry (not part of the product boundary): the two merge kernels alone on merge input from the host -- raw: n_frames x 4
+// GcRaw (320 bytes per frame, unpack_core.h), bits: the frames' side-info records, state_in / state_out: 256 uint16 each, side:
+// n_frames x 4 records out.  tests/test_gpu_bulk.py runs it on random input beside the rule's host form.
+extern "C" int pdmp3_hip_debug_merge(pdmp3_hip_ctx* ctx, const void* raw, const pdmp3_frame_bits* bits, int n_frames,
+                                     const uint16_t* state_in, uint16_t* state_out, pdmp3_gc_side* side) {
+  if (!ctx || !raw || !bits || !state_in || !state_out || !side || n_frames <= 0)
+    return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_debug_merge: bad argument", hipSuccess);
+  HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+  const size_t n = (size_t)n_frames, nblk = (n + kMergeBlk - 1) / kMergeBlk, nsup = (nblk + kMergeSuper - 1) / kMergeSuper;
+  GcRaw* d_raw = nullptr; pdmp3_frame_bits* d_bits = nullptr; uint32_t* d_outc = nullptr; unsigned* d_cnt = nullptr;
+  uint16_t* d_st = nullptr; pdmp3_gc_side* d_side = nullptr;
+  int rc = PDMP3_HIP_OK;
+  do {
+#define DM_STEP(call, text) if ((call) != hipSuccess) { rc = fail(PDMP3_HIP_EDEVICE, text, hipGetLastError()); break; }
+    DM_STEP(hipMalloc((void**)&d_raw, n * 4 * sizeof(GcRaw)), "hipMalloc raw")
+    DM_STEP(hipMalloc((void**)&d_bits, n * sizeof(pdmp3_frame_bits)), "hipMalloc bits")
+    DM_STEP(hipMalloc((void**)&d_outc, (nblk + nsup) * kMergeLanes * sizeof(uint32_t)), "hipMalloc outcomes")
+    DM_STEP(hipMalloc((void**)&d_cnt, (nsup + 1) * sizeof(unsigned)), "hipMalloc counters")
+    DM_STEP(hipMalloc((void**)&d_st, 2 * 256 * sizeof(uint16_t)), "hipMalloc state")
+    DM_STEP(hipMalloc((void**)&d_side, n * 4 * sizeof(pdmp3_gc_side)), "hipMalloc side")
+    DM_STEP(hipMemset(d_cnt, 0, (nsup + 1) * sizeof(unsigned)), "memset counters")
+    DM_STEP(hipMemset(d_side, 0xee, n * 4 * sizeof(pdmp3_gc_side)), "memset side")          // (every byte of the records is the kernel's to write)
+    DM_STEP(hipMemcpy(d_raw, raw, n * 4 * sizeof(GcRaw), hipMemcpyHostToDevice), "H2D raw")
+    DM_STEP(hipMemcpy(d_bits, bits, n * sizeof(pdmp3_frame_bits), hipMemcpyHostToDevice), "H2D bits")
+    DM_STEP(hipMemcpy(d_st, state_in, 256 * sizeof(uint16_t), hipMemcpyHostToDevice), "H2D state")
+    hipLaunchKernelGGL(k_merge_outcome, dim3((unsigned)nblk), dim3(kMergeLanes), 0, 0, d_raw, d_bits, n_frames, d_outc, d_outc + nblk * kMergeLanes, d_cnt);
+    hipLaunchKernelGGL(k_merge_apply, dim3((unsigned)nblk), dim3(kMergeLanes), 0, 0, d_raw, d_bits, n_frames, d_outc, d_outc + nblk * kMergeLanes,
+                       d_st, d_st + 256, d_side);
+    DM_STEP(hipGetLastError(), "launch merge kernels")
+    DM_STEP(hipDeviceSynchronize(), "sync")
+    DM_STEP(hipMemcpy(side, d_side, n * 4 * sizeof(pdmp3_gc_side), hipMemcpyDeviceToHost), "D2H side")
+    DM_STEP(hipMemcpy(state_out, d_st + 256, 256 * sizeof(uint16_t), hipMemcpyDeviceToHost), "D2H state")
+    unsigned left[64] = {0};                              // (the super-blocks' counters are back at zero: the next launch finds them so)
+    DM_STEP(hipMemcpy(left, d_cnt, (nsup < 64 ? nsup : 64) * sizeof(unsigned), hipMemcpyDeviceToHost), "D2H counters")
+    for (size_t i = 0; i < (nsup < 64 ? nsup : 64); i++) if (left[i]) rc = fail(PDMP3_HIP_EDEVICE, "pdmp3_hip_debug_merge: a super-block's counter did not wrap", hipSuccess);
+#undef DM_STEP
+  } while (0);
+  (void)hipFree(d_raw); (void)hipFree(d_bits); (void)hipFree(d_outc); (void)hipFree(d_cnt); (void)hipFree(d_st); (void)hipFree(d_side);
+  return rc;
+}
+
 // Debug/profiling entry (not part of the product boundary): per-chunk shader-clock
 // ticks spent in each pipeline phase.  d_prof: uint64 [n_chunks][10].
 extern "C" int pdmp3_hip_debug_profile_phases(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,

@@ -186,7 +186,16 @@ extern "C" int emul_unpack_frames(const pdmp3_frame_bits* bits, const uint8_t* r
 // block, the two ISO switches that keep the one-past-the-end slots zero): merge_blocks -- the form of the two kernels --
 // against merge_slot, records and carried state.  Returns 0, or 1 + the index of the first frame whose records differ,
 // or -1 when only the state differs.
+// (emul_merge_case: the same, and the case goes to the caller -- the merge input, the frames' records, the incoming state, and
+//  what the rule makes of them -- for the GPU test that runs the two kernels on it; any of the pointers may be NULL)
+extern "C" int emul_merge_case(uint64_t seed, int n_frames, int p_set, int p_copy, int p_mono, int p_new, void* raw_out, pdmp3_frame_bits* bits_out,
+                               uint16_t* st_in_out, pdmp3_gc_side* side_ref, uint16_t* st_ref);
 extern "C" int emul_merge_fuzz(uint64_t seed, int n_frames, int p_set, int p_copy, int p_mono, int p_new) {
+  return emul_merge_case(seed, n_frames, p_set, p_copy, p_mono, p_new, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+extern "C" int emul_merge_raw_bytes() { return (int)sizeof(GcRaw); }
+extern "C" int emul_merge_case(uint64_t seed, int n_frames, int p_set, int p_copy, int p_mono, int p_new, void* raw_out, pdmp3_frame_bits* bits_out,
+                               uint16_t* st_in_out, pdmp3_gc_side* side_ref, uint16_t* st_ref) {
   auto rnd = [&seed]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(seed >> 33); };
   std::vector<GcRaw> raw((size_t)n_frames * 4);
   std::vector<pdmp3_frame_bits> bits((size_t)n_frames);
@@ -227,6 +236,11 @@ extern "C" int emul_merge_fuzz(uint64_t seed, int n_frames, int p_set, int p_cop
   std::vector<uint32_t> outc((size_t)merge_outcome_rows(n_frames) * kMergeLanes + 1, 0);
   for (int t = 0; t < kMergeSlots; ++t) merge_slot(t, raw.data(), bits.data(), n_frames, st_in, st_a, side_a.data());
   merge_blocks(raw.data(), bits.data(), n_frames, st_in, st_b, side_b.data(), outc.data());
+  if (raw_out) memcpy(raw_out, raw.data(), raw.size() * sizeof(GcRaw));
+  if (bits_out) memcpy(bits_out, bits.data(), bits.size() * sizeof(pdmp3_frame_bits));
+  if (st_in_out) memcpy(st_in_out, st_in, sizeof st_in);
+  if (side_ref) memcpy(side_ref, side_a.data(), side_a.size() * sizeof(pdmp3_gc_side));
+  if (st_ref) memcpy(st_ref, st_a, sizeof st_a);
   for (int f = 0; f < n_frames; f++)
     if (memcmp(&side_a[(size_t)f * 4], &side_b[(size_t)f * 4], 4 * sizeof(pdmp3_gc_side)) != 0) return 1 + f;
   return memcmp(st_a, st_b, kMergeSlots * sizeof(uint16_t)) != 0 ? -1 : 0;

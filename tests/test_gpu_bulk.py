@@ -589,3 +589,43 @@ def test_decoders_side_by_side_into_device_memory():
     assert not errs, errs
     for i in range(len(files)):
         assert np.array_equal(outs[i].cpu().numpy(), want[i]), i
+
+
+@pytest.mark.parametrize("p_set,p_copy,p_mono,p_new", [(90, 30, 0, 0), (10, 90, 30, 20), (3, 50, 0, 1)])
+def test_merge_kernels_on_random_merge_input(emul, p_set, p_copy, p_mono, p_new):
+    """k_merge_outcome + k_merge_apply alone (pdmp3_hip_debug_merge) on the random merge input of
+    test_unpack_emul.test_merge_by_blocks_on_random_merge_input, against what the rule (merge_slot, host build) makes of it:
+    every byte of the records -- the kernel writes all 128 of each -- and the carried state; windows of one block, of one
+    super-block and a frame, of 40 super-blocks and more (the rows of outcomes in front of a block are staged 40 at a time),
+    last blocks of 1 and of 31 frames; the super-blocks' counters back at zero after every launch"""
+    import ctypes as C
+    from pdmp3_amd import hip
+    from pdmp3_amd.hip import SIDE_DTYPE
+    eng = hip.Engine()
+    lib = eng.lib
+    lib.pdmp3_hip_debug_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pdmp3_hip_debug_merge.restype = C.c_int
+    emul.emul_merge_case.argtypes = [C.c_uint64] + [C.c_int] * 5 + [C.c_void_p] * 5
+    raw_bytes = emul.emul_merge_raw_bytes()
+    assert raw_bytes == 80
+
+    def p(a):
+        return a.ctypes.data_as(C.c_void_p)
+    try:
+        for k, n in enumerate([1, 32, 33, 255, 257, 2049, 8192, 10271, 12289]):
+            raw = np.zeros((n, 4, raw_bytes), np.uint8)
+            bits = np.zeros((n, 80), np.uint8)
+            st_in = np.zeros(256, np.uint16)
+            side_ref = np.zeros((n, 4), SIDE_DTYPE)
+            st_ref = np.zeros(256, np.uint16)
+            rc = emul.emul_merge_case(0xBEEF + 131 * k + p_copy, n, p_set, p_copy, p_mono, p_new, p(raw), p(bits), p(st_in), p(side_ref), p(st_ref))
+            assert rc == 0, (n, rc)                          # (the host form of the kernels agrees with the rule on this case)
+            side = np.zeros((n, 4), SIDE_DTYPE)
+            st_out = np.zeros(256, np.uint16)
+            rc = lib.pdmp3_hip_debug_merge(eng.h, p(raw), p(bits), n, p(st_in), p(st_out), p(side))
+            assert rc == 0, (n, lib.pdmp3_hip_last_error())
+            bad = np.nonzero((side.view(np.uint8).reshape(n, -1) != side_ref.view(np.uint8).reshape(n, -1)).any(axis=1))[0]
+            assert bad.size == 0, (n, bad[:5])
+            assert np.array_equal(st_out[:232], st_ref[:232]), n
+    finally:
+        eng.close()
