@@ -3209,9 +3209,11 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
   if (threads <= 0) {
     const int c = usable_cpus();
     threads = c > 64 ? 64 : c;
-    /* (the pool only copies PCM out: at most 6 threads, 4 below 16 usable CPUs -- the scan, the submitter and on a
-     *  device destination the split scan's threads want cores too) */
-    if (bits_mode && threads > (c >= 16 ? 6 : 4)) threads = c >= 16 ? 6 : 4;
+    /* (the pool only copies PCM out: at most 4 threads -- the scan, the submitter and on a device destination the split scan's
+     *  threads want cores too, and more copy threads take memory bandwidth from the scanning thread, which bounds the
+     *  host-memory destinations: the hour to pageable memory, five interleaved runs, 3 / 4 / 6 / 8 threads: 9.0 / 9.0 / 8.2 /
+     *  8.1 M frames/s; six was the default for a while in round 5) */
+    if (bits_mode && threads > 4) threads = 4;
   }
   /* frames per GPU batch.  Bits mode: k_unpack is bound by the length of one lane's chain, not by throughput, and two of
    * its workgroups (16 frames each) fit a CU: 8192 frames fill the chip once, 68 -> 84 us against 4096.  The slots hold
