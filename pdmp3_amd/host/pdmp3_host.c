@@ -2961,7 +2961,7 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
   sub = P->sub;
   K = P->K;
   long long total = 0, frames = 0, w = 0;
-  int end = 0, engine_ok = 1, n_windows = 0;
+  int end = 0, engine_ok = 1, n_windows = 0, gave_up = 0;
   double t_win = 0, t_open = 0, t_fill = 0, t_more = 0;
   const char* tr = getenv("PDMP3_BULK_TRACE");
   const int trace2 = tr && atoi(tr) >= 2;
@@ -2987,7 +2987,9 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
      *  32.2 against 33.8 M frames/s without, five interleaved runs.  The GPU is the bound by then, and two windows cost it more
      *  than one.  And capped FIRST windows -- cap / 8, cap / 8, cap / 4, cap / 2, as the one-thread scan has them -- so that the
      *  third window does not wait until it is full while two tiny ones are the GPU's: 33.4 against 33.7 M, six runs each.) */
-    const int lim = b->cap;
+    /* (a destination in host memory: windows of `target` frames -- 4096 unless the caller named a size -- or, for a stream that
+     *  fits a slot, the slot: bulk_decode_impl's cur_target) */
+    const int lim = b->pcm_pinned == 2 || b->cur_target <= 0 || b->cur_target > b->cap ? b->cap : b->cur_target;
     if (opened && par_fits(b, pw, lim)) {
       par_append(b, pw);
       for (int i = 0; i < pw->n; i++) total += 2304 * pw->nch[i];
@@ -3018,6 +3020,14 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
       n_windows++;
       if (bits_close_window(b) != PDMP3_OK) engine_ok = 0;
       t_fill += now_s() - t4;
+    } else if (opened) {
+      /* a private window that does not fit an EMPTY window of the engine (slots of a handful of frames: the window's pool has
+       * no room for the reservoir image a private window starts with): not a stream for the split scan -- the one-thread scan
+       * decodes it again from its first frame (PAR_GIVEN_UP), nothing is wrong with the engine */
+      pw_free(pw);
+      gave_up = 1;
+      pthread_mutex_lock(&P->mu); P->abort = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
+      break;
     } else { engine_ok = 0; pw_free(pw); }
     if (!engine_ok) { pthread_mutex_lock(&P->mu); P->abort = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu); break; }
   }
@@ -3030,7 +3040,8 @@ static long long par_drive(struct bulk* b, const unsigned char* mp3, size_t n, i
   const int fin = par_finish(P);
   const int ok = fin == 0 && end == 1 && engine_ok && frames == nf;
   atomic_fetch_sub(&g_par_active, 1);
-  if (!ok && tr) fprintf(stderr, "bulk trace: split scan given up: pre-pass verdict %d, end %d, engine %d, frames %lld of %lld, %d windows\n", fin, end, engine_ok, frames, nf, n_windows);
+  if (!ok && tr) fprintf(stderr, "bulk trace: split scan given up: pre-pass verdict %d, end %d, engine %d, frames %lld of %lld, %d windows%s\n", fin, end, engine_ok, frames, nf, n_windows,
+                         gave_up ? " (a private window larger than an empty window of the engine)" : "");
   if (!engine_ok) { b->failed = 1; return -1; }
   if (!ok) { b->par_given_up++; return PAR_GIVEN_UP; }
   b->par_taken++;
@@ -3401,12 +3412,17 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
       if (b->bits_mode && est0 > b->target && est0 + est0 / 16 <= b->cap) b->cur_target = b->cap;
     }
   }
-  /* The split scan pays where the scan is the bound: with the PCM left in device memory (13 -> 18 M frames/s).  Towards host
-   * memory the PCIe link bounds the pipeline and the extra threads only take memory bandwidth from the DMA engines
-   * (measured: pinned 10.4 -> 8.3 M frames/s, pageable 9.1 -> 7.9 M) -- there the one-thread scan stays, unless
-   * PDMP3_BULK_SCAN_THREADS asks for the split explicitly. */
-  if (b->bits_mode && b->pool_mode && !b->carry && b->scan_threads > 0 && (b->pcm_pinned == 2 || b->scan_forced)) {
-    total = par_drive(b, mp3, n, b->scan_threads);
+  /* The split scan: with the PCM left in device memory the scan is the bound without it (13 -> 18 M frames/s in round 4, 35 now).
+   * Towards host memory the link bounds the pipeline -- 12.7 ms for the hour's PCM at 50 GB/s -- but the ONE-thread scan takes
+   * 12.4 ms of its own beside it and loses to every disturbance (pinned 8.9-9.8 M frames/s, pageable 8.2-9.6 on one box): since
+   * round 5 host destinations take the split scan as well, with four scanners and the engine's windows closed at 4096 frames (a
+   * window's PCM leaves when the window is done): pinned 10.2-10.4, pageable 9.35-9.54, five interleaved runs.  (Round 4's split
+   * scan, with its pre-pass on the scanners' mutex and eight scanners, LOST there: pinned 10.4 -> 8.3.)
+   * (Decoders whose windows the caller made shorter than 1024 frames keep the one-thread scan for host destinations.)
+   * PDMP3_BULK_SCAN_THREADS=0: the one-thread scan everywhere. */
+  if (b->bits_mode && b->pool_mode && !b->carry && b->scan_threads > 0 && (b->pcm_pinned == 2 || b->scan_forced || b->target >= 1024)) {
+    /* (host destinations: four scanners at most -- the link bounds the pipeline there, the scan only has to stay off its path) */
+    total = par_drive(b, mp3, n, b->pcm_pinned == 2 || b->scan_forced || b->scan_threads < 4 ? b->scan_threads : 4);
     if (total == PAR_GIVEN_UP) {
       /* not a stream the split scan can take after all (something irregular further in): what has gone to the engine
        * is let through, then the stream is decoded again from its first frame by the one-thread scanner */

@@ -629,3 +629,30 @@ def test_merge_kernels_on_random_merge_input(emul, p_set, p_copy, p_mono, p_new)
             assert np.array_equal(st_out[:232], st_ref[:232]), n
     finally:
         eng.close()
+
+
+def test_device_destination_with_slots_of_a_few_frames():
+    """a decoder whose windows hold 1 or 3 frames and a device pointer as destination: the split scan is taken (the PCM stays on
+    the device) and finds that not even one of its private windows fits an empty window of the engine (a window's pool has no room
+    for the reservoir image a private window starts with) -- it gives the stream up, not the engine, and the one-thread scan decodes
+    it: same PCM as the default decoder's"""
+    import torch
+    from pdmp3_amd import api
+    mp3 = packer.generate(n_frames=60, seed=0xD7, sfreq=0, mode=1, mode_ext=2, bitrate_index=11)
+    ref = api.BulkDecoder(threads=2)
+    try:
+        want = ref.decode(mp3)
+    finally:
+        ref.close()
+    for window in (1, 3):
+        b = api.BulkDecoder(threads=2, window_frames=window)
+        try:
+            out = torch.zeros(want.size, dtype=torch.int16, device="cuda:0")
+            torch.cuda.synchronize()
+            b.decode_into_device(mp3, out)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want), window
+            taken, given = b.split_scans()
+            assert taken + given == 1, (window, taken, given)
+        finally:
+            b.close()
