@@ -3418,9 +3418,11 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
    * round 5 host destinations take the split scan as well, with four scanners and the engine's windows closed at 4096 frames (a
    * window's PCM leaves when the window is done): pinned 10.2-10.4, pageable 9.35-9.54, five interleaved runs.  (Round 4's split
    * scan, with its pre-pass on the scanners' mutex and eight scanners, LOST there: pinned 10.4 -> 8.3.)
-   * (Decoders whose windows the caller made shorter than 1024 frames keep the one-thread scan for host destinations.)
+   * (Decoders whose windows the caller made shorter than 1024 frames, and hosts with fewer than 12 usable CPUs -- two scanners by
+   * default: measured nowhere --, keep the one-thread scan for host destinations.)
    * PDMP3_BULK_SCAN_THREADS=0: the one-thread scan everywhere. */
-  if (b->bits_mode && b->pool_mode && !b->carry && b->scan_threads > 0 && (b->pcm_pinned == 2 || b->scan_forced || b->target >= 1024)) {
+  if (b->bits_mode && b->pool_mode && !b->carry && b->scan_threads > 0 &&
+      (b->pcm_pinned == 2 || b->scan_forced || (b->target >= 1024 && b->scan_threads >= 4))) {
     /* (host destinations: four scanners at most -- the link bounds the pipeline there, the scan only has to stay off its path) */
     total = par_drive(b, mp3, n, b->pcm_pinned == 2 || b->scan_forced || b->scan_threads < 4 ? b->scan_threads : 4);
     if (total == PAR_GIVEN_UP) {
