@@ -53,7 +53,7 @@ pdmp3_amd_bulk* pdmp3_amd_bulk_new(int threads, int window_frames);
  * thread puts into the engine's slots in stream order, results identical to the one-thread scan; by default 12 / 8 / 4 / 2 with
  * 32 / 16 / 12 / 6 usable CPUs when the PCM stays in device memory, where the scan is the bound, four of them at most for
  * destinations in host memory (there with the engine's windows closed at 4096 frames; decoders made with windows shorter than
- * 1024 frames keep the one-thread scan); given explicitly: that many for every destination and for streams from 4 private
+ * 1024 frames, and hosts with fewer than 12 usable CPUs, keep the one-thread scan); given explicitly: that many for every destination and for streams from 4 private
  * windows on instead of 12; 0: never; decoders of one process that scan
  * at the same time share: the second takes half the scanners, the third a third ...), PDMP3_BULK_PREPASS_THREADS=n (1 .. 8
  * parts of the pre-pass, all but the first with a thread of their own that hops from a guessed header; 6 / 3 / 1 by default
