@@ -70,26 +70,36 @@ int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding);
 #define PDMP3_ENC_FLOAT_32 0x200
 int pdmp3_amd_set_encoding(pdmp3_handle* id, int encoding);
 
-/* ISO-correct switches (NOT in the reference).  The reference departs from ISO 11172-3 in five places
- *  and this library reproduces them by default -- that is what "drop-in" means.  A bit set here selects
- * the standard's behaviour for that item instead, from the next frame parsed on:
+/* ISO-correct switches (NOT in the reference).  The reference departs from ISO 11172-3 in the places
+ * below (SURVEY H1-H5, and what an independent decoder showed on top of H3 in round 6) and this library reproduces them
+ * by default -- that is what "drop-in" means.  A bit set here selects the standard's behaviour for that item instead,
+ * from the next frame parsed on:
  *   PDMP3_ISO_TABLE33   H1  count1table_select = 1 decodes with the standard's table B (4-bit codes); the reference's
  *                           table index points into the middle of table 24 (pdmp3.c:569)
- *   PDMP3_ISO_MS_BOUND  H2  MS stereo up to the LARGER of the two channels' count1 (pdmp3.c:1920 stops at the smaller)
+ *   PDMP3_ISO_MS_BOUND  H2  MS stereo on EVERY line (pdmp3.c:1920 stops at the smaller of the two channels' count1 --
+ *                           and counts in reordered lines, so that in short blocks even "the larger count1" would
+ *                           leave coded lines unrotated)
  *   PDMP3_ISO_IS_SHORT  H3  intensity stereo on short blocks multiplies by the ratios, window by window
  *                           (pdmp3.c:2191 keeps them in `unsigned`, 2212-2213 assign the sample to both channels)
  *   PDMP3_ISO_SF21      H4  long scalefactor band 21 has scalefactor 0 (pdmp3.c:1896-1901 reads scalefac_l[21], the next
  *                           array's first element)
  *   PDMP3_ISO_SF12      H5  short scalefactor band 12 has scalefactor 0 (pdmp3.c:1864-1869 reads scalefac_s[12][w], for
  *                           granule 1 / channel 1 the bits of the previous granule's output)
- * Nothing in the reference defines these modes, so they are checked against the oracle's restatement of the same
- * switches only ("parity unpinned").  Returns PDMP3_ERR for unknown bits. */
+ *   PDMP3_ISO_IS_BOUND      the rest of the standard's intensity stereo (2.4.3.4.9.3): is_pos is the RIGHT channel's
+ *                           scalefactor (pdmp3.c:2163, 2200 read the left one's), the intensity region starts above the
+ *                           right channel's last non-zero line -- per window in short blocks -- (pdmp3.c:1946-1965: above
+ *                           its count1), the last band takes the position of the band below it (pdmp3.c:1953, 1961 leave
+ *                           it out), intensity-coded lines are not M/S-rotated.  Implies PDMP3_ISO_IS_SHORT's arithmetic.
+ * Nothing in the reference defines these modes.  Since round 6 they are PINNED by an independent ISO decoder: FFmpeg's
+ * mpegaudiodec decodes the packer's conforming streams to within 2 LSB of PDMP3_ISO_ALL (tests/golden/iso_*.npz,
+ * tools/make_iso_golden.py).  Returns PDMP3_ERR for unknown bits. */
 #define PDMP3_ISO_TABLE33  0x01u
 #define PDMP3_ISO_MS_BOUND 0x02u
 #define PDMP3_ISO_IS_SHORT 0x04u
 #define PDMP3_ISO_SF21     0x08u
 #define PDMP3_ISO_SF12     0x10u
-#define PDMP3_ISO_ALL      0x1fu
+#define PDMP3_ISO_IS_BOUND 0x20u
+#define PDMP3_ISO_ALL      0x3fu
 int pdmp3_amd_set_quirks(pdmp3_handle* id, unsigned iso_mask);
 
 /* CLI driver: NULL-terminated list of .mp3 paths ("-" = stdin); writes

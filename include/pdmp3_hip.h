@@ -84,15 +84,24 @@ typedef struct pdmp3_gc_side {
 
 /* pdmp3_gc_side.iso (identical in all gc records of one frame) -- SURVEY 8f #4, "ISO-correct switches".  The reference
  * departs from ISO 11172-3 in five places; by default this engine reproduces them bit for bit.  A caller
- * that wants the standard's behaviour sets these bits (include/pdmp3.h: pdmp3_amd_set_quirks does it for a handle).  Two
- * of the five live in the transforms and travel in the record; the other three (H1 the count1 table, H4 / H5 the
+ * that wants the standard's behaviour sets these bits (include/pdmp3.h: pdmp3_amd_set_quirks does it for a handle).  Three
+ * of the six live in the transforms and travel in the record; the other three (H1 the count1 table, H4 / H5 the
  * one-past-the-end scalefactors) are decided where the records are built: a record with scalefac_l[21] = 0 and
- * scalefac_s[12][w] = 0 IS the standard's.  NOTHING in the reference pins these modes: parity is against the oracle's
- * restatement of the same switches ("unpinned"). */
-#define PDMP3_GC_ISO_MS_ALL    0x01u  /* H2: MS stereo on every line below the LARGER count1 (P:1920 stops at the smaller) */
+ * scalefac_s[12][w] = 0 IS the standard's.  Nothing in the reference pins these modes; since round 6 an independent ISO
+ * decoder does (FFmpeg, through tests/golden/iso_*.npz: DESIGN.md section 4). */
+#define PDMP3_GC_ISO_MS_ALL    0x01u  /* H2: MS stereo on every line (P:1920 stops at the smaller count1, counted in reordered
+                                         lines; until round 5 this bit meant "below the larger count1", which in short blocks
+                                         leaves coded lines of the last band unrotated) */
 #define PDMP3_GC_ISO_IS_SHORT  0x02u  /* H3: intensity stereo on short blocks multiplies by the ratios of the line's own
                                          window (P:2191 holds them in `unsigned`, P:2212-2213 assign instead of multiply,
                                          P:2203 takes the window from the un-reordered position) */
+#define PDMP3_GC_ISO_IS_STD    0x04u  /* round 6, found with an independent ISO decoder (FFmpeg): the whole
+                                         of the standard's intensity stereo -- is_pos from the RIGHT channel's scalefactors
+                                         (P:2163 / P:2200 read the left one's), the intensity region bounded by the right
+                                         channel's last non-zero line, per window in short blocks (P:1946-1965 use its count1),
+                                         the last band (long 21, short 12) with the position of the band below (P:1961 / P:1953
+                                         leave it out), the block shape from the right channel, no M/S rotation of intensity-coded
+                                         lines.  Implies the arithmetic of PDMP3_GC_ISO_IS_SHORT */
 
 #define PDMP3_GC_LINES          576
 #define PDMP3_FRAME_GCS         4                 /* [gr][ch] = 2 x 2                */
@@ -316,8 +325,8 @@ typedef struct pdmp3_frame_bits {
   uint8_t  scfsi[2];                        /* [ch]: bit b = band group b reuses granule 0, P:73 */
   uint8_t  iso;                             /* PDMP3_ISO_* of include/pdmp3.h for this frame (0 = the reference's behaviour):
                                                TABLE33 selects the code book, SF21 / SF12 keep the one-past-the-end
-                                               scalefactor slots of the records zero, MS_BOUND / IS_SHORT become the
-                                               records' PDMP3_GC_ISO_* bits */
+                                               scalefactor slots of the records zero, MS_BOUND / IS_SHORT / IS_BOUND
+                                               become the records' PDMP3_GC_ISO_* bits */
   uint8_t  reserved[12];
   pdmp3_gc_bits gc[4];                      /* [gr][ch] */
 } pdmp3_frame_bits;                         /* 80 bytes */

@@ -40,6 +40,17 @@ typedef struct pk_cfg {
   int fill_pct;         /* how much of the available bits to use, e.g. 90 */
   int big_pct;          /* chance (per 1000) that a big_values pair uses the linbits range */
   int gain_lo, gain_hi; /* global_gain range */
+  /* round 6 (0 = the streams of rounds 1-5, bit for bit) */
+  int iso_strict;       /* 1: only what EVERY conforming decoder reads the same way -- no region index past band 22
+                           (reference H7), scfsi = 0 for a channel with a short-block granule (ISO 11172-3 2.4.2.7),
+                           both channels of a joint-stereo granule share the block shape, the window sequence is
+                           long -> start -> short ... -> stop -> long per channel: the streams of the
+                           fixtures made with an independent ISO decoder (tools/make_iso_golden.py) */
+  int is_cut_pct;       /* chance (per 100) that the right channel of a granule codes no line at or above a random
+                           bound: the bands above it are what intensity stereo acts on */
+  int narrow_scales;    /* 1: scalefactors <= 7, subblock_gain <= 2 -- a coded line is never more than 2^-11 below its
+                           global gain.  (The fixtures' other decoder is FFmpeg's FIXED-point one: lines it flushes
+                           to zero move its intensity-stereo bound, which the standard defines on the coded integers) */
 } pk_cfg;
 
 /* Writes n_frames frames into out (capacity cap bytes; n_frames * 1500 + 4096 always suffices) and returns the

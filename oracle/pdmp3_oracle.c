@@ -51,6 +51,7 @@ static inline unsigned sfb_s(unsigned sfreq, unsigned i) { return ot_sfb[sfreq *
  * place through all stages, plus unpacked side info. */
 typedef struct frame_ws {
   float is[2][2][576];
+  int16_t q[2][2][576];         /* the coded integers as they came (before P:1829 / P:1786): stage_stereo_std's zero test */
   unsigned count1[2][2], global_gain[2][2], scalefac_scale[2][2], preflag[2][2];
   unsigned wsf[2][2], block_type[2][2], mixed[2][2], subblock_gain[2][2][3];
   uint32_t sf_l[2][2][22];      /* value as the reference would read it */
@@ -226,13 +227,90 @@ static void intensity_short(frame_ws* w, unsigned gr, unsigned sfb) {
   }
 }
 
+/* NOT the reference: joint stereo with intensity positions as ISO 11172-3 2.4.3.4.9.3 has them (PDMP3_GC_ISO_IS_STD;
+ * pinned against FFmpeg's mpegaudiodec through tests/golden/iso_*.npz, tools/make_iso_golden.py).  Where the reference
+ * departs (beyond SURVEY H3): it takes is_pos from the LEFT channel's scalefactors (P:2163, P:2200), bounds the
+ * intensity region by count1 of the right channel (P:1946-1965) instead of by its last non-zero line -- per window in
+ * short blocks --, leaves the last band (long 21 / short 12) out (P:1961, P:1953) where the standard gives it the
+ * position of the band below, and rotates M/S over lines that are intensity coded.  Lines are in reordered order here
+ * (P:1786 ran): in a short band starting at line a, line a + 3 j + win belongs to window win. */
+static void stage_stereo_std(frame_ws* w, unsigned gr) {
+  const unsigned sfreq = w->sfreq;
+  const int shortb = (w->wsf[gr][1] == 1 && w->block_type[gr][1] == 2), mixed = shortb && w->mixed[gr][1] != 0;
+  uint8_t is_pos_of[576];                                  /* 7 = not intensity coded */
+  memset(is_pos_of, 7, sizeof is_pos_of);
+  if (w->mode_ext & 0x1) {
+    /* "zero" is said of the CODED value (2.4.3.4.9.3), so the test reads the integers, which are in bitstream order:
+     * short band sfb, window win = lines 3 s[sfb] + win len .. + len */
+    const int16_t* q = w->q[gr][1];
+    int any_short = 0;
+    if (shortb) {
+      const unsigned first = mixed ? 3 : 0;
+      for (unsigned win = 0; win < 3; win++) {
+        int last = -1;                                     /* last band of this window with a non-zero line */
+        for (unsigned sfb = first; sfb < 13; sfb++) {
+          const unsigned a = 3 * sfb_s(sfreq, sfb), len = sfb_s(sfreq, sfb + 1) - sfb_s(sfreq, sfb);
+          for (unsigned j = 0; j < len; j++) if (q[a + win * len + j] != 0) last = (int)sfb;
+        }
+        if (last >= 0) any_short = 1;
+        for (unsigned sfb = first; sfb < 13; sfb++) {
+          const unsigned a = 3 * sfb_s(sfreq, sfb), len = sfb_s(sfreq, sfb + 1) - sfb_s(sfreq, sfb);
+          if ((int)sfb <= last) continue;                  /* a non-zero line in this band or above: not intensity */
+          const unsigned pos = w->sf_s[gr][1][sfb < 12 ? sfb : 11][win];
+          if (pos >= 7) continue;
+          for (unsigned j = 0; j < len; j++) is_pos_of[a + 3 * j + win] = (uint8_t)pos;      /* reordered position */
+        }
+      }
+    }
+    if (!shortb || (mixed && !any_short)) {
+      const unsigned nb = shortb ? 8 : 22, top = shortb ? 36 : 576;
+      int last = -1;
+      for (unsigned i = 0; i < top; i++) if (q[i] != 0) last = (int)i;
+      for (unsigned sfb = 0; sfb < nb; sfb++) {
+        const unsigned a = sfb_l(sfreq, sfb), b = sfb < 21 ? sfb_l(sfreq, sfb + 1) : 576;
+        if ((int)a <= last) continue;
+        const unsigned pos = w->sf_l[gr][1][sfb < 21 ? sfb : 20];
+        if (pos >= 7) continue;
+        for (unsigned i = a; i < b; i++) is_pos_of[i] = (uint8_t)pos;
+      }
+    }
+  }
+  if (w->mode_ext & 0x2) {
+    unsigned c0 = w->count1[gr][0], c1 = w->count1[gr][1];
+    unsigned max_pos = (c0 > c1) ? c1 : c0;
+    if (w->iso & PDMP3_GC_ISO_MS_ALL) max_pos = 576;
+    for (unsigned i = 0; i < max_pos; i++) {
+      if (is_pos_of[i] != 7) continue;
+      float left = (w->is[gr][0][i] + w->is[gr][1][i]) * (O_INV_SQRT_2);
+      float right = (w->is[gr][0][i] - w->is[gr][1][i]) * (O_INV_SQRT_2);
+      w->is[gr][0][i] = left;
+      w->is[gr][1][i] = right;
+    }
+  }
+  for (unsigned i = 0; i < 576; i++) {
+    const unsigned pos = is_pos_of[i];
+    if (pos == 7) continue;
+    float rl, rr;
+    if (pos == 6) { rl = 1.0f; rr = 0.0f; }
+    else { float t = ot_is_ratios[pos]; rl = t / (1.0f + t); rr = 1.0f / (1.0f + t); }
+    float left = rl * w->is[gr][0][i];
+    float right = rr * w->is[gr][0][i];
+    w->is[gr][0][i] = left;
+    w->is[gr][1][i] = right;
+  }
+}
+
 /* P:1911-1972 L3_Stereo */
 static void stage_stereo(frame_ws* w, unsigned gr) {
   if (w->mode != 1 || w->mode_ext == 0) return;
+  if ((w->iso & PDMP3_GC_ISO_IS_STD) && (w->mode_ext & 0x1)) { stage_stereo_std(w, gr); return; }
   if (w->mode_ext & 0x2) {
     unsigned c0 = w->count1[gr][0], c1 = w->count1[gr][1];
     unsigned max_pos = (c0 > c1) ? c1 : c0;            /* P:1920 picks the smaller (H2) */
-    if (w->iso & PDMP3_GC_ISO_MS_ALL) max_pos = (c0 > c1) ? c0 : c1;   /* the standard's (unpinned) */
+    /* the standard's: every line.  (Lines at and above the larger count1 are zero in both channels before the reorder,
+     * but P:1786 ran: in a short band that count1 cuts through, lines of the coded windows sit ABOVE count1 in reordered
+     * order -- "up to the larger count1", rounds 4-5, left those unrotated; found against FFmpeg in round 6) */
+    if (w->iso & PDMP3_GC_ISO_MS_ALL) max_pos = 576;
     for (unsigned i = 0; i < max_pos; i++) {
       float left = (w->is[gr][0][i] + w->is[gr][1][i]) * (O_INV_SQRT_2);
       float right = (w->is[gr][0][i] - w->is[gr][1][i]) * (O_INV_SQRT_2);
@@ -375,7 +453,7 @@ static void unpack_frame(frame_ws* w, const int16_t* spectra, const pdmp3_gc_sid
     for (unsigned ch = 0; ch < 2; ch++) {
       const pdmp3_gc_side* s = &side[gr * 2 + ch];
       const int16_t* sp = spectra + (gr * 2 + ch) * 576;
-      for (unsigned i = 0; i < 576; i++) w->is[gr][ch][i] = (float)sp[i];
+      for (unsigned i = 0; i < 576; i++) { w->is[gr][ch][i] = (float)sp[i]; w->q[gr][ch][i] = sp[i]; }
       w->count1[gr][ch] = s->count1;
       w->global_gain[gr][ch] = s->global_gain;
       w->scalefac_scale[gr][ch] = (s->flags & PDMP3_GC_SCALEFAC_SCALE) ? 1 : 0;

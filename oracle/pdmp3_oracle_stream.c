@@ -54,7 +54,8 @@ struct orc_stream {
 #define ORC_ISO_IS_SHORT 0x04u
 #define ORC_ISO_SF21 0x08u
 #define ORC_ISO_SF12 0x10u
-void orc_stream_set_quirks(orc_stream* s, unsigned iso_mask) { s->iso = iso_mask & 0x1fu; }
+#define ORC_ISO_IS_BOUND 0x20u
+void orc_stream_set_quirks(orc_stream* s, unsigned iso_mask) { s->iso = iso_mask & 0x3fu; }
 
 orc_stream* orc_stream_new(void) { return (orc_stream*)calloc(1, sizeof(orc_stream)); }
 void orc_stream_delete(orc_stream* s) { free(s); }
@@ -440,7 +441,8 @@ static void frame_to_records(const orc_stream* s, int16_t* spectra, pdmp3_gc_sid
       if (s->iso & ORC_ISO_SF12) for (unsigned w = 0; w < 3; w++) r->scalefac_s[12][w] = 0;
     }
   for (unsigned g = 0; g < 4; g++)
-    sd[g].iso = (uint8_t)(((s->iso & ORC_ISO_MS_BOUND) ? PDMP3_GC_ISO_MS_ALL : 0) | ((s->iso & ORC_ISO_IS_SHORT) ? PDMP3_GC_ISO_IS_SHORT : 0));
+    sd[g].iso = (uint8_t)(((s->iso & ORC_ISO_MS_BOUND) ? PDMP3_GC_ISO_MS_ALL : 0) | ((s->iso & ORC_ISO_IS_SHORT) ? PDMP3_GC_ISO_IS_SHORT : 0) |
+                        ((s->iso & ORC_ISO_IS_BOUND) ? PDMP3_GC_ISO_IS_STD : 0));
 }
 
 /* P:1024 Decode_L3 for the frame just parsed, via the record boundary */

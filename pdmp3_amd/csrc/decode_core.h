@@ -559,7 +559,7 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
   const bool joint = (g.nch == 2) && (g.mode == 1) && (g.mode_ext != 0);
   const bool ms = joint && (g.mode_ext & 2);
   const bool is = joint && (g.mode_ext & 1);
-  const int cmin = ((g.count1_0 > g.count1_1) != ((g.iso & PDMP3_GC_ISO_MS_ALL) != 0)) ? g.count1_1 : g.count1_0;   // P:1920 (H2): the smaller; ISO switch: the larger
+  const int cmin = (g.iso & PDMP3_GC_ISO_MS_ALL) ? 576 : (g.count1_0 > g.count1_1 ? g.count1_1 : g.count1_0);   // P:1920 (H2): the smaller; ISO switch: every line
   const int kind0 = g.kind(0), kind1 = g.kind(1);
   if (FAST && !DUMP && NI == 9) {
     if (kind0 == 0 && (g.nch == 1 || kind1 == 0) && !is) {     // wave-uniform
@@ -619,17 +619,75 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
       if (g.nch == 2) dump0[4 * 576 + PD_LINE(i)] = x1[i];
     }
   }
+  // PDMP3_GC_ISO_IS_STD (NOT the reference; pinned against FFmpeg): the standard's intensity stereo.
+  // ispos[i] = the intensity position of the lane's line i, 7 = not intensity coded.  A band (of a window, in short
+  // blocks) is intensity coded when the RIGHT channel holds no non-zero value in it or above it and the right channel's
+  // scalefactor there -- the last band borrows the one below -- is not 7; the block shape is the right channel's.
+  const bool is_std = is && (g.iso & PDMP3_GC_ISO_IS_STD);
+  int ispos[NI];
+  PD_UNROLL for (int i = 0; i < NI; i++) ispos[i] = 7;
+  if (is_std) {
+    const uint8_t* sd1 = L.side[1];
+    // the last band with a non-zero line: of the long part, and of each window of the short part (as floats: PD_SHFL_XOR)
+    float lastl = -1.0f, last0 = -1.0f, last1 = -1.0f, last2 = -1.0f;
+    PD_NOUNROLL for (int i = 0; i < 9; i++) {        // (all 576 lines, also for the peek-only granule, NI = 1)
+      const int d = lane + 64 * i;
+      const unsigned e = tg ? gtab[kind1 * 576 + d] : S.ltab[kind1][d];
+      const int idx = (int)(e >> 10);
+      if (L.spec[1][e & 1023] != 0) {
+        const float b = (float)(idx < 22 ? idx : (idx - 22) / 3);
+        const int w = idx < 22 ? -1 : (idx - 22) % 3;
+        lastl = (w < 0 && b > lastl) ? b : lastl;
+        last0 = (w == 0 && b > last0) ? b : last0;
+        last1 = (w == 1 && b > last1) ? b : last1;
+        last2 = (w == 2 && b > last2) ? b : last2;
+      }
+    }
+    PD_NOUNROLL for (int m = 1; m < 64; m <<= 1) {
+      const float ol = PD_SHFL_XOR(lastl, m), o0 = PD_SHFL_XOR(last0, m), o1 = PD_SHFL_XOR(last1, m), o2 = PD_SHFL_XOR(last2, m);
+      lastl = ol > lastl ? ol : lastl;
+      last0 = o0 > last0 ? o0 : last0;
+      last1 = o1 > last1 ? o1 : last1;
+      last2 = o2 > last2 ? o2 : last2;
+    }
+    const bool any_short = last0 >= 0.0f || last1 >= 0.0f || last2 >= 0.0f;
+    PD_UNROLL for (int i = 0; i < NI; i++) {
+      const int d = PD_LINE(i);
+      const unsigned e = tg ? gtab[kind1 * 576 + d] : S.ltab[kind1][d];
+      const int idx = (int)(e >> 10);
+      bool coded;
+      int pos;
+      if (idx < 22) {
+        coded = !any_short && (float)idx > lastl;
+        pos = sd1[8 + (idx < 21 ? idx : 20)];
+      } else {
+        const int b = (idx - 22) / 3, w = (idx - 22) % 3;
+        const float lw = w == 0 ? last0 : (w == 1 ? last1 : last2);
+        coded = (float)b > lw;
+        pos = sd1[30 + (b < 12 ? b : 11) * 3 + w];
+      }
+      ispos[i] = (coded && pos < 7) ? pos : 7;
+    }
+  }
   if (ms) {   // P:1921-1928
     PD_UNROLL for (int i = 0; i < NI; i++) {
       const float sum = x0[i] + x1[i], dif = x0[i] - x1[i];
       const float l = (float)((double)sum * 0.70710678118654752440);
       const float r = (float)((double)dif * 0.70710678118654752440);
-      const bool in = PD_LINE(i) < cmin;
+      const bool in = PD_LINE(i) < cmin && ispos[i] == 7;
       x0[i] = in ? l : x0[i];
       x1[i] = in ? r : x1[i];
     }
   }
-  if (is) {   // P:1932-1971; block shape taken from channel 0.  Rare (no common encoder emits it).
+  if (is_std) {
+    PD_UNROLL for (int i = 0; i < NI; i++) {
+      const float l = cb->isr_l[ispos[i] & 7] * x0[i];
+      const float r = cb->isr_r[ispos[i] & 7] * x0[i];
+      x1[i] = ispos[i] != 7 ? r : x1[i];
+      x0[i] = ispos[i] != 7 ? l : x0[i];
+    }
+  }
+  if (is && !is_std) {   // P:1932-1971; block shape taken from channel 0.  Rare (no common encoder emits it).
     const uint8_t* sd0 = L.side[0];
     const int c1 = g.count1_1;
     PD_NOUNROLL for (int i = 0; i < NI; i++) {
@@ -723,7 +781,7 @@ template <bool TG, bool SCALES>
 PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalTables& T, const GranuleInfo& g) {
   const bool two = g.nch == 2;
   const bool ms = two && (g.mode == 1) && (g.mode_ext & 2);
-  const int cmin = ((g.count1_0 > g.count1_1) != ((g.iso & PDMP3_GC_ISO_MS_ALL) != 0)) ? g.count1_1 : g.count1_0;   // P:1920 (H2): the smaller; ISO switch: the larger
+  const int cmin = (g.iso & PDMP3_GC_ISO_MS_ALL) ? 576 : (g.count1_0 > g.count1_1 ? g.count1_1 : g.count1_0);   // P:1920 (H2): the smaller; ISO switch: every line
   const uint32_t* sp0 = reinterpret_cast<const uint32_t*>(&L.spec[0][0]);
   const uint32_t* sp1 = reinterpret_cast<const uint32_t*>(&L.spec[1][0]);
   const char* sc0 = reinterpret_cast<const char*>(&L.scale[0][0]);

@@ -482,7 +482,8 @@ PD_HD void side_fields(const pdmp3_frame_bits& F, int g, pdmp3_gc_side* rec) {
   const int nch = ((F.frame & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 ? 1 : 2;
   rec->frame = F.frame & (uint8_t)~PDMP3_FR_NEWSTREAM;
   // the ISO switches of the frame (include/pdmp3.h PDMP3_ISO_*: MS_BOUND = 2, IS_SHORT = 4) as the records' PDMP3_GC_ISO_* bits
-  rec->iso = (uint8_t)(((F.iso & 0x02u) ? PDMP3_GC_ISO_MS_ALL : 0u) | ((F.iso & 0x04u) ? PDMP3_GC_ISO_IS_SHORT : 0u));
+  rec->iso = (uint8_t)(((F.iso & 0x02u) ? PDMP3_GC_ISO_MS_ALL : 0u) | ((F.iso & 0x04u) ? PDMP3_GC_ISO_IS_SHORT : 0u) |
+                       ((F.iso & 0x20u) ? PDMP3_GC_ISO_IS_STD : 0u));
   if (ch >= nch) return;
   const pdmp3_gc_bits& s = F.gc[g];
   rec->global_gain = s.global_gain;

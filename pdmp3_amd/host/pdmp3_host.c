@@ -823,7 +823,8 @@ static void emit_records(pdmp3_handle* id, const frame_header* H, const side_inf
     const unsigned gr = g >> 1, ch = g & 1;
     pdmp3_gc_side* r = &sd[g];
     r->frame = fr;
-    r->iso = (uint8_t)(((id->iso & PDMP3_ISO_MS_BOUND) ? PDMP3_GC_ISO_MS_ALL : 0) | ((id->iso & PDMP3_ISO_IS_SHORT) ? PDMP3_GC_ISO_IS_SHORT : 0));
+    r->iso = (uint8_t)(((id->iso & PDMP3_ISO_MS_BOUND) ? PDMP3_GC_ISO_MS_ALL : 0) | ((id->iso & PDMP3_ISO_IS_SHORT) ? PDMP3_GC_ISO_IS_SHORT : 0) |
+                       ((id->iso & PDMP3_ISO_IS_BOUND) ? PDMP3_GC_ISO_IS_STD : 0));
     if (ch >= nch) { memset(spectra + g * 576, 0, 576 * sizeof(int16_t)); continue; }
     r->count1 = id->count1[gr][ch];
     r->global_gain = (uint8_t)S->global_gain[gr][ch];

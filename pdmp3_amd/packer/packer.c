@@ -69,20 +69,29 @@ static const uint16_t* sfb_l_of(int f) { return f == 0 ? kSfbLong0 : f == 1 ? kS
 
 /* writes one granule-channel's main data (scalefactors + Huffman) into `w`,
  * using at most `budget` bits; fills the side-info fields it decides */
-static void gen_gc(const pk_cfg* c, bw* w, gc_side* s, unsigned budget, int gr, const unsigned scfsi[4], unsigned* used) {
-  const size_t start = w->bits;
-  memset(s, 0, sizeof *s);
+static unsigned draw_block_type(const pk_cfg* c) {
   unsigned pct = rndn(100), bt = 0, acc = 0;
   for (int k = 0; k < 4; k++) { acc += (unsigned)c->block_pct[k]; if (pct < acc) { bt = (unsigned)k; break; } }
+  return bt;
+}
+
+/* pre_bt < 0: the block type is drawn here (the streams of rounds 1-5, bit for bit); otherwise it was drawn by the
+ * caller (iso_strict: scfsi depends on both granules' types; pre_mixed >= 0 likewise).  line_cap: no line at or above it is coded (the right
+ * channel of an intensity-stereo granule: is_cut_pct). */
+static void gen_gc(const pk_cfg* c, bw* w, gc_side* s, unsigned budget, int gr, const unsigned scfsi[4], unsigned* used,
+                   int pre_bt, int pre_mixed, unsigned line_cap) {
+  const size_t start = w->bits;
+  memset(s, 0, sizeof *s);
+  const unsigned bt = pre_bt < 0 ? draw_block_type(c) : (unsigned)pre_bt;
   s->win_switch = bt != 0;
   s->block_type = bt;
-  s->mixed = (bt == 2 && (int)rndn(100) < c->mixed_pct);
+  s->mixed = pre_mixed >= 0 ? (unsigned)(bt == 2 && pre_mixed) : (unsigned)(bt == 2 && (int)rndn(100) < c->mixed_pct);
   s->global_gain = (unsigned)c->gain_lo + rndn((unsigned)(c->gain_hi - c->gain_lo + 1));
-  s->scalefac_compress = rndn(16);
+  s->scalefac_compress = rndn(c->narrow_scales ? 14 : 16);     /* narrow: scalefactors <= 7 (slen <= 3) */
   s->preflag = rndn(2);
   s->scalefac_scale = rndn(2);
   s->count1table = ((int)rndn(100) < c->table33_pct) ? 1 : 0;
-  for (int k = 0; k < 3; k++) s->subblock_gain[k] = rndn(8);
+  for (int k = 0; k < 3; k++) s->subblock_gain[k] = rndn(c->narrow_scales ? 3 : 8);
   if (budget < 160) {            /* nothing fits: an empty granule (part2_3_length = 0) */
     s->part2_3_length = 0;
     s->big_values = 0;
@@ -112,7 +121,7 @@ static void gen_gc(const pk_cfg* c, bw* w, gc_side* s, unsigned budget, int gr, 
   } else {
     s->region0 = rndn(14);                         /* region0 + region1 + 2 <= 22 */
     s->region1 = rndn(8);
-    if (rndn(50) == 0) { s->region0 = 15; s->region1 = 6 + rndn(2); }   /* indices 23/24: reference H7 */
+    if (!c->iso_strict && rndn(50) == 0) { s->region0 = 15; s->region1 = 6 + rndn(2); }   /* indices 23/24: reference H7 */
     for (int k = 0; k < 3; k++) s->table_select[k] = rndn(32);
   }
   for (int k = 0; k < 3; k++) if (s->table_select[k] == 4 || s->table_select[k] == 14) s->table_select[k] = rndn(2) ? 0 : 15;
@@ -129,7 +138,7 @@ static void gen_gc(const pk_cfg* c, bw* w, gc_side* s, unsigned budget, int gr, 
   const unsigned want_big = rndn(289);            /* <= 288 (reference H8) */
   unsigned nbig = 0, pos = 0;
   const unsigned soft = (unsigned)((uint64_t)budget * (60 + rndn(41)) / 100);   /* leave room for count1 */
-  while (nbig < want_big && pos + 2 <= 576) {
+  while (nbig < want_big && pos + 2 <= line_cap) {
     const unsigned tn = pos < r1 ? s->table_select[0] : pos < r2 ? s->table_select[1] : s->table_select[2];
     const int book = kHuffBookOfTable[tn];
     unsigned need = 0;
@@ -159,7 +168,7 @@ static void gen_gc(const pk_cfg* c, bw* w, gc_side* s, unsigned budget, int gr, 
   /* count1 quads with the ISO code books (table 32 = book 15, table 33 = ISO book) */
   const int qbook = s->count1table ? PDMP3_HUFF_BOOK_ISO33 : kHuffBookOfTable[32];
   const unsigned want_q = rndn((576 - pos) / 4 + 1);
-  for (unsigned q = 0; q < want_q && pos + 4 <= 576; q++) {
+  for (unsigned q = 0; q < want_q && pos + 4 <= line_cap; q++) {
     const unsigned val = rndn(16);
     unsigned nz = 0;
     for (int k = 0; k < 4; k++) nz += (val >> k) & 1;
@@ -170,7 +179,10 @@ static void gen_gc(const pk_cfg* c, bw* w, gc_side* s, unsigned budget, int gr, 
     pos += 4;
   }
   /* a few stuffing bits now and then (the decoder jumps to part2_3 end, P:2113) */
-  if (rndn(4) == 0) { unsigned st = rndn(24); if ((w->bits - start) + st <= budget) bw_put(w, rndn(1u << 12), st > 12 ? 12 : st); }
+  /* (not under iso_strict: what follows the last code word inside part2_3_length is read as more quads by every decoder,
+   *  and whether a LAST quad that overruns the part is kept differs -- P:2104 drops it, FFmpeg keeps it when it ends at
+   *  line 576) */
+  if (!c->iso_strict && rndn(4) == 0) { unsigned st = rndn(24); if ((w->bits - start) + st <= budget) bw_put(w, rndn(1u << 12), st > 12 ? 12 : st); }
   s->part2_3_length = (unsigned)(w->bits - start);
   if (s->part2_3_length > 4095) s->part2_3_length = 4095;
   *used = s->part2_3_length;
@@ -192,6 +204,7 @@ size_t pk_generate(const pk_cfg* c, int n_frames, uint8_t* out, size_t cap) {
   bw w = {md, md_cap, 0};
   size_t area_start = 0;            /* bytes: sum of main-data sizes of earlier frames */
   unsigned pad_rest = 0;
+  int prev_bt[2] = {0, 0}, run_mixed[2] = {0, 0};   /* iso_strict: the previous granule's block type per channel, the run's mixed flag */
   for (int f = 0; f < n_frames; f++) {
     unsigned bri = (unsigned)c->bitrate_index;
     if (c->vbr) bri = (unsigned)c->vbr_lo + rndn((unsigned)(c->vbr_hi - c->vbr_lo + 1));
@@ -218,12 +231,39 @@ size_t pk_generate(const pk_cfg* c, int n_frames, uint8_t* out, size_t cap) {
     gc_side gs[2][2];
     unsigned scfsi[2][4];
     for (int ch = 0; ch < nch; ch++) for (int b = 0; b < 4; b++) scfsi[ch][b] = rndn(2);
+    int pre_bt[2][2] = {{-1, -1}, {-1, -1}}, pre_mixed[2][2] = {{-1, -1}, {-1, -1}};
+    if (c->iso_strict) {
+      /* ISO 11172-3 2.4.2.7: scfsi is 0 when a granule of the channel has block_type 2 (decoders disagree about
+       * what a copy from a short-block granule means); intensity stereo: both channels share the block shape */
+      for (int gr = 0; gr < 2; gr++) {
+        /* ... and the window sequence is the standard's (2.4.3.4.10.3: long -> start -> short ... -> stop -> long):
+         * decoders may rely on it (FFmpeg's short-block overlap assumes the six zero samples a start window ends with) */
+        for (int ch = 0; ch < nch; ch++) {
+          const int in_short = prev_bt[ch] == 1 || prev_bt[ch] == 2;
+          const unsigned p = rndn(100);
+          if (!in_short) pre_bt[gr][ch] = p < (unsigned)(c->block_pct[1] + c->block_pct[2]) ? 1 : 0;
+          else pre_bt[gr][ch] = p < (unsigned)(c->block_pct[0] + c->block_pct[3]) ? 3 : 2;
+          /* one mixed_block_flag per run of short blocks: a mixed granule leaves a long window's tail in subbands
+           * 0-1, which a pure short granule behind it would have to add under its first two windows */
+          if (pre_bt[gr][ch] == 1) run_mixed[ch] = (int)rndn(100) < c->mixed_pct;
+          pre_mixed[gr][ch] = run_mixed[ch];
+        }
+        /* joint stereo: one window shape for both channels (the reference rotates M/S after its reorder, the
+         * standard before: they pair different lines when the shapes differ; encoders never let them) */
+        if (nch == 2 && c->mode == 1 && c->mode_ext) { pre_bt[gr][1] = pre_bt[gr][0]; pre_mixed[gr][1] = pre_mixed[gr][0]; run_mixed[1] = run_mixed[0]; }
+        for (int ch = 0; ch < nch; ch++) prev_bt[ch] = pre_bt[gr][ch];
+      }
+      for (int ch = 0; ch < nch; ch++)
+        if (pre_bt[0][ch] == 2 || pre_bt[1][ch] == 2) for (int b = 0; b < 4; b++) scfsi[ch][b] = 0;
+    }
     unsigned left = avail;
     for (int gr = 0; gr < 2; gr++)
       for (int ch = 0; ch < nch; ch++) {
         const unsigned share = left / (unsigned)((2 - gr) * nch - ch);
         unsigned budget = share > 4095 ? 4095 : share, used = 0;
-        gen_gc(c, &w, &gs[gr][ch], budget, gr, scfsi[ch], &used);
+        unsigned line_cap = 576;
+        if (ch == 1 && c->is_cut_pct > 0 && (int)rndn(100) < c->is_cut_pct) line_cap = 2 * rndn(240);
+        gen_gc(c, &w, &gs[gr][ch], budget, gr, scfsi[ch], &used, pre_bt[gr][ch], pre_mixed[gr][ch], line_cap);
         left -= used;
       }
     /* side info */

@@ -115,16 +115,26 @@ FS_GAIN_OF = {"ms_loud_clip": (122, 134)}         # big_prob 0.02: more linbits-
 CASES_FS = {name + "_fs": dict(kw, gain_range=FS_GAIN_OF.get(name, FS_GAIN)) for name, kw in CASES.items()}
 ALL_CASES = dict(CASES, **CASES_FS)
 
-# The ISO-correct switches (include/pdmp3_hip.h PDMP3_GC_ISO_*: 1 = MS up to the larger count1, 2 = intensity
-# stereo on short blocks by the standard) as record corpora.  UNPINNED: the reference has no such mode, the oracle's
-# restatement of the same switches is all there is to compare with -- no golden fixtures.
+# The ISO-correct switches (include/pdmp3_hip.h PDMP3_GC_ISO_*: 1 = MS on every line, 2 = intensity stereo on
+# short blocks multiplies by the ratios, 4 = the rest of the standard's intensity stereo) as record corpora: the kernels
+# against the oracle's restatement of the same switches.  What pins that restatement is not here: FFmpeg's decode of
+# conforming packer streams, tests/golden/iso_*.npz (tests/test_iso_pin.py).
 ISO_CASES = {
     "iso_ms_all_441": dict(CASES["ms_mixed_blocks_441"], iso=1, gain_range=FS_GAIN),
     "iso_ms_count1_skew": dict(CASES["ms_count1_skew"], iso=1, gain_range=FS_GAIN),
     "iso_is_short_441": dict(CASES["is_short_441"], iso=2, gain_range=FS_GAIN),
     "iso_ms_is_short_480": dict(CASES["ms_is_short_480"], iso=3, gain_range=FS_GAIN),
     "iso_ms_is_long_480": dict(CASES["ms_is_long_480"], iso=3, gain_range=FS_GAIN),
-    "iso_bits_on_stereo_plain": dict(CASES["stereo_plain_320"], iso=3, gain_range=FS_GAIN),      # (no joint stereo: the bits change nothing)
+    "iso_bits_on_stereo_plain": dict(CASES["stereo_plain_320"], iso=7, gain_range=FS_GAIN),      # (no joint stereo: the bits change nothing)
+    # round 6, PDMP3_GC_ISO_IS_STD (4): the whole of the standard's intensity stereo -- positions from the right channel,
+    # bound by its last non-zero line (per window), last band included, no M/S on intensity-coded lines.  The two
+    # channels draw their block shapes independently here: the right channel's counts, in the kernel and in the oracle
+    "iso_std_is_long_441": dict(CASES["is_long_441"], iso=7, gain_range=FS_GAIN),
+    "iso_std_ms_is_long_480": dict(CASES["ms_is_long_480"], iso=7, gain_range=FS_GAIN),
+    "iso_std_is_short_441": dict(CASES["is_short_441"], iso=7, gain_range=FS_GAIN),
+    "iso_std_ms_is_short_480": dict(CASES["ms_is_short_480"], iso=7, gain_range=FS_GAIN),
+    "iso_std_ms_is_mixed_320": dict(mode=MODE_JOINT, mode_ext=3, sfreq=2, block_mix=(20, 10, 60, 10), mixed_prob=0.8,
+                                    count1_range=(20, 400), sf_max=8, iso=7, gain_range=FS_GAIN, zero_gc_prob=0.15),
 }
 
 # int16 tolerance per case, in LSB, as literal numbers.  +-1 LSB (north_star; P:2028-2031 is the step an LSB is defined

@@ -15,7 +15,7 @@ from test_pipeline_emul import emul_decode, emul_decode_granules, emul_decode_ri
 from test_unpack_emul import emul_unpack
 from util import assert_pcm_close, nch_of
 
-ISO_TABLE33, ISO_MS_BOUND, ISO_IS_SHORT, ISO_SF21, ISO_SF12, ISO_ALL = 0x01, 0x02, 0x04, 0x08, 0x10, 0x1f
+ISO_TABLE33, ISO_MS_BOUND, ISO_IS_SHORT, ISO_SF21, ISO_SF12, ISO_IS_BOUND, ISO_ALL = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x3f
 
 
 def _streams():
