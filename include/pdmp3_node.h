@@ -7,8 +7,11 @@
  * and the polyphase FIFO (pdmp3.c:2006-2019), two granules deep -- so every range but the first starts two frames
  * early and discards what those frames decode to (further back where the frames in front of the cut are mono: channel
  * 1's state is the last stereo frame's), NO collective runs inside the decode, and the one exchange of the path is the
- * final PCM gather to the first GPU: grouped ncclSend / ncclRecv over RCCL, every sender straight into its place in the
- * destination (xGMI is point to point: the root's seven ingress links work in parallel).
+ * final PCM gather to the first GPU: ncclSend / ncclRecv over RCCL, every sender straight into its place in the
+ * destination (xGMI is point to point: the root's seven ingress links work in parallel).  Since round 6 the exchange is
+ * PIPELINED with the decode: a shard is decoded in slices (state carried from slice to slice, no extra halos) and a
+ * slice's PCM leaves on a second stream while the next slices decode; every entry point puts the caller's current HIP
+ * device back before it returns.
  *
  * In libpdmp3_hip.so (pdmp3_amd/csrc/node.hip).  RCCL is looked up at run time (librccl.so.1 / librccl.so, the copy a
  * process has loaded already if there is one): the library does not link against it, and a process that never creates
@@ -31,16 +34,21 @@ extern "C" {
 typedef struct pdmp3_node pdmp3_node;
 
 /* how the PCM gets to the first device */
-#define PDMP3_NODE_RCCL 0   /* grouped ncclSend / ncclRecv (ncclCommInitAll over the devices): the product path */
+#define PDMP3_NODE_RCCL 0   /* ncclSend / ncclRecv, the root's receives grouped per slice (ncclCommInitAll over the devices): the
+                               intended product path -- EXPERIMENTAL with more than one GPU: no machine this library was developed
+                               on had two, the exchange between different devices has never executed (one rank: tested) */
 #define PDMP3_NODE_COPY 1   /* device-to-device copies (hipMemcpyPeerAsync), no RCCL: the transport of the tests that run several
                                ranks on ONE GPU (RCCL refuses a device that is listed twice); same shards, same halos, same result */
 
 typedef struct pdmp3_node_timing {
   double prepare_ms;        /* upload of the records (decode_records) / generation on the devices (decode_generated) */
-  double decode_ms;         /* all ranks' kernels: from the first launch to the last one's end (wall clock, ranks in parallel) */
-  double gather_ms;         /* the exchange: PCM of ranks 1 .. n-1 into the destination on rank 0's device */
+  double decode_ms;         /* the kernels: first launch to the last one's end on a rank's compute stream (HIP events), the slowest rank */
+  double gather_ms;         /* the exchange: first transfer's start to the last one's end on a rank's transfer stream, the slowest
+                               rank -- it STARTS when the first slice is decoded and runs under the later slices' kernels */
   long long gather_bytes;   /* bytes that crossed between devices */
   int rccl_ranks;           /* ncclCommCount of rank 0's communicator (0 with PDMP3_NODE_COPY) */
+  int slices;               /* pieces each shard was decoded and sent in ($PDMP3_NODE_SLICES, default 8; never under 4096 frames) */
+  double total_ms;          /* decode + exchange as they ran, overlapped: wall clock from the first launch to the last byte */
 } pdmp3_node_timing;
 
 /* One engine (pdmp3_hip_create) and one HIP stream per entry of devices[]; with PDMP3_NODE_RCCL one communicator over

@@ -51,8 +51,13 @@ bool rccl_load(Rccl& r) {
 struct Rank {
   int device = 0;
   pdmp3_hip_ctx* ctx = nullptr;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // the rank's kernels
+  hipStream_t xfer = nullptr;        // its share of the exchange: a slice's PCM leaves while the next slice decodes
   ncclComm_t comm = nullptr;
+  void* d_state = nullptr;           // synthesis state carried from slice to slice of the shard (pdmp3_hip_state_bytes)
+  hipEvent_t ev_slice = nullptr;     // "this slice's PCM is complete" (recorded on stream, waited for on xfer)
+  hipEvent_t ev_d0 = nullptr, ev_d1 = nullptr, ev_x0 = nullptr, ev_x1 = nullptr;   // timing: decode / exchange, first start to last end
+  long long moved = 0;               // bytes this rank sent to another device in this call
   // the shard's buffers on the device, kept from call to call (grown when a larger shard comes)
   int16_t* d_spectra = nullptr;
   pdmp3_gc_side* d_side = nullptr;
@@ -62,6 +67,14 @@ struct Rank {
   long long first = 0, count = 0, discard = 0, lo = 0;
   int rc = PDMP3_HIP_OK;
   char err[256] = "";
+};
+
+// every pdmp3_node_* entry point runs hipSetDevice for its ranks on the CALLER's thread: the caller's current device is
+// put back on every way out (a Python caller's torch.cuda.current_device() moved to the last GPU)
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+  ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
 };
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -77,6 +90,7 @@ int node_fail(int code, const char* fmt, const char* a = "", const char* b = "")
 
 struct pdmp3_node {
   int n = 0, transport = PDMP3_NODE_RCCL;
+  int slices = 8;                    // $PDMP3_NODE_SLICES: pieces a shard is decoded and sent in (include/pdmp3_node.h)
   std::vector<Rank> rank;
   Rccl rccl;
   int rccl_ranks = 0;
@@ -113,11 +127,15 @@ extern "C" void pdmp3_node_shard(long long n_frames, int rank, int world, const 
 
 extern "C" void pdmp3_node_destroy(pdmp3_node* node) {
   if (!node) return;
+  DeviceGuard guard;
   for (Rank& r : node->rank) {
     (void)hipSetDevice(r.device);
     if (r.stream) (void)hipStreamSynchronize(r.stream);
+    if (r.xfer) (void)hipStreamSynchronize(r.xfer);
     if (r.comm && node->rccl.CommDestroy) (void)node->rccl.CommDestroy(r.comm);
-    (void)hipFree(r.d_spectra); (void)hipFree(r.d_side); (void)hipFree(r.d_pcm);
+    (void)hipFree(r.d_spectra); (void)hipFree(r.d_side); (void)hipFree(r.d_pcm); (void)hipFree(r.d_state);
+    for (hipEvent_t e : {r.ev_slice, r.ev_d0, r.ev_d1, r.ev_x0, r.ev_x1}) if (e) (void)hipEventDestroy(e);
+    if (r.xfer) (void)hipStreamDestroy(r.xfer);
     if (r.stream) (void)hipStreamDestroy(r.stream);
     if (r.ctx) pdmp3_hip_destroy(r.ctx);
   }
@@ -133,16 +151,23 @@ extern "C" int pdmp3_node_create(const int* devices, int n, int transport, pdmp3
       for (int j = 0; j < i; j++)
         if (devices[i] == devices[j])
           return node_fail(PDMP3_HIP_EINVAL, "pdmp3_node_create: a device listed twice needs PDMP3_NODE_COPY (RCCL takes every GPU once)");
+  DeviceGuard guard;
   pdmp3_node* node = new pdmp3_node;
   node->n = n; node->transport = transport;
+  if (const char* e = getenv("PDMP3_NODE_SLICES")) { const int v = atoi(e); if (v >= 1 && v <= 64) node->slices = v; }
   node->rank.resize((size_t)n);
   for (int i = 0; i < n; i++) {
     Rank& r = node->rank[(size_t)i];
     r.device = devices[i];
     if (pdmp3_hip_create(r.device, &r.ctx) != PDMP3_HIP_OK) { pdmp3_node_destroy(node); return PDMP3_HIP_EDEVICE; }   // (text: the engine's)
-    if (hipSetDevice(r.device) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(r.device) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&r.xfer, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&r.ev_slice, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&r.ev_d0) != hipSuccess || hipEventCreate(&r.ev_d1) != hipSuccess ||
+        hipEventCreate(&r.ev_x0) != hipSuccess || hipEventCreate(&r.ev_x1) != hipSuccess ||
+        hipMalloc(&r.d_state, pdmp3_hip_state_bytes()) != hipSuccess) {
       pdmp3_node_destroy(node);
-      return node_fail(PDMP3_HIP_EDEVICE, "pdmp3_node_create: hipStreamCreate failed");
+      return node_fail(PDMP3_HIP_EDEVICE, "pdmp3_node_create: streams / events / state block");
     }
   }
   if (transport == PDMP3_NODE_RCCL) {
@@ -198,62 +223,91 @@ int on_all_ranks(pdmp3_node* node, F body) {
   return PDMP3_HIP_OK;
 }
 
-// the exchange: rank k's frames [lo, hi) -- its PCM behind the discarded halo -- into d_pcm + lo on rank 0's device
-int gather(pdmp3_node* node, int16_t* d_pcm, pdmp3_node_timing* t) {
+// Decode and exchange, pipelined (SURVEY 8e's one collective, BASELINE configs[4] "with RCCL PCM gather"): a rank's shard
+// is decoded in `slices` consecutive pieces -- the synthesis state goes from piece to piece through the rank's state
+// block, so the pieces cost no halo -- and piece i's PCM leaves on the rank's SECOND stream as soon as its kernel is done
+// (an event), under the kernels of pieces i + 1 ...: at the C5 shape the exchange (7 x 576 MB into one GPU, ~3.8 ms over
+// seven xGMI links by SURVEY 5's arithmetic) is 4 x the decode (0.93 ms per shard), so what the pipeline buys is the decode
+// hidden under the exchange and the exchange started a slice's worth early, not the other way round.
+//   RCCL:  sender k: ncclSend(piece) on comm k / stream xfer k;  root: ncclRecv(piece from k) for every k, one group per
+//          piece, on the root's xfer stream -- point-to-point pairs, matched in order per pair.
+//   COPY:  hipMemcpyPeerAsync on the sender's xfer stream (several ranks on one GPU: the tests' transport).
+// Rank 0's own pieces are device-to-device copies on its xfer stream.  Every thread ends by draining its two streams.
+int decode_and_gather(pdmp3_node* node, int16_t* d_pcm, pdmp3_node_timing* t) {
   const double t0 = now_ms();
-  long long moved = 0;
   Rank& root = node->rank[0];
-  auto src_of = [](Rank& r) { return (const char*)r.d_pcm + (size_t)r.discard * PDMP3_FRAME_PCM_BYTES; };
-  auto bytes_of = [](Rank& r) { return (size_t)(r.count - r.discard) * PDMP3_FRAME_PCM_BYTES; };
-  auto dst_of = [&](Rank& r) { return (char*)d_pcm + (size_t)r.lo * PDMP3_FRAME_PCM_BYTES; };
-  // rank 0's own share never leaves its device
-  if (hipSetDevice(root.device) != hipSuccess ||
-      hipMemcpyAsync(dst_of(root), src_of(root), bytes_of(root), hipMemcpyDeviceToDevice, root.stream) != hipSuccess)
-    return node_fail(PDMP3_HIP_EDEVICE, "pdmp3_node: copy of rank 0's PCM failed");
-  if (node->transport == PDMP3_NODE_RCCL && node->n > 1) {
-    // one group: every sender's ncclSend on its own communicator and stream, the root's ncclRecv for each of them --
-    // point-to-point transfers that run side by side on the root's ingress links (RCCL has no int16: bytes)
+  // the same cut for every rank: piece j of a shard = frames [j q, (j + 1) q) of its [0, count), q from the LARGEST shard
+  // (shards differ by at most one frame + their halos), so that the root's receives pair with the senders' sends
+  long long longest = 0;
+  for (Rank& r : node->rank) if (r.count > longest) longest = r.count;
+  int S = node->slices;
+  while (S > 1 && longest / S < 4096) S--;                       // no piece under 4096 frames: below that a launch does not fill the GPU
+  const long long q = (longest + S - 1) / S;
+  auto piece = [&](const Rank& r, int j, long long* a, long long* b) {   // frames [a, b) of the rank's buffer that piece j SENDS
+    long long lo = (long long)j * q, hi = lo + q;
+    if (hi > r.count) hi = r.count;
+    if (lo < r.discard) lo = r.discard;                          // the halo's PCM stays behind
+    *a = lo; *b = hi > lo ? hi : lo;
+  };
+  const int rc = on_all_ranks(node, [&](int k, Rank& r) {
     const Rccl& R = node->rccl;
-    ncclResult_t rc = R.GroupStart();
-    for (int k = 1; k < node->n && rc == ncclSuccess; k++) {
-      Rank& r = node->rank[(size_t)k];
-      if (!bytes_of(r)) continue;
-      rc = R.Send(src_of(r), bytes_of(r), ncclChar, 0, r.comm, r.stream);
-      if (rc == ncclSuccess) rc = R.Recv(dst_of(r), bytes_of(r), ncclChar, k, root.comm, root.stream);
-      moved += (long long)bytes_of(r);
+    const bool rccl = node->transport == PDMP3_NODE_RCCL && node->n > 1;
+    r.moved = 0;
+    auto fail = [&](const char* what) { r.rc = PDMP3_HIP_EDEVICE; snprintf(r.err, sizeof r.err, "pdmp3_node: %s (device %d)", what, r.device); };
+    if (hipMemsetAsync(r.d_state, 0, pdmp3_hip_state_bytes(), r.stream) != hipSuccess) return fail("hipMemsetAsync of the state block");
+    if (hipEventRecord(r.ev_d0, r.stream) != hipSuccess || hipEventRecord(r.ev_x0, r.xfer) != hipSuccess) return fail("hipEventRecord");
+    for (int j = 0; j < S; j++) {
+      const long long lo = (long long)j * q, hi = lo + q < r.count ? lo + q : r.count;
+      if (hi > lo) {
+        r.rc = pdmp3_hip_decode_frames(r.ctx, r.d_spectra + (size_t)lo * 2304, r.d_side + (size_t)lo * 4, (int)(hi - lo), r.d_state,
+                                       r.d_pcm + (size_t)lo * 2304, 0, r.stream);
+        if (r.rc != PDMP3_HIP_OK) return;
+      }
+      if (hipEventRecord(r.ev_slice, r.stream) != hipSuccess || hipStreamWaitEvent(r.xfer, r.ev_slice, 0) != hipSuccess) return fail("slice event");
+      long long a, b;
+      piece(r, j, &a, &b);
+      const size_t bytes = (size_t)(b - a) * PDMP3_FRAME_PCM_BYTES;
+      const char* src = (const char*)r.d_pcm + (size_t)a * PDMP3_FRAME_PCM_BYTES;
+      char* dst = (char*)d_pcm + (size_t)(r.first + a) * PDMP3_FRAME_PCM_BYTES;
+      if (k == 0) {
+        if (bytes && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, r.xfer) != hipSuccess) return fail("copy of rank 0's PCM");
+        if (rccl) {
+          // the root's receives for piece j of every other rank: one group, side by side on its ingress links
+          ncclResult_t g = R.GroupStart();
+          for (int m = 1; m < node->n && g == ncclSuccess; m++) {
+            const Rank& o = node->rank[(size_t)m];
+            long long oa, ob;
+            piece(o, j, &oa, &ob);
+            if (ob > oa) g = R.Recv((char*)d_pcm + (size_t)(o.first + oa) * PDMP3_FRAME_PCM_BYTES, (size_t)(ob - oa) * PDMP3_FRAME_PCM_BYTES, ncclChar, m, r.comm, r.xfer);
+          }
+          const ncclResult_t g2 = R.GroupEnd();
+          if (g != ncclSuccess || g2 != ncclSuccess) { r.rc = PDMP3_HIP_EDEVICE; snprintf(r.err, sizeof r.err, "pdmp3_node: ncclRecv: %s", R.GetErrorString(g != ncclSuccess ? g : g2)); return; }
+        }
+      } else if (bytes) {
+        if (rccl) {
+          const ncclResult_t g = R.Send(src, bytes, ncclChar, 0, r.comm, r.xfer);
+          if (g != ncclSuccess) { r.rc = PDMP3_HIP_EDEVICE; snprintf(r.err, sizeof r.err, "pdmp3_node: ncclSend: %s", R.GetErrorString(g)); return; }
+        } else if (hipMemcpyPeerAsync(dst, root.device, src, r.device, bytes, r.xfer) != hipSuccess) return fail("hipMemcpyPeerAsync");
+        r.moved += (long long)bytes;
+      }
     }
-    const ncclResult_t rc2 = R.GroupEnd();
-    if (rc != ncclSuccess || rc2 != ncclSuccess)
-      return node_fail(PDMP3_HIP_EDEVICE, "pdmp3_node: RCCL gather: %s", R.GetErrorString(rc != ncclSuccess ? rc : rc2));
-  } else {
-    for (int k = 1; k < node->n; k++) {
-      Rank& r = node->rank[(size_t)k];
-      if (!bytes_of(r)) continue;
-      // (ordered behind the rank's decode: enqueued on ITS stream; the destination belongs to the root's device)
-      if (hipSetDevice(r.device) != hipSuccess ||
-          hipMemcpyPeerAsync(dst_of(r), root.device, src_of(r), r.device, bytes_of(r), r.stream) != hipSuccess)
-        return node_fail(PDMP3_HIP_EDEVICE, "pdmp3_node: hipMemcpyPeerAsync failed");
-      moved += (long long)bytes_of(r);
-    }
-  }
-  for (Rank& r : node->rank) {
-    if (hipSetDevice(r.device) != hipSuccess || hipStreamSynchronize(r.stream) != hipSuccess)
-      return node_fail(PDMP3_HIP_EDEVICE, "pdmp3_node: synchronising the gather failed");
-  }
-  if (t) { t->gather_ms = now_ms() - t0; t->gather_bytes = moved; t->rccl_ranks = node->rccl_ranks; }
-  return PDMP3_HIP_OK;
-}
-
-int decode_all(pdmp3_node* node, pdmp3_node_timing* t) {
-  const double t0 = now_ms();
-  const int rc = on_all_ranks(node, [](int, Rank& r) {
-    if (r.count <= 0) return;
-    // (one pdmp3_hip_decode_frames call takes an int: shards of more than 2^31 - 1 frames do not exist)
-    r.rc = pdmp3_hip_decode_frames(r.ctx, r.d_spectra, r.d_side, (int)r.count, nullptr, r.d_pcm, 0, r.stream);
-    if (r.rc == PDMP3_HIP_OK && hipStreamSynchronize(r.stream) != hipSuccess) { r.rc = PDMP3_HIP_EDEVICE; snprintf(r.err, sizeof r.err, "pdmp3_node: decode on device %d failed", r.device); }
+    if (hipEventRecord(r.ev_d1, r.stream) != hipSuccess || hipEventRecord(r.ev_x1, r.xfer) != hipSuccess) return fail("hipEventRecord");
+    if (hipStreamSynchronize(r.stream) != hipSuccess || hipStreamSynchronize(r.xfer) != hipSuccess) return fail("decode / exchange failed");
   });
-  if (t) t->decode_ms = now_ms() - t0;
-  return rc;
+  if (rc != PDMP3_HIP_OK) return rc;
+  if (t) {
+    t->total_ms = now_ms() - t0;
+    t->slices = S;
+    t->rccl_ranks = node->rccl_ranks;
+    for (Rank& r : node->rank) {
+      float d = 0.0f, x = 0.0f;
+      (void)hipSetDevice(r.device);
+      if (hipEventElapsedTime(&d, r.ev_d0, r.ev_d1) == hipSuccess && d > t->decode_ms) t->decode_ms = d;
+      if (hipEventElapsedTime(&x, r.ev_x0, r.ev_x1) == hipSuccess && x > t->gather_ms) t->gather_ms = x;
+      t->gather_bytes += r.moved;
+    }
+  }
+  return PDMP3_HIP_OK;
 }
 
 }  // namespace
@@ -263,6 +317,7 @@ extern "C" int pdmp3_node_decode_records(pdmp3_node* node, const int16_t* spectr
   if (!node || n_frames < 0 || (n_frames && (!spectra || !side || !d_pcm))) return node_fail(PDMP3_HIP_EINVAL, "pdmp3_node_decode_records: bad argument");
   if (t) memset(t, 0, sizeof *t);
   if (!n_frames) return PDMP3_HIP_OK;
+  DeviceGuard guard;
   if (n_frames / node->n + 8 > 0x7fffffffLL) return node_fail(PDMP3_HIP_EINVAL, "pdmp3_node_decode_records: shards of more than 2^31 frames");
   // the cut's way back past mono frames is read off the records' own flag bytes (any record of a frame carries them)
   std::vector<uint8_t> flags((size_t)n_frames);
@@ -290,8 +345,7 @@ extern "C" int pdmp3_node_decode_records(pdmp3_node* node, const int16_t* spectr
     }
   });
   if (t) t->prepare_ms = now_ms() - t0;
-  if (rc == PDMP3_HIP_OK) rc = decode_all(node, t);
-  if (rc == PDMP3_HIP_OK) rc = gather(node, d_pcm, t);
+  if (rc == PDMP3_HIP_OK) rc = decode_and_gather(node, d_pcm, t);
   return rc;
 }
 
@@ -299,6 +353,7 @@ extern "C" int pdmp3_node_decode_generated(pdmp3_node* node, uint64_t seed, long
   if (!node || n_frames < 0 || (n_frames && !d_pcm)) return node_fail(PDMP3_HIP_EINVAL, "pdmp3_node_decode_generated: bad argument");
   if (t) memset(t, 0, sizeof *t);
   if (!n_frames) return PDMP3_HIP_OK;
+  DeviceGuard guard;
   if (n_frames / node->n + 8 > 0x7fffffffLL) return node_fail(PDMP3_HIP_EINVAL, "pdmp3_node_decode_generated: shards of more than 2^31 frames");
   for (int k = 0; k < node->n; k++) {
     Rank& r = node->rank[(size_t)k];
@@ -313,7 +368,6 @@ extern "C" int pdmp3_node_decode_generated(pdmp3_node* node, uint64_t seed, long
     if (r.rc == PDMP3_HIP_OK && hipStreamSynchronize(r.stream) != hipSuccess) { r.rc = PDMP3_HIP_EDEVICE; snprintf(r.err, sizeof r.err, "pdmp3_node: generation on device %d failed", r.device); }
   });
   if (t) t->prepare_ms = now_ms() - t0;
-  if (rc == PDMP3_HIP_OK) rc = decode_all(node, t);
-  if (rc == PDMP3_HIP_OK) rc = gather(node, d_pcm, t);
+  if (rc == PDMP3_HIP_OK) rc = decode_and_gather(node, d_pcm, t);
   return rc;
 }

@@ -82,7 +82,7 @@ NODE_RCCL, NODE_COPY = 0, 1
 
 class NodeTiming(C.Structure):
     _fields_ = [("prepare_ms", C.c_double), ("decode_ms", C.c_double), ("gather_ms", C.c_double),
-                ("gather_bytes", C.c_longlong), ("rccl_ranks", C.c_int)]
+                ("gather_bytes", C.c_longlong), ("rccl_ranks", C.c_int), ("slices", C.c_int), ("total_ms", C.c_double)]
 
 
 def node_shard(n_frames, rank, world, frame_flags=None):

@@ -2682,7 +2682,7 @@ static void* par_scanner(void* arg) {
         break;
       }
       if (w >= pub && w < pub + 2) {
-        if (P->spin) for (int i = 0; i < 64; i++) __builtin_ia32_pause(); else sched_yield();
+        if (P->spin) for (int i = 0; i < 64; i++) hp_pause(); else sched_yield();
       } else {
         const struct timespec nap = {0, 20000};
         (void)nanosleep(&nap, NULL);

@@ -28,7 +28,7 @@ def test_gpu_engine_on_iso_records(engine, oracle, name):
     for k in range(3):
         assert np.array_equal(ws[:, :, :nch, k].view(np.uint32), gs[:, :, :nch, k].view(np.uint32)), "stage %d" % k
     assert_pcm_close(got, want, 1, name)
-    for chunk in (0, 1, 3) + ((-3,) if engine.has_persistent_kernel() else ()):   # granule kernel, chunks with halos, persistent kernel (opt-in build)
+    for chunk in (0, 1, 3):   # granule kernel, chunks with halos (the persistent kernel: tests/ring_variant_checks.py)
         assert np.array_equal(gpu_decode(engine, sp, sd, chunk=chunk), got), chunk
 
 

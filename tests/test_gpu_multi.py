@@ -17,13 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_two_ranks_gathered_pcm_equals_unsharded(engine, tmp_path):
     import torch
-    n = 3000
+    n = 9000                                                 # (two slices of >= 4096 frames per shard: the pipelined exchange's piece arithmetic)
     out = str(tmp_path / "gathered.npy")
     env = dict(os.environ, PDMP3_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--frames", str(n), "--dump-gathered", out]
+           "--frames", str(n), "--dump-gathered", out, "--strong-frames", "24000"]
     # a fresh child process (never an exec from this process, which has initialised the GPU)
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -31,6 +31,11 @@ def test_bench_two_ranks_gathered_pcm_equals_unsharded(engine, tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_gpu"] == n
     assert d["gather_bytes"] == n * 4608 and d["gather_ms"] > 0 and d["value"] > 0
+    # round 6: the measured step is decode + exchange (sliced, overlapped on real hardware; blocking through host memory with
+    # gloo here); the decode-only figure of rounds 1-5 beside it, and the fixed-stream (strong-scaling) leg
+    assert d["slices"] == 2 and d["value_decode_only"] >= d["value"] and 0.0 <= d["overlap_frac"] <= 1.0
+    assert d["parity"]["pipelined_gather_equals_one_piece_gather"] is True
+    assert d["strong_scaling"]["frames_per_gpu"] == 12000 and d["strong_scaling"]["frames_per_s"] > 0, d["strong_scaling"]
     # the line explains itself: what each rank ran, how many ranks the collective library saw (0 here:
     # gloo stands in for RCCL on the one GPU), and the parity of the gathered PCM around the shard boundary
     assert [r["rank"] for r in d["ranks"]] == [0, 1] and all("k_decode" in r["kernel"] for r in d["ranks"])

@@ -53,8 +53,48 @@ def test_generated_stream_in_shards_on_one_gpu(engine, world):
         lo1 = n // world + (1 if n % world else 0)
         assert tm.rccl_ranks == 0 and tm.gather_bytes == (n - lo1) * 4608
         assert torch.equal(pcm, _unsharded(engine, n))
+        # round 6: the shard goes in slices (state carried from slice to slice), a slice's PCM leaves while the next decodes
+        assert tm.slices == max(s for s in range(1, 9) if s == 1 or (lo1 + 2) // s >= 4096), tm.slices
+        assert tm.total_ms > 0 and tm.decode_ms > 0 and tm.gather_ms > 0
         pcm2, _ = node.decode_generated(SEED_C5, 777)        # the node's buffers are kept and reused: a smaller stream after a larger one
         assert torch.equal(pcm2, _unsharded(engine, 777))
+    finally:
+        node.close()
+
+
+@pytest.mark.parametrize("slices", [1, 2, 5, 8])
+def test_sliced_exchange_is_the_unsliced_one(engine, slices, monkeypatch):
+    """$PDMP3_NODE_SLICES: any number of pieces per shard, same PCM (3 ranks on one GPU, 50 001 frames: pieces of >= 4096
+    frames, the last one shorter, the first one of ranks 1 and 2 starting behind the halo)"""
+    import torch
+    from pdmp3_amd.hip import NodeDecoder, NODE_COPY
+    monkeypatch.setenv("PDMP3_NODE_SLICES", str(slices))
+    n = 50001
+    node = NodeDecoder([0] * 3, NODE_COPY)
+    try:
+        pcm, tm = node.decode_generated(SEED_C5, n)
+        assert tm.slices == min(slices, 4)                   # 16 669 frames per shard: at most 4 pieces of >= 4096
+        assert torch.equal(pcm, _unsharded(engine, n))
+    finally:
+        node.close()
+
+
+def test_two_gpus_over_rccl_equals_the_engine(engine):
+    """the documented product path, as soon as a box has two GPUs: NodeDecoder([0, 1], NODE_RCCL) against the
+    unsharded decode -- and the caller's current device is still device 0 afterwards.  Skipped on the one-GPU test box:
+    until this has passed on hardware the RCCL transport with more than one rank is EXPERIMENTAL (include/pdmp3_node.h)."""
+    import torch
+    from pdmp3_amd.hip import NodeDecoder, NODE_RCCL
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU here: the exchange between different devices cannot run")
+    n = 250000
+    torch.cuda.set_device(0)
+    node = NodeDecoder([0, 1], NODE_RCCL)
+    try:
+        pcm, tm = node.decode_generated(SEED_C5, n)
+        assert torch.cuda.current_device() == 0
+        assert tm.rccl_ranks == 2 and tm.gather_bytes == (n // 2) * 4608 and tm.slices == 8
+        assert torch.equal(pcm, _unsharded(engine, n))
     finally:
         node.close()
 

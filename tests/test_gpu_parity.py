@@ -325,26 +325,3 @@ def test_gpu_granule_kernel_gives_up_waiting_for_other_workgroups(monkeypatch, o
         assert torch.equal(f1, f2)
     finally:
         eng.close()
-
-
-@pytest.mark.parametrize("name", ["ms_mixed_blocks_441", "ms_short_heavy_480", "mono_441", "mono_320", "ms_resets", "dual_480_fs", "ms_is_short_480_fs"])
-def test_gpu_persistent_granule_kernel_equals_independent_chunks(engine, name):
-    """k_decode_p (chunk_frames = PDMP3_HIP_CHUNK_PERSISTENT: 16 waves going round a range of frames, ring of LDS mailboxes, one
-    halo per range) on the device against independent chunks: PCM and carried state bit-identical -- H5-heavy, mono (every
-    frame through run_chunk inside the loop), RESET frames, the stereo / mono / stereo stream cut by range boundaries; the
-    engine makes ranges of >= 8 frames, so 64-frame corpora are 8 workgroups"""
-    import torch
-    from test_pipeline_emul import _mode_switch_records
-    if not engine.has_persistent_kernel():
-        pytest.skip("libpdmp3_hip.so built without -DPDMP3_WITH_RING_KERNEL (the default since round 5: the kernel lost its benchmark)")
-    for sp, sd in (corpus.case(name), _mode_switch_records()):
-        dsp, dsd = engine.upload(sp, sd)
-        n = sp.shape[0]
-        a = torch.zeros((n, 2304), dtype=torch.int16, device=engine.tdev)
-        b = torch.zeros_like(a)
-        sa, sb = engine.new_state(), engine.new_state()
-        engine.decode(dsp, dsd, a, state=sa, chunk_frames=-3)
-        assert "k_decode_p" in engine.last_launch_kernel()
-        engine.decode(dsp, dsd, b, state=sb, chunk_frames=3)
-        torch.cuda.synchronize()
-        assert torch.equal(a, b) and torch.equal(sa, sb), name
