@@ -79,8 +79,28 @@ typedef struct pdmp3_gc_side {
   uint8_t  scalefac_s[13][3]; /* P:98; [12][w] = out-of-bounds value
                                  or PDMP3_SF_PEEK                                  */
   uint8_t  iso;               /* PDMP3_GC_ISO_*: 0 = the reference's behaviour (below)  */
-  uint8_t  reserved[58];      /* must be zero                                      */
+  uint8_t  lsf;               /* PDMP3_LSF_*: 0 = an MPEG-1 frame (all the reference knows) */
+  uint8_t  lsf_slen[4];       /* channel 1 of an LSF intensity-stereo frame: the widths ... */
+  uint8_t  lsf_nsfb[4];       /* ... and the sizes of its four scalefactor partitions       */
+  uint8_t  reserved[49];      /* must be zero                                      */
 } pdmp3_gc_side;              /* 128 bytes                                         */
+
+/* pdmp3_gc_side.lsf -- MPEG-2 LSF and "MPEG-2.5" frames (ISO/IEC 13818-3; SURVEY 8f #4, last third).  NOT the reference,
+ * which rejects them (P:1293): there is no reference behaviour to reproduce, so an LSF frame is decoded by the standard
+ * -- as if every PDMP3_GC_ISO_* bit were set, with scalefac_l[21] = scalefac_s[12][w] = 0 -- and pinned by FFmpeg's decode
+ * of the same streams (tests/golden/lsf_*.npz).  What differs from an MPEG-1 record:
+ *   - the frame has ONE granule: the records [1][ch] of its frame slot are ignored, the synthesis state passes over them
+ *     untouched, the frame's PCM is the first HALF of its place (576 sample-frames: 2304 bytes stereo, 1152 mono);
+ *   - the sampling frequency is kLsfSampleRates[3 * version + (frame & 3)] (pdmp3_amd/csrc/lsf_tables.h): six more
+ *     scalefactor-band tables; a mixed block's long part is bands 0..5 (36 lines), not 0..7;
+ *   - PDMP3_GC_PREFLAG is what scalefac_compress >= 500 implies (no preflag bit in the stream);
+ *   - intensity stereo (13818-3 2.4.3.2): is_pos p scales ONE channel by i0^((p + 1) / 2) (p odd: left, p even: right),
+ *     i0 = 2^(-1/4) or 2^(-1/2) by PDMP3_LSF_IS_SCALE; "not intensity coded" is the largest value the partition's
+ *     slen can hold, so channel 1's record carries its partitions (lsf_slen / lsf_nsfb, in transmission order: long
+ *     bands, or band by band x window).                                                                              */
+#define PDMP3_LSF_VERSION_MASK  0x03u  /* 1 = MPEG-2 LSF (22.05 / 24 / 16 kHz), 2 = MPEG-2.5 (11.025 / 12 / 8 kHz); identical
+                                          in all gc records of one frame */
+#define PDMP3_LSF_IS_SCALE      0x04u  /* channel 1: intensity_scale = scalefac_compress & 1 */
 
 /* pdmp3_gc_side.iso (identical in all gc records of one frame) -- SURVEY 8f #4, "ISO-correct switches".  The reference
  * departs from ISO 11172-3 in five places; by default this engine reproduces them bit for bit.  A caller

@@ -51,6 +51,11 @@ typedef struct pk_cfg {
   int narrow_scales;    /* 1: scalefactors <= 7, subblock_gain <= 2 -- a coded line is never more than 2^-11 below its
                            global gain.  (The fixtures' other decoder is FFmpeg's FIXED-point one: lines it flushes
                            to zero move its intensity-stereo bound, which the standard defines on the coded integers) */
+  int version;          /* 0 = MPEG-1 (what the reference decodes); 1 = MPEG-2 LSF (22.05 / 24 / 16 kHz for sfreq 0 / 1 / 2),
+                           2 = "MPEG-2.5" (11.025 / 12 / 8 kHz): one granule per frame, 9 / 17 bytes of side info, 9-bit
+                           scalefac_compress with the partition tables of 13818-3 2.4.3.2, bit rates 8 .. 160 kbps
+                           (bitrate_index 1 .. 14) -- streams the reference rejects (pdmp3.c:1293), decoded behind
+                           PDMP3_ISO_LSF (include/pdmp3.h) */
 } pk_cfg;
 
 /* Writes n_frames frames into out (capacity cap bytes; n_frames * 1500 + 4096 always suffices) and returns the

@@ -44,8 +44,33 @@ const float* orc_table_nwin(void) { build_tables(); return &g_nwin[0][0]; }
 void orc_synth_reset(orc_synth* st) { memset(st, 0, sizeof *st); }
 
 /* sfb boundary accessors over the contiguous l[23] s[14] layout (P:108-112) */
-static inline unsigned sfb_l(unsigned sfreq, unsigned i) { return ot_sfb[sfreq * 37 + i]; }
-static inline unsigned sfb_s(unsigned sfreq, unsigned i) { return ot_sfb[sfreq * 37 + 23 + i]; }
+/* sfreq 3..8: MPEG-2 LSF / MPEG-2.5 (ISO/IEC 13818-3 table B.8) -- NOT the reference, which decodes MPEG-1 only
+ * (P:1293); restated independently of pdmp3_amd/csrc/lsf_tables.h, both pinned by FFmpeg (tests/golden/lsf_*.npz) */
+static const uint16_t ot_lsf_l[6][23] = {
+  {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576},   /* 22.05 kHz */
+  {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 114, 136, 162, 194, 232, 278, 332, 394, 464, 540, 576},   /* 24 */
+  {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576},   /* 16 */
+  {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576},   /* 11.025 */
+  {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576},   /* 12 */
+  {0, 12, 24, 36, 48, 60, 72, 88, 108, 132, 160, 192, 232, 280, 336, 400, 476, 566, 568, 570, 572, 574, 576},   /* 8 */
+};
+static const uint16_t ot_lsf_s[6][14] = {
+  {0, 4, 8, 12, 18, 24, 32, 42, 56, 74, 100, 132, 174, 192},
+  {0, 4, 8, 12, 18, 26, 36, 48, 62, 80, 104, 136, 180, 192},
+  {0, 4, 8, 12, 18, 26, 36, 48, 62, 80, 104, 134, 174, 192},
+  {0, 4, 8, 12, 18, 26, 36, 48, 62, 80, 104, 134, 174, 192},
+  {0, 4, 8, 12, 18, 26, 36, 48, 62, 80, 104, 134, 174, 192},
+  {0, 8, 16, 24, 36, 52, 72, 96, 124, 160, 162, 164, 166, 192},
+};
+/* orc_debug_24k_330 (tests only): band 18 of the 24 kHz long table starts at line 330, as in FFmpeg's and mpg123's
+ * tables (the standard, LAME, libmad and minimp3 have 332): shows that the 24 kHz fixtures' residual is that one entry */
+int g_orc_24k_330 = 0;
+void orc_debug_24k_330(int on) { g_orc_24k_330 = on; }
+static inline unsigned sfb_l(unsigned sfreq, unsigned i) {
+  if (sfreq == 4 && i == 18 && g_orc_24k_330) return 330;
+  return sfreq < 3 ? ot_sfb[sfreq * 37 + i] : ot_lsf_l[sfreq - 3][i];
+}
+static inline unsigned sfb_s(unsigned sfreq, unsigned i) { return sfreq < 3 ? ot_sfb[sfreq * 37 + 23 + i] : ot_lsf_s[sfreq - 3][i]; }
 
 /* One frame's working set: the reference's id->g_main_data.is (P:99), in
  * place through all stages, plus unpacked side info. */
@@ -58,7 +83,9 @@ typedef struct frame_ws {
   uint32_t sf_s[2][2][13][3];
   int sf_s_peek[2][2];          /* H5: [12][w] comes from the bits of is[0][0][w] */
   unsigned iso;                 /* PDMP3_GC_ISO_* of the frame's records: the standard's behaviour instead of H2 / H3 */
-  unsigned sfreq, mode, mode_ext, nch;
+  unsigned sfreq, mode, mode_ext, nch;     /* sfreq: 0..2 MPEG-1, 3..8 LSF (3 * version + the header's field) */
+  unsigned ver;                 /* 0 MPEG-1, 1 MPEG-2 LSF, 2 MPEG-2.5: one granule, the standard's behaviour throughout */
+  unsigned lsf_is_scale, lsf_slen[4], lsf_nsfb[4];   /* LSF intensity stereo: channel 1's intensity_scale and partitions */
 } frame_ws;
 
 /* float value -> what `Requantize_Pow_43(is)` indexes with (P:2129-2131):
@@ -227,6 +254,17 @@ static void intensity_short(frame_ws* w, unsigned gr, unsigned sfb) {
   }
 }
 
+/* LSF: the "not intensity coded" value of the right channel's scalefactor number bi (transmission order) */
+static unsigned lsf_illegal(const frame_ws* w, unsigned bi) {
+  unsigned acc = 0;
+
+  for (unsigned k = 0; k < 4; k++) {
+    acc += w->lsf_nsfb[k];
+    if (bi < acc) return (1u << w->lsf_slen[k]) - 1u;
+  }
+  return 0;                      /* beyond the transmitted ones: scalefactor 0, slen 0 */
+}
+
 /* NOT the reference: joint stereo with intensity positions as ISO 11172-3 2.4.3.4.9.3 has them (PDMP3_GC_ISO_IS_STD;
  * pinned against FFmpeg's mpegaudiodec through tests/golden/iso_*.npz, tools/make_iso_golden.py).  Where the reference
  * departs (beyond SURVEY H3): it takes is_pos from the LEFT channel's scalefactors (P:2163, P:2200), bounds the
@@ -237,8 +275,13 @@ static void intensity_short(frame_ws* w, unsigned gr, unsigned sfb) {
 static void stage_stereo_std(frame_ws* w, unsigned gr) {
   const unsigned sfreq = w->sfreq;
   const int shortb = (w->wsf[gr][1] == 1 && w->block_type[gr][1] == 2), mixed = shortb && w->mixed[gr][1] != 0;
-  uint8_t is_pos_of[576];                                  /* 7 = not intensity coded */
-  memset(is_pos_of, 7, sizeof is_pos_of);
+  const unsigned nlong_mixed = w->ver ? 6 : 8;             /* a mixed block's long part: 36 lines = 8 MPEG-1 bands, 6 LSF bands */
+  const unsigned NONE = 255;
+  uint8_t is_pos_of[576];                                  /* NONE = not intensity coded */
+  memset(is_pos_of, NONE, sizeof is_pos_of);
+  /* the position that means "not intensity coded": 7 in MPEG-1; with LSF the largest value the scalefactor's slen holds
+   * (13818-3 2.4.3.2), by partition of the right channel's scalefactors in transmission order */
+#define ILLEGAL_OF(bi) (w->ver ? lsf_illegal(w, (bi)) : 7u)
   if (w->mode_ext & 0x1) {
     /* "zero" is said of the CODED value (2.4.3.4.9.3), so the test reads the integers, which are in bitstream order:
      * short band sfb, window win = lines 3 s[sfb] + win len .. + len */
@@ -256,21 +299,23 @@ static void stage_stereo_std(frame_ws* w, unsigned gr) {
         for (unsigned sfb = first; sfb < 13; sfb++) {
           const unsigned a = 3 * sfb_s(sfreq, sfb), len = sfb_s(sfreq, sfb + 1) - sfb_s(sfreq, sfb);
           if ((int)sfb <= last) continue;                  /* a non-zero line in this band or above: not intensity */
-          const unsigned pos = w->sf_s[gr][1][sfb < 12 ? sfb : 11][win];
-          if (pos >= 7) continue;
+          const unsigned sb = sfb < 12 ? sfb : 11;
+          const unsigned pos = w->sf_s[gr][1][sb][win];
+          const unsigned ill = ILLEGAL_OF((mixed ? nlong_mixed + (sb - 3) * 3 : sb * 3) + win);
+          if (w->ver ? pos == ill : pos >= 7) continue;
           for (unsigned j = 0; j < len; j++) is_pos_of[a + 3 * j + win] = (uint8_t)pos;      /* reordered position */
         }
       }
     }
     if (!shortb || (mixed && !any_short)) {
-      const unsigned nb = shortb ? 8 : 22, top = shortb ? 36 : 576;
+      const unsigned nb = shortb ? nlong_mixed : 22, top = shortb ? 36 : 576;
       int last = -1;
       for (unsigned i = 0; i < top; i++) if (q[i] != 0) last = (int)i;
       for (unsigned sfb = 0; sfb < nb; sfb++) {
         const unsigned a = sfb_l(sfreq, sfb), b = sfb < 21 ? sfb_l(sfreq, sfb + 1) : 576;
         if ((int)a <= last) continue;
         const unsigned pos = w->sf_l[gr][1][sfb < 21 ? sfb : 20];
-        if (pos >= 7) continue;
+        if (w->ver ? pos == ILLEGAL_OF(sfb < 21 ? sfb : 20) : pos >= 7) continue;
         for (unsigned i = a; i < b; i++) is_pos_of[i] = (uint8_t)pos;
       }
     }
@@ -280,18 +325,24 @@ static void stage_stereo_std(frame_ws* w, unsigned gr) {
     unsigned max_pos = (c0 > c1) ? c1 : c0;
     if (w->iso & PDMP3_GC_ISO_MS_ALL) max_pos = 576;
     for (unsigned i = 0; i < max_pos; i++) {
-      if (is_pos_of[i] != 7) continue;
+      if (is_pos_of[i] != NONE) continue;
       float left = (w->is[gr][0][i] + w->is[gr][1][i]) * (O_INV_SQRT_2);
       float right = (w->is[gr][0][i] - w->is[gr][1][i]) * (O_INV_SQRT_2);
       w->is[gr][0][i] = left;
       w->is[gr][1][i] = right;
     }
   }
+#undef ILLEGAL_OF
   for (unsigned i = 0; i < 576; i++) {
     const unsigned pos = is_pos_of[i];
-    if (pos == 7) continue;
+    if (pos == NONE) continue;
     float rl, rr;
-    if (pos == 6) { rl = 1.0f; rr = 0.0f; }
+    if (w->ver) {
+      /* 13818-3 2.4.3.2: i0 = 2^(-1/4) (intensity_scale 0) or 2^(-1/2); p odd: left x i0^((p + 1) / 2), p even: right x i0^(p / 2) */
+      const float f = (float)pow(2.0, -(double)((w->lsf_is_scale + 1) * ((pos + 1) >> 1)) / 4.0);
+      rl = (pos & 1) ? f : 1.0f;
+      rr = (pos & 1) ? 1.0f : f;
+    } else if (pos == 6) { rl = 1.0f; rr = 0.0f; }
     else { float t = ot_is_ratios[pos]; rl = t / (1.0f + t); rr = 1.0f / (1.0f + t); }
     float left = rl * w->is[gr][0][i];
     float right = rr * w->is[gr][0][i];
@@ -303,7 +354,7 @@ static void stage_stereo_std(frame_ws* w, unsigned gr) {
 /* P:1911-1972 L3_Stereo */
 static void stage_stereo(frame_ws* w, unsigned gr) {
   if (w->mode != 1 || w->mode_ext == 0) return;
-  if ((w->iso & PDMP3_GC_ISO_IS_STD) && (w->mode_ext & 0x1)) { stage_stereo_std(w, gr); return; }
+  if ((w->iso & PDMP3_GC_ISO_IS_STD) && ((w->mode_ext & 0x1) || w->ver)) { stage_stereo_std(w, gr); return; }
   if (w->mode_ext & 0x2) {
     unsigned c0 = w->count1[gr][0], c1 = w->count1[gr][1];
     unsigned max_pos = (c0 > c1) ? c1 : c0;            /* P:1920 picks the smaller (H2) */
@@ -449,6 +500,14 @@ static void unpack_frame(frame_ws* w, const int16_t* spectra, const pdmp3_gc_sid
   w->mode_ext = (fr & PDMP3_FR_MODEEXT_MASK) >> PDMP3_FR_MODEEXT_SHIFT;
   w->nch = (w->mode == 3) ? 1 : 2;
   w->iso = side[0].iso;
+  w->ver = side[0].lsf & PDMP3_LSF_VERSION_MASK;
+  if (w->ver > 2) w->ver = 2;
+  if (w->ver) {
+    w->sfreq = 3 * w->ver + (w->sfreq > 2 ? 2 : w->sfreq);
+    w->iso |= PDMP3_GC_ISO_MS_ALL | PDMP3_GC_ISO_IS_SHORT | PDMP3_GC_ISO_IS_STD;      /* no reference behaviour exists for LSF */
+    w->lsf_is_scale = (side[1].lsf & PDMP3_LSF_IS_SCALE) ? 1 : 0;
+    for (unsigned k = 0; k < 4; k++) { w->lsf_slen[k] = side[1].lsf_slen[k]; w->lsf_nsfb[k] = side[1].lsf_nsfb[k]; }
+  }
   for (unsigned gr = 0; gr < 2; gr++)
     for (unsigned ch = 0; ch < 2; ch++) {
       const pdmp3_gc_side* s = &side[gr * 2 + ch];
@@ -488,8 +547,9 @@ int orc_decode_frames_f32(orc_synth* st, const int16_t* spectra, const pdmp3_gc_
     unpack_frame(w, spectra + (size_t)f * 2304, sd);
     if (sd[0].frame & PDMP3_FR_RESET) orc_synth_reset(st);   /* P:1757-1766, P:1996-2003 */
     float* stg = stages ? stages + (size_t)f * 4 * 4 * 576 : NULL;
-    /* P:1029-1047 Decode_L3 */
-    for (unsigned gr = 0; gr < 2; gr++) {
+    /* P:1029-1047 Decode_L3 (an LSF frame has one granule: the records [1][ch] do not exist) */
+    const unsigned ngr = w->ver ? 1 : 2;
+    for (unsigned gr = 0; gr < ngr; gr++) {
       for (unsigned ch = 0; ch < w->nch; ch++) {
         stage_requantize(w, gr, ch);
         stage_reorder(w, gr, ch);
@@ -511,13 +571,13 @@ int orc_decode_frames_f32(orc_synth* st, const int16_t* spectra, const pdmp3_gc_
     /* P:2307-2345 Convert_Frame_S16 for a whole frame */
     if (pcm_f32) {
       float* of = pcm_f32 + (size_t)f * 2304;
-      for (unsigned gr = 0; gr < 2; gr++)
+      for (unsigned gr = 0; gr < ngr; gr++)
         for (unsigned i = 0; i < 576; i++)
           for (unsigned ch = 0; ch < w->nch; ch++) of[(gr * 576 + i) * w->nch + ch] = fs[gr][ch][i];
     }
     int16_t* o = pcm + (size_t)f * 2304;
     if (pcm)
-    for (unsigned gr = 0; gr < 2; gr++)
+    for (unsigned gr = 0; gr < ngr; gr++)
       for (unsigned i = 0; i < 576; i++) {
         uint32_t v = out[gr][i];
         if (w->nch == 1) o[gr * 576 + i] = (int16_t)(v & 0xffff);

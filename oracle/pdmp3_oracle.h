@@ -89,6 +89,8 @@ void orc_stream_set_tap(orc_stream*, orc_tap* tap);
 /* NOT the reference: the ISO-correct switches of include/pdmp3.h (PDMP3_ISO_*, same bit values) restated, so that the
  * library's modes have something to be compared with.  Nothing pins them ("parity unpinned"). */
 void orc_stream_set_quirks(orc_stream*, unsigned iso_mask);
+/* tests only: the 24 kHz long band table with FFmpeg's / mpg123's entry 330 where the standard has 332 (pdmp3_oracle.c) */
+void orc_debug_24k_330(int on);
 
 /* Whole-buffer convenience that mimics the CLI driver loop pdmp3() (P:2540):
  * read(16 KiB) -> on NEED_MORE feed 4096 bytes -> ... ; returns PCM bytes. */

@@ -29,6 +29,8 @@ struct orc_stream {
   int16_t frame_pcm[2304];           /* id->out[2][576] after Convert, interleaved */
   /* header, P:56-70 */
   unsigned h_id, h_layer, h_protection, h_bitrate_index, h_sfreq, h_padding, h_mode, h_mode_ext;
+  unsigned h_ver;                    /* 0 MPEG-1 (all the reference takes), 1 MPEG-2 LSF, 2 MPEG-2.5: only with ORC_ISO_LSF */
+  unsigned lsf_class1, lsf_slen1[4]; /* LSF: channel 1's scalefactor partitions of the frame just parsed (intensity positions) */
   /* side info, P:71-95 */
   unsigned main_data_begin, scfsi[2][4];
   unsigned part2_3_length[2][2], big_values[2][2], global_gain[2][2], scalefac_compress[2][2];
@@ -55,7 +57,31 @@ struct orc_stream {
 #define ORC_ISO_SF21 0x08u
 #define ORC_ISO_SF12 0x10u
 #define ORC_ISO_IS_BOUND 0x20u
-void orc_stream_set_quirks(orc_stream* s, unsigned iso_mask) { s->iso = iso_mask & 0x3fu; }
+#define ORC_ISO_LSF 0x40u                /* accept MPEG-2 LSF / MPEG-2.5 frames (the reference returns an error: P:1293) */
+void orc_stream_set_quirks(orc_stream* s, unsigned iso_mask) { s->iso = iso_mask & 0x7fu; }
+
+/* ---- MPEG-2 LSF / MPEG-2.5 (ISO/IEC 13818-3): NOT the reference.  Constants restated here independently of
+ * pdmp3_amd/csrc/lsf_tables.h; what pins both is FFmpeg's decode of the same streams (tests/golden/lsf_*.npz). ---- */
+extern int g_orc_24k_330;
+static const unsigned lsf_rates[9] = {44100, 48000, 32000, 22050, 24000, 16000, 11025, 12000, 8000};
+static const unsigned lsf_bitrates[15] = {0, 8000, 16000, 24000, 32000, 40000, 48000, 56000, 64000, 80000, 96000, 112000, 128000, 144000, 160000};
+static const uint16_t lsf_l[6][23] = {
+  {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576},
+  {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 114, 136, 162, 194, 232, 278, 332, 394, 464, 540, 576},
+  {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576},
+  {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576},
+  {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576},
+  {0, 12, 24, 36, 48, 60, 72, 88, 108, 132, 160, 192, 232, 280, 336, 400, 476, 566, 568, 570, 572, 574, 576},
+};
+/* nr_of_sfb_block (13818-3 2.4.3.2): [class][0 long, 1 short, 2 mixed][partition] */
+static const uint8_t lsf_nsfb[6][3][4] = {
+  {{6, 5, 5, 5}, {9, 9, 9, 9}, {6, 9, 9, 9}},
+  {{6, 5, 7, 3}, {9, 9, 12, 6}, {6, 9, 12, 6}},
+  {{11, 10, 0, 0}, {18, 18, 0, 0}, {15, 18, 0, 0}},
+  {{7, 7, 7, 0}, {12, 12, 12, 0}, {6, 15, 12, 0}},
+  {{6, 6, 6, 3}, {12, 9, 9, 6}, {6, 12, 9, 6}},
+  {{8, 8, 5, 0}, {15, 12, 9, 0}, {6, 18, 9, 0}},
+};
 
 orc_stream* orc_stream_new(void) { return (orc_stream*)calloc(1, sizeof(orc_stream)); }
 void orc_stream_delete(orc_stream* s) { free(s); }
@@ -123,11 +149,19 @@ static int read_header(orc_stream* s) {
   unsigned b1 = get_byte(s), b2 = get_byte(s), b3 = get_byte(s), b4 = get_byte(s);
   if (b1 == O_EOF || b2 == O_EOF || b3 == O_EOF || b4 == O_EOF) return ORC_ERR;
   unsigned header = (b1 << 24) | (b2 << 16) | (b3 << 8) | b4;
-  while ((header & 0xfff00000u) != 0xfff00000u) {
+  /* (ORC_ISO_LSF: eleven sync bits, so that MPEG-2.5's 0xFFE + ID 0 is seen; 0xFFE + ID 1 is reserved and fails below) */
+  const unsigned sync = (s->iso & ORC_ISO_LSF) ? 0xffe00000u : 0xfff00000u;
+  while ((header & sync) != sync) {
     b1 = b2; b2 = b3; b3 = b4;
     b4 = get_byte(s);
     if (b4 == O_EOF) return ORC_ERR;
     header = (b1 << 24) | (b2 << 16) | (b3 << 8) | b4;
+  }
+  s->h_ver = 0;
+  if (s->iso & ORC_ISO_LSF) {
+    const unsigned v = (header >> 19) & 3;              /* 11 MPEG-1, 10 MPEG-2, 00 MPEG-2.5, 01 reserved */
+    if (v == 1) { s->h_layer = 0; return ORC_ERR; }
+    s->h_ver = v == 3 ? 0 : v == 2 ? 1 : 2;
   }
   s->h_id = (header & 0x00080000u) >> 19;
   s->h_layer = (header & 0x00060000u) >> 17;
@@ -137,7 +171,7 @@ static int read_header(orc_stream* s) {
   s->h_padding = (header & 0x00000200u) >> 9;
   s->h_mode = (header & 0x000000c0u) >> 6;
   s->h_mode_ext = (header & 0x00000030u) >> 4;
-  if (s->h_id != 1) return ORC_ERR;
+  if (s->h_id != 1 && !s->h_ver) return ORC_ERR;
   if (s->h_bitrate_index == 0) return ORC_ERR;
   if (s->h_bitrate_index == 15) return ORC_ERR;
   if (s->h_sfreq == 3) return ORC_ERR;
@@ -177,6 +211,7 @@ static unsigned side_bits(orc_stream* s, unsigned n) {
 }
 
 static unsigned frame_size(const orc_stream* s) {   /* P:1135-1138 */
+  if (s->h_ver) return 72 * lsf_bitrates[s->h_bitrate_index] / lsf_rates[3 * s->h_ver + s->h_sfreq] + s->h_padding;   /* 13818-3: 576 samples a frame */
   return (144 * ot_bitrates[(s->h_layer - 1) * 15 + s->h_bitrate_index]) / ot_sfreq[s->h_sfreq] + s->h_padding;
 }
 
@@ -186,6 +221,40 @@ static int read_audio_l3(orc_stream* s) {
   unsigned framesize = frame_size(s);
   if (framesize > 2000) return ORC_ERR;
   unsigned sideinfo_size = (nch == 1) ? 17 : 32;
+  if (s->h_ver) {
+    /* 13818-3 2.4.1.7: one granule; main_data_begin 8 bits, 1 / 2 private bits, no scfsi; scalefac_compress 9 bits, no
+     * preflag bit (scalefac_compress >= 500 implies it: read_main_l3) */
+    sideinfo_size = (nch == 1) ? 9 : 17;
+    if (get_bytes(s, sideinfo_size, s->side_vec) == ORC_OK) { s->side_ptr = 0; s->side_idx = 0; }
+    s->main_data_begin = side_bits(s, 8);
+    (void)side_bits(s, nch == 1 ? 1 : 2);
+    for (unsigned ch = 0; ch < nch; ch++) {
+      for (unsigned b = 0; b < 4; b++) s->scfsi[ch][b] = 0;
+      s->part2_3_length[0][ch] = side_bits(s, 12);
+      s->big_values[0][ch] = side_bits(s, 9);
+      s->global_gain[0][ch] = side_bits(s, 8);
+      s->scalefac_compress[0][ch] = side_bits(s, 9);
+      s->win_switch_flag[0][ch] = side_bits(s, 1);
+      if (s->win_switch_flag[0][ch] == 1) {
+        s->block_type[0][ch] = side_bits(s, 2);
+        s->mixed_block_flag[0][ch] = side_bits(s, 1);
+        for (unsigned r = 0; r < 2; r++) s->table_select[0][ch][r] = side_bits(s, 5);
+        for (unsigned w = 0; w < 3; w++) s->subblock_gain[0][ch][w] = side_bits(s, 3);
+        s->region0_count[0][ch] = (s->block_type[0][ch] == 2 && s->mixed_block_flag[0][ch] == 0) ? 8 : 7;
+        s->region1_count[0][ch] = 20 - s->region0_count[0][ch];
+      } else {
+        for (unsigned r = 0; r < 3; r++) s->table_select[0][ch][r] = side_bits(s, 5);
+        s->region0_count[0][ch] = side_bits(s, 4);
+        s->region1_count[0][ch] = side_bits(s, 3);
+        s->block_type[0][ch] = 0;
+        s->mixed_block_flag[0][ch] = 0;
+      }
+      s->preflag[0][ch] = 0;
+      s->scalefac_scale[0][ch] = side_bits(s, 1);
+      s->count1table_select[0][ch] = side_bits(s, 1);
+    }
+    return ORC_OK;
+  }
   /* P:1576-1586 Get_Sideinfo: pointers are reset only when all bytes arrived */
   if (get_bytes(s, sideinfo_size, s->side_vec) == ORC_OK) { s->side_ptr = 0; s->side_idx = 0; }
   s->main_data_begin = side_bits(s, 9);
@@ -265,7 +334,7 @@ static int huffman_decode(orc_stream* s, unsigned table, int* x, int* y, int* v,
   const uint16_t* ht = &ot_huff_nodes[ot_huff_main[table].off];
   /* ORC_ISO_TABLE33: the tree the standard means by table 33 -- the last 31 nodes of the array (P:504-515); the
    * reference's g_huffman_main[33] points at node 2261 instead (P:569, H1) */
-  if (table == 33 && (s->iso & ORC_ISO_TABLE33)) ht = &ot_huff_nodes[2804 - 31];
+  if (table == 33 && ((s->iso & ORC_ISO_TABLE33) || s->h_ver)) ht = &ot_huff_nodes[2804 - 31];
   do {
     if ((ht[point] & 0xff00) == 0) {
       error = 0;
@@ -306,9 +375,23 @@ static void read_huffman(orc_stream* s, unsigned part_2_start, unsigned gr, unsi
 #define PUT(pos, val) do { if ((pos) < 576) is[(pos)] = (val); } while (0)
   if (s->part2_3_length[gr][ch] == 0) {
     for (is_pos = 0; is_pos < 576; is_pos++) is[is_pos] = 0;
+    if (s->h_ver) s->count1[gr][ch] = 0;                 /* (LSF: nothing of the reference's to reproduce) */
     return;                                              /* count1 stays stale (H6) */
   }
   bit_pos_end = part_2_start + s->part2_3_length[gr][ch] - 1;
+  if (s->h_ver) {
+    /* LSF: the same rule over the LSF band tables; nothing lies beyond band 22 (no H7); at 8 kHz three short bands are 72 lines */
+    uint16_t lbuf[23];
+    memcpy(lbuf, lsf_l[3 * (s->h_ver - 1) + s->h_sfreq], sizeof lbuf);
+    if (s->h_ver == 1 && s->h_sfreq == 1 && g_orc_24k_330) lbuf[18] = 330;                  /* (tests only: pdmp3_oracle.c sfb_l) */
+    const uint16_t* l = lbuf;
+    if (s->win_switch_flag[gr][ch] == 1 && s->block_type[gr][ch] == 2) { r1 = (s->h_ver == 2 && s->h_sfreq == 2) ? 72 : 36; r2 = 576; }
+    else {
+      unsigned i1 = s->region0_count[gr][ch] + 1, i2 = s->region0_count[gr][ch] + s->region1_count[gr][ch] + 2;
+      r1 = l[i1 > 22 ? 22 : i1];
+      r2 = l[i2 > 22 ? 22 : i2];
+    }
+  } else
   if (s->win_switch_flag[gr][ch] == 1 && s->block_type[gr][ch] == 2) { r1 = 36; r2 = 576; }
   else {
     r1 = ot_sfb[s->h_sfreq * 37 + s->region0_count[gr][ch] + 1];
@@ -346,10 +429,46 @@ static int read_main_l3(orc_stream* s) {
   unsigned framesize = frame_size(s);
   if (framesize > 2000) return ORC_ERR;
   unsigned sideinfo_size = (nch == 1) ? 17 : 32;
+  if (s->h_ver) sideinfo_size = (nch == 1) ? 9 : 17;
   unsigned main_data_size = framesize - sideinfo_size - 4;
   if (s->h_protection == 0) main_data_size -= 2;
   int res = get_main_data(s, main_data_size, s->main_data_begin);
   if (res != ORC_OK) return res;
+  if (s->h_ver) {
+    /* 13818-3 2.4.3.2: scalefac_compress -> four slen and, by block shape, four partition sizes; the scalefactors come
+     * in band order (short: band by band, window by window; mixed: 6 long bands, then short bands 3..11) */
+    for (unsigned ch = 0; ch < nch; ch++) {
+      unsigned part_2_start = main_pos(s);
+      const unsigned sfc = s->scalefac_compress[0][ch];
+      const int right = (s->h_mode == 1 && (s->h_mode_ext & 1) && ch == 1);
+      unsigned slen[4], cls;
+      if (right) {
+        const unsigned h = sfc >> 1;
+        if (h < 180) { slen[0] = h / 36; slen[1] = (h % 36) / 6; slen[2] = h % 6; slen[3] = 0; cls = 3; }
+        else if (h < 244) { slen[0] = ((h - 180) % 64) >> 4; slen[1] = ((h - 180) % 16) >> 2; slen[2] = (h - 180) % 4; slen[3] = 0; cls = 4; }
+        else { slen[0] = (h - 244) / 3; slen[1] = (h - 244) % 3; slen[2] = 0; slen[3] = 0; cls = 5; }
+      } else if (sfc < 400) { slen[0] = (sfc >> 4) / 5; slen[1] = (sfc >> 4) % 5; slen[2] = (sfc % 16) >> 2; slen[3] = sfc % 4; cls = 0; }
+      else if (sfc < 500) { slen[0] = ((sfc - 400) >> 2) / 5; slen[1] = ((sfc - 400) >> 2) % 5; slen[2] = (sfc - 400) % 4; slen[3] = 0; cls = 1; }
+      else { slen[0] = (sfc - 500) / 3; slen[1] = (sfc - 500) % 3; slen[2] = 0; slen[3] = 0; cls = 2; s->preflag[0][ch] = 1; }
+      const int shortb = (s->win_switch_flag[0][ch] != 0 && s->block_type[0][ch] == 2), mixed = shortb && s->mixed_block_flag[0][ch] != 0;
+      const uint8_t* nsf = lsf_nsfb[cls][shortb ? (mixed ? 2 : 1) : 0];
+      if (ch == 1) { s->lsf_class1 = cls; for (unsigned k = 0; k < 4; k++) s->lsf_slen1[k] = slen[k]; }
+      unsigned vals[40], n = 0;
+      for (unsigned k = 0; k < 4; k++)
+        for (unsigned i = 0; i < nsf[k]; i++) vals[n++] = main_bits(s, slen[k]);
+      for (; n < 40; n++) vals[n] = 0;
+      for (unsigned sfb = 0; sfb < 21; sfb++) s->scalefac_l[0][ch][sfb] = 0;
+      for (unsigned sfb = 0; sfb < 12; sfb++) for (unsigned w = 0; w < 3; w++) s->scalefac_s[0][ch][sfb][w] = 0;
+      if (!shortb) for (unsigned sfb = 0; sfb < 21; sfb++) s->scalefac_l[0][ch][sfb] = vals[sfb];
+      else if (!mixed) { for (unsigned sfb = 0; sfb < 12; sfb++) for (unsigned w = 0; w < 3; w++) s->scalefac_s[0][ch][sfb][w] = vals[sfb * 3 + w]; }
+      else {
+        for (unsigned sfb = 0; sfb < 6; sfb++) s->scalefac_l[0][ch][sfb] = vals[sfb];
+        for (unsigned sfb = 3; sfb < 12; sfb++) for (unsigned w = 0; w < 3; w++) s->scalefac_s[0][ch][sfb][w] = vals[6 + (sfb - 3) * 3 + w];
+      }
+      read_huffman(s, part_2_start, 0, ch);
+    }
+    return ORC_OK;
+  }
   for (unsigned gr = 0; gr < 2; gr++)
     for (unsigned ch = 0; ch < nch; ch++) {
       unsigned part_2_start = main_pos(s);
@@ -411,8 +530,15 @@ static void frame_to_records(const orc_stream* s, int16_t* spectra, pdmp3_gc_sid
       int16_t* sp = spectra + (gr * 2 + ch) * 576;
       r->frame = (uint8_t)((s->h_sfreq & 3) | ((s->h_mode & 3) << PDMP3_FR_MODE_SHIFT) |
                            ((s->h_mode_ext & 3) << PDMP3_FR_MODEEXT_SHIFT) | (reset ? PDMP3_FR_RESET : 0));
+      r->lsf = (uint8_t)s->h_ver;
       memset(sp, 0, 576 * sizeof *sp);
       if (ch >= nch) continue;
+      if (s->h_ver && gr == 1) continue;                 /* an LSF frame has one granule: these records are not read */
+      if (s->h_ver && ch == 1 && s->h_mode == 1 && (s->h_mode_ext & 1)) {
+        const int shortb = (s->win_switch_flag[0][1] != 0 && s->block_type[0][1] == 2), mixed = shortb && s->mixed_block_flag[0][1] != 0;
+        if (s->scalefac_compress[0][1] & 1) r->lsf |= PDMP3_LSF_IS_SCALE;
+        for (unsigned k = 0; k < 4; k++) { r->lsf_slen[k] = (uint8_t)s->lsf_slen1[k]; r->lsf_nsfb[k] = lsf_nsfb[s->lsf_class1][shortb ? (mixed ? 2 : 1) : 0][k]; }
+      }
       for (unsigned i = 0; i < 576; i++) sp[i] = (int16_t)s->is[gr][ch][i];
       r->count1 = (uint16_t)s->count1[gr][ch];
       r->global_gain = (uint8_t)s->global_gain[gr][ch];
@@ -437,8 +563,8 @@ static void frame_to_records(const orc_stream* s, int16_t* spectra, pdmp3_gc_sid
         r->scalefac_l[21] = (uint8_t)s->scalefac_s[0][0][0][0];
         for (unsigned w = 0; w < 3; w++) r->scalefac_s[12][w] = PDMP3_SF_PEEK;
       }
-      if (s->iso & ORC_ISO_SF21) r->scalefac_l[21] = 0;
-      if (s->iso & ORC_ISO_SF12) for (unsigned w = 0; w < 3; w++) r->scalefac_s[12][w] = 0;
+      if ((s->iso & ORC_ISO_SF21) || s->h_ver) r->scalefac_l[21] = 0;
+      if ((s->iso & ORC_ISO_SF12) || s->h_ver) for (unsigned w = 0; w < 3; w++) r->scalefac_s[12][w] = 0;
     }
   for (unsigned g = 0; g < 4; g++)
     sd[g].iso = (uint8_t)(((s->iso & ORC_ISO_MS_BOUND) ? PDMP3_GC_ISO_MS_ALL : 0) | ((s->iso & ORC_ISO_IS_SHORT) ? PDMP3_GC_ISO_IS_SHORT : 0) |
@@ -466,12 +592,13 @@ static void decode_current_frame(orc_stream* s) {
 static void convert_frame_s16(orc_stream* s, unsigned char* outbuf, size_t buflen, size_t* done) {
   unsigned nch = (s->h_mode == 3) ? 1 : 2;
   unsigned framesz = 2 * nch;
+  const unsigned per_frame = s->h_ver ? 576 : 2 * 576;    /* (an LSF frame is one granule) */
   size_t nsamps = buflen / framesz;
-  if (nsamps > (2 * 576 - s->ostart)) nsamps = 2 * 576 - s->ostart;
+  if (nsamps > (per_frame - s->ostart)) nsamps = per_frame - s->ostart;
   *done = nsamps * framesz;
   memcpy(outbuf, (const unsigned char*)s->frame_pcm + (size_t)s->ostart * framesz, nsamps * framesz);
   s->ostart += (unsigned)nsamps;
-  if (s->ostart == 2 * 576) s->ostart = 0;
+  if (s->ostart == per_frame) s->ostart = 0;
 }
 
 /* P:2431-2481 */
@@ -530,7 +657,7 @@ int orc_stream_decode(orc_stream* s, const unsigned char* in, size_t insize, uns
 int orc_stream_getformat(orc_stream* s, long* rate, int* channels, int* enc) {
   if (!(s && rate && channels && enc)) return ORC_ERR;
   *enc = ENC_SIGNED_16;
-  *rate = (long)ot_sfreq[s->h_sfreq];
+  *rate = s->h_ver ? (long)lsf_rates[3 * s->h_ver + s->h_sfreq] : (long)ot_sfreq[s->h_sfreq];
   *channels = (s->h_mode == 3) ? 1 : 2;
   s->new_header = -1;
   return ORC_OK;

@@ -17,7 +17,7 @@ SIDE_DTYPE = np.dtype([
     ("count1", "<u2"), ("global_gain", "u1"), ("flags", "u1"),
     ("subblock_gain", "u1", (3,)), ("frame", "u1"),
     ("scalefac_l", "u1", (22,)), ("scalefac_s", "u1", (13, 3)),
-    ("iso", "u1"), ("reserved", "u1", (58,)),
+    ("iso", "u1"), ("lsf", "u1"), ("lsf_slen", "u1", (4,)), ("lsf_nsfb", "u1", (4,)), ("reserved", "u1", (49,)),
 ])
 FRAME_SPECTRA_INT16 = 4 * 576
 FRAME_PCM_INT16 = 2304

@@ -17,6 +17,7 @@
 
 #include "../../include/pdmp3_packer.h"
 #include "../csrc/tables_data.h"
+#include "../csrc/lsf_tables.h"
 
 /* ---------- rng ---------- */
 static uint64_t rng_state;
@@ -66,6 +67,11 @@ typedef struct {
 } gc_side;
 
 static const uint16_t* sfb_l_of(int f) { return f == 0 ? kSfbLong0 : f == 1 ? kSfbLong1 : kSfbLong2; }
+/* version 0 = MPEG-1 (the reference's streams), 1 = MPEG-2 LSF, 2 = MPEG-2.5: lsf_tables.h */
+static const uint16_t* sfb_l_v(const pk_cfg* c) { return c->version ? kLsfSfbLong[(c->version - 1) * 3 + c->sfreq] : sfb_l_of(c->sfreq); }
+static const uint16_t* sfb_s_v(const pk_cfg* c) {
+  return c->version ? kLsfSfbShort[(c->version - 1) * 3 + c->sfreq] : c->sfreq == 0 ? kSfbShort0 : c->sfreq == 1 ? kSfbShort1 : kSfbShort2;
+}
 
 /* writes one granule-channel's main data (scalefactors + Huffman) into `w`,
  * using at most `budget` bits; fills the side-info fields it decides */
@@ -79,7 +85,7 @@ static unsigned draw_block_type(const pk_cfg* c) {
  * caller (iso_strict: scfsi depends on both granules' types; pre_mixed >= 0 likewise).  line_cap: no line at or above it is coded (the right
  * channel of an intensity-stereo granule: is_cut_pct). */
 static void gen_gc(const pk_cfg* c, bw* w, gc_side* s, unsigned budget, int gr, const unsigned scfsi[4], unsigned* used,
-                   int pre_bt, int pre_mixed, unsigned line_cap) {
+                   int pre_bt, int pre_mixed, unsigned line_cap, int is_right) {
   const size_t start = w->bits;
   memset(s, 0, sizeof *s);
   const unsigned bt = pre_bt < 0 ? draw_block_type(c) : (unsigned)pre_bt;
@@ -99,6 +105,31 @@ static void gen_gc(const pk_cfg* c, bw* w, gc_side* s, unsigned budget, int gr, 
     return;
   }
   /* scalefactors */
+  if (c->version) {
+    /* LSF (13818-3 2.4.3.2): 9-bit scalefac_compress -> four slen and the partition sizes of lsf_tables.h; no scfsi, no
+     * preflag bit (implied by scalefac_compress >= 500).  is_right: channel 1 of an intensity-stereo frame has its own
+     * classes, and its scalefactors are intensity positions: the largest value of a partition means "not intensity
+     * coded" (which not every decoder honours: iso_strict streams do not use it) */
+    uint8_t slen[4];
+    int pf, cls, again;
+    const int shape = (s->win_switch && s->block_type == 2) ? (s->mixed ? 2 : 1) : 0;
+    do {
+      s->scalefac_compress = rndn(512);
+      cls = lsf_slen_of(s->scalefac_compress, is_right, slen, &pf);
+      again = c->narrow_scales && (slen[0] > 3 || slen[1] > 3 || slen[2] > 3 || slen[3] > 3);
+      /* iso_strict: no intensity position that means "not intensity coded" -- the largest value of its slen, which for
+       * slen 0 is the only value there is (FFmpeg, the fixtures' decoder, reads those as positions) */
+      if (is_right && c->iso_strict)
+        for (int k = 0; k < 4; k++) if (kLsfNsfb[cls][shape][k] && !slen[k]) again = 1;
+    } while (again);
+    s->preflag = (unsigned)pf;
+    for (int k = 0; k < 4; k++)
+      for (int i = 0; i < kLsfNsfb[cls][shape][k]; i++) {
+        unsigned range = 1u << slen[k];
+        if (is_right && c->iso_strict && range > 1) range -= 1;
+        bw_put(w, rndn(range), slen[k]);
+      }
+  } else {
   const unsigned slen1 = kSlen[s->scalefac_compress * 2], slen2 = kSlen[s->scalefac_compress * 2 + 1];
   if (s->win_switch && s->block_type == 2) {
     unsigned first = 0;
@@ -113,6 +144,7 @@ static void gen_gc(const pk_cfg* c, bw* w, gc_side* s, unsigned budget, int gr, 
       for (int k = lo[b]; k < lo[b + 1]; k++) bw_put(w, rndn(1u << nb), nb);
     }
   }
+  }
   /* tables / regions */
   if (s->win_switch) {
     s->region0 = (s->block_type == 2 && !s->mixed) ? 8 : 7;
@@ -126,10 +158,10 @@ static void gen_gc(const pk_cfg* c, bw* w, gc_side* s, unsigned budget, int gr, 
   }
   for (int k = 0; k < 3; k++) if (s->table_select[k] == 4 || s->table_select[k] == 14) s->table_select[k] = rndn(2) ? 0 : 15;
   unsigned r1, r2;
-  if (s->win_switch && s->block_type == 2) { r1 = 36; r2 = 576; }
+  if (s->win_switch && s->block_type == 2) { r1 = (c->version == 2 && c->sfreq == 2) ? 72 : 36; r2 = 576; }   /* (8 kHz: three short bands are 72 lines) */
   else {
-    const uint16_t* l = sfb_l_of(c->sfreq);
-    const uint16_t* sh = c->sfreq == 0 ? kSfbShort0 : c->sfreq == 1 ? kSfbShort1 : kSfbShort2;
+    const uint16_t* l = sfb_l_v(c);
+    const uint16_t* sh = sfb_s_v(c);
     const unsigned i1 = s->region0 + 1, i2 = s->region0 + s->region1 + 2;
     r1 = i1 < 23 ? l[i1] : sh[i1 - 23];
     r2 = i2 < 23 ? l[i2] : sh[i2 - 23];
@@ -193,7 +225,9 @@ size_t pk_generate(const pk_cfg* c, int n_frames, uint8_t* out, size_t cap) {
   build_enc();
   rng_state = c->seed;
   const int nch = c->mode == 3 ? 1 : 2;
-  const unsigned side_bytes = nch == 1 ? 17 : 32;
+  const unsigned side_bytes = c->version ? (nch == 1 ? 9 : 17) : (nch == 1 ? 17 : 32);
+  const int ngr = c->version ? 1 : 2;
+  if (c->version < 0 || c->version > 2) return 0;
   /* main-data byte stream of all frames, and where each frame's own area starts */
   const size_t md_cap = (size_t)n_frames * 1500 + 4096;
   uint8_t* md = (uint8_t*)calloc(md_cap, 1);
@@ -208,20 +242,25 @@ size_t pk_generate(const pk_cfg* c, int n_frames, uint8_t* out, size_t cap) {
   for (int f = 0; f < n_frames; f++) {
     unsigned bri = (unsigned)c->bitrate_index;
     if (c->vbr) bri = (unsigned)c->vbr_lo + rndn((unsigned)(c->vbr_hi - c->vbr_lo + 1));
-    const unsigned br = kBitratesL3[bri], sf = kSampleRates[c->sfreq];
+    const unsigned br = c->version ? kLsfBitrates[bri] : kBitratesL3[bri];
+    const unsigned sf = c->version ? kLsfSampleRates[3 * c->version + c->sfreq] : kSampleRates[c->sfreq];
+    const unsigned spf = c->version ? 72u : 144u;       /* 576 samples a frame with LSF: 72 br / sf bytes (13818-3 2.4.3.1) */
     unsigned pad = 0;
-    pad_rest += (144u * br) % sf;
+    pad_rest += (spf * br) % sf;
     if (pad_rest >= sf) { pad = 1; pad_rest -= sf; }
-    const unsigned fbytes = 144u * br / sf + pad;
+    const unsigned fbytes = spf * br / sf + pad;
     const unsigned msize = fbytes - 4 - side_bytes - (c->crc ? 2 : 0);
     fsize[f] = msize;
-    hdrs[f] = 0xFFF00000u | (1u << 19) | (1u << 17) | ((c->crc ? 0u : 1u) << 16) | (bri << 12) |
+    /* sync + ID: 0xFFF + 1 = MPEG-1; 0xFFF + 0 = MPEG-2 LSF; 0xFFE + 0 = "MPEG-2.5" (eleven sync bits, 00) */
+    const unsigned sync_id = c->version == 0 ? (0xFFF00000u | (1u << 19)) : c->version == 1 ? 0xFFF00000u : 0xFFE00000u;
+    hdrs[f] = sync_id | (1u << 17) | ((c->crc ? 0u : 1u) << 16) | (bri << 12) |
               ((unsigned)c->sfreq << 10) | (pad << 9) | ((unsigned)c->mode << 6) | ((unsigned)c->mode_ext << 4) | (1u << 2);
     /* where may this frame's data start? */
     size_t pos_bytes = (w.bits + 7) >> 3;
     size_t start = pos_bytes;
     if (!c->reservoir && start < area_start) start = area_start;
-    if (area_start > 511 && start < area_start - 511) start = area_start - 511;
+    const size_t back = c->version ? 255 : 511;         /* main_data_begin: 9 bits, 8 with LSF */
+    if (area_start > back && start < area_start - back) start = area_start - back;
     if (f == 0) start = 0;
     const unsigned begin = (unsigned)(area_start - start);
     w.bits = start * 8;
@@ -235,7 +274,7 @@ size_t pk_generate(const pk_cfg* c, int n_frames, uint8_t* out, size_t cap) {
     if (c->iso_strict) {
       /* ISO 11172-3 2.4.2.7: scfsi is 0 when a granule of the channel has block_type 2 (decoders disagree about
        * what a copy from a short-block granule means); intensity stereo: both channels share the block shape */
-      for (int gr = 0; gr < 2; gr++) {
+      for (int gr = 0; gr < ngr; gr++) {
         /* ... and the window sequence is the standard's (2.4.3.4.10.3: long -> start -> short ... -> stop -> long):
          * decoders may rely on it (FFmpeg's short-block overlap assumes the six zero samples a start window ends with) */
         for (int ch = 0; ch < nch; ch++) {
@@ -245,7 +284,7 @@ size_t pk_generate(const pk_cfg* c, int n_frames, uint8_t* out, size_t cap) {
           else pre_bt[gr][ch] = p < (unsigned)(c->block_pct[0] + c->block_pct[3]) ? 3 : 2;
           /* one mixed_block_flag per run of short blocks: a mixed granule leaves a long window's tail in subbands
            * 0-1, which a pure short granule behind it would have to add under its first two windows */
-          if (pre_bt[gr][ch] == 1) run_mixed[ch] = (int)rndn(100) < c->mixed_pct;
+          if (pre_bt[gr][ch] == 1) run_mixed[ch] = (int)rndn(100) < c->mixed_pct && !(c->version == 2 && c->sfreq == 2);   /* (8 kHz: no mixed blocks, lsf_tables.h) */
           pre_mixed[gr][ch] = run_mixed[ch];
         }
         /* joint stereo: one window shape for both channels (the reference rotates M/S after its reorder, the
@@ -257,25 +296,31 @@ size_t pk_generate(const pk_cfg* c, int n_frames, uint8_t* out, size_t cap) {
         if (pre_bt[0][ch] == 2 || pre_bt[1][ch] == 2) for (int b = 0; b < 4; b++) scfsi[ch][b] = 0;
     }
     unsigned left = avail;
-    for (int gr = 0; gr < 2; gr++)
+    for (int gr = 0; gr < ngr; gr++)
       for (int ch = 0; ch < nch; ch++) {
-        const unsigned share = left / (unsigned)((2 - gr) * nch - ch);
+        const unsigned share = left / (unsigned)((ngr - gr) * nch - ch);
         unsigned budget = share > 4095 ? 4095 : share, used = 0;
         unsigned line_cap = 576;
         if (ch == 1 && c->is_cut_pct > 0 && (int)rndn(100) < c->is_cut_pct) line_cap = 2 * rndn(240);
-        gen_gc(c, &w, &gs[gr][ch], budget, gr, scfsi[ch], &used, pre_bt[gr][ch], pre_mixed[gr][ch], line_cap);
+        gen_gc(c, &w, &gs[gr][ch], budget, gr, scfsi[ch], &used, pre_bt[gr][ch], pre_mixed[gr][ch], line_cap,
+               c->version && ch == 1 && c->mode == 1 && (c->mode_ext & 1));
         left -= used;
       }
     /* side info */
     bw sw = {sides + (size_t)f * 40, 40, 0};
-    bw_put(&sw, begin, 9);
-    bw_put(&sw, 0, nch == 1 ? 5 : 3);
-    for (int ch = 0; ch < nch; ch++) for (int b = 0; b < 4; b++) bw_put(&sw, scfsi[ch][b], 1);
-    for (int gr = 0; gr < 2; gr++)
+    if (c->version) {                       /* 13818-3 2.4.1.7: 8 + 1 (mono) / 2 (stereo) private bits, no scfsi */
+      bw_put(&sw, begin, 8);
+      bw_put(&sw, 0, nch == 1 ? 1 : 2);
+    } else {
+      bw_put(&sw, begin, 9);
+      bw_put(&sw, 0, nch == 1 ? 5 : 3);
+      for (int ch = 0; ch < nch; ch++) for (int b = 0; b < 4; b++) bw_put(&sw, scfsi[ch][b], 1);
+    }
+    for (int gr = 0; gr < ngr; gr++)
       for (int ch = 0; ch < nch; ch++) {
         const gc_side* s = &gs[gr][ch];
         bw_put(&sw, s->part2_3_length, 12); bw_put(&sw, s->big_values, 9); bw_put(&sw, s->global_gain, 8);
-        bw_put(&sw, s->scalefac_compress, 4); bw_put(&sw, s->win_switch, 1);
+        bw_put(&sw, s->scalefac_compress, c->version ? 9 : 4); bw_put(&sw, s->win_switch, 1);
         if (s->win_switch) {
           bw_put(&sw, s->block_type, 2); bw_put(&sw, s->mixed, 1);
           bw_put(&sw, s->table_select[0], 5); bw_put(&sw, s->table_select[1], 5);
@@ -284,7 +329,8 @@ size_t pk_generate(const pk_cfg* c, int n_frames, uint8_t* out, size_t cap) {
           for (int k = 0; k < 3; k++) bw_put(&sw, s->table_select[k], 5);
           bw_put(&sw, s->region0, 4); bw_put(&sw, s->region1, 3);
         }
-        bw_put(&sw, s->preflag, 1); bw_put(&sw, s->scalefac_scale, 1); bw_put(&sw, s->count1table, 1);
+        if (!c->version) bw_put(&sw, s->preflag, 1);
+        bw_put(&sw, s->scalefac_scale, 1); bw_put(&sw, s->count1table, 1);
       }
     area_start += msize;
   }

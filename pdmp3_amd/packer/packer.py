@@ -14,7 +14,7 @@ class Cfg(C.Structure):
                 ("crc", C.c_int), ("block_pct", C.c_int * 4), ("mixed_pct", C.c_int), ("reservoir", C.c_int),
                 ("table33_pct", C.c_int), ("fill_pct", C.c_int), ("big_pct", C.c_int),
                 ("gain_lo", C.c_int), ("gain_hi", C.c_int), ("iso_strict", C.c_int), ("is_cut_pct", C.c_int),
-                ("narrow_scales", C.c_int)]
+                ("narrow_scales", C.c_int), ("version", C.c_int)]
 
 
 _lib = None
@@ -32,11 +32,12 @@ def _load():
 
 def generate(n_frames, seed=1, sfreq=0, mode=1, mode_ext=2, bitrate_index=14, vbr=False, vbr_lo=5, vbr_hi=14,
              crc=False, block_pct=(70, 10, 10, 10), mixed_pct=50, reservoir=True, table33_pct=0, fill_pct=92,
-             big_pct=5, gain=(110, 150), iso_strict=False, is_cut_pct=0, narrow_scales=False) -> bytes:
-    """bitrate_index 14 = 320 kbps, 9 = 128 kbps (Layer III)."""
+             big_pct=5, gain=(110, 150), iso_strict=False, is_cut_pct=0, narrow_scales=False, version=0) -> bytes:
+    """bitrate_index 14 = 320 kbps, 9 = 128 kbps (Layer III, MPEG-1); version 1 / 2 = MPEG-2 LSF / MPEG-2.5 (include/pdmp3_packer.h:
+    other rates and bit rates, 8 .. 160 kbps)."""
     cfg = Cfg(seed, sfreq, mode, mode_ext, bitrate_index, int(vbr), vbr_lo, vbr_hi, int(crc),
               (C.c_int * 4)(*block_pct), mixed_pct, int(reservoir), table33_pct, fill_pct, big_pct, gain[0], gain[1],
-              int(iso_strict), is_cut_pct, int(narrow_scales))
+              int(iso_strict), is_cut_pct, int(narrow_scales), version)
     cap = n_frames * 1500 + 4096
     buf = np.zeros(cap, dtype=np.uint8)
     n = _load().pk_generate(C.byref(cfg), n_frames, buf.ctypes.data_as(C.c_void_p), cap)
