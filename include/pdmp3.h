@@ -100,6 +100,16 @@ int pdmp3_amd_set_encoding(pdmp3_handle* id, int encoding);
 #define PDMP3_ISO_SF12     0x10u
 #define PDMP3_ISO_IS_BOUND 0x20u
 #define PDMP3_ISO_ALL      0x3fu
+/* ... and one more bit that is not about HOW MPEG-1 is decoded but about WHAT is accepted (not part of PDMP3_ISO_ALL):
+ *   PDMP3_ISO_LSF       MPEG-2 LSF (22.05 / 24 / 16 kHz) and "MPEG-2.5" (11.025 / 12 / 8 kHz) Layer III streams (ISO/IEC
+ *                       13818-3) are decoded -- one granule, 576 sample-frames per frame.  The reference returns an error
+ *                       for their headers (pdmp3.c:1293) and so does this library without the bit.  An LSF frame is decoded
+ *                       by the standard throughout (the other switches are implied for it: there is no reference behaviour
+ *                       to reproduce); pinned by FFmpeg's decode of packer streams of all six rates
+ *                       (tests/golden/lsf_*.npz).  pdmp3_read hands out frames of 576 sample-frames then; its "1152 bytes
+ *                       buffered" rule is unchanged.  The whole-stream decoder takes LSF streams with its
+ *                       Huffman stage on the host (include/pdmp3_bulk.h). */
+#define PDMP3_ISO_LSF      0x40u
 int pdmp3_amd_set_quirks(pdmp3_handle* id, unsigned iso_mask);
 
 /* CLI driver: NULL-terminated list of .mp3 paths ("-" = stdin); writes

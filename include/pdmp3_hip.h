@@ -233,6 +233,18 @@ int pdmp3_hip_decode_frames_f32(pdmp3_hip_ctx* ctx,
                                 int chunk_frames,
                                 void* stream);
 
+/* MPEG-2 LSF / MPEG-2.5 frames (pdmp3_gc_side.lsf != 0, above; SURVEY 8f #4 -- nothing in the reference: it rejects the
+ * streams, pdmp3.c:1293).  n_frames consecutive frames of ONE stream, all LSF and all of one channel count; records and
+ * spectra in the usual layout ([n_frames][2][2], of which only [0][ch] is read: an LSF frame is one granule).  The PCM
+ * comes out in stream order, 576 sample-frames per frame: stereo frame f at bytes [f * 2304, + 2304); mono frame f at
+ * byte (f / 2) * 4608 + (f % 2) * 1152, 1152 bytes (a PAIR of mono frames in the first half of a 4608-byte place, like
+ * the granules of an MPEG-1 mono frame).  _f32: the same places counted in floats.  d_state as for
+ * pdmp3_hip_decode_frames, and the same state block: MPEG-1 and LSF launches may follow each other on it. */
+int pdmp3_hip_decode_lsf_frames(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,
+                                int n_frames, void* d_state, int16_t* d_pcm, void* stream);
+int pdmp3_hip_decode_lsf_frames_f32(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,
+                                    int n_frames, void* d_state, float* d_pcm, void* stream);
+
 /* Same, additionally dumping float32 stage outputs for parity tests
  * (d_stages: float [n_frames][2][2][4][576]; stage 0 = after requantize +
  * reorder, 1 = after stereo, 2 = after antialias, 3 = after hybrid synthesis
@@ -301,6 +313,10 @@ int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_frames);
  * int16 again.  Call with nothing in flight: the slots' PCM buffers are re-allocated (9216 bytes per frame for float)
  * and the pdmp3_hip_stream_*pcm accessors return the new ones, to be read as float.  Not for the _to / _bits forms. */
 int pdmp3_hip_stream_set_f32(pdmp3_hip_stream* hs, int on);
+/* The records of the following submits are LSF frames (on != 0: decoded like pdmp3_hip_decode_lsf_frames, PCM in its layout;
+ * the _to forms take row_bytes 2304 for stereo and 1152 for mono frames then) or MPEG-1 frames again (0).  Batches are
+ * homogeneous: the host splits them where the stream changes version or channel count.  Not for the _bits forms. */
+int pdmp3_hip_stream_set_lsf(pdmp3_hip_stream* hs, int on);
 /* undo the slot's latest pdmp3_hip_stream_submit beyond its first keep_frames frames: the carried synthesis state
  * (P:1755, P:1983) becomes what it was after frame keep_frames - 1 of that batch.  Blocks.  (pdmp3_read hands frames
  * out in the reference's order; frames it decoded ahead that the reference turns out not to reach are taken back.) */

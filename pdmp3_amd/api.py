@@ -27,6 +27,7 @@ API_EXPORTS = ["pdmp3_new", "pdmp3_delete", "pdmp3_open_feed", "pdmp3_feed", "pd
                "pdmp3_decode", "pdmp3_getformat", "pdmp3", "pdmp3_amd_set_encoding", "pdmp3_amd_set_quirks"]
 # include/pdmp3.h: the ISO-correct switches
 ISO_TABLE33, ISO_MS_BOUND, ISO_IS_SHORT, ISO_SF21, ISO_SF12, ISO_IS_BOUND, ISO_ALL = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x3f
+ISO_LSF = 0x40            # include/pdmp3.h PDMP3_ISO_LSF: MPEG-2 LSF / MPEG-2.5 streams are decoded (the reference rejects them)
 PDMP3_ENC_SIGNED_16, PDMP3_ENC_FLOAT_32 = 0xD0, 0x200
 
 

@@ -277,8 +277,10 @@ struct ConstBank {
   float isr_l[16];        // is_ratio_l for is_pos 0..6 (P:2166-2172); [7] unused;
   float isr_r[16];        // [8..15]: the reference reads past is_ratios[] (H3) -> defined as t = 0
   float dwin[512];        // g_synth_dtbl (P:740-870)
-  uint16_t sfb_l[3][24];  // g_sf_band_indices[].l (P:879-892), padded
-  uint16_t sfb_s[3][16];  // g_sf_band_indices[].s
+  uint16_t sfb_l[9][24];  // [0..2]: g_sf_band_indices[].l (P:879-892), padded; [3..8]: the LSF rates (lsf_tables.h; not the reference)
+  uint16_t sfb_s[9][16];  // g_sf_band_indices[].s
+  float isr_lsf_l[2][32]; // LSF intensity stereo (13818-3 2.4.3.2): [intensity_scale][is_pos] -> the left channel's factor ...
+  float isr_lsf_r[2][32]; // ... and the right one's: i0^((p + 1) / 2) for the channel p's parity picks, 1 for the other
 };
 
 // (BankPtr, the pointer to the bank, and PD_LAUNDER: top of the file)
@@ -349,8 +351,10 @@ struct LaneRegs {
 // Uniform per-granule facts, decoded from the side records in LDS.
 struct GranuleInfo {
   int fr;                  // the frame's flag byte (PDMP3_FR_*)
-  int nch, sfreq, mode, mode_ext;
-  int iso;                 // PDMP3_GC_ISO_* of the frame's records (0: the reference's behaviour)
+  int nch, sfreq, mode, mode_ext;   // sfreq: 0..2 MPEG-1; 3..8 LSF (3 * version + the frame byte's field: lsf_tables.h)
+  int ver;                 // 0 MPEG-1, 1 MPEG-2 LSF, 2 MPEG-2.5 (pdmp3_gc_side.lsf; granules of an LSF launch come in pairs of FRAMES: engine.hip k_lsf_pair)
+  int lsf_scale;           // LSF: intensity_scale of channel 1
+  int iso;                 // PDMP3_GC_ISO_* of the frame's records (0: the reference's behaviour); all set for LSF
   int count1_0, count1_1, flags0, flags1;
   PD_MFN int flags(int ch) const { return ch ? flags1 : flags0; }
   PD_MFN bool is_short(int ch) const {
@@ -372,6 +376,15 @@ PD_FN GranuleInfo granule_info(const WaveData& L) {
   g.iso = PD_UNIFORM(L.side[0][offsetof(pdmp3_gc_side, iso)]);
   g.sfreq = fr & PDMP3_FR_SFREQ_MASK;
   if (g.sfreq > 2) g.sfreq = 2;
+  const int lsf0 = PD_UNIFORM(L.side[0][offsetof(pdmp3_gc_side, lsf)]);
+  g.ver = lsf0 & PDMP3_LSF_VERSION_MASK;
+  if (g.ver > 2) g.ver = 2;
+  g.lsf_scale = 0;
+  if (g.ver) {                // (wave-uniform; an MPEG-1 granule pays one scalar compare for all of this)
+    g.sfreq += 3 * g.ver;
+    g.iso |= PDMP3_GC_ISO_MS_ALL | PDMP3_GC_ISO_IS_SHORT | PDMP3_GC_ISO_IS_STD;     // no reference behaviour exists for LSF: the standard's
+    g.lsf_scale = (PD_UNIFORM(L.side[1][offsetof(pdmp3_gc_side, lsf)]) & PDMP3_LSF_IS_SCALE) ? 1 : 0;
+  }
   g.mode = (fr & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT;
   g.mode_ext = (fr & PDMP3_FR_MODEEXT_MASK) >> PDMP3_FR_MODEEXT_SHIFT;
   g.nch = (g.mode == 3) ? 1 : 2;
@@ -562,7 +575,7 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
   const int cmin = (g.iso & PDMP3_GC_ISO_MS_ALL) ? 576 : (g.count1_0 > g.count1_1 ? g.count1_1 : g.count1_0);   // P:1920 (H2): the smaller; ISO switch: every line
   const int kind0 = g.kind(0), kind1 = g.kind(1);
   if (FAST && !DUMP && NI == 9) {
-    if (kind0 == 0 && (g.nch == 1 || kind1 == 0) && !is) {     // wave-uniform
+    if (kind0 == 0 && (g.nch == 1 || kind1 == 0) && !is && g.ver == 0) {     // wave-uniform (the fast path's band addresses are MPEG-1's)
       ph_requant_long<TG, SCALES>(lane, L, S, T, g);
       return;
     }
@@ -624,8 +637,9 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
   // blocks) is intensity coded when the RIGHT channel holds no non-zero value in it or above it and the right channel's
   // scalefactor there -- the last band borrows the one below -- is not 7; the block shape is the right channel's.
   const bool is_std = is && (g.iso & PDMP3_GC_ISO_IS_STD);
+  constexpr int kIsNone = 255;
   int ispos[NI];
-  PD_UNROLL for (int i = 0; i < NI; i++) ispos[i] = 7;
+  PD_UNROLL for (int i = 0; i < NI; i++) ispos[i] = kIsNone;
   if (is_std) {
     const uint8_t* sd1 = L.side[1];
     // the last band with a non-zero line: of the long part, and of each window of the short part (as floats: PD_SHFL_XOR)
@@ -656,17 +670,30 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
       const unsigned e = tg ? gtab[kind1 * 576 + d] : S.ltab[kind1][d];
       const int idx = (int)(e >> 10);
       bool coded;
-      int pos;
+      int pos, bi;               // bi: the scalefactor's number in transmission order (LSF: which partition it came in)
       if (idx < 22) {
         coded = !any_short && (float)idx > lastl;
-        pos = sd1[8 + (idx < 21 ? idx : 20)];
+        bi = idx < 21 ? idx : 20;
+        pos = sd1[8 + bi];
       } else {
-        const int b = (idx - 22) / 3, w = (idx - 22) % 3;
+        const int b = (idx - 22) / 3, w = (idx - 22) % 3, bb = b < 12 ? b : 11;
         const float lw = w == 0 ? last0 : (w == 1 ? last1 : last2);
         coded = (float)b > lw;
-        pos = sd1[30 + (b < 12 ? b : 11) * 3 + w];
+        pos = sd1[30 + bb * 3 + w];
+        bi = (kind1 == 2 ? 6 + (bb - 3) * 3 : bb * 3) + w;
       }
-      ispos[i] = (coded && pos < 7) ? pos : 7;
+      if (g.ver) {
+        // 13818-3 2.4.3.2: "not intensity coded" is the largest value the scalefactor's slen holds
+        int acc = 0, ill = 0;
+        bool found = false;
+        PD_UNROLL for (int k = 0; k < 4; k++) {
+          acc += sd1[offsetof(pdmp3_gc_side, lsf_nsfb) + k];
+          const int v = (1 << sd1[offsetof(pdmp3_gc_side, lsf_slen) + k]) - 1;
+          ill = (!found && bi < acc) ? v : ill;
+          found = found || bi < acc;
+        }
+        ispos[i] = (coded && pos != ill) ? (pos & 31) : kIsNone;
+      } else ispos[i] = (coded && pos < 7) ? pos : kIsNone;
     }
   }
   if (ms) {   // P:1921-1928
@@ -674,17 +701,18 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
       const float sum = x0[i] + x1[i], dif = x0[i] - x1[i];
       const float l = (float)((double)sum * 0.70710678118654752440);
       const float r = (float)((double)dif * 0.70710678118654752440);
-      const bool in = PD_LINE(i) < cmin && ispos[i] == 7;
+      const bool in = PD_LINE(i) < cmin && ispos[i] == kIsNone;
       x0[i] = in ? l : x0[i];
       x1[i] = in ? r : x1[i];
     }
   }
   if (is_std) {
     PD_UNROLL for (int i = 0; i < NI; i++) {
-      const float l = cb->isr_l[ispos[i] & 7] * x0[i];
-      const float r = cb->isr_r[ispos[i] & 7] * x0[i];
-      x1[i] = ispos[i] != 7 ? r : x1[i];
-      x0[i] = ispos[i] != 7 ? l : x0[i];
+      const float kl = g.ver ? cb->isr_lsf_l[g.lsf_scale][ispos[i] & 31] : cb->isr_l[ispos[i] & 7];
+      const float kr = g.ver ? cb->isr_lsf_r[g.lsf_scale][ispos[i] & 31] : cb->isr_r[ispos[i] & 7];
+      const float l = kl * x0[i], r = kr * x0[i];
+      x1[i] = ispos[i] != kIsNone ? r : x1[i];
+      x0[i] = ispos[i] != kIsNone ? l : x0[i];
     }
   }
   if (is && !is_std) {   // P:1932-1971; block shape taken from channel 0.  Rare (no common encoder emits it).
@@ -1308,6 +1336,8 @@ struct DecodeArgs {
   unsigned chain_epoch;          // 0: independent chunks (halo), as described above
   unsigned debug_flags;          // tests: PD_DEBUG_FAR_TIMEOUT = every wait for another workgroup gives up at once
   int sf_hint;                   // the sampling frequency the workgroups' line tables are loaded for
+  int n_gran;                    // granules in the batch when that is not 2 n_frames (0 = it is): an LSF launch of an ODD number of
+                                 // frames -- its last record-frame holds one (engine.hip k_lsf_pair; chunk kernels only)
 };
 constexpr unsigned PD_DEBUG_FAR_TIMEOUT = 1u;
 
@@ -1337,7 +1367,9 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   const int f0 = chunk * a.chunk_frames;
   int f1 = state_only ? f0 : f0 + a.chunk_frames;
   if (f1 > a.n_frames) f1 = a.n_frames;
-  const int g_begin = 2 * f0, g_end = 2 * f1;
+  const int g_begin = 2 * f0;
+  int g_end = 2 * f1;
+  if (a.n_gran > 0 && g_end > a.n_gran) g_end = a.n_gran;
   int g_start = 0;
   // the third halo granule is there for ONE thing, the H5 peek two granules later: it is decoded "peek-only"
   // (26 lines, one subband, three IMDCT outputs; ph_peek_tail) unless it is also granule 0 of the batch, whose
@@ -1386,6 +1418,10 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   // trip instead of two before the first granule can start)
   int cur_sfreq = reinterpret_cast<const uint8_t*>(a.side + (size_t)g_first * 2)[7] & PDMP3_FR_SFREQ_MASK;
   if (cur_sfreq > 2) cur_sfreq = 2;
+  {
+    int v = reinterpret_cast<const uint8_t*>(a.side + (size_t)g_first * 2)[offsetof(pdmp3_gc_side, lsf)] & PDMP3_LSF_VERSION_MASK;
+    cur_sfreq += 3 * (v > 2 ? 2 : v);
+  }
 
   PD_PHASE(
     ph_prefetch(lane, R, a.spectra + (size_t)g_first * 1152, a.side + (size_t)g_first * 2);
@@ -1423,7 +1459,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       cur_sfreq = gi.sfreq;
     }
     PD_TICK(0)
-    const bool reset_here = gr == 0 && (gi.fr & PDMP3_FR_RESET);
+    const bool reset_here = (gr == 0 || gi.ver) && (gi.fr & PDMP3_FR_RESET);     // (an LSF launch: every granule is a frame)
     const int nch_g = gi.nch;
     PD_TICK(1)
     float* dmp = DUMP ? a.stages + ((size_t)f * 16 + gr * 8) * 576 : nullptr;

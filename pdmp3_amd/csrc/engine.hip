@@ -128,6 +128,24 @@ __global__ __launch_bounds__(64, PDMP3_WAVES_PER_EU) void k_decode_prof(DecodeAr
   run_chunk<false, true>(a, T, (BankPtr)&c_bank, (int)blockIdx.x, L[w], L[w].tab);
 }
 
+// LSF launches (launch_decode): record-frame p of the output = the first granules ([0][ch]: 2 x 576 int16 of spectra, 2 x 128
+// bytes of side records) of the input's frames 2 p and 2 p + 1; a missing second one (odd n) is zeroed and never decoded.
+__global__ __launch_bounds__(256) void k_lsf_pair(const int16_t* in_sp, const pdmp3_gc_side* in_sd, int n_frames, int16_t* out_sp, pdmp3_gc_side* out_sd) {
+  const int p = blockIdx.x;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  for (int gr = 0; gr < 2; gr++) {
+    const int f = 2 * p + gr;
+    const uint4* ssp = reinterpret_cast<const uint4*>(in_sp + (size_t)f * 2304);
+    const uint4* ssd = reinterpret_cast<const uint4*>(in_sd + (size_t)f * 4);
+    uint4* dsp = reinterpret_cast<uint4*>(out_sp + (size_t)p * 2304 + gr * 1152);
+    uint4* dsd = reinterpret_cast<uint4*>(out_sd + (size_t)p * 4 + gr * 2);
+    for (int k = threadIdx.x; k < 144 + 16; k += blockDim.x) {
+      if (k < 144) dsp[k] = f < n_frames ? ssp[k] : zero;
+      else dsd[k - 144] = f < n_frames ? ssd[k - 144] : zero;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void k_generate(uint64_t seed, int64_t first, int16_t* spectra, pdmp3_gc_side* side) {
   const int64_t gc = blockIdx.x;           // (frame_local*4 + gr*2 + ch)
   const int64_t f = gc >> 2;
@@ -455,7 +473,7 @@ struct pdmp3_hip_ctx {
   uint16_t* d_linetab;
   float* d_win;
   float* d_frag;            // frag_long [10][64] | frag_short [10][64] | frag_mat [8][64] | taps [16][64]
-  void* d_tab_image;        // [3] TabLds images
+  void* d_tab_image;        // [kNumSfreq] TabLds images
   int chain_mode;           // PDMP3_HIP_CHAIN=0: independent chunks with halos everywhere; otherwise launches up to
                             // gran_max_frames take the granule kernel (k_decode_g)
   int gran_max_frames;      // launches up to this many frames take the granule kernel (PDMP3_HIP_GRAN_MAX)
@@ -556,7 +574,7 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     CREATE_STEP(hipMalloc(&c->d_linetab, H.linetab.size() * sizeof(uint16_t)), "hipMalloc linetab")
     CREATE_STEP(hipMalloc(&c->d_win, H.win.size() * sizeof(float)), "hipMalloc win")
     CREATE_STEP(hipMalloc(&c->d_frag, (10 + 10 + 8 + 16) * 64 * sizeof(float)), "hipMalloc frag")
-    CREATE_STEP(hipMalloc(&c->d_tab_image, 3 * sizeof(TabLds)), "hipMalloc table images")
+    CREATE_STEP(hipMalloc(&c->d_tab_image, kNumSfreq * sizeof(TabLds)), "hipMalloc table images")
     CREATE_STEP(hipMalloc((void**)&c->d_unpack, sizeof(UnpackTables)), "hipMalloc unpack tables")
     { const char* up = getenv("PDMP3_HIP_UNPACK_PROF");
       if (up && *up == '1') CREATE_STEP(hipMalloc((void**)&c->d_uprof, 2048 * 8 * sizeof(unsigned long long)), "hipMalloc unpack prof") }
@@ -567,7 +585,7 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     CREATE_STEP(hipMemcpy(c->d_frag + 10 * 64, H.frag_short.data(), 10 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_short")
     CREATE_STEP(hipMemcpy(c->d_frag + 20 * 64, H.frag_mat.data(), 8 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_mat")
     CREATE_STEP(hipMemcpy(c->d_frag + 28 * 64, H.taps.data(), 16 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload taps")
-    CREATE_STEP(hipMemcpy(c->d_tab_image, H.tab_image.data(), 3 * sizeof(TabLds), hipMemcpyHostToDevice), "upload table images")
+    CREATE_STEP(hipMemcpy(c->d_tab_image, H.tab_image.data(), kNumSfreq * sizeof(TabLds), hipMemcpyHostToDevice), "upload table images")
     CREATE_STEP(hipMemcpy(c->d_unpack, U, sizeof(UnpackTables), hipMemcpyHostToDevice), "upload unpack tables")
     c->unpack_n16 = (int)((offsetof(UnpackTables, lut) + (size_t)U->n_lut * 4 + 15) / 16);
     CREATE_STEP(hipDeviceSynchronize(), "sync after uploads")
@@ -659,7 +677,7 @@ static void chain_release(pdmp3_hip_ctx* c, const void* key) {     // (its launc
 static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3_gc_side* d_side, int n_frames,
                          void* d_state, int16_t* d_pcm, float* d_stages, int chunk_frames, void* stream,
                          unsigned long long* d_prof = nullptr, float* d_state_tmp = nullptr, float* d_pcm_f32 = nullptr,
-                         const void* owner = nullptr, bool leave_state_in_tmp = false) {
+                         const void* owner = nullptr, bool leave_state_in_tmp = false, bool lsf = false) {
   // owner: the stream object whose launches these are (they are ordered: one chain scratch for all of them);
   // leave_state_in_tmp: the caller swaps its two state buffers instead of having the new state copied back
   if (!c || n_frames < 0) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: bad argument", hipSuccess);
@@ -671,7 +689,24 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   if (n_frames == 0) return PDMP3_HIP_OK;
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(c->device), "hipSetDevice");     // (a bare call may come from a thread whose current device is another one)
-  const int chunk_frames_arg = chunk_frames;             // (0 = the engine's choice)
+  // LSF (pdmp3_gc_side.lsf != 0): a frame is ONE granule.  The kernels keep their two-granule frames: the
+  // launch's n frames are regrouped on the device into ceil(n / 2) record-frames whose granules are consecutive FRAMES
+  // (k_lsf_pair: [0][ch] of frame 2 p and of frame 2 p + 1), decoded by the chunk kernel -- an odd last frame is a
+  // record-frame of one granule (DecodeArgs::n_gran) -- and the PCM comes out in stream order, 576 sample-frames a frame.
+  int16_t* d_pair_sp = nullptr;
+  pdmp3_gc_side* d_pair_sd = nullptr;
+  int n_gran = 0;
+  if (lsf) {
+    if (d_stages || d_prof) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_lsf_frames: no stage dumps / profiles of LSF launches", hipSuccess);
+    const int np = (n_frames + 1) / 2;
+    HIP_TRY(hipMallocAsync((void**)&d_pair_sp, (size_t)np * PDMP3_FRAME_SPECTRA_BYTES, s), "hipMallocAsync LSF pairs");
+    if (hipMallocAsync((void**)&d_pair_sd, (size_t)np * PDMP3_FRAME_SIDE_BYTES, s) != hipSuccess) { (void)hipFreeAsync(d_pair_sp, s); return fail(PDMP3_HIP_ENOMEM, "hipMallocAsync LSF pairs", hipGetLastError()); }
+    hipLaunchKernelGGL(k_lsf_pair, dim3(np), dim3(256), 0, s, d_spectra, d_side, n_frames, d_pair_sp, d_pair_sd);
+    n_gran = n_frames;
+    d_spectra = d_pair_sp; d_side = d_pair_sd; n_frames = np;
+    if (chunk_frames <= 1) chunk_frames = 0;             // (never the granule kernels: they hand on whole frames)
+  }
+  const int chunk_frames_arg = lsf ? 2 : chunk_frames;   // (0 = the engine's choice; an LSF launch: chunks)
   if (chunk_frames <= 0) chunk_frames = auto_chunk(n_frames, c->wave_slots);
   if (d_stages || chunk_frames > n_frames) chunk_frames = n_frames;
   DecodeArgs a;
@@ -692,6 +727,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.chunk_frames = chunk_frames;
   a.prof = d_prof;
   a.chain_state = nullptr; a.chain_flag = nullptr; a.chain_epoch = 0; a.debug_flags = c->debug_flags; a.sf_hint = c->sf_hint;
+  a.n_gran = n_gran;
   bool gran = false, ring = false;
   const bool plain = !d_stages && !d_prof;
   // the persistent granule kernel: launches of at least ring_min_frames frames (and chunk_frames = -3: always)
@@ -768,6 +804,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
     const hipError_t ef = hipFreeAsync(d_state_tmp, s);
     if (e == hipSuccess && ef != hipSuccess) { what = "hipFreeAsync state"; e = ef; }
   }
+  if (d_pair_sp) { (void)hipFreeAsync(d_pair_sp, s); (void)hipFreeAsync(d_pair_sd, s); }
   if (e != hipSuccess) return fail(PDMP3_HIP_EDEVICE, what, e);
   return PDMP3_HIP_OK;
 }
@@ -792,6 +829,17 @@ extern "C" int pdmp3_hip_decode_frames_f32(pdmp3_hip_ctx* ctx, const int16_t* d_
                                            int n_frames, void* d_state, float* d_pcm, int chunk_frames, void* stream) {
   if (!d_pcm) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames_f32: d_pcm is NULL", hipSuccess);
   return launch_decode(ctx, d_spectra, d_side, n_frames, d_state, nullptr, nullptr, chunk_frames, stream, nullptr, nullptr, d_pcm);
+}
+
+// LSF frames (include/pdmp3_hip.h): n_frames one-granule frames of one channel count -> PCM in stream order
+extern "C" int pdmp3_hip_decode_lsf_frames(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,
+                                           int n_frames, void* d_state, int16_t* d_pcm, void* stream) {
+  return launch_decode(ctx, d_spectra, d_side, n_frames, d_state, d_pcm, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, false, true);
+}
+extern "C" int pdmp3_hip_decode_lsf_frames_f32(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,
+                                               int n_frames, void* d_state, float* d_pcm, void* stream) {
+  if (!d_pcm) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_lsf_frames_f32: d_pcm is NULL", hipSuccess);
+  return launch_decode(ctx, d_spectra, d_side, n_frames, d_state, nullptr, nullptr, 0, stream, nullptr, nullptr, d_pcm, nullptr, false, true);
 }
 
 extern "C" int pdmp3_hip_decode_frames_stages(pdmp3_hip_ctx* ctx, const int16_t* d_spectra, const pdmp3_gc_side* d_side,
@@ -834,6 +882,7 @@ struct pdmp3_hip_stream {
   int sf_cur;
   int have_bits;
   int f32;                   // PCM as float (pdmp3_hip_stream_set_f32): the slots' PCM buffers hold 9216 bytes per frame
+  int lsf;                   // the records of the submits are LSF frames (pdmp3_hip_stream_set_lsf): pdmp3_hip_decode_lsf_frames' layout
 };
 
 extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
@@ -928,7 +977,18 @@ extern "C" const int16_t* pdmp3_hip_stream_pcm(pdmp3_hip_stream* hs) { return pd
 // PCM of a batch to its destination: into the slot's pinned buffer, or -- when the caller hands over pinned host
 // memory (pdmp3_hip_host_alloc) or DEVICE memory of its own -- straight to where it is wanted, `row` bytes per frame (4608; 2304 = mono frames
 // packed densely out of their 4608-byte slots).
-static int download_pcm(StreamSlot& t, size_t n, void* host_dst, int row) {
+static int download_pcm(StreamSlot& t, size_t n, void* host_dst, int row, bool lsf = false) {
+  if (lsf && host_dst) {
+    // LSF frames (pdmp3_hip_decode_lsf_frames): stereo frames lie back to back, 2304 bytes each; mono frames in pairs in the
+    // first half of a 4608-byte place
+    if (row == PDMP3_FRAME_PCM_BYTES / 2) {
+      HIP_TRY(hipMemcpyAsync(host_dst, t.d_pcm, n * (size_t)row, hipMemcpyDefault, t.stream), "pcm (direct, LSF)");
+    } else {
+      if (n / 2) HIP_TRY(hipMemcpy2DAsync(host_dst, 2304, t.d_pcm, PDMP3_FRAME_PCM_BYTES, 2304, n / 2, hipMemcpyDefault, t.stream), "pcm (direct, LSF mono)");
+      if (n & 1) HIP_TRY(hipMemcpyAsync((char*)host_dst + (n / 2) * 2304, (const char*)t.d_pcm + (n / 2) * PDMP3_FRAME_PCM_BYTES, 1152, hipMemcpyDefault, t.stream), "pcm (direct, LSF mono tail)");
+    }
+    return PDMP3_HIP_OK;
+  }
   if (!host_dst) {
     HIP_TRY(hipMemcpyAsync(t.h_pcm, t.d_pcm, n * PDMP3_FRAME_PCM_BYTES, hipMemcpyDeviceToHost, t.stream), "D2H pcm");
   } else if (row == PDMP3_FRAME_PCM_BYTES) {
@@ -994,6 +1054,10 @@ extern "C" int pdmp3_hip_stream_submit(pdmp3_hip_stream* hs, int slot, int n_fra
   return submit_records(hs, slot, n_frames, nullptr, PDMP3_FRAME_PCM_BYTES);
 }
 extern "C" int pdmp3_hip_stream_submit_to(pdmp3_hip_stream* hs, int slot, int n_frames, void* pinned_dst, int row_bytes) {
+  if (pinned_dst && hs && hs->lsf) {
+    if (row_bytes != PDMP3_FRAME_PCM_BYTES / 2 && row_bytes != PDMP3_FRAME_PCM_BYTES / 4)
+      return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_to: row_bytes of LSF frames must be 2304 (stereo) or 1152 (mono)", hipSuccess);
+  } else
   if (pinned_dst && row_bytes != PDMP3_FRAME_PCM_BYTES && row_bytes != PDMP3_FRAME_PCM_BYTES / 2)
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_to: row_bytes must be 4608 or 2304", hipSuccess);
   return submit_records(hs, slot, n_frames, pinned_dst, row_bytes);
@@ -1021,15 +1085,15 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
     if (hipPointerGetAttributes(&pa, host_dst) != hipSuccess) { (void)hipGetLastError(); dst_ok = false; }
     else dst_ok = (pa.type == hipMemoryTypeHost && !pa.isManaged) || (pa.type == hipMemoryTypeDevice && pa.device == hs->ctx->device);
   }
-  if (n_frames <= hs->ctx->direct_max_frames && dst_ok && (!host_dst || row == PDMP3_FRAME_PCM_BYTES)) {
+  if (n_frames <= hs->ctx->direct_max_frames && dst_ok && (!host_dst || row == PDMP3_FRAME_PCM_BYTES) && !(hs->lsf && host_dst)) {
     // (a stream object with ONE slot -- the streaming API's -- has one HIP stream: its batches are in order anyway, and
     //  its wait is for that stream: no events at all, each of which is a call here and a packet of its own on the queue)
     const bool lone = hs->n_slots == 1;
     if (!lone && hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
     void* dst = host_dst ? host_dst : (void*)t.h_pcm;
     int rc = hs->f32
-        ? launch_decode(hs->ctx, t.h_spectra, t.h_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)dst, hs, true)
-        : launch_decode(hs->ctx, t.h_spectra, t.h_side, n_frames, hs->d_state, (int16_t*)dst, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, true);
+        ? launch_decode(hs->ctx, t.h_spectra, t.h_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)dst, hs, true, hs->lsf != 0)
+        : launch_decode(hs->ctx, t.h_spectra, t.h_side, n_frames, hs->d_state, (int16_t*)dst, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, true, hs->lsf != 0);
     if (rc != PDMP3_HIP_OK) return rc;
     float* const was_prev = hs->d_state_prev;
     hs->d_state_prev = hs->d_state;            // (what pdmp3_hip_stream_rewind goes back to)
@@ -1049,16 +1113,25 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
   if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
   HIP_TRY(hipMemcpyAsync(hs->d_state_prev, hs->d_state, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, t.stream), "keep the state");
   int rc = hs->f32
-      ? launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs)
-      : launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs);
+      ? launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs, false, hs->lsf != 0)
+      : launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, false, hs->lsf != 0);
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
   hs->have_state_ev = 1;
   if (hs->f32) HIP_TRY(hipMemcpyAsync(t.h_pcm, t.d_pcm, n * PDMP3_FRAME_PCM_F32_BYTES, hipMemcpyDeviceToHost, t.stream), "D2H pcm");
-  else rc = download_pcm(t, n, host_dst, row);
+  else rc = download_pcm(t, n, host_dst, row, hs->lsf != 0);
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(t.done, t.stream), "record done event");
   t.busy = 1;
+  return PDMP3_HIP_OK;
+}
+
+// The records of this stream object's following submits are LSF frames (on != 0: decoded like pdmp3_hip_decode_lsf_frames,
+// the PCM in its layout) or MPEG-1 frames again.  A setting of the host's for the next submit; the synthesis state is
+// the same block either way.
+extern "C" int pdmp3_hip_stream_set_lsf(pdmp3_hip_stream* hs, int on) {
+  if (!hs) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_set_lsf: NULL", hipSuccess);
+  hs->lsf = on != 0;
   return PDMP3_HIP_OK;
 }
 
@@ -1101,8 +1174,8 @@ extern "C" int pdmp3_hip_stream_rewind(pdmp3_hip_stream* hs, int slot, int keep_
     const int16_t* sp = t.direct ? t.h_spectra : t.d_spectra;
     const pdmp3_gc_side* sd = t.direct ? t.h_side : t.d_side;
     const int rc = hs->f32
-        ? launch_decode(hs->ctx, sp, sd, keep_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs)
-        : launch_decode(hs->ctx, sp, sd, keep_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs);
+        ? launch_decode(hs->ctx, sp, sd, keep_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs, false, hs->lsf != 0)
+        : launch_decode(hs->ctx, sp, sd, keep_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, false, hs->lsf != 0);
     if (rc != PDMP3_HIP_OK) return rc;
   }
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");

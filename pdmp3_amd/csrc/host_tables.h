@@ -19,6 +19,7 @@
 #include "decode_core.h"
 #include "unpack_core.h"
 #include "tables_data.h"
+#include "lsf_tables.h"
 
 namespace pdmp3 {
 
@@ -39,8 +40,10 @@ struct HostTables {
   bool ldexp_forms_exact;
 };
 
-inline const uint16_t* sfb_long_of(int sfreq) { return sfreq == 0 ? kSfbLong0 : (sfreq == 1 ? kSfbLong1 : kSfbLong2); }
-inline const uint16_t* sfb_short_of(int sfreq) { return sfreq == 0 ? kSfbShort0 : (sfreq == 1 ? kSfbShort1 : kSfbShort2); }
+// sfreq 0..2: the reference's MPEG-1 tables; 3..8: MPEG-2 LSF / MPEG-2.5 (lsf_tables.h)
+inline const uint16_t* sfb_long_of(int sfreq) { return sfreq >= 3 ? kLsfSfbLong[sfreq - 3] : sfreq == 0 ? kSfbLong0 : (sfreq == 1 ? kSfbLong1 : kSfbLong2); }
+inline const uint16_t* sfb_short_of(int sfreq) { return sfreq >= 3 ? kLsfSfbShort[sfreq - 3] : sfreq == 0 ? kSfbShort0 : (sfreq == 1 ? kSfbShort1 : kSfbShort2); }
+constexpr int kNumSfreq = 9;
 
 inline void build_tab_images(HostTables& H);
 inline void build_host_tables(HostTables& H) {
@@ -55,10 +58,18 @@ inline void build_host_tables(HostTables& H) {
     else { cb.isr_l[i] = t / (1.0f + t); cb.isr_r[i] = 1.0f / (1.0f + t); }
   }
   for (int i = 0; i < 512; i++) cb.dwin[i] = kSynthD[i];
-  for (int f = 0; f < 3; f++) {
+  for (int f = 0; f < kNumSfreq; f++) {
     for (int i = 0; i < 23; i++) cb.sfb_l[f][i] = sfb_long_of(f)[i];
     for (int i = 0; i < 14; i++) cb.sfb_s[f][i] = sfb_short_of(f)[i];
   }
+  // LSF intensity stereo (13818-3 2.4.3.2; the oracle evaluates the same expression): position p scales one channel by
+  // i0^((p + 1) / 2), i0 = 2^(-1/4) (intensity_scale 0) or 2^(-1/2): p odd the left one, p even the right one
+  for (int sc = 0; sc < 2; sc++)
+    for (int pp = 0; pp < 32; pp++) {
+      const float f = (float)pow(2.0, -(double)((sc + 1) * ((pp + 1) >> 1)) / 4.0);
+      cb.isr_lsf_l[sc][pp] = (pp & 1) ? f : 1.0f;
+      cb.isr_lsf_r[sc][pp] = (pp & 1) ? 1.0f : f;
+    }
   H.win.assign(kImdctWin, kImdctWin + 144);
   H.t1.resize(kT1Size);
   H.t2.resize(kT2Size);
@@ -75,8 +86,8 @@ inline void build_host_tables(HostTables& H) {
   H.pow43.resize(8207);
   for (int i = 0; i < 8207; i++) H.pow43[i] = (float)pow((float)i, 4.0 / 3.0);
 
-  H.linetab.assign(3 * 3 * 576, 0);
-  for (int f = 0; f < 3; f++) {
+  H.linetab.assign(kNumSfreq * 3 * 576, 0);
+  for (int f = 0; f < kNumSfreq; f++) {
     const uint16_t* l = sfb_long_of(f);
     const uint16_t* s = sfb_short_of(f);
     uint16_t* tl = &H.linetab[(f * 3 + 0) * 576];
@@ -152,8 +163,8 @@ inline void build_tab_images(HostTables& H) {
       H.taps[(8 + k) * 64 + lane] = -kSynthD[64 * k + 32 + i];
     }
   }
-  H.tab_image.resize(3);
-  for (int sf = 0; sf < 3; sf++) {
+  H.tab_image.resize(kNumSfreq);
+  for (int sf = 0; sf < kNumSfreq; sf++) {
     TabLds& S = H.tab_image[sf];
     memset(&S, 0, sizeof S);
     for (int k = 0; k < 144; k++) (&S.win[0][0])[k] = H.win[k];

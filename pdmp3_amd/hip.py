@@ -26,6 +26,7 @@ FRAME_SIDE_BYTES = 512
 EXPORTS = [
     "pdmp3_hip_create", "pdmp3_hip_destroy", "pdmp3_hip_last_error", "pdmp3_hip_state_bytes", "pdmp3_hip_last_launch_kind", "pdmp3_hip_pci_bus_id",
     "pdmp3_hip_decode_frames", "pdmp3_hip_decode_frames_f32", "pdmp3_hip_decode_frames_stages", "pdmp3_hip_generate_frames",
+    "pdmp3_hip_decode_lsf_frames", "pdmp3_hip_decode_lsf_frames_f32", "pdmp3_hip_stream_set_lsf",
     "pdmp3_host_generate_frames",
     "pdmp3_hip_stream_create", "pdmp3_hip_stream_destroy", "pdmp3_hip_stream_reset", "pdmp3_hip_stream_spectra",
     "pdmp3_hip_stream_side", "pdmp3_hip_stream_pcm", "pdmp3_hip_stream_decode",
@@ -244,6 +245,14 @@ class Engine:
         self._check(self.lib.pdmp3_hip_decode_frames(
             self.h, spectra.data_ptr(), side.data_ptr(), n,
             state.data_ptr() if state is not None else None, pcm.data_ptr(), int(chunk_frames), self._stream()))
+
+    def decode_lsf(self, spectra, side, pcm, n_frames=None, state=None):
+        """pdmp3_hip_decode_lsf_frames: n MPEG-2 LSF / 2.5 frames (records with lsf != 0, one channel count) -> PCM in stream
+        order, 576 sample-frames per frame (layout: include/pdmp3_hip.h); pcm int16 or float32 tensor"""
+        n = int(spectra.shape[0]) if n_frames is None else int(n_frames)
+        f = self.lib.pdmp3_hip_decode_lsf_frames_f32 if pcm.dtype == self.torch.float32 else self.lib.pdmp3_hip_decode_lsf_frames
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._check(f(self.h, spectra.data_ptr(), side.data_ptr(), n, state.data_ptr() if state is not None else None, pcm.data_ptr(), self._stream()))
 
     def has_persistent_kernel(self):
         """was the library built with -DPDMP3_WITH_RING_KERNEL (k_decode_p, an opt-in since round 5)?  Asked by trying:

@@ -25,6 +25,7 @@
 #include "../../include/pdmp3.h"
 #include "../../include/pdmp3_hip.h"
 #include "../csrc/tables_data.h"
+#include "../csrc/lsf_tables.h"
 
 #include <fcntl.h>
 #include <pthread.h>
@@ -104,7 +105,11 @@ static void build_luts(void) {
 /* ------------------------------------------------------------------------ */
 typedef struct {
   unsigned id, layer, protection, bitrate_index, sfreq, padding, mode, mode_ext;
+  unsigned ver;                      /* 0 = MPEG-1 (all the reference takes, P:1293); 1 = MPEG-2 LSF, 2 = MPEG-2.5: only with PDMP3_ISO_LSF */
 } frame_header;
+/* samples per channel a frame decodes to: 1152; an LSF frame is ONE granule */
+static inline unsigned frame_samples(const frame_header* H) { return H->ver ? 576u : 1152u; }
+static inline unsigned sfreq9(const frame_header* H) { return 3 * H->ver + H->sfreq; }
 
 typedef struct {
   unsigned main_data_begin, scfsi[2][4];
@@ -178,7 +183,7 @@ struct pdmp3_handle {
   int l_new_header;                /* id->new_header of the reference */
   struct ra_entry {                /* a frame parsed and sent to the engine but not handed out yet */
     size_t processed_after; unsigned istart_after; frame_header hdr; uint8_t nch, nh;
-  } ra[BATCH_MAX];
+  } ra[BATCH_MAX];                 /* (a batch is homogeneous: all MPEG-1, or all LSF of one version and channel count) */
   int ra_head, ra_n, ra_inflight;  /* ra_inflight: the batch is still on the GPU */
   parse_snap ra_before[BATCH_MAX]; /* the parser as it was before each of these frames */
   main_out ra_out[BATCH_MAX];      /* their decoded main data (the helpers of read_ahead write these) */
@@ -344,17 +349,27 @@ static int read_header(pdmp3_handle* id) {
   for (int i = 0; i < 4; i++) b[i] = ring_byte(id);
   if (b[0] == BYTE_EOF || b[1] == BYTE_EOF || b[2] == BYTE_EOF || b[3] == BYTE_EOF) return PDMP3_ERR;
   uint32_t h = (b[0] << 24) | (b[1] << 16) | (b[2] << 8) | b[3];
-  while ((h & 0xfff00000u) != 0xfff00000u) {     /* byte-aligned 12-bit sync */
+  /* PDMP3_ISO_LSF (not the reference): eleven sync bits, so that MPEG-2.5's 0xFFE + ID 0 is a header too; never in bits
+   * mode (the device's Huffman stage reads MPEG-1 side info only: include/pdmp3_bulk.h) */
+  const int lsf_ok = (id->iso & PDMP3_ISO_LSF) && !id->side_to_bits;
+  const uint32_t sync = lsf_ok ? 0xffe00000u : 0xfff00000u;
+  while ((h & sync) != sync) {                   /* byte-aligned 12-bit sync */
     unsigned nb = ring_byte(id);
     if (nb == BYTE_EOF) return PDMP3_ERR;
     h = (h << 8) | nb;
   }
   frame_header* H = &id->hdr;
+  H->ver = 0;
+  if (lsf_ok) {
+    const unsigned v = (h >> 19) & 3;              /* 11 MPEG-1, 10 MPEG-2 LSF, 00 MPEG-2.5, 01 reserved */
+    if (v == 1) { H->layer = 0; return PDMP3_ERR; }
+    H->ver = v == 3 ? 0 : v == 2 ? 1 : 2;
+  }
   H->id = (h >> 19) & 1; H->layer = (h >> 17) & 3; H->protection = (h >> 16) & 1;
   H->bitrate_index = (h >> 12) & 15; H->sfreq = (h >> 10) & 3; H->padding = (h >> 9) & 1;
   H->mode = (h >> 6) & 3; H->mode_ext = (h >> 4) & 3;
   /* MPEG-1 only; free format, index 15, sfreq 3 and layer 0 rejected (P:1293-1315) */
-  if (H->id != 1 || H->bitrate_index == 0 || H->bitrate_index == 15 || H->sfreq == 3 || H->layer == 0)
+  if ((H->id != 1 && !H->ver) || H->bitrate_index == 0 || H->bitrate_index == 15 || H->sfreq == 3 || H->layer == 0)
     return PDMP3_ERR;
   H->layer = 4 - H->layer;
   if (!id->new_header) id->new_header = 1;
@@ -392,10 +407,61 @@ static inline unsigned side_bits(side_cur* c, unsigned n) {          /* n <= 12 
 }
 
 static unsigned frame_bytes(const frame_header* H) {   /* P:1135-1138; the 42 quotients there are, computed once */
+  if (H->ver) return lsf_frame_bytes(H->ver, kLsfBitrates[H->bitrate_index], sfreq9(H), H->padding);
   return g_frame_q[H->bitrate_index][H->sfreq] + H->padding;
+}
+static inline unsigned side_info_bytes(const frame_header* H) {
+  const unsigned nch = H->mode == 3 ? 1 : 2;
+  return H->ver ? (nch == 1 ? 9 : 17) : (nch == 1 ? 17 : 32);
+}
+
+/* 13818-3 2.4.1.7 (not the reference): ONE granule; main_data_begin 8 bits, 1 / 2 private bits, no scfsi; a 9-bit
+ * scalefac_compress, no preflag bit (scalefac_compress >= 500 implies it, except for the right channel of an
+ * intensity-stereo frame, whose scalefac_compress is a different code: lsf_tables.h) */
+static void read_side_info_lsf(pdmp3_handle* id) {
+  const unsigned nch = id->hdr.mode == 3 ? 1 : 2, nbytes = side_info_bytes(&id->hdr);
+  unsigned got = ring_filled(id);
+  if (got > nbytes) got = nbytes;
+  else if (got < nbytes) id->ring_short = 1;
+  ring_take(id, id->side_vec, got);
+  if (got == nbytes) { id->side_ptr = 0; id->side_idx = 0; }
+  side_info* S = &id->si;
+  side_cur sc = {id->side_vec, id->side_ptr * 8 + id->side_idx};
+  S->main_data_begin = side_bits(&sc, 8);
+  (void)side_bits(&sc, nch == 1 ? 1 : 2);
+  for (unsigned ch = 0; ch < nch; ch++) {
+    for (unsigned b = 0; b < 4; b++) S->scfsi[ch][b] = 0;
+    S->part2_3_length[0][ch] = side_bits(&sc, 12);
+    S->big_values[0][ch] = side_bits(&sc, 9);
+    S->global_gain[0][ch] = side_bits(&sc, 8);
+    S->scalefac_compress[0][ch] = side_bits(&sc, 9);
+    S->win_switch[0][ch] = side_bits(&sc, 1);
+    if (S->win_switch[0][ch]) {
+      S->block_type[0][ch] = side_bits(&sc, 2);
+      S->mixed[0][ch] = side_bits(&sc, 1);
+      S->table_select[0][ch][0] = side_bits(&sc, 5);
+      S->table_select[0][ch][1] = side_bits(&sc, 5);
+      for (unsigned w = 0; w < 3; w++) S->subblock_gain[0][ch][w] = side_bits(&sc, 3);
+      S->region0_count[0][ch] = (S->block_type[0][ch] == 2 && !S->mixed[0][ch]) ? 8 : 7;
+      S->region1_count[0][ch] = 20 - S->region0_count[0][ch];
+    } else {
+      for (unsigned r = 0; r < 3; r++) S->table_select[0][ch][r] = side_bits(&sc, 5);
+      S->region0_count[0][ch] = side_bits(&sc, 4);
+      S->region1_count[0][ch] = side_bits(&sc, 3);
+      S->block_type[0][ch] = 0;
+      S->mixed[0][ch] = 0;
+    }
+    const int is_right = id->hdr.mode == 1 && (id->hdr.mode_ext & 1) && ch == 1;
+    S->preflag[0][ch] = !is_right && S->scalefac_compress[0][ch] >= 500;
+    S->scalefac_scale[0][ch] = side_bits(&sc, 1);
+    S->count1table_select[0][ch] = side_bits(&sc, 1) ? 2 : 0;       /* 2: the standard's table B (as with PDMP3_ISO_TABLE33) */
+  }
+  id->side_ptr = sc.pos >> 3;
+  id->side_idx = sc.pos & 7;
 }
 
 static void read_side_info(pdmp3_handle* id) {
+  if (id->hdr.ver) { read_side_info_lsf(id); return; }
   const unsigned nch = id->hdr.mode == 3 ? 1 : 2, nbytes = nch == 1 ? 17 : 32;
   unsigned got = ring_filled(id);
   if (got > nbytes) got = nbytes;
@@ -646,6 +712,7 @@ static void decode_huffman(bitreader* b, const frame_header* H, const side_info*
   if (S->part2_3_length[gr][ch] == 0) {           /* all zero; count1 keeps its old value (H6) */
     memset(is, 0, 576 * sizeof *is);
     out->count1_set[gr][ch] = 0;
+    if (H->ver) { out->count1[gr][ch] = 0; out->count1_set[gr][ch] = 1; }      /* (LSF: nothing of the reference's to reproduce) */
     return;
   }
   const unsigned end = part2_start + S->part2_3_length[gr][ch] - 1;   /* last bit of this part */
@@ -655,6 +722,16 @@ static void decode_huffman(bitreader* b, const frame_header* H, const side_info*
    * Host and device Huffman both give zeros there.) */
   memset(is, 0, 576 * sizeof *is);
   unsigned r1, r2;
+  if (H->ver) {
+    /* LSF: the same rule over the LSF band tables; nothing lies beyond band 22; at 8 kHz three short bands are 72 lines */
+    const uint16_t* l = kLsfSfbLong[sfreq9(H) - 3];
+    if (S->win_switch[gr][ch] && S->block_type[gr][ch] == 2) { r1 = sfreq9(H) == 8 ? 72 : 36; r2 = 576; }
+    else {
+      const unsigned i1 = S->region0_count[gr][ch] + 1, i2 = S->region0_count[gr][ch] + S->region1_count[gr][ch] + 2;
+      r1 = l[i1 > 22 ? 22 : i1];
+      r2 = l[i2 > 22 ? 22 : i2];
+    }
+  } else
   if (S->win_switch[gr][ch] && S->block_type[gr][ch] == 2) { r1 = 36; r2 = 576; }
   else {
     /* l[23] s[14] are contiguous in the reference: indices 23, 24 read s[0], s[1] (H7) */
@@ -718,6 +795,33 @@ static void decode_main(const uint8_t* reservoir, const frame_header* H, const s
   memset(out->sf_l_set, 0, sizeof out->sf_l_set);
   memset(out->sf_s_set, 0, sizeof out->sf_s_set);
   out->sf_l_copy[0] = out->sf_l_copy[1] = 0;
+  if (H->ver) {
+    /* 13818-3 2.4.3.2: scalefac_compress -> four slen and, by block shape, four partition sizes (lsf_tables.h); the
+     * scalefactors come in band order (short: band by band, window by window; mixed: 6 long bands, then short bands
+     * 3..11); what is not transmitted is 0.  Every scalefactor of the granule is (re)written: nothing is carried. */
+    for (unsigned ch = 0; ch < nch; ch++) {
+      const unsigned part2_start = b.bitpos;
+      uint8_t slen[4];
+      int pf;
+      const int cls = lsf_slen_of(S->scalefac_compress[0][ch], H->mode == 1 && (H->mode_ext & 1) && ch == 1, slen, &pf);
+      const int shortb = S->win_switch[0][ch] && S->block_type[0][ch] == 2, mixed = shortb && S->mixed[0][ch];
+      const uint8_t* nsf = kLsfNsfb[cls][shortb ? (mixed ? 2 : 1) : 0];
+      uint8_t vals[40];
+      unsigned n = 0;
+      for (unsigned k = 0; k < 4; k++)
+        for (unsigned i = 0; i < nsf[k]; i++) vals[n++] = (uint8_t)get_bits(&b, slen[k]);
+      for (; n < 40; n++) vals[n] = 0;
+      memset(out->sf_l[0][ch], 0, sizeof out->sf_l[0][ch]);
+      memset(out->sf_s[0][ch], 0, sizeof out->sf_s[0][ch]);
+      if (!shortb) memcpy(out->sf_l[0][ch], vals, 21);
+      else if (!mixed) memcpy(out->sf_s[0][ch], vals, 36);
+      else { memcpy(out->sf_l[0][ch], vals, 6); memcpy(out->sf_s[0][ch][3], vals + 6, 27); }
+      out->sf_l_set[0][ch] = 0x1fffff;
+      out->sf_s_set[0][ch] = 0xfff;
+      decode_huffman(&b, H, S, part2_start, 0, ch, out);
+    }
+    return;
+  }
   for (unsigned gr = 0; gr < 2; gr++)
     for (unsigned ch = 0; ch < nch; ch++) {
       const unsigned part2_start = b.bitpos;
@@ -754,8 +858,8 @@ static void decode_main(const uint8_t* reservoir, const frame_header* H, const s
 /* merge one frame's main data into the state that survives frames (scalefactors, count1, is) */
 static void apply_main(pdmp3_handle* id, const frame_header* H, const main_out* out) {
   static const uint8_t lo[5] = {0, 6, 11, 16, 21};
-  const unsigned nch = H->mode == 3 ? 1 : 2;
-  for (unsigned gr = 0; gr < 2; gr++)
+  const unsigned nch = H->mode == 3 ? 1 : 2, ngr = H->ver ? 1 : 2;
+  for (unsigned gr = 0; gr < ngr; gr++)
     for (unsigned ch = 0; ch < nch; ch++) {
       for (unsigned sfb = 0; sfb < 21; sfb++)
         if (out->sf_l_set[gr][ch] >> sfb & 1) id->scalefac_l[gr][ch][sfb] = out->sf_l[gr][ch][sfb];
@@ -776,7 +880,8 @@ static int stage_main_data(pdmp3_handle* id) {
   const unsigned nch = id->hdr.mode == 3 ? 1 : 2;
   const unsigned fb = frame_bytes(&id->hdr);
   if (fb > 2000) return PDMP3_ERR;
-  unsigned size = fb - (nch == 1 ? 17 : 32) - 4;
+  unsigned size = fb - side_info_bytes(&id->hdr) - 4;
+  (void)nch;
   if (id->hdr.protection == 0) size -= 2;
   if (id->pool_sink) return fill_reservoir_pool(id, size, id->si.main_data_begin);
   return fill_reservoir(id, size, id->si.main_data_begin);
@@ -792,7 +897,7 @@ static int read_frame_staged(pdmp3_handle* id) {
   if (id->hdr.layer != 3) return PDMP3_ERR;
   id->fb_valid = 0;
   if (frame_bytes(&id->hdr) <= 2000) {
-    if (id->side_to_bits && ring_filled(id) >= 32) read_side_info_bits(id);
+    if (id->side_to_bits && ring_filled(id) >= 32 && !id->hdr.ver) read_side_info_bits(id);
     else read_side_info(id);
   }
   return stage_main_data(id);
@@ -823,9 +928,20 @@ static void emit_records(pdmp3_handle* id, const frame_header* H, const side_inf
     const unsigned gr = g >> 1, ch = g & 1;
     pdmp3_gc_side* r = &sd[g];
     r->frame = fr;
+    r->lsf = (uint8_t)H->ver;
     r->iso = (uint8_t)(((id->iso & PDMP3_ISO_MS_BOUND) ? PDMP3_GC_ISO_MS_ALL : 0) | ((id->iso & PDMP3_ISO_IS_SHORT) ? PDMP3_GC_ISO_IS_SHORT : 0) |
                        ((id->iso & PDMP3_ISO_IS_BOUND) ? PDMP3_GC_ISO_IS_STD : 0));
-    if (ch >= nch) { memset(spectra + g * 576, 0, 576 * sizeof(int16_t)); continue; }
+    if (ch >= nch || (H->ver && gr == 1)) { memset(spectra + g * 576, 0, 576 * sizeof(int16_t)); continue; }   /* (an LSF frame is one granule) */
+    if (H->ver && ch == 1 && H->mode == 1 && (H->mode_ext & 1)) {
+      /* channel 1 of an LSF intensity-stereo frame: its scalefactors are intensity positions, whose "not intensity
+       * coded" value depends on the partition a position came in (include/pdmp3_hip.h) */
+      uint8_t slen[4];
+      int pf;
+      const int cls = lsf_slen_of(S->scalefac_compress[0][1], 1, slen, &pf);
+      const int shortb = S->win_switch[0][1] && S->block_type[0][1] == 2, mixed = shortb && S->mixed[0][1];
+      if (S->scalefac_compress[0][1] & 1) r->lsf |= PDMP3_LSF_IS_SCALE;
+      for (unsigned k = 0; k < 4; k++) { r->lsf_slen[k] = slen[k]; r->lsf_nsfb[k] = kLsfNsfb[cls][shortb ? (mixed ? 2 : 1) : 0][k]; }
+    }
     r->count1 = id->count1[gr][ch];
     r->global_gain = (uint8_t)S->global_gain[gr][ch];
     r->flags = (uint8_t)((S->scalefac_scale[gr][ch] ? PDMP3_GC_SCALEFAC_SCALE : 0) |
@@ -848,8 +964,8 @@ static void emit_records(pdmp3_handle* id, const frame_header* H, const side_inf
       r->scalefac_s[12][0] = r->scalefac_s[12][1] = r->scalefac_s[12][2] = PDMP3_SF_PEEK;
     }
     /* the ISO switches (pdmp3_amd_set_quirks; not the reference): bands 21 / 12 have scalefactor 0 */
-    if (id->iso & PDMP3_ISO_SF21) r->scalefac_l[21] = 0;
-    if (id->iso & PDMP3_ISO_SF12) r->scalefac_s[12][0] = r->scalefac_s[12][1] = r->scalefac_s[12][2] = 0;
+    if ((id->iso & PDMP3_ISO_SF21) || H->ver) r->scalefac_l[21] = 0;
+    if ((id->iso & PDMP3_ISO_SF12) || H->ver) r->scalefac_s[12][0] = r->scalefac_s[12][1] = r->scalefac_s[12][2] = 0;
   }
   if (id->tap_side) {
     if (id->tap_n < id->tap_cap) {
@@ -864,11 +980,12 @@ static void emit_records(pdmp3_handle* id, const frame_header* H, const side_inf
 static size_t drain_frame(pdmp3_handle* id, unsigned char* out, size_t buflen) {
   const unsigned nch = id->l_hdr.mode == 3 ? 1 : 2;        /* the CURRENT header's channel count, as in the reference */
   const unsigned sh = (id->enc_f32 ? 2 : 1) + (nch - 1), bps = 1u << sh;
+  const unsigned spf = frame_samples(&id->l_hdr);         /* 1152; 576 for an LSF frame (one granule) */
   size_t n = buflen >> sh;
-  if (n > 1152u - id->ostart) n = 1152u - id->ostart;
+  if (n > spf - id->ostart) n = spf - id->ostart;
   if (out) memcpy(out, (const unsigned char*)id->last_pcm + (size_t)id->ostart * bps, n * bps);
   id->ostart += (unsigned)n;
-  if (id->ostart == 1152) id->ostart = 0;
+  if (id->ostart >= spf) id->ostart = 0;
   return n * bps;
 }
 
@@ -1109,8 +1226,10 @@ static int read_ahead(pdmp3_handle* id) {
     snap_save(id, snap);
     id->ring_short = 0;
     const int r = read_frame_staged(id);
-    /* undone unless it succeeded on bytes that were all there */
-    if (r != PDMP3_OK || id->ring_short || id->processed - snap->processed > avail) {
+    /* undone unless it succeeded on bytes that were all there -- and belongs into this batch: the engine takes LSF
+     * frames in launches of their own, all of one channel count (pdmp3_hip_stream_set_lsf) */
+    if (r != PDMP3_OK || id->ring_short || id->processed - snap->processed > avail ||
+        id->hdr.ver != id->ra[0].hdr.ver || (id->hdr.ver && (id->hdr.mode == 3) != (id->ra[0].hdr.mode == 3))) {
       snap_restore(id, snap);
       break;
     }
@@ -1140,6 +1259,7 @@ static int read_ahead(pdmp3_handle* id) {
     emit_records(id, jobs[i].H, jobs[i].S, i == 0 ? reset0 : 0, spectra + (size_t)i * 2304, side + (size_t)i * 4);
   }
   if (id->hs) {
+    (void)pdmp3_hip_stream_set_lsf(id->hs, id->ra[0].hdr.ver != 0);
     if (pdmp3_hip_stream_submit(id->hs, 0, id->ra_n) != PDMP3_HIP_OK) {
       fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
       id->ra_n = 0;
@@ -1187,9 +1307,13 @@ static int read_impl(pdmp3_handle* id, unsigned char* outmemory, size_t outsize,
     }
     id->l_processed = e->processed_after; id->l_istart = e->istart_after; id->l_hdr = e->hdr;
     if (!id->l_new_header && e->nh) id->l_new_header = 1;
-    const size_t fbytes = (id->enc_f32 ? 4608u : 2304u) * e->nch;
-    const unsigned char* pcm = id->hs ? (const unsigned char*)pdmp3_hip_stream_pcm(id->hs) +
-                                            (size_t)id->ra_head * (id->enc_f32 ? 9216u : 4608u) : NULL;
+    /* where frame ra_head of the batch lies in the slot's PCM (include/pdmp3_hip.h): an MPEG-1 frame in its own 4608-byte
+     * place (9216 as float); LSF frames -- half the samples -- back to back when stereo, in pairs per place when mono */
+    const size_t place = id->enc_f32 ? 9216u : 4608u;
+    const size_t fbytes = (e->hdr.ver ? place / 4 : place / 2) * e->nch;
+    const size_t off = !e->hdr.ver ? (size_t)id->ra_head * place
+                       : e->nch == 2 ? (size_t)id->ra_head * fbytes : (size_t)(id->ra_head >> 1) * place + (size_t)(id->ra_head & 1) * fbytes;
+    const unsigned char* pcm = id->hs ? (const unsigned char*)pdmp3_hip_stream_pcm(id->hs) + off : NULL;
     id->ra_head++;
     if (pcm && id->ostart == 0 && outsize >= fbytes) {    /* whole frame fits: copy straight through */
       memcpy(outmemory, pcm, fbytes);
@@ -1263,8 +1387,9 @@ int pdmp3_amd_set_encoding(pdmp3_handle* id, int encoding) {
   if (ra_rollback(id) != PDMP3_OK) return PDMP3_ERR;          /* frames read ahead were decoded in the other format */
   if (id->ostart) {                                            /* the frame under the cursor was, too: convert what is left */
     const unsigned nch = id->l_hdr.mode == 3 ? 1 : 2;
-    if (want) { float* f = (float*)id->last_pcm; for (int k = (int)(1152 * nch) - 1; k >= 0; k--) f[k] = (float)id->last_pcm[k] / 32767.0f; }
-    else { const float* f = (const float*)id->last_pcm; for (unsigned k = 0; k < 1152 * nch; k++) { float v = f[k] * 32767.0f; id->last_pcm[k] = (int16_t)(v > 32767.0f ? 32767 : v < -32767.0f ? -32767 : (int)v); } }
+    const unsigned spf = frame_samples(&id->l_hdr);
+    if (want) { float* f = (float*)id->last_pcm; for (int k = (int)(spf * nch) - 1; k >= 0; k--) f[k] = (float)id->last_pcm[k] / 32767.0f; }
+    else { const float* f = (const float*)id->last_pcm; for (unsigned k = 0; k < spf * nch; k++) { float v = f[k] * 32767.0f; id->last_pcm[k] = (int16_t)(v > 32767.0f ? 32767 : v < -32767.0f ? -32767 : (int)v); } }
   }
   if (id->hs && pdmp3_hip_stream_set_f32(id->hs, want) != PDMP3_HIP_OK) return PDMP3_ERR;
   id->enc_f32 = want;
@@ -1275,7 +1400,7 @@ int pdmp3_amd_set_encoding(pdmp3_handle* id, int encoding) {
 /* ISO-correct switches (include/pdmp3.h): from the next frame parsed on.  Frames that pdmp3_read has
  * parsed ahead keep the mode they were parsed in. */
 int pdmp3_amd_set_quirks(pdmp3_handle* id, unsigned iso_mask) {
-  if (!id || (iso_mask & ~PDMP3_ISO_ALL)) return PDMP3_ERR;
+  if (!id || (iso_mask & ~(PDMP3_ISO_ALL | PDMP3_ISO_LSF))) return PDMP3_ERR;
   id->iso = iso_mask;
   return PDMP3_OK;
 }
@@ -1283,7 +1408,7 @@ int pdmp3_amd_set_quirks(pdmp3_handle* id, unsigned iso_mask) {
 int pdmp3_getformat(pdmp3_handle* id, long* rate, int* channels, int* encoding) {
   if (!(id && rate && channels && encoding)) return PDMP3_ERR;
   *encoding = id->enc_f32 ? PDMP3_ENC_FLOAT_32 : PDMP3_ENC_SIGNED_16;
-  *rate = (long)kSampleRates[id->l_hdr.sfreq];
+  *rate = (long)kLsfSampleRates[sfreq9(&id->l_hdr)];
   *channels = id->l_hdr.mode == 3 ? 1 : 2;
   id->new_header = -1;
   id->l_new_header = -1;
@@ -1375,6 +1500,8 @@ typedef struct {                      /* a window that is on the GPU */
   int direct;                         /* the GPU downloads straight to dst (pinned caller memory): nothing to copy */
   uint8_t* nch;
   long long sub_seq;                  /* its place in the submitter's queue */
+  int lsf;                            /* a window of LSF frames (all of one version and channel count): half the PCM per frame,
+                                         laid out as include/pdmp3_hip.h pdmp3_hip_decode_lsf_frames says */
 } bulk_flight;
 
 /* split scan: a window as a scanner thread leaves it -- what bits_push / fill_reservoir_pool write into an engine slot,
@@ -1407,6 +1534,8 @@ struct bulk {
   int trace2; double tr_t0;           /* $PDMP3_BULK_TRACE >= 2: per-window lines, times from the stream's start */
   int count_only;                     /* scan: stage A alone */
   int bits_mode;                      /* main data goes to the device undecoded (pdmp3_hip_stream_submit_bits) */
+  int device, window_arg;             /* what bulk_new was given (the LSF decoder below is made with the same) */
+  struct bulk* lsf_alt;               /* bits mode + PDMP3_ISO_LSF: the host-Huffman decoder LSF streams go through (bulk_decode_impl) */
   pdmp3_frame_bits* bits_dst; uint8_t* res_dst;   /* where stage A writes the current window (bits mode) */
   int bits_n, bits_slot, bits_open;
   pdmp3_frame_bits* rec_bits; uint8_t* rec_res;   /* parse-only bits mode: caller memory */
@@ -1574,6 +1703,22 @@ static int bulk_collect(struct bulk* b, int slot, const unsigned char** jsrc, un
   if (f->direct) return PDMP3_OK;
   const unsigned char* src = (const unsigned char*)pdmp3_hip_stream_slot_pcm(b->hs, slot);
   const int to_device = b->pcm_pinned == 2;       /* memory the host cannot write: copies go through the engine */
+  if (f->lsf) {
+    /* stereo frames lie back to back (2304 bytes each), mono frames in pairs in the first half of a 4608-byte place */
+    size_t off = 0;
+    const size_t fb = f->all_stereo == 2 ? 2304 : 1152;
+    for (int i = 0; i < f->n && off < f->dst_cap;) {
+      const int run = f->all_stereo == 2 ? f->n - i : ((i & 1) || i + 1 == f->n ? 1 : 2);
+      const unsigned char* from = f->all_stereo == 2 ? src + (size_t)i * 2304 : src + (size_t)(i >> 1) * 4608 + (size_t)(i & 1) * 1152;
+      size_t n = (size_t)run * fb;
+      if (n > f->dst_cap - off) n = f->dst_cap - off;
+      if (to_device) { if (pdmp3_hip_copy_to_dest(f->dst + off, from, n) != PDMP3_HIP_OK) return PDMP3_ERR; }
+      else memcpy(f->dst + off, from, n);
+      off += (size_t)run * fb;
+      i += run;
+    }
+    return PDMP3_OK;
+  }
   if (f->all_stereo == 2 || (f->all_stereo == 1 && jbytes && !to_device)) {
     const size_t row = f->all_stereo == 2 ? 4608 : 2304;
     size_t n = (size_t)f->n * row;
@@ -1605,7 +1750,7 @@ static int bulk_collect(struct bulk* b, int slot, const unsigned char** jsrc, un
 /* a window whose frames all have the same channel count and that fits its destination goes there directly when
  * the destination is pinned */
 static void flight_plan(struct bulk* b, bulk_flight* f) {
-  const size_t row = f->all_stereo == 2 ? 4608 : 2304;
+  const size_t row = (f->all_stereo == 2 ? 4608 : 2304) >> (f->lsf ? 1 : 0);
   f->direct = b->pcm_pinned && f->all_stereo != 0 && f->dst && (size_t)f->n * row <= f->dst_cap;
   /* (a window that cannot go there directly -- mixed mono / stereo frames, or the tail that does not fit -- is staged in
    * the slot's pinned buffer and copied by bulk_collect, through the engine when the destination is device memory) */
@@ -1630,11 +1775,13 @@ static int bulk_finish_b(struct bulk* b) {
     emit_records(id, &j->hdr, &j->si, j->reset, w->spectra + (size_t)i * 2304, w->side + (size_t)i * 4);
     const unsigned nch = j->hdr.mode == 3 ? 1 : 2;
     if (f) { f->nch[i] = (uint8_t)nch; f->all_stereo = f->all_stereo < 0 ? (int)nch : (f->all_stereo == (int)nch ? f->all_stereo : 0); }
-    b->pcm_emitted += 2304u * nch;
+    b->pcm_emitted += 2u * frame_samples(&j->hdr) * nch;
   }
   if (f) {
+    f->lsf = w->n && w->jobs[0].hdr.ver != 0;     /* (bulk_push closes a window where the version -- or an LSF stream's channel count -- changes) */
     flight_plan(b, f);
-    if (pdmp3_hip_stream_submit_to(b->hs, w->slot, w->n, f->direct ? f->dst : NULL, f->all_stereo == 1 ? 2304 : 4608) != PDMP3_HIP_OK) {
+    (void)pdmp3_hip_stream_set_lsf(b->hs, f->lsf);
+    if (pdmp3_hip_stream_submit_to(b->hs, w->slot, w->n, f->direct ? f->dst : NULL, (f->all_stereo == 1 ? 2304 : 4608) >> (f->lsf ? 1 : 0)) != PDMP3_HIP_OK) {
       fprintf(stderr, "pdmp3: engine failure: %s\n", pdmp3_hip_last_error());
       return PDMP3_ERR;
     }
@@ -2087,6 +2234,11 @@ static int bulk_push(struct bulk* b) {
   if (b->count_only) { id->need_reset = 0; return PDMP3_OK; }
   if (b->bits_mode) return bits_push(b);
   bulk_window* w = &b->win[b->cur];
+  /* the engine takes LSF frames in launches of their own, all of one channel count: such a frame opens a new window */
+  if (w->n && (id->hdr.ver != w->jobs[0].hdr.ver || (id->hdr.ver && (id->hdr.mode == 3) != (w->jobs[0].hdr.mode == 3)))) {
+    if (bulk_rotate(b) != PDMP3_OK) { b->failed = 1; return PDMP3_ERR; }
+    w = &b->win[b->cur];
+  }
   frame_job* j = &w->jobs[w->n++];
   j->hdr = id->hdr;
   j->si = id->si;
@@ -2393,6 +2545,7 @@ static void header_fields(uint32_t h, frame_header* H) {
   H->id = (h >> 19) & 1; H->layer = 4 - ((h >> 17) & 3); H->protection = (h >> 16) & 1;
   H->bitrate_index = (h >> 12) & 15; H->sfreq = (h >> 10) & 3; H->padding = (h >> 9) & 1;
   H->mode = (h >> 6) & 3; H->mode_ext = (h >> 4) & 3;
+  H->ver = 0;                                      /* (the split scan and the window estimates are MPEG-1's: bits mode never takes LSF) */
 }
 static inline uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
@@ -3122,6 +3275,7 @@ long long pdmp3_amd_test_split_scan(const unsigned char* mp3, size_t n, int wind
 
 void pdmp3_amd_bulk_delete(struct bulk* b) {
   if (!b) return;
+  if (b->lsf_alt) { pdmp3_amd_bulk_delete(b->lsf_alt); b->lsf_alt = NULL; }
   if (b->th) {
     pthread_mutex_lock(&b->mu);
     b->quit = 1;
@@ -3218,6 +3372,7 @@ static void bind_thread(pthread_t t, const cpu_set_t* set) { if (CPU_COUNT(set) 
  * parse-only decoder (host tests on machines without a GPU). */
 static struct bulk* bulk_new(int threads, int window_frames, int with_engine, int bits_mode, int device) {
   pthread_once(&g_lut_once, build_luts);
+  const int window_arg = window_frames;
   if (threads <= 0) {
     const int c = usable_cpus();
     threads = c > 64 ? 64 : c;
@@ -3240,6 +3395,8 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
   if (!b) return NULL;
   b->cap = window_frames;
   b->target = target;
+  b->device = device;
+  b->window_arg = window_arg;
   {
     /* split scan (par_drive): 12 scanners where the process has 32 CPUs, 8 with 16 (they live for the few milliseconds of a
      * stream's scan; with the PCM left in HBM the scanners, the upload and the kernels all take about 0.2 ms per 8192 frames, and
@@ -3387,6 +3544,16 @@ static int bulk_drain(struct bulk* b) {
 static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size_t n, unsigned char* pcm, size_t pcm_cap,
                                   long* rate, int* channels, int drain) {
   if (!b || !b->hs || (!mp3 && n) || (!pcm && pcm_cap)) return -1;
+  /* PDMP3_ISO_LSF on a decoder whose Huffman stage is on the device: that stage reads MPEG-1 side info only, so a stream
+   * that opens with an MPEG-2 LSF / 2.5 header goes through a host-Huffman decoder this one keeps for the purpose
+   * (same device, same threads and window, same switches; the call is synchronous then) */
+  if (b->bits_mode && (b->id->iso & PDMP3_ISO_LSF) && n >= 4 && mp3[0] == 0xff && (mp3[1] & 0xe0) == 0xe0 && (mp3[1] & 0x18) != 0x18 && (mp3[1] & 0x18) != 0x08) {
+    if (!b->lsf_alt) b->lsf_alt = bulk_new(b->nth, b->window_arg, 1, 0, b->device);
+    if (!b->lsf_alt) return -1;
+    if (bulk_drain(b) != PDMP3_OK) return -1;     /* (this decoder's own streams first: the PCM destinations may overlap) */
+    b->lsf_alt->id->iso = b->id->iso;
+    return bulk_decode_impl(b->lsf_alt, mp3, n, pcm, pcm_cap, rate, channels, 1);
+  }
   bulk_begin(b);
   /* Device Huffman: nothing to reset on the host side -- the stream's first frame carries PDMP3_FR_RESET (synthesis
    * state) and, unless parse state is carried over (pdmp3()), PDMP3_FR_NEWSTREAM (scalefactors / count1), so
@@ -3446,7 +3613,7 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
   if (drain || !b->bits_mode || !ok) ok = bulk_drain(b) == PDMP3_OK && ok;
   else if (b->pool_mode) ok = sub_drain_copied(b) == PDMP3_OK && ok;      /* the submitter has taken the main data out of `mp3` */
   b->t_tail += now_s() - t_driven;
-  if (rate) *rate = (long)kSampleRates[b->id->hdr.sfreq];
+  if (rate) *rate = (long)kLsfSampleRates[sfreq9(&b->id->hdr)];
   if (channels) *channels = b->id->hdr.mode == 3 ? 1 : 2;
   if (getenv("PDMP3_BULK_TRACE")) {
     fprintf(stderr, "bulk trace: scan loop %.2f ms (of it waiting for the submitter %.2f ms), tail %.2f ms (cumulative)\n",
@@ -3625,7 +3792,7 @@ static void cli_stream_file(pdmp3_handle* id, const char* filename, FILE* fp) {
   size_t done;
   int res;
   while ((res = pdmp3_read(id, out, INBUF_SIZE, &done)) != PDMP3_ERR) {
-    write_raw(filename, out, done, done ? (long)kSampleRates[id->l_hdr.sfreq] : 0, id->l_hdr.mode == 3 ? 1 : 2);
+    write_raw(filename, out, done, done ? (long)kLsfSampleRates[sfreq9(&id->l_hdr)] : 0, id->l_hdr.mode == 3 ? 1 : 2);
     if (res == PDMP3_NEED_MORE) {
       unsigned char in[4096];
       const size_t n = fread(in, 1, sizeof in, fp);
@@ -3688,7 +3855,7 @@ void pdmp3(char* const* mp3s) {
   const int streaming_only = force && *force && *force != '0';
   /* $PDMP3_CLI_ISO = mask of PDMP3_ISO_* (include/pdmp3.h): the standard's behaviour instead of the reference's; default 0 */
   const char* iso_env = getenv("PDMP3_CLI_ISO");
-  const unsigned iso = iso_env ? (unsigned)strtoul(iso_env, NULL, 0) & PDMP3_ISO_ALL : 0u;
+  const unsigned iso = iso_env ? (unsigned)strtoul(iso_env, NULL, 0) & (PDMP3_ISO_ALL | PDMP3_ISO_LSF) : 0u;
   (void)pdmp3_amd_set_quirks(id, iso);
   struct bulk* b = NULL;
   int bulk_used = 0, loop_used = 0;

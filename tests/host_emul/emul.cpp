@@ -37,6 +37,37 @@ extern "C" int emul_decode_frames(const int16_t* spectra, const pdmp3_gc_side* s
   return 0;
 }
 
+// LSF frames (pdmp3_hip_decode_lsf_frames: engine.hip k_lsf_pair + the chunk kernel with DecodeArgs::n_gran): the pairing
+// done here on the host, then the same run_chunk
+extern "C" int emul_decode_lsf_frames(const int16_t* spectra, const pdmp3_gc_side* side, int n_frames,
+                                      float* state, int16_t* pcm, float* pcm_f32, int chunk_frames) {
+  static HostTables H;
+  static bool ready = false;
+  if (!ready) { build_host_tables(H); ready = true; }
+  GlobalTables T{H.pow43.data(), H.linetab.data(), H.win.data(), H.frag_long.data(), H.frag_short.data(), H.frag_mat.data(), H.taps.data(), H.tab_image.data()};
+  const int np = (n_frames + 1) / 2;
+  std::vector<int16_t> psp((size_t)np * 2304, 0);
+  std::vector<pdmp3_gc_side> psd((size_t)np * 4);
+  memset(psd.data(), 0, psd.size() * sizeof(pdmp3_gc_side));
+  for (int f = 0; f < n_frames; f++) {
+    memcpy(&psp[(size_t)(f >> 1) * 2304 + (f & 1) * 1152], spectra + (size_t)f * 2304, 1152 * sizeof(int16_t));
+    memcpy(&psd[(size_t)(f >> 1) * 4 + (f & 1) * 2], side + (size_t)f * 4, 2 * sizeof(pdmp3_gc_side));
+  }
+  if (chunk_frames <= 0) chunk_frames = np;
+  std::vector<float> state_next(kStateFloats);
+  DecodeArgs a{psp.data(), psd.data(), pcm, pcm_f32, state, state ? state_next.data() : nullptr, nullptr, np, chunk_frames, nullptr, nullptr, nullptr, 0u};
+  a.n_gran = n_frames;
+  const int nchunks = (np + chunk_frames - 1) / chunk_frames;
+  auto L = std::make_unique<WaveLds>();
+  for (int c = 0; c < nchunks; ++c) {
+    WaveLds& Lr = *L;
+    if (pcm_f32) emu::run_wave([&] { run_chunk<false, false, true>(a, T, &H.cb, c, Lr, Lr.tab); });
+    else emu::run_wave([&] { run_chunk<false>(a, T, &H.cb, c, Lr, Lr.tab); });
+  }
+  if (state) std::copy(state_next.begin(), state_next.end(), state);
+  return 0;
+}
+
 // float PCM form (pdmp3_hip_decode_frames_f32)
 extern "C" int emul_decode_frames_f32(const int16_t* spectra, const pdmp3_gc_side* side, int n_frames,
                                       float* state, float* pcm, int chunk_frames) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/iso_*.npz: what an independent ISO decoder (FFmpeg's mpegaudiodec, tools/ffmpeg_ref.py) decodes the
+"""Writes tests/golden/iso_*.npz and tests/golden/lsf_*.npz: what an independent ISO decoder (FFmpeg's mpegaudiodec, tools/ffmpeg_ref.py) decodes the
 conforming packer streams of tests/iso_streams.py to.  BUILD CONTAINER ONLY (the decoder lives in the image's kaleido
 wheel); the fixtures travel, this script's dependencies do not.
 
@@ -28,13 +28,14 @@ from oracle.oracle import Oracle                     # noqa: E402
 from pdmp3_amd.packer import packer                  # noqa: E402
 
 
-def oracle_f32(orc, mp3, iso, nch):
+def oracle_f32(orc, mp3, iso, nch, lsf=False):
     """the oracle's binary32 PCM x 32768 (FFmpeg's full scale; the reference's own int16 uses 32767, P:2028), clipped:
-    [channels][samples]"""
+    [channels][samples].  lsf: 576 sample-frames per frame (the first half of each frame's place)"""
     _, sp, sd = orc.decode_buffer_like_cli_iso(mp3, iso, tap_frames=4096)
     _, f32 = orc.decode_f32(sp, sd)
     n = sp.shape[0]
-    x = f32.reshape(n * 1152, 2).T if nch == 2 else f32[:, :1152].reshape(1, -1)
+    spf = 576 if lsf else 1152
+    x = f32[:, :spf * 2].reshape(n * spf, 2).T if nch == 2 else f32[:, :spf].reshape(1, -1)
     return np.clip(x * 32768.0, -32768.0, 32767.0)
 
 
@@ -67,6 +68,34 @@ def main():
                                 rate=rate, channels=nch, offset=off, pcm=k.T.astype(np.int16))
             print(json.dumps(row))
     json.dump(report, open(os.path.join(ROOT, "profiles", "r06_iso_pin.json"), "w"), indent=1)
+    # ---- MPEG-2 LSF / MPEG-2.5: the same for tests/iso_streams.py LSF_STREAMS (PDMP3_ISO_LSF; the switches are implied) ----
+    report = []
+    import ctypes as C
+    with FFmpegRef() as ff:
+        for name, kw in iso_streams.LSF_STREAMS.items():
+            mp3 = packer.generate(**kw)
+            nch, rate = iso_streams.nch_of(kw), iso_streams.lsf_rate_of(kw)
+            t = ff.decode(mp3, rate, nch)[:nch]
+            theirs = np.where(t < 0, t * 32768.0, t * 32767.0)
+            k = np.round(theirs)
+            assert np.abs(theirs - k).max() < 2e-3, "FFmpeg's output is not int16"
+            ours = oracle_f32(orc, mp3, 0x40, nch, lsf=True)
+            off, e = align(ours / 32768.0, k / 32768.0, max_shift=600)
+            assert off == 0, (name, off, e)
+            m = min(ours.shape[1], k.shape[1])
+            err = np.abs(ours[:, :m] - k[:, :m])
+            row = {"stream": name, "rate": rate, "frames_ffmpeg": k.shape[1] // 576, "frames_ours": ours.shape[1] // 576, "peak_lsb": float(np.abs(k).max()),
+                   "max": float(err.max()), "rms": float(np.sqrt((err ** 2).mean()))}
+            if rate == 24000:
+                orc.lib.orc_debug_24k_330(1)
+                o330 = oracle_f32(orc, mp3, 0x40, nch, lsf=True)
+                orc.lib.orc_debug_24k_330(0)
+                row["max_with_ffmpegs_330"] = float(np.abs(o330[:, :m] - k[:, :m]).max())
+            report.append(row)
+            np.savez_compressed(os.path.join(out_dir, name + ".npz"), kwargs=json.dumps(kw), sha256=hashlib.sha256(mp3).hexdigest(),
+                                rate=rate, channels=nch, offset=off, pcm=k.T.astype(np.int16))
+            print(json.dumps(row))
+    json.dump(report, open(os.path.join(ROOT, "profiles", "r06_lsf_pin.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
