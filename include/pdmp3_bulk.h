@@ -90,11 +90,18 @@ void pdmp3_amd_bulk_split_scans(const pdmp3_amd_bulk* b, long long* taken, long 
 /* ISO-correct switches (include/pdmp3.h: PDMP3_ISO_*, pdmp3_amd_set_quirks) for the streams decoded from now on;
  * 0 (the default) = the reference's behaviour, bit for bit.  The CLI driver reads the mask from $PDMP3_CLI_ISO. */
 int pdmp3_amd_bulk_set_quirks(pdmp3_amd_bulk* b, unsigned iso_mask);
+/* PDMP3_ISO_LSF (MPEG-2 LSF / MPEG-2.5 streams, which the reference rejects): the device's Huffman stage reads MPEG-1 side
+ * info only, so LSF streams take the HOST Huffman stage -- a host_huffman decoder decodes them in its windows like any
+ * stream (a window closes where the version, or an LSF stream's channel count, changes); a device-Huffman decoder
+ * hands a stream that OPENS with an LSF header to a host-Huffman decoder it creates for the purpose (same device, threads,
+ * window and switches; the call is synchronous then) and rejects LSF frames inside an MPEG-1 stream. */
 
 /* PCM bytes (return value) and frames pdmp3() would produce for this stream;
  * header / side-info / reservoir pass only, no Huffman, no GPU.  Use it to
  * size the output of pdmp3_amd_bulk_decode. */
 long long pdmp3_amd_scan_buffer(const unsigned char* mp3, size_t n, long long* frames);
+/* ... with a decoder's switches (pdmp3_amd_bulk_set_quirks): PDMP3_ISO_LSF makes MPEG-2 LSF / 2.5 frames count */
+long long pdmp3_amd_scan_buffer_iso(const unsigned char* mp3, size_t n, unsigned iso_mask, long long* frames);
 
 /* Decode one whole stream with a fresh decoder state.  Returns the PCM byte
  * count pdmp3() writes for it; pcm[0 .. min(return, pcm_cap)) holds them

@@ -14,7 +14,7 @@ PDMP3_ENC_SIGNED_16 = 0xD0
 _LIB = None
 
 BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads", "pdmp3_amd_bulk_split_scans", "pdmp3_amd_bulk_set_quirks",
-                "pdmp3_amd_scan_buffer", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_decode_async", "pdmp3_amd_bulk_wait", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
+                "pdmp3_amd_scan_buffer", "pdmp3_amd_scan_buffer_iso", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_decode_async", "pdmp3_amd_bulk_wait", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
                 "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits", "pdmp3_amd_bulk_parse_pool", "pdmp3_amd_pcm_alloc", "pdmp3_amd_pcm_free", "pdmp3_amd_stream_loop", "pdmp3_amd_write_wav"]
 
 # include/pdmp3_hip.h: pdmp3_gc_bits / pdmp3_frame_bits
@@ -229,12 +229,15 @@ class RingReplay(RuntimeError):
     """PDMP3_BULK_REPLAY: the reference would replay its input ring on this stream (include/pdmp3_bulk.h)"""
 
 
-def scan_buffer(mp3):
-    """(pcm_bytes, frames) the CLI driver would produce for this stream (include/pdmp3_bulk.h)."""
+def scan_buffer(mp3, iso=0):
+    """(pcm_bytes, frames) the CLI driver would produce for this stream (include/pdmp3_bulk.h); iso: the decoder's switches
+    (PDMP3_ISO_LSF changes what counts as a frame)"""
     lib = load_library()
     a = _as_u8(mp3)
     frames = C.c_longlong(0)
-    total = lib.pdmp3_amd_scan_buffer(a.ctypes.data_as(C.c_void_p), len(mp3), C.byref(frames))
+    lib.pdmp3_amd_scan_buffer_iso.restype = C.c_longlong
+    lib.pdmp3_amd_scan_buffer_iso.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.POINTER(C.c_longlong)]
+    total = lib.pdmp3_amd_scan_buffer_iso(a.ctypes.data_as(C.c_void_p), len(mp3), iso, C.byref(frames))
     if total == -2:
         raise RingReplay("the reference replays its input ring on this stream (no finite output)")
     return total, frames.value
@@ -268,6 +271,7 @@ class BulkDecoder:
         self.lib.pdmp3_amd_bulk_set_quirks.argtypes = [C.c_void_p, C.c_uint]
         if self.lib.pdmp3_amd_bulk_set_quirks(self.h, iso_mask) != 0:
             raise ValueError("pdmp3_amd_bulk_set_quirks: unknown bits in %#x" % iso_mask)
+        self.iso = iso_mask
 
     def decode_into(self, mp3, out: np.ndarray):
         a = _as_u8(mp3)
@@ -324,7 +328,7 @@ class BulkDecoder:
         streams go through the pipeline back to back (pdmp3_amd_bulk_decode_async)."""
         outs = []
         for m in mp3s:
-            total, _ = scan_buffer(m)
+            total, _ = scan_buffer(m, getattr(self, "iso", 0))
             out = np.empty(max(total, 2) // 2, dtype=np.int16)
             got, _, _ = self.decode_into_async(m, out)
             assert got == total, (got, total)
@@ -334,7 +338,7 @@ class BulkDecoder:
 
     def decode(self, mp3):
         """-> interleaved int16 PCM (numpy), exactly the CLI driver's output for these bytes."""
-        total, _ = scan_buffer(mp3)
+        total, _ = scan_buffer(mp3, getattr(self, "iso", 0))
         out = np.empty(max(total, 2) // 2, dtype=np.int16)
         got, rate, ch = self.decode_into(mp3, out)
         assert got == total, (got, total)

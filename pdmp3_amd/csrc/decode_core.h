@@ -366,6 +366,10 @@ struct GranuleInfo {
   PD_MFN int kind(int ch) const { return is_short(ch) ? (is_mixed(ch) ? 2 : 1) : 0; }
 };
 
+// RARE = false: the caller knows that the granule is neither LSF nor intensity stereo (frame_is_rare below: the kernels
+// send such frames down a second copy of their code, so that the copy every ordinary granule goes through is as tight as
+// it was before those features existed -- inlined into the one loop they cost the chunk kernel 5 % in round 6)
+template <bool RARE = true>
 PD_FN GranuleInfo granule_info(const WaveData& L) {
   GranuleInfo g;
   // (the first dword of each record: count1 u16, global_gain, flags; byte 7: frame flags)
@@ -376,11 +380,14 @@ PD_FN GranuleInfo granule_info(const WaveData& L) {
   g.iso = PD_UNIFORM(L.side[0][offsetof(pdmp3_gc_side, iso)]);
   g.sfreq = fr & PDMP3_FR_SFREQ_MASK;
   if (g.sfreq > 2) g.sfreq = 2;
-  const int lsf0 = PD_UNIFORM(L.side[0][offsetof(pdmp3_gc_side, lsf)]);
-  g.ver = lsf0 & PDMP3_LSF_VERSION_MASK;
-  if (g.ver > 2) g.ver = 2;
+  g.ver = 0;
   g.lsf_scale = 0;
-  if (g.ver) {                // (wave-uniform; an MPEG-1 granule pays one scalar compare for all of this)
+  if (RARE) {
+    const int lsf0 = PD_UNIFORM(L.side[0][offsetof(pdmp3_gc_side, lsf)]);
+    g.ver = lsf0 & PDMP3_LSF_VERSION_MASK;
+    if (g.ver > 2) g.ver = 2;
+  }
+  if (RARE && g.ver) {                // (wave-uniform; an MPEG-1 granule pays one scalar compare for all of this)
     g.sfreq += 3 * g.ver;
     g.iso |= PDMP3_GC_ISO_MS_ALL | PDMP3_GC_ISO_IS_SHORT | PDMP3_GC_ISO_IS_STD;     // no reference behaviour exists for LSF: the standard's
     g.lsf_scale = (PD_UNIFORM(L.side[1][offsetof(pdmp3_gc_side, lsf)]) & PDMP3_LSF_IS_SCALE) ? 1 : 0;
@@ -393,6 +400,15 @@ PD_FN GranuleInfo granule_info(const WaveData& L) {
   g.flags0 = (int)(w0 >> 24);
   g.flags1 = (int)(w1 >> 24);
   return g;
+}
+
+// A frame the fast copies of the kernels do not take: intensity stereo (joint stereo with mode_extension bit 0) or LSF.
+// rec = any gc record of the frame.
+PD_FN bool frame_is_rare(const pdmp3_gc_side* rec) {
+  const uint8_t* b = reinterpret_cast<const uint8_t*>(rec);
+  const unsigned fr = b[7];
+  const bool is = ((fr & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 1 && (fr & (1u << PDMP3_FR_MODEEXT_SHIFT));
+  return is || (b[offsetof(pdmp3_gc_side, lsf)] & PDMP3_LSF_VERSION_MASK) != 0;
 }
 
 PD_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -553,6 +569,151 @@ PD_FN void ph_scales(int lane, WaveData& L) {
 // REORDERED lines l, l + 64, ..., l + 512 of both channels (consecutive lanes
 // touch consecutive LDS words: no bank conflicts on the int16 / u16 tables).
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// ph_stereo_is: joint stereo of a granule that HAS intensity stereo (mode_extension bit 0) -- the reference's
+// (P:1932-1971 with its H3 defects) or the standard's (PDMP3_GC_ISO_IS_STD; always for LSF) -- plus the granule's M/S
+// rotation.  Works in place on L.xr[ch][reordered line] (ph_requant has stored the requantised lines there), lines
+// lane + 64 i, i < ni (9; 1 for the peek-only halo granule).  Only in the RARE copies of the kernels' code (ph_requant).
+// ---------------------------------------------------------------------------
+PD_FN void ph_stereo_is(int lane, WaveData* Lp, const TabLds* Sp, BankPtr cb, const uint16_t* linetab, GranuleInfo g, int ni, int tg) {
+  WaveData& L = *Lp;
+  const TabLds& S = *Sp;
+  const uint16_t* gtab = linetab + (size_t)g.sfreq * 3 * 576;
+  const bool ms = (g.mode_ext & 2) != 0;
+  const int cmin = (g.iso & PDMP3_GC_ISO_MS_ALL) ? 576 : (g.count1_0 > g.count1_1 ? g.count1_1 : g.count1_0);
+  const int kind0 = g.kind(0), kind1 = g.kind(1);
+  const bool is_std = (g.iso & PDMP3_GC_ISO_IS_STD) != 0;
+  constexpr int kIsNone = 255;
+  const uint8_t* sd0 = L.side[0];
+  const uint8_t* sd1 = L.side[1];
+  // PDMP3_GC_ISO_IS_STD (NOT the reference; pinned against FFmpeg, DESIGN.md section 4): the standard's intensity stereo.
+  // A band (of a window, in short blocks) is intensity coded when the RIGHT channel holds no non-zero value in it or
+  // above it and the right channel's scalefactor there -- the last band borrows the one below -- is not the "off"
+  // value (7; LSF: the largest its slen holds); the block shape is the right channel's.
+  float lastl = -1.0f, last0 = -1.0f, last1 = -1.0f, last2 = -1.0f;
+  bool any_short = false;
+  if (is_std) {
+    // the last band with a non-zero line: of the long part, and of each window of the short part (as floats: PD_SHFL_XOR)
+    PD_NOUNROLL for (int i = 0; i < 9; i++) {        // (all 576 lines, also for the peek-only granule)
+      const int d = lane + 64 * i;
+      const unsigned e = tg ? gtab[kind1 * 576 + d] : S.ltab[kind1][d];
+      const int idx = (int)(e >> 10);
+      if (L.spec[1][e & 1023] != 0) {
+        const float b = (float)(idx < 22 ? idx : (idx - 22) / 3);
+        const int w = idx < 22 ? -1 : (idx - 22) % 3;
+        lastl = (w < 0 && b > lastl) ? b : lastl;
+        last0 = (w == 0 && b > last0) ? b : last0;
+        last1 = (w == 1 && b > last1) ? b : last1;
+        last2 = (w == 2 && b > last2) ? b : last2;
+      }
+    }
+    PD_NOUNROLL for (int m = 1; m < 64; m <<= 1) {
+      const float ol = PD_SHFL_XOR(lastl, m), o0 = PD_SHFL_XOR(last0, m), o1 = PD_SHFL_XOR(last1, m), o2 = PD_SHFL_XOR(last2, m);
+      lastl = ol > lastl ? ol : lastl;
+      last0 = o0 > last0 ? o0 : last0;
+      last1 = o1 > last1 ? o1 : last1;
+      last2 = o2 > last2 ? o2 : last2;
+    }
+    any_short = last0 >= 0.0f || last1 >= 0.0f || last2 >= 0.0f;
+  }
+  PD_NOUNROLL for (int i = 0; i < ni; i++) {
+    const int d = lane + 64 * i;
+    float a0 = L.xr[0][d], a1 = L.xr[1][d];
+    if (is_std) {
+      const unsigned e = tg ? gtab[kind1 * 576 + d] : S.ltab[kind1][d];
+      const int idx = (int)(e >> 10);
+      bool coded;
+      int pos, bi;               // bi: the scalefactor's number in transmission order (LSF: which partition it came in)
+      if (idx < 22) {
+        coded = !any_short && (float)idx > lastl;
+        bi = idx < 21 ? idx : 20;
+        pos = sd1[8 + bi];
+      } else {
+        const int b = (idx - 22) / 3, w = (idx - 22) % 3, bb = b < 12 ? b : 11;
+        const float lw = w == 0 ? last0 : (w == 1 ? last1 : last2);
+        coded = (float)b > lw;
+        pos = sd1[30 + bb * 3 + w];
+        bi = (kind1 == 2 ? 6 + (bb - 3) * 3 : bb * 3) + w;
+      }
+      int ispos;
+      if (g.ver) {
+        // 13818-3 2.4.3.2: "not intensity coded" is the largest value the scalefactor's slen holds
+        int acc = 0, ill = 0;
+        bool found = false;
+        PD_NOUNROLL for (int k = 0; k < 4; k++) {
+          acc += sd1[offsetof(pdmp3_gc_side, lsf_nsfb) + k];
+          const int v = (1 << sd1[offsetof(pdmp3_gc_side, lsf_slen) + k]) - 1;
+          ill = (!found && bi < acc) ? v : ill;
+          found = found || bi < acc;
+        }
+        ispos = (coded && pos != ill) ? (pos & 31) : kIsNone;
+      } else ispos = (coded && pos < 7) ? pos : kIsNone;
+      if (ispos == kIsNone) {
+        if (ms && d < cmin) {    // P:1921-1928
+          const float sum = a0 + a1, dif = a0 - a1;
+          a0 = (float)((double)sum * 0.70710678118654752440);
+          a1 = (float)((double)dif * 0.70710678118654752440);
+        }
+      } else {
+        const float kl = g.ver ? cb->isr_lsf_l[g.lsf_scale][ispos & 31] : cb->isr_l[ispos & 7];
+        const float kr = g.ver ? cb->isr_lsf_r[g.lsf_scale][ispos & 31] : cb->isr_r[ispos & 7];
+        const float x = a0;
+        a0 = kl * x;
+        a1 = kr * x;
+      }
+    } else {
+      // the reference's: M/S first (P:1921-1928), then P:1932-1971 with the block shape taken from channel 0
+      if (ms && d < cmin) {
+        const float sum = a0 + a1, dif = a0 - a1;
+        a0 = (float)((double)sum * 0.70710678118654752440);
+        a1 = (float)((double)dif * 0.70710678118654752440);
+      }
+      const int c1 = g.count1_1;
+      bool do_long = false, do_short = false;
+      int sfb = 0, win = 0;
+      if (kind0 == 0) {
+        sfb = (tg ? gtab[d] : S.ltab[0][d]) >> 10;
+        do_long = (sfb < 21);
+      } else if (kind0 == 2 && d < 36) {
+        sfb = (tg ? gtab[d] : S.ltab[0][d]) >> 10;
+        do_long = (sfb < 8);
+      } else {
+        // band of POSITION d in the un-reordered [win][j] layout (P:2203)
+        PD_NOUNROLL for (int b = 0; b < 13; b++) {
+          const int lo = 3 * cb->sfb_s[g.sfreq][b], hi = 3 * cb->sfb_s[g.sfreq][b + 1];
+          // (ISO switch: the lines are in reordered order by now, position lo + 3 j + w belongs to window w)
+          if (d >= lo && d < hi) { sfb = b; win = (g.iso & PDMP3_GC_ISO_IS_SHORT) ? (d - lo) % 3 : (d - lo) / ((hi - lo) / 3); }
+        }
+        do_short = (sfb < 12) && (kind0 == 1 || sfb >= 3);
+      }
+      if (do_long && (int)cb->sfb_l[g.sfreq][sfb] >= c1) {
+        const int is_pos = sd0[8 + sfb];
+        if (is_pos != 7) {
+          const float l = cb->isr_l[is_pos & 15] * a0;
+          const float r = cb->isr_r[is_pos & 15] * a0;
+          a0 = l; a1 = r;
+        }
+      }
+      if (do_short && 3 * (int)cb->sfb_s[g.sfreq][sfb] >= c1) {
+        const int is_pos = sd0[30 + sfb * 3 + win];
+        if (is_pos != 7 && (g.iso & PDMP3_GC_ISO_IS_SHORT)) {   // the standard's: the ratios of the long case, multiplied
+          const float l = cb->isr_l[is_pos & 15] * a0;
+          const float r = cb->isr_r[is_pos & 15] * a0;
+          a0 = l; a1 = r;
+        } else if (is_pos != 7) {   // H3: sample forced through `unsigned` (x86-64 conversion semantics)
+          const float xv = a0;
+          long long t = (xv >= 9.2233720368547758e18f || xv < -9.2233720368547758e18f || xv != xv)
+                            ? (long long)0x8000000000000000ull : (long long)xv;
+          const float vv = (float)(uint32_t)(unsigned long long)t;
+          a0 = vv; a1 = vv;
+        }
+      }
+    }
+    L.xr[0][d] = a0;
+    L.xr[1][d] = a1;
+  }
+}
+
 template <bool TG, bool SCALES> PD_FN void ph_requant_long(int lane, WaveData& L, const TabLds& S, const GlobalTables& T, const GranuleInfo& g);   // (below)
 PD_FN void ph_scales(int lane, WaveData& L);
 
@@ -561,17 +722,17 @@ PD_FN void ph_scales(int lane, WaveData& L);
 // the granule's (granule kernel: one table block per workgroup) -- then the line table is read from global memory.
 // SCALES: the band scales (ph_scales) are computed in here -- in the fast path while the loads from the full |is|^(4/3)
 // table are in flight (straight-line callers, which have nothing else to put there).
-template <bool DUMP, int NI = 9, bool FAST = false, bool TG = false, bool SCALES = false>
+template <bool DUMP, int NI = 9, bool FAST = false, bool TG = false, bool SCALES = false, bool RARE = true>
 PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const GlobalTables& T, float* dump0, float* dump1,
                       const GranuleInfo* gi = nullptr) {
   // (gi: the granule's facts, read once by the caller -- every granule_info() is an LDS round trip and four
   //  v_readfirstlane at the head of a phase, and the phase fences keep the compiler from sharing one between phases)
-  const GranuleInfo g = gi ? *gi : granule_info(L);
+  const GranuleInfo g = gi ? *gi : granule_info<RARE>(L);
   const bool tg = TG && (g.sfreq != S.sfreq);                       // wave-uniform
   const uint16_t* gtab = T.linetab + (size_t)g.sfreq * 3 * 576;
   const bool joint = (g.nch == 2) && (g.mode == 1) && (g.mode_ext != 0);
   const bool ms = joint && (g.mode_ext & 2);
-  const bool is = joint && (g.mode_ext & 1);
+  const bool is = RARE && joint && (g.mode_ext & 1);                // (RARE = false: no such granule comes this way)
   const int cmin = (g.iso & PDMP3_GC_ISO_MS_ALL) ? 576 : (g.count1_0 > g.count1_1 ? g.count1_1 : g.count1_0);   // P:1920 (H2): the smaller; ISO switch: every line
   const int kind0 = g.kind(0), kind1 = g.kind(1);
   if (FAST && !DUMP && NI == 9) {
@@ -632,146 +793,32 @@ PD_FN void ph_requant(int lane, WaveData& L, const TabLds& S, BankPtr cb, const 
       if (g.nch == 2) dump0[4 * 576 + PD_LINE(i)] = x1[i];
     }
   }
-  // PDMP3_GC_ISO_IS_STD (NOT the reference; pinned against FFmpeg, DESIGN.md section 4): the standard's intensity stereo.
-  // ispos[i] = the intensity position of the lane's line i, 7 = not intensity coded.  A band (of a window, in short
-  // blocks) is intensity coded when the RIGHT channel holds no non-zero value in it or above it and the right channel's
-  // scalefactor there -- the last band borrows the one below -- is not 7; the block shape is the right channel's.
-  const bool is_std = is && (g.iso & PDMP3_GC_ISO_IS_STD);
-  constexpr int kIsNone = 255;
-  int ispos[NI];
-  PD_UNROLL for (int i = 0; i < NI; i++) ispos[i] = kIsNone;
-  if (is_std) {
-    const uint8_t* sd1 = L.side[1];
-    // the last band with a non-zero line: of the long part, and of each window of the short part (as floats: PD_SHFL_XOR)
-    float lastl = -1.0f, last0 = -1.0f, last1 = -1.0f, last2 = -1.0f;
-    PD_NOUNROLL for (int i = 0; i < 9; i++) {        // (all 576 lines, also for the peek-only granule, NI = 1)
-      const int d = lane + 64 * i;
-      const unsigned e = tg ? gtab[kind1 * 576 + d] : S.ltab[kind1][d];
-      const int idx = (int)(e >> 10);
-      if (L.spec[1][e & 1023] != 0) {
-        const float b = (float)(idx < 22 ? idx : (idx - 22) / 3);
-        const int w = idx < 22 ? -1 : (idx - 22) % 3;
-        lastl = (w < 0 && b > lastl) ? b : lastl;
-        last0 = (w == 0 && b > last0) ? b : last0;
-        last1 = (w == 1 && b > last1) ? b : last1;
-        last2 = (w == 2 && b > last2) ? b : last2;
-      }
-    }
-    PD_NOUNROLL for (int m = 1; m < 64; m <<= 1) {
-      const float ol = PD_SHFL_XOR(lastl, m), o0 = PD_SHFL_XOR(last0, m), o1 = PD_SHFL_XOR(last1, m), o2 = PD_SHFL_XOR(last2, m);
-      lastl = ol > lastl ? ol : lastl;
-      last0 = o0 > last0 ? o0 : last0;
-      last1 = o1 > last1 ? o1 : last1;
-      last2 = o2 > last2 ? o2 : last2;
-    }
-    const bool any_short = last0 >= 0.0f || last1 >= 0.0f || last2 >= 0.0f;
-    PD_UNROLL for (int i = 0; i < NI; i++) {
-      const int d = PD_LINE(i);
-      const unsigned e = tg ? gtab[kind1 * 576 + d] : S.ltab[kind1][d];
-      const int idx = (int)(e >> 10);
-      bool coded;
-      int pos, bi;               // bi: the scalefactor's number in transmission order (LSF: which partition it came in)
-      if (idx < 22) {
-        coded = !any_short && (float)idx > lastl;
-        bi = idx < 21 ? idx : 20;
-        pos = sd1[8 + bi];
-      } else {
-        const int b = (idx - 22) / 3, w = (idx - 22) % 3, bb = b < 12 ? b : 11;
-        const float lw = w == 0 ? last0 : (w == 1 ? last1 : last2);
-        coded = (float)b > lw;
-        pos = sd1[30 + bb * 3 + w];
-        bi = (kind1 == 2 ? 6 + (bb - 3) * 3 : bb * 3) + w;
-      }
-      if (g.ver) {
-        // 13818-3 2.4.3.2: "not intensity coded" is the largest value the scalefactor's slen holds
-        int acc = 0, ill = 0;
-        bool found = false;
-        PD_UNROLL for (int k = 0; k < 4; k++) {
-          acc += sd1[offsetof(pdmp3_gc_side, lsf_nsfb) + k];
-          const int v = (1 << sd1[offsetof(pdmp3_gc_side, lsf_slen) + k]) - 1;
-          ill = (!found && bi < acc) ? v : ill;
-          found = found || bi < acc;
-        }
-        ispos[i] = (coded && pos != ill) ? (pos & 31) : kIsNone;
-      } else ispos[i] = (coded && pos < 7) ? pos : kIsNone;
-    }
-  }
-  if (ms) {   // P:1921-1928
+  // Intensity stereo is rare (no common encoder emits it) and its code is long: it is a function of its own that works
+  // on the lines in LDS (ph_stereo_is) and exists only in the RARE copies of the kernels' code.  The M/S rotation of such
+  // a granule is done there too (the standard's intensity stereo leaves the coded lines out of it).
+  if (ms && !is) {   // P:1921-1928
     PD_UNROLL for (int i = 0; i < NI; i++) {
       const float sum = x0[i] + x1[i], dif = x0[i] - x1[i];
       const float l = (float)((double)sum * 0.70710678118654752440);
       const float r = (float)((double)dif * 0.70710678118654752440);
-      const bool in = PD_LINE(i) < cmin && ispos[i] == kIsNone;
+      const bool in = PD_LINE(i) < cmin;
       x0[i] = in ? l : x0[i];
       x1[i] = in ? r : x1[i];
-    }
-  }
-  if (is_std) {
-    PD_UNROLL for (int i = 0; i < NI; i++) {
-      const float kl = g.ver ? cb->isr_lsf_l[g.lsf_scale][ispos[i] & 31] : cb->isr_l[ispos[i] & 7];
-      const float kr = g.ver ? cb->isr_lsf_r[g.lsf_scale][ispos[i] & 31] : cb->isr_r[ispos[i] & 7];
-      const float l = kl * x0[i], r = kr * x0[i];
-      x1[i] = ispos[i] != kIsNone ? r : x1[i];
-      x0[i] = ispos[i] != kIsNone ? l : x0[i];
-    }
-  }
-  if (is && !is_std) {   // P:1932-1971; block shape taken from channel 0.  Rare (no common encoder emits it).
-    const uint8_t* sd0 = L.side[0];
-    const int c1 = g.count1_1;
-    PD_NOUNROLL for (int i = 0; i < NI; i++) {
-      const int d = PD_LINE(i);
-      float a0 = 0.0f, a1 = 0.0f;
-      PD_UNROLL for (int k = 0; k < NI; k++) if (k == i) { a0 = x0[k]; a1 = x1[k]; }
-      bool do_long = false, do_short = false;
-      int sfb = 0, win = 0;
-      if (kind0 == 0) {
-        sfb = (tg ? gtab[d] : S.ltab[0][d]) >> 10;
-        do_long = (sfb < 21);
-      } else if (kind0 == 2 && d < 36) {
-        sfb = (tg ? gtab[d] : S.ltab[0][d]) >> 10;
-        do_long = (sfb < 8);
-      } else {
-        // band of POSITION d in the un-reordered [win][j] layout (P:2203)
-        PD_NOUNROLL for (int b = 0; b < 13; b++) {
-          const int lo = 3 * cb->sfb_s[g.sfreq][b], hi = 3 * cb->sfb_s[g.sfreq][b + 1];
-          // (ISO switch: the lines are in reordered order by now, position lo + 3 j + w belongs to window w)
-          if (d >= lo && d < hi) { sfb = b; win = (g.iso & PDMP3_GC_ISO_IS_SHORT) ? (d - lo) % 3 : (d - lo) / ((hi - lo) / 3); }
-        }
-        do_short = (sfb < 12) && (kind0 == 1 || sfb >= 3);
-      }
-      if (do_long && (int)cb->sfb_l[g.sfreq][sfb] >= c1) {
-        const int is_pos = sd0[8 + sfb];
-        if (is_pos != 7) {
-          const float l = cb->isr_l[is_pos & 15] * a0;
-          const float r = cb->isr_r[is_pos & 15] * a0;
-          a0 = l; a1 = r;
-        }
-      }
-      if (do_short && 3 * (int)cb->sfb_s[g.sfreq][sfb] >= c1) {
-        const int is_pos = sd0[30 + sfb * 3 + win];
-        if (is_pos != 7 && (g.iso & PDMP3_GC_ISO_IS_SHORT)) {   // the standard's: the ratios of the long case, multiplied
-          const float l = cb->isr_l[is_pos & 15] * a0;
-          const float r = cb->isr_r[is_pos & 15] * a0;
-          a0 = l; a1 = r;
-        } else if (is_pos != 7) {   // H3: sample forced through `unsigned` (x86-64 conversion semantics)
-          const float xv = a0;
-          long long t = (xv >= 9.2233720368547758e18f || xv < -9.2233720368547758e18f || xv != xv)
-                            ? (long long)0x8000000000000000ull : (long long)xv;
-          const float vv = (float)(uint32_t)(unsigned long long)t;
-          a0 = vv; a1 = vv;
-        }
-      }
-      PD_UNROLL for (int k = 0; k < NI; k++) if (k == i) { x0[k] = a0; x1[k] = a1; }
     }
   }
   PD_UNROLL for (int i = 0; i < NI; i++) {
     L.xr[0][PD_LINE(i)] = x0[i];
     if (g.nch == 2) L.xr[1][PD_LINE(i)] = x1[i];
   }
+  if (is) {
+    PD_WAVE_SYNC();
+    ph_stereo_is(lane, &L, &S, cb, T.linetab, g, NI, tg ? 1 : 0);
+    PD_WAVE_SYNC();
+  }
   if (DUMP) {
     PD_UNROLL for (int i = 0; i < NI; i++) {
-      dump1[PD_LINE(i)] = x0[i];
-      if (g.nch == 2) dump1[4 * 576 + PD_LINE(i)] = x1[i];
+      dump1[PD_LINE(i)] = L.xr[0][PD_LINE(i)];
+      if (g.nch == 2) dump1[4 * 576 + PD_LINE(i)] = L.xr[1][PD_LINE(i)];
     }
   }
 #undef PD_LINE
@@ -1317,6 +1364,8 @@ PD_FN int last_stereo_or_reset(const pdmp3_gc_side* side, int f_lo, int f_hi) {
 // ---------------------------------------------------------------------------
 // One chunk = one wavefront.
 // ---------------------------------------------------------------------------
+struct DecodeArgs;
+PD_FN bool chunk_is_rare(const DecodeArgs& a, int chunk);      // (below)
 struct DecodeArgs {
   const int16_t* spectra;        // [n_frames][2][2][576]
   const pdmp3_gc_side* side;     // [n_frames][2][2]
@@ -1341,6 +1390,31 @@ struct DecodeArgs {
 };
 constexpr unsigned PD_DEBUG_FAR_TIMEOUT = 1u;
 
+// Does the chunk -- its frames, its halo (four frames back cover the three granules of the longest one) and, when the
+// frame before it is mono, the far stereo frames run_chunk's pre-halo goes back to -- hold a frame_is_rare() frame?  Then
+// the wave runs the RARE copy of run_chunk.  Wave-uniform; one byte pair per lane and 64 frames.
+PD_FN bool chunk_is_rare(const DecodeArgs& a, int chunk) {
+  const int lane = PD_LANE();
+  if (a.n_gran > 0) return true;                                  // an LSF launch
+  const int f0 = chunk * a.chunk_frames;
+  int f1 = f0 + a.chunk_frames;
+  if (f1 > a.n_frames) f1 = a.n_frames;
+  bool rare = false;
+  for (int base = f0 - 4 < 0 ? 0 : f0 - 4; base < f1; base += 64) {
+    const int f = base + lane;
+    rare = rare || (f < f1 && frame_is_rare(a.side + (size_t)f * 4));
+  }
+  if (PD_ANY(rare)) return true;
+  if (f0 > 0) {
+    const uint8_t fb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f0 - 1) * 4)[7];
+    if (((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 && !(fb & PDMP3_FR_RESET)) {
+      const int fs = last_stereo_or_reset(a.side, 0, f0 - 1);     // (where the pre-halo starts: run_chunk)
+      if (fs >= 0 && (frame_is_rare(a.side + (size_t)fs * 4) || (fs > 0 && frame_is_rare(a.side + (size_t)(fs - 1) * 4)))) return true;
+    }
+  }
+  return false;
+}
+
 constexpr int kProfSlots = 12;
 
 // PD_PHASE: a phase body, then the wave-level fence that orders its LDS traffic against the next phase's
@@ -1358,7 +1432,7 @@ PD_FN void gran_publish_regs(int lane, const LaneRegs& R, const DecodeArgs& a, i
 // frequency; otherwise (granule kernel: S belongs to the workgroup and is there already) granules of another sampling
 // frequency read the global line table (ph_requant's TG).  gp: granule kernel only -- where the closing state goes.
 // state_only: decode nothing -- only derive the state at the START of the chunk (its halo), into *state_only.
-template <bool DUMP, bool PROF = false, bool F32 = false, bool OWN_TABS = true>
+template <bool DUMP, bool PROF = false, bool F32 = false, bool OWN_TABS = true, bool RARE = true>
 PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int chunk, WaveData& L, TabLds& S,
                      const GranPos* gp = nullptr, LaneRegs* state_only = nullptr) {
   LaneRegs R;
@@ -1418,7 +1492,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   // trip instead of two before the first granule can start)
   int cur_sfreq = reinterpret_cast<const uint8_t*>(a.side + (size_t)g_first * 2)[7] & PDMP3_FR_SFREQ_MASK;
   if (cur_sfreq > 2) cur_sfreq = 2;
-  {
+  if (RARE) {
     int v = reinterpret_cast<const uint8_t*>(a.side + (size_t)g_first * 2)[offsetof(pdmp3_gc_side, lsf)] & PDMP3_LSF_VERSION_MASK;
     cur_sfreq += 3 * (v > 2 ? 2 : v);
   }
@@ -1453,7 +1527,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     PD_LAUNDER(cb);
     // the granule's facts (wave-uniform, scalar registers), read ONCE here for all its phases; the commit phase below
     // overwrites the side records with the next granule's
-    const GranuleInfo gi = granule_info(L);
+    const GranuleInfo gi = granule_info<RARE>(L);
     if (OWN_TABS && gi.sfreq != cur_sfreq) {      // wave-uniform: first granule, or the stream changed sampling rate
       PD_PHASE(load_linetab(lane, S, T, gi.sfreq))
       cur_sfreq = gi.sfreq;
@@ -1464,7 +1538,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
     PD_TICK(1)
     float* dmp = DUMP ? a.stages + ((size_t)f * 16 + gr * 8) * 576 : nullptr;
     if (g == g_peek) {                     // wave-uniform: lines 0..63, boundary sb 0 | 1, three IMDCT outputs
-      PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<false, 1, false, !OWN_TABS>(lane, L, S, cb, T, nullptr, nullptr, &gi))
+      PD_PHASE(if (reset_here) state_zero(lane, R); ph_requant<false, 1, false, !OWN_TABS, false, RARE>(lane, L, S, cb, T, nullptr, nullptr, &gi))
       PD_TICK(2)
       PD_PHASE(
         if (g_next < g_end) ph_prefetch(lane, R, a.spectra + (size_t)g_next * 1152, a.side + (size_t)g_next * 2);
@@ -1475,7 +1549,7 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
       PD_TICK(4)
     } else {
       PD_SETPRIO(PD_PRIO_REQUANT);
-      PD_PHASE(if (reset_here) state_zero(lane, R); if (!(PD_EXP_SKIP & 1)) ph_requant<DUMP, 9, PD_CHUNK_FAST_REQUANT != 0, !OWN_TABS>(lane, L, S, cb, T, dmp, dmp + 576, &gi))
+      PD_PHASE(if (reset_here) state_zero(lane, R); if (!(PD_EXP_SKIP & 1)) ph_requant<DUMP, 9, PD_CHUNK_FAST_REQUANT != 0, !OWN_TABS, false, RARE>(lane, L, S, cb, T, dmp, dmp + 576, &gi))
       PD_TICK(2)
       PD_SETPRIO(PD_PRIO_AA);
       PD_PHASE(
@@ -1535,8 +1609,9 @@ PD_FN void run_chunk(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, int
   if (!DUMP && !PROF && gp) {
     // granule kernel, a frame that took this path: the wave of the next frame may be waiting for the state it leaves
     // (stereo frames publish theirs; after a mono frame nobody takes anything from the chain)
+    // (... nor after a frame_is_rare() frame: the frames around it treat it like a mono frame, run_granule_wave)
     const uint8_t fbl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f1 - 1) * 4)[7];
-    if (((fbl & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3) {
+    if (((fbl & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 && !frame_is_rare(a.side + (size_t)(f1 - 1) * 4)) {
       PD_PHASE(gran_publish_regs(lane, R, a, 2 * f1 - 1, *gp))
     }
   }
@@ -1689,6 +1764,7 @@ PD_FN void gran_publish_regs(int lane, const LaneRegs& R, const DecodeArgs& a, i
   if (fn >= a.n_frames) return;
   const uint8_t nb = reinterpret_cast<const uint8_t*>(a.side + (size_t)fn * 4)[7];
   if (((nb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) == 3 || (nb & PDMP3_FR_RESET)) return;
+  if (frame_is_rare(a.side + (size_t)fn * 4)) return;             // (it goes the way mono frames go)
   const int ch = lane >> 5, i = lane & 31;
   if (gp.ring) {
     if (g + 1 >= gp.g_end) return;              // (the next range derives its opening state itself)
@@ -1979,7 +2055,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
       PD_PHASE(ph_prefetch(lane, R1, a.spectra + (size_t)(g - 1) * 1152, a.side + (size_t)(g - 1) * 2))
       PD_PHASE(ph_commit(lane, L, R1))
       PD_PHASE(ph_scales(lane, L))
-      PD_PHASE((ph_requant<false, 1, false, true>(lane, L, S, cb, T, nullptr, nullptr)))
+      PD_PHASE((ph_requant<false, 1, false, true, false, false>(lane, L, S, cb, T, nullptr, nullptr)))
       PD_PHASE(ph_antialias(lane, L, cb, true))
       PD_PHASE(ph_peek_tail(lane, L, S, R1, T))
       GranMb& mb = gp.mb[gran_next_place(gp)];          // (a frame's two granules are neighbours in one workgroup: WPW is even)
@@ -1994,7 +2070,7 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
       if (fresh && f == 0 && a.state_in && !(reinterpret_cast<const uint8_t*>(a.side)[7] & PDMP3_FR_RESET) && lane < 3) tail = a.state_in[lane];
       PD_PHASE(ph_commit(lane, L, R0))
       PD_PHASE(ph_scales(lane, L))
-      PD_PHASE((ph_requant<false, 1, false, true>(lane, L, S, cb, T, nullptr, nullptr)))
+      PD_PHASE((ph_requant<false, 1, false, true, false, false>(lane, L, S, cb, T, nullptr, nullptr)))
       PD_PHASE(ph_antialias(lane, L, cb, true))
       const float head = ph_peek_head(lane, L, S, T);
       PD_WAVE_SYNC();
@@ -2013,8 +2089,9 @@ PD_FN void run_granule(const DecodeArgs& a, const GlobalTables& T, BankPtr cb, i
   PD_GT(2)
   gran_tabs_wait(gp);
   PD_LAUNDER(cb);
-  const GranuleInfo gi = granule_info(L);         // (the granule's facts, read once for the three phases that want them)
-  if (!(PD_EXP_SKIP & 1)) { PD_PHASE((ph_requant<false, 9, true, true, true>(lane, L, S, cb, T, nullptr, nullptr, &gi))) }
+  const GranuleInfo gi = granule_info<false>(L);  // (the granule's facts, read once for the three phases that want them; frames that are
+                                                  //  frame_is_rare() do not come this way: run_granule_wave)
+  if (!(PD_EXP_SKIP & 1)) { PD_PHASE((ph_requant<false, 9, true, true, true, false>(lane, L, S, cb, T, nullptr, nullptr, &gi))) }
   PD_GT(3)
   // A SIMD issues from its OLDEST wave first: of the four waves that share one -- places w, w + 4, w + 8, w + 12 of the
   // workgroup -- the first gets through requantisation in 5 k ticks and the last in 12 k (profiles/r04_gran_profile.txt),
@@ -2131,16 +2208,22 @@ PD_FN void run_granule_wave(const DecodeArgs& a, const GlobalTables& T, BankPtr 
   const uint8_t pb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f > 0 ? f - 1 : 0) * 4)[7];
   const uint8_t nb = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f + 1 < a.n_frames ? f + 1 : f) * 4)[7];
   const uint8_t fl = reinterpret_cast<const uint8_t*>(a.side + (size_t)(2 * f + 1) * 2 + 1)[3];
-  const bool stereo = ((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
+  // (frames with intensity stereo -- and LSF ones, should a caller hand them to this kernel -- go the way mono frames
+  //  go: decoded as a whole by the wave of their first granule, with run_chunk's RARE copy; to the frames around them
+  //  they look like mono frames do: nothing is taken from them through the chain)
+  const bool rare = frame_is_rare(a.side + (size_t)f * 4);
+  const bool prev_rare = frame_is_rare(a.side + (size_t)(f > 0 ? f - 1 : 0) * 4);
+  const bool next_rare = frame_is_rare(a.side + (size_t)(f + 1 < a.n_frames ? f + 1 : f) * 4);
+  const bool stereo = ((fb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 && !rare;
   const bool fresh = f == 0 || (fb & PDMP3_FR_RESET);       // its input state is the caller's / zero
-  const bool prev_stereo = ((pb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
+  const bool prev_stereo = ((pb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 && !prev_rare;
   const bool chained = stereo && (fresh || prev_stereo);
   const bool h5 = (fl & PDMP3_GC_WIN_SWITCH) && ((fl & PDMP3_GC_BLOCK_TYPE_MASK) >> PDMP3_GC_BLOCK_TYPE_SHIFT) == 2;
   bool next_takes = false;
   if (chained) {
     // who takes this granule's state from the chain: granule 1 of the same frame; or the next frame, if it is a stereo
     // frame that does not start from zero (this frame being stereo, it then goes this way too)
-    next_takes = gr == 0 || (f + 1 < a.n_frames && ((nb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 && !(nb & PDMP3_FR_RESET));
+    next_takes = gr == 0 || (f + 1 < a.n_frames && ((nb & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 && !(nb & PDMP3_FR_RESET) && !next_rare);
     if (RING) {
       if (g + 1 >= gp.g_end) next_takes = false;          // (the next range derives its opening state itself)
       const bool halo_frame = g < g_emit;                 // (then this frame is chained or fresh: run_granule_ring chose it so)
@@ -2186,8 +2269,10 @@ PD_FN void run_granule_ring(const DecodeArgs& a, const GlobalTables& T, BankPtr 
     const uint8_t b0 = reinterpret_cast<const uint8_t*>(a.side + (size_t)f0 * 4)[7];
     const uint8_t b1 = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f0 - 1) * 4)[7];
     const uint8_t b2 = reinterpret_cast<const uint8_t*>(a.side + (size_t)(f0 > 1 ? f0 - 2 : 0) * 4)[7];
-    const bool st0 = ((b0 & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3, st1 = ((b1 & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
-    const bool st2 = ((b2 & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3;
+    // ("stereo" as run_granule_wave reads it: frame_is_rare() frames go the way mono frames go)
+    const bool st0 = ((b0 & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 && !frame_is_rare(a.side + (size_t)f0 * 4);
+    const bool st1 = ((b1 & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 && !frame_is_rare(a.side + (size_t)(f0 - 1) * 4);
+    const bool st2 = ((b2 & PDMP3_FR_MODE_MASK) >> PDMP3_FR_MODE_SHIFT) != 3 && !frame_is_rare(a.side + (size_t)(f0 > 1 ? f0 - 2 : 0) * 4);
     const bool needs_state = st0 && !(b0 & PDMP3_FR_RESET) && st1;          // (else: zero, or the frame derives its own -- run_granule_wave)
     if (needs_state) {
       const bool prev_goes_granule_way = (b1 & PDMP3_FR_RESET) || f0 == 1 || st2;

@@ -50,7 +50,10 @@ __global__ __launch_bounds__(64 * WPW, PDMP3_WAVES_PER_EU) void k_decode(DecodeA
   const int n_wgs = (n_chunks + WPW - 1) / WPW;
   const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * WPW + w;
   if (chunk >= n_chunks) return;
-  run_chunk<DUMP, false, F32>(a, T, (BankPtr)&c_bank, chunk, L[w], L[w].tab);
+  // Two copies of the chunk's code: the one every ordinary chunk runs, compiled without intensity stereo and LSF, and the
+  // full one for chunks that hold such a frame (decode_core.h chunk_is_rare: a look at the chunk's frame bytes).
+  if (DUMP || chunk_is_rare(a, chunk)) run_chunk<DUMP, false, F32, true, true>(a, T, (BankPtr)&c_bank, chunk, L[w], L[w].tab);
+  else run_chunk<DUMP, false, F32, true, false>(a, T, (BankPtr)&c_bank, chunk, L[w], L[w].tab);
 }
 
 // One granule per wave (decode_core.h run_granule): WPW consecutive granules per workgroup, the workgroup's place in the
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(64 * 16) __attribute__((amdgpu_waves_per_eu(4, 4)))
 __global__ __launch_bounds__(64, PDMP3_WAVES_PER_EU) void k_decode_prof(DecodeArgs a, GlobalTables T) {
   __shared__ WaveLds L[1];
   const int w = threadIdx.x >> 6;
-  run_chunk<false, true>(a, T, (BankPtr)&c_bank, (int)blockIdx.x, L[w], L[w].tab);
+  run_chunk<false, true, false, true, false>(a, T, (BankPtr)&c_bank, (int)blockIdx.x, L[w], L[w].tab);   // (the copy ordinary chunks run)
 }
 
 // LSF launches (launch_decode): record-frame p of the output = the first granules ([0][ch]: 2 x 576 int16 of spectra, 2 x 128

@@ -3511,13 +3511,17 @@ static void bulk_begin(struct bulk* b) {
 }
 
 /* frames and PCM bytes pdmp3() would produce for this stream: stage A alone */
-long long pdmp3_amd_scan_buffer(const unsigned char* mp3, size_t n, long long* frames) {
+long long pdmp3_amd_scan_buffer_iso(const unsigned char* mp3, size_t n, unsigned iso_mask, long long* frames);
+long long pdmp3_amd_scan_buffer(const unsigned char* mp3, size_t n, long long* frames) { return pdmp3_amd_scan_buffer_iso(mp3, n, 0, frames); }
+/* ... with the switches a decoder was given (pdmp3_amd_bulk_set_quirks): only PDMP3_ISO_LSF changes what a scan counts */
+long long pdmp3_amd_scan_buffer_iso(const unsigned char* mp3, size_t n, unsigned iso_mask, long long* frames) {
   pthread_once(&g_lut_once, build_luts);
   struct bulk b;
   memset(&b, 0, sizeof b);
   b.id = (pdmp3_handle*)calloc(1, sizeof *b.id);
   if (!b.id) return -1;
   b.id->host_only = 1;
+  b.id->iso = iso_mask & (PDMP3_ISO_ALL | PDMP3_ISO_LSF);
   b.count_only = 1;
   const long long total = bulk_drive(&b, mp3 ? mp3 : (const unsigned char*)"", mp3 ? n : 0);
   if (frames) *frames = b.frames;
@@ -3875,7 +3879,7 @@ void pdmp3(char* const* mp3s) {
     }
     long long total = -1;
     if (data) {
-      total = pdmp3_amd_scan_buffer(data, (size_t)size, NULL);
+      total = pdmp3_amd_scan_buffer_iso(data, (size_t)size, iso, NULL);
       if (total == PDMP3_BULK_REPLAY && bulk_used) {            /* the reference would not terminate on this file */
         fprintf(stderr, "pdmp3: %s: the reference decoder replays its input ring on this stream; skipped\n", filename);
         total = 0;

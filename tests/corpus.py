@@ -33,13 +33,16 @@ def resolve_aliases(side):
 
 def make_frames(n, seed, mode=MODE_JOINT, mode_ext=2, sfreq=0, block_mix=(70, 10, 10, 10),
                 mixed_prob=0.5, count1_range=(0, 576), gain_range=(120, 170), big_prob=1 / 200.0,
-                max_small=15, sf_max=8, reset_every=0, zero_gc_prob=0.05, is_pos_max=8, iso=0):
-    """Random frames.  block_mix = percentages of block types 0,1,2,3."""
+                max_small=15, sf_max=8, reset_every=0, zero_gc_prob=0.05, is_pos_max=8, iso=0, mode_ext_choices=None):
+    """Random frames.  block_mix = percentages of block types 0,1,2,3.  mode_ext_choices: the frame's mode_extension is
+    drawn from these (frames with and without intensity stereo in one stream: the kernels' two copies of their code)"""
     rs = np.random.RandomState(seed)
     spectra = np.zeros((n, 2, 2, 576), dtype=np.int16)
     side = np.zeros((n, 2, 2), dtype=SIDE_DTYPE)
     cum = np.cumsum(block_mix)
     for f in range(n):
+        if mode_ext_choices is not None:
+            mode_ext = int(mode_ext_choices[rs.randint(0, len(mode_ext_choices))])
         fr = (sfreq & 3) | (mode << FR_MODE_SHIFT) | (mode_ext << FR_MODEEXT_SHIFT)
         if f == 0 or (reset_every and f % reset_every == 0):
             fr |= FR_RESET
@@ -133,6 +136,12 @@ ISO_CASES = {
     "iso_std_ms_is_long_480": dict(CASES["ms_is_long_480"], iso=7, gain_range=FS_GAIN),
     "iso_std_is_short_441": dict(CASES["is_short_441"], iso=7, gain_range=FS_GAIN),
     "iso_std_ms_is_short_480": dict(CASES["ms_is_short_480"], iso=7, gain_range=FS_GAIN),
+    # frames with and without intensity stereo side by side: the granule kernel sends the former down its whole-frame path
+    # (like mono frames), the chunk kernel runs its RARE copy for chunks that hold one (decode_core.h frame_is_rare)
+    "iso_std_ext_varies_441": dict(mode=MODE_JOINT, mode_ext=2, mode_ext_choices=(2, 2, 2, 3, 1, 0, 2), sfreq=0, block_mix=(40, 15, 30, 15),
+                                   count1_range=(100, 576), sf_max=8, iso=7, gain_range=FS_GAIN),
+    "ref_ext_varies_480": dict(mode=MODE_JOINT, mode_ext=2, mode_ext_choices=(2, 2, 3, 1, 0, 2, 2), sfreq=1, block_mix=(40, 15, 30, 15),
+                               count1_range=(100, 500), sf_max=8, iso=0, gain_range=FS_GAIN),
     "iso_std_ms_is_mixed_320": dict(mode=MODE_JOINT, mode_ext=3, sfreq=2, block_mix=(20, 10, 60, 10), mixed_prob=0.8,
                                     count1_range=(20, 400), sf_max=8, iso=7, gain_range=FS_GAIN, zero_gc_prob=0.15),
 }

@@ -30,8 +30,12 @@ extern "C" int emul_decode_frames(const int16_t* spectra, const pdmp3_gc_side* s
   auto L = std::make_unique<WaveLds>();
   for (int c = 0; c < nchunks; ++c) {
     WaveLds& Lr = *L;
+    // like engine.hip k_decode: the copy of the chunk's code without intensity stereo / LSF unless the chunk holds such a frame
     if (stages) emu::run_wave([&] { run_chunk<true>(a, T, &H.cb, c, Lr, Lr.tab); });
-    else emu::run_wave([&] { run_chunk<false>(a, T, &H.cb, c, Lr, Lr.tab); });
+    else emu::run_wave([&] {
+      if (chunk_is_rare(a, c)) run_chunk<false, false, false, true, true>(a, T, &H.cb, c, Lr, Lr.tab);
+      else run_chunk<false, false, false, true, false>(a, T, &H.cb, c, Lr, Lr.tab);
+    });
   }
   if (state) std::copy(state_next.begin(), state_next.end(), state);
   return 0;
@@ -82,7 +86,10 @@ extern "C" int emul_decode_frames_f32(const int16_t* spectra, const pdmp3_gc_sid
   auto L = std::make_unique<WaveLds>();
   for (int c = 0; c < nchunks; ++c) {
     WaveLds& Lr = *L;
-    emu::run_wave([&] { run_chunk<false, false, true>(a, T, &H.cb, c, Lr, Lr.tab); });
+    emu::run_wave([&] {
+      if (chunk_is_rare(a, c)) run_chunk<false, false, true, true, true>(a, T, &H.cb, c, Lr, Lr.tab);
+      else run_chunk<false, false, true, true, false>(a, T, &H.cb, c, Lr, Lr.tab);
+    });
   }
   if (state) std::copy(state_next.begin(), state_next.end(), state);
   return 0;

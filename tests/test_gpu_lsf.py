@@ -62,7 +62,7 @@ def test_gpu_engine_lsf_launch_on_records(engine, oracle, name):
     dsp, dsd = engine.upload(sp, sd)
     pcm = torch.zeros(((n + 1) // 2, 2304), dtype=torch.int16, device=engine.tdev)
     engine.decode_lsf(dsp, dsd, pcm)
-    assert "k_decode<" in engine.last_launch_kernel()
+    assert "independent chunks" in engine.last_launch_kernel()          # (never the granule kernels: they hand on whole frames)
     torch.cuda.synchronize()
     got = pairs_to_samples(pcm.cpu().numpy(), n, nch)
     assert np.abs(got.astype(np.int32) - want).max() <= 1
