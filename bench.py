@@ -162,6 +162,9 @@ def boundary_parity(gathered, seed, n_per_rank, world):
                      "gathered PCM, frames within +-2 of each of the %d shard boundaries + stream head and tail" % (world - 1))
 
 
+MFMA_BUSY_FRAC = None      # from the same PMC summary as `traffic` (SQ_VALU_MFMA_BUSY_CYCLES), when that is of this kernel
+
+
 def measured_traffic(frames, n_halo):
     """HBM bytes per launch of k_decode from the committed PMC passes
     (profiles/*_pmc_summary.json; separate rocprofv3 --pmc runs of this same
@@ -182,6 +185,8 @@ def measured_traffic(frames, n_halo):
             return None, "stale: %s was measured on another version of the kernel" % os.path.basename(files[-1])
         fetch_kb = d["fetch"]["per_dispatch"]["FETCH_SIZE"]
         write_kb = d["write"]["per_dispatch"]["WRITE_SIZE"]
+        global MFMA_BUSY_FRAC
+        MFMA_BUSY_FRAC = d.get("mfma_busy_frac")
         return int((2.0 * fetch_kb + write_kb) * 1024), os.path.basename(files[-1])
     except Exception:
         return None, None
@@ -626,7 +631,12 @@ def main():
     tf = (n + halo) * ALGO_FLOP_PER_FRAME / (kern_ms * 1e-3) / 1e12
     out["roofline_fp32"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(tf / FP32_PEAK_TFLOPS, 5), "algorithmic_flop_per_frame": ALGO_FLOP_PER_FRAME,
-                            "dtype": "f32 (v_mfma_f32_16x16x4_f32 + VALU)"}
+                            "dtype": "f32 (v_mfma_f32_16x16x4_f32 + VALU)",
+                            # `frac` divides DIRECT-FORM flops (what the reference's loops would execute) by time: the kernel runs the
+                            # folded transforms, a quarter of those flops -- it is an algorithmic rate, not a utilisation.  What the
+                            # matrix pipe really does, from the PMC pass of this kernel (profiles/*_pmc_summary.json):
+                            "what_frac_is": "direct-form-equivalent flops / time / peak: an algorithmic rate, NOT the matrix pipe's utilisation",
+                            "mfma_busy_frac": round(MFMA_BUSY_FRAC, 4) if (MFMA_BUSY_FRAC and traffic) else None}
     if world == 1:
         # BASELINE.json's metric, second half ("PCM max-abs-diff vs ref"): the PCM the last timed step left in HBM, all
         # of it, against the CPU decoder on the same generated frames.  After the timed region; the checker is never timed.

@@ -44,16 +44,39 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 //  constant address the same source compiles to a kernel that issues 40 more vector loads per granule and takes 1.45 ms
 //  instead of 1.05 ms for 131072 frames -- measured on MI355X, ROCm 7.2; profiles/r03_kernel_experiments.txt.)
 template <bool DUMP, bool F32 = false, int WPW = 1>
-__global__ __launch_bounds__(64 * WPW, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a, GlobalTables T, int n_chunks) {
+__global__ __launch_bounds__(64 * WPW, PDMP3_WAVES_PER_EU) void k_decode(DecodeArgs a, GlobalTables T, int n_chunks, unsigned* rare_flag, unsigned rare_epoch) {
   __shared__ WaveLds L[WPW];
   const int w = threadIdx.x >> 6;
   const int n_wgs = (n_chunks + WPW - 1) / WPW;
   const int chunk = xcd_contiguous((int)blockIdx.x, n_wgs) * WPW + w;
   if (chunk >= n_chunks) return;
-  // Two copies of the chunk's code: the one every ordinary chunk runs, compiled without intensity stereo and LSF, and the
-  // full one for chunks that hold such a frame (decode_core.h chunk_is_rare: a look at the chunk's frame bytes).
-  if (DUMP || chunk_is_rare(a, chunk)) run_chunk<DUMP, false, F32, true, true>(a, T, (BankPtr)&c_bank, chunk, L[w], L[w].tab);
-  else run_chunk<DUMP, false, F32, true, false>(a, T, (BankPtr)&c_bank, chunk, L[w], L[w].tab);
+  // Two KERNELS per launch of chunks: this one is compiled without intensity stereo and LSF -- the code every ordinary
+  // chunk runs, as tight as it was before those existed (both copies in one kernel cost it a spilled register and 4 % of
+  // a 131072-frame launch: profiles/r06_kernel_experiments.txt) -- and leaves the chunks that hold such a frame
+  // (decode_core.h chunk_is_rare: a look at the chunk's frame bytes) to k_decode_rare behind it, which it tells so.
+  if (DUMP) { run_chunk<DUMP, false, F32, true, true>(a, T, (BankPtr)&c_bank, chunk, L[w], L[w].tab); return; }
+  // (rare_flag: a word of the engine's, rare_epoch: this launch's number -- k_decode_rare goes home at once unless the word
+  //  says that this launch has a chunk for it; never reset.  Kernel parameters, not DecodeArgs: the granule kernels, which
+  //  keep every argument in scalar registers, slowed down by 2.5 % with two more of them)
+  if (rare_flag && chunk_is_rare(a, chunk)) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(rare_flag, rare_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  run_chunk<DUMP, false, F32, true, false>(a, T, (BankPtr)&c_bank, chunk, L[w], L[w].tab);
+}
+
+// ... the second kernel of the launch: nothing to do unless the first one found a chunk with a frame_is_rare() frame
+// (the flag is an epoch number: never reset), then those chunks, with the full code (intensity stereo, LSF)
+template <bool F32>
+__global__ __launch_bounds__(64, PDMP3_WAVES_PER_EU) void k_decode_rare(DecodeArgs a, GlobalTables T, int n_chunks, int always, const unsigned* rare_flag, unsigned rare_epoch) {
+  __shared__ WaveLds L[1];
+  const int chunk = (int)blockIdx.x;
+  if (chunk >= n_chunks) return;
+  if (!always) {
+    if (__hip_atomic_load(rare_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != rare_epoch) return;
+    if (!chunk_is_rare(a, chunk)) return;
+  }
+  run_chunk<false, false, F32, true, true>(a, T, (BankPtr)&c_bank, chunk, L[0], L[0].tab);
 }
 
 // One granule per wave (decode_core.h run_granule): WPW consecutive granules per workgroup, the workgroup's place in the
@@ -466,6 +489,7 @@ struct ChainBuf {
 struct ChainUse { float* state; unsigned* flag; unsigned epoch; };
 constexpr int kChainBufs = 32;
 
+constexpr int kRareSlots = 4096;      // a flag word per launch, taken round robin: two launches share one only if 4096 others lie between them
 struct pdmp3_hip_ctx {
   int device;
   int wave_slots;           // waves of k_decode the device holds at once (CUs x 4 SIMDs x 2)
@@ -477,6 +501,8 @@ struct pdmp3_hip_ctx {
   float* d_win;
   float* d_frag;            // frag_long [10][64] | frag_short [10][64] | frag_mat [8][64] | taps [16][64]
   void* d_tab_image;        // [kNumSfreq] TabLds images
+  unsigned* d_rare_flags;   // [kRareSlots] epoch numbers (DecodeArgs::rare_flag): "this launch of chunks holds a chunk for k_decode_rare"
+  std::atomic<unsigned> rare_epoch;
   int chain_mode;           // PDMP3_HIP_CHAIN=0: independent chunks with halos everywhere; otherwise launches up to
                             // gran_max_frames take the granule kernel (k_decode_g)
   int gran_max_frames;      // launches up to this many frames take the granule kernel (PDMP3_HIP_GRAN_MAX)
@@ -527,6 +553,7 @@ extern "C" void pdmp3_hip_destroy(pdmp3_hip_ctx* c) {
   (void)hipFree(c->d_win);
   (void)hipFree(c->d_frag);
   (void)hipFree(c->d_tab_image);
+  (void)hipFree(c->d_rare_flags);
   (void)hipFree(c->d_unpack);
   (void)hipFree(c->d_uprof);
   for (ChainBuf& b : c->chain) { (void)hipFree(b.state); (void)hipFree(b.flag); }
@@ -589,6 +616,9 @@ extern "C" int pdmp3_hip_create(int device, pdmp3_hip_ctx** out) {
     CREATE_STEP(hipMemcpy(c->d_frag + 20 * 64, H.frag_mat.data(), 8 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload frag_mat")
     CREATE_STEP(hipMemcpy(c->d_frag + 28 * 64, H.taps.data(), 16 * 64 * sizeof(float), hipMemcpyHostToDevice), "upload taps")
     CREATE_STEP(hipMemcpy(c->d_tab_image, H.tab_image.data(), kNumSfreq * sizeof(TabLds), hipMemcpyHostToDevice), "upload table images")
+    CREATE_STEP(hipMalloc((void**)&c->d_rare_flags, kRareSlots * sizeof(unsigned)), "hipMalloc rare flags")
+    CREATE_STEP(hipMemset(c->d_rare_flags, 0, kRareSlots * sizeof(unsigned)), "hipMemset rare flags")
+    c->rare_epoch.store(1);
     CREATE_STEP(hipMemcpy(c->d_unpack, U, sizeof(UnpackTables), hipMemcpyHostToDevice), "upload unpack tables")
     c->unpack_n16 = (int)((offsetof(UnpackTables, lut) + (size_t)U->n_lut * 4 + 15) / 16);
     CREATE_STEP(hipDeviceSynchronize(), "sync after uploads")
@@ -788,13 +818,23 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   } else {
     c->last_kind = PDMP3_HIP_LAUNCH_CHUNKS;
     if (d_prof) hipLaunchKernelGGL(k_decode_prof, dim3(nchunks), dim3(64), 0, s, a, T);
-    else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
-    else if (d_pcm_f32) hipLaunchKernelGGL((k_decode<false, true>), dim3(nchunks), dim3(64), 0, s, a, T, nchunks);
-    else {
-      // (development: PDMP3_HIP_DEBUG_LDS_PAD = bytes of dynamic LDS added to every workgroup of the chunk kernel, which
-      //  lowers the number of waves a CU holds -- 24576: one wave per SIMD instead of two; tools/occupancy_scaling.py)
-      static const int lds_pad = [] { const char* e = getenv("PDMP3_HIP_DEBUG_LDS_PAD"); return e ? atoi(e) : 0; }();
-      hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), (size_t)lds_pad, s, a, T, nchunks);
+    else if (d_stages) hipLaunchKernelGGL(k_decode<true>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks, (unsigned*)nullptr, 0u);
+    else if (lsf) {                                // every chunk of an LSF launch is k_decode_rare's
+      if (d_pcm_f32) hipLaunchKernelGGL(k_decode_rare<true>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks, 1, (const unsigned*)nullptr, 0u);
+      else hipLaunchKernelGGL(k_decode_rare<false>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks, 1, (const unsigned*)nullptr, 0u);
+    } else {
+      const unsigned ep = c->rare_epoch.fetch_add(1);
+      unsigned* flag = c->d_rare_flags + (ep % kRareSlots);
+      if (d_pcm_f32) {
+        hipLaunchKernelGGL((k_decode<false, true>), dim3(nchunks), dim3(64), 0, s, a, T, nchunks, flag, ep);
+        hipLaunchKernelGGL(k_decode_rare<true>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks, 0, (const unsigned*)flag, ep);
+      } else {
+        // (development: PDMP3_HIP_DEBUG_LDS_PAD = bytes of dynamic LDS added to every workgroup of the chunk kernel, which
+        //  lowers the number of waves a CU holds -- 24576: one wave per SIMD instead of two; tools/occupancy_scaling.py)
+        static const int lds_pad = [] { const char* e = getenv("PDMP3_HIP_DEBUG_LDS_PAD"); return e ? atoi(e) : 0; }();
+        hipLaunchKernelGGL(k_decode<false>, dim3(nchunks), dim3(64), (size_t)lds_pad, s, a, T, nchunks, flag, ep);
+        hipLaunchKernelGGL(k_decode_rare<false>, dim3(nchunks), dim3(64), 0, s, a, T, nchunks, 0, (const unsigned*)flag, ep);
+      }
     }
   }
   hipError_t e = hipGetLastError();

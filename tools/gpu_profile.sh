@@ -2,7 +2,7 @@
 # Profiles that get committed under profiles/ (run on the GPU box via gpurun):
 #   1. rocprofv3 --kernel-trace --stats of the default bench workload (C2 launches only)
 #   2. PMC passes (separate runs) on the same workload: FETCH_SIZE, WRITE_SIZE, SQ mix
-TAG=${1:-r01}
+TAG=${1:-r06}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -68,6 +68,20 @@ for d in sorted(glob.glob(os.path.join(out, "*", "p_counter_collection.csv"))):
         agg[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
     n = max(1, len(disp))
     summary[name] = {"dispatches": n, "per_dispatch": {k: v / n for k, v in sorted(agg.items())}}
+    # the same pass's kernel trace: the average duration of the counted dispatches (PMC passes run slower than the plain ones)
+    try:
+        tr = list(csv.DictReader(open(os.path.join(os.path.dirname(d), "p_kernel_trace.csv"))))
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in tr if want in r.get("Kernel_Name", "")]
+        if durs: summary[name]["avg_ns_under_pmc"] = sum(durs) / len(durs)
+    except Exception:
+        pass
+# what the matrix pipe really does: SQ_VALU_MFMA_BUSY_CYCLES / (duration x shader clock x SIMDs), the C2 launch
+SCLK_HZ, SIMDS = 2.4e9, 1024
+if "sq3" in summary and summary["sq3"].get("avg_ns_under_pmc"):
+    busy = summary["sq3"]["per_dispatch"].get("SQ_VALU_MFMA_BUSY_CYCLES")
+    if busy:
+        summary["mfma_busy_frac"] = busy / (summary["sq3"]["avg_ns_under_pmc"] * 1e-9 * SCLK_HZ * SIMDS)
+        summary["mfma_busy_frac_how"] = "SQ_VALU_MFMA_BUSY_CYCLES per dispatch / (that pass's average kernel duration x 2.4 GHz x 1024 SIMDs), k_decode_g at C2"
 import hashlib
 h = hashlib.sha256()
 for f in ("pdmp3_amd/csrc/decode_core.h", "pdmp3_amd/csrc/engine.hip"):
