@@ -24,12 +24,14 @@
  *   5. additions, all prefixed pdmp3_amd_: float output below, whole-stream decoding in pdmp3_bulk.h.
  * Not a difference in results, but visible to a process: pdmp3_read decodes the frames the ring already holds as one
  * batch and uses helper threads for their scalefactors + Huffman data (started on first use, shared by all handles).
- * After a batch the helpers SPIN for 0.2-0.5 ms before they go to sleep: a caller that reads every 50-100 us -- the
- * reference driver's cadence -- keeps them awake, i.e. one streaming handle can hold 3 more cores at 100 %; and only ONE
- * handle at a time gets them (a handle that reads while another one has the helpers decodes its batch alone), so with
- * several handles reading at once the rate of each depends on who got the helpers.  PDMP3_STREAM_THREADS=0 turns them off.
+ * After a batch the helpers look for the next one for about 50 us (PDMP3_STREAM_SPIN pause instructions, default 4000;
+ * 20000 = the 0.2-0.5 ms of rounds 3-5, which kept three more cores at 100 % under a caller that reads at the reference
+ * driver's cadence) and then sleep on a condition; and only ONE handle at a time gets them (a handle that reads while
+ * another one has the helpers decodes its batch alone), so with several handles reading at once the rate of each depends
+ * on who got the helpers.  PDMP3_STREAM_THREADS=0 turns them off.
  * Environment: PDMP3_STREAM_THREADS = number of helpers (default min(3, CPUs - 1); 0 = the
- * calling thread only), PDMP3_NO_READAHEAD = one frame per batch, PDMP3_DEVICE = HIP device of new handles.
+ * calling thread only), PDMP3_STREAM_SPIN (above), PDMP3_NO_READAHEAD = one frame per batch, PDMP3_DEVICE = HIP device of
+ * new handles.
  * There is no CPU decode path: pdmp3_new() returns NULL (and sets *error when given) if no HIP device / engine
  * library is available.
  */

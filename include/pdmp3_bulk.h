@@ -167,6 +167,18 @@ long long pdmp3_amd_stream_loop(const unsigned char* mp3, size_t n, unsigned cha
  * CLI driver writes "<first name>.wav" instead of ".raw" when PDMP3_CLI_WAV=1 is set.  PDMP3_OK or PDMP3_ERR. */
 int pdmp3_amd_write_wav(const char* path, const void* pcm, size_t bytes, long rate, int channels, int float32);
 
+/* A corpus of whole files over the GPUs of a node -- SURVEY 8e's second partitioning ("C4: whole files per GPU, largest
+ * first"), the C form of pdmp3_amd/sharding.py assign_files + one decoder per device (nothing of the
+ * reference's: it has one handle and one thread).  devices[]: HIP device numbers, one host thread and one whole-stream
+ * decoder per entry (a device listed twice gets two decoders); the files are dealt largest first, each device's files are
+ * decoded one after the other with the asynchronous call, nothing is exchanged between devices.  pcm[i] (capacity
+ * pcm_caps[i]; size it with pdmp3_amd_scan_buffer_iso) receives file i's PCM, pcm_bytes[i] the byte count pdmp3() would
+ * write for it.  threads_per_decoder / window_frames / host_huffman as for pdmp3_amd_bulk_new_on.  0, or -1. */
+void pdmp3_amd_corpus_assign(const size_t* sizes, int n_files, int world, int* rank_of);
+int pdmp3_amd_corpus_decode(const int* devices, int n_devices, const unsigned char* const* mp3s, const size_t* sizes, int n_files,
+                            unsigned char* const* pcm, const size_t* pcm_caps, long long* pcm_bytes, unsigned iso_mask,
+                            int threads_per_decoder, int window_frames, int host_huffman);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ PDMP3_ENC_SIGNED_16 = 0xD0
 _LIB = None
 
 BULK_EXPORTS = ["pdmp3_amd_bulk_new", "pdmp3_amd_bulk_new_ex", "pdmp3_amd_bulk_new_on", "pdmp3_amd_bulk_delete", "pdmp3_amd_bulk_threads", "pdmp3_amd_bulk_split_scans", "pdmp3_amd_bulk_set_quirks",
-                "pdmp3_amd_scan_buffer", "pdmp3_amd_scan_buffer_iso", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_decode_async", "pdmp3_amd_bulk_wait", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
+                "pdmp3_amd_scan_buffer", "pdmp3_amd_scan_buffer_iso", "pdmp3_amd_corpus_assign", "pdmp3_amd_corpus_decode", "pdmp3_amd_bulk_decode", "pdmp3_amd_bulk_decode_async", "pdmp3_amd_bulk_wait", "pdmp3_amd_bulk_new_parse_only", "pdmp3_amd_bulk_parse",
                 "pdmp3_amd_bulk_new_parse_bits", "pdmp3_amd_bulk_parse_bits", "pdmp3_amd_bulk_parse_pool", "pdmp3_amd_pcm_alloc", "pdmp3_amd_pcm_free", "pdmp3_amd_stream_loop", "pdmp3_amd_write_wav"]
 
 # include/pdmp3_hip.h: pdmp3_gc_bits / pdmp3_frame_bits
@@ -421,3 +421,39 @@ class PinnedPCM:
             self.array = None
             self.lib.pdmp3_amd_pcm_free(self.ptr)
             self.ptr = None
+
+
+def corpus_assign(sizes, world):
+    """pdmp3_amd_corpus_assign (include/pdmp3_bulk.h): device slot per file, largest first -- == sharding.assign_files; no GPU needed"""
+    lib = load_library()
+    n = len(sizes)
+    arr = (C.c_size_t * n)(*[int(x) for x in sizes])
+    out = (C.c_int * n)()
+    lib.pdmp3_amd_corpus_assign.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.pdmp3_amd_corpus_assign.restype = None
+    lib.pdmp3_amd_corpus_assign(arr, n, world, out)
+    return list(out)
+
+
+def corpus_decode(devices, mp3s, iso=0, threads=2, window_frames=0, host_huffman=False):
+    """pdmp3_amd_corpus_decode: whole files over the devices of a node from C (one decoder and host thread per entry of
+    `devices`) -> list of int16 arrays"""
+    lib = load_library()
+    n = len(mp3s)
+    bufs = [_as_u8(m) for m in mp3s]
+    totals = [max(0, scan_buffer(m, iso)[0]) for m in mp3s]
+    outs = [np.empty(max(t, 2) // 2, dtype=np.int16) for t in totals]
+    PP = C.c_void_p * n
+    srcs = PP(*[b.ctypes.data for b in bufs])
+    dsts = PP(*[o.ctypes.data for o in outs])
+    sizes = (C.c_size_t * n)(*[len(m) for m in mp3s])
+    caps = (C.c_size_t * n)(*[o.nbytes for o in outs])
+    got = (C.c_longlong * n)()
+    dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+    lib.pdmp3_amd_corpus_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_uint, C.c_int, C.c_int, C.c_int]
+    rc = lib.pdmp3_amd_corpus_decode(dev, len(devices), srcs, sizes, n, dsts, caps, got, iso, threads, window_frames, int(host_huffman))
+    if rc != 0:
+        raise RuntimeError("pdmp3_amd_corpus_decode failed")
+    assert list(got) == totals, (list(got), totals)
+    return [o[:t // 2] for o, t in zip(outs, totals)]

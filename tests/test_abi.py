@@ -95,3 +95,20 @@ def test_no_gpu_means_loud_failure():
     h = C.c_void_p()
     assert lib.pdmp3_hip_create(0, C.byref(h)) != 0
     assert b"hipSetDevice" in lib.pdmp3_hip_last_error()
+
+
+def test_corpus_assign_in_c_equals_sharding_assign_files():
+    """pdmp3_amd_corpus_assign (include/pdmp3_bulk.h, the dealer of pdmp3_amd_corpus_decode) == sharding.assign_files: largest
+    first, ties to the lower slot -- 300 random corpora; no GPU"""
+    import random
+    from pdmp3_amd import api
+    from pdmp3_amd.sharding import assign_files
+    rnd = random.Random(7)
+    for _ in range(300):
+        n, w = rnd.randint(1, 40), rnd.randint(1, 9)
+        sizes = [rnd.choice([100, 100, 5000, rnd.randint(1, 10 ** 7)]) for _ in range(n)]
+        want = [None] * n
+        for k, g in enumerate(assign_files(sizes, w)):
+            for i in g:
+                want[i] = k
+        assert api.corpus_assign(sizes, w) == want

@@ -93,6 +93,22 @@ def test_corpus_dealt_over_devices(oracle):
         assert outs[i].shape == want.shape and np.abs(outs[i].astype(np.int32) - want).max() <= 1, i
 
 
+def test_corpus_dealt_over_devices_from_c(oracle):
+    """the same from C: pdmp3_amd_corpus_decode (include/pdmp3_bulk.h) deals the files largest first over its devices -- two
+    entries, both device 0 on the test box -- with a decoder and a host thread each; an LSF file among them (PDMP3_ISO_LSF)"""
+    from pdmp3_amd import api
+    kinds = [dict(sfreq=0, mode=1, mode_ext=2, bitrate_index=14), dict(sfreq=1, mode=3, bitrate_index=7),
+             dict(sfreq=2, mode=0, mode_ext=0, vbr=True, block_pct=(40, 10, 40, 10), mixed_pct=50),
+             dict(sfreq=0, mode=2, bitrate_index=12, block_pct=(10, 10, 70, 10))]
+    files = [packer.generate(n_frames=300 + 131 * k, seed=700 + k, **kinds[k % 4]) for k in range(9)]
+    files.append(packer.generate(n_frames=200, seed=77, sfreq=2, mode=1, mode_ext=2, bitrate_index=8, version=1, iso_strict=True))
+    for host_huffman in (False, True):
+        outs = api.corpus_decode([0, 0], files, iso=api.ISO_LSF, threads=2, window_frames=256, host_huffman=host_huffman)
+        for i, f in enumerate(files):
+            want = np.frombuffer(oracle.decode_buffer_like_cli_iso(f, api.ISO_LSF), dtype=np.int16)
+            assert outs[i].shape == want.shape and want.size > 0 and np.abs(outs[i].astype(np.int32) - want).max() <= 1, (i, host_huffman)
+
+
 @pytest.mark.parametrize("world", [2, 3, 5])
 def test_record_shards_of_a_mode_switching_stream(engine, world):
     """frame-range shards of a stream with stereo / mono / stereo runs: each rank's first frame comes from the records'
