@@ -24,7 +24,7 @@
  *   5. additions, all prefixed pdmp3_amd_: float output below, whole-stream decoding in pdmp3_bulk.h.
  * Not a difference in results, but visible to a process: pdmp3_read decodes the frames the ring already holds as one
  * batch and uses helper threads for their scalefactors + Huffman data (started on first use, shared by all handles).
- * After a batch the helpers look for the next one for about 50 us (PDMP3_STREAM_SPIN pause instructions, default 4000;
+ * After a batch the helpers look for the next one for about 15 us (PDMP3_STREAM_SPIN pause instructions, default 1000: 101 k / 202 k frames/s at 25 / 13 us of CPU per frame against 109 k / 208 k at 37 / 19 with 20000, profiles/r06_stream_api.json;
  * 20000 = the 0.2-0.5 ms of rounds 3-5, which kept three more cores at 100 % under a caller that reads at the reference
  * driver's cadence) and then sleep on a condition; and only ONE handle at a time gets them (a handle that reads while
  * another one has the helpers decodes its batch alone), so with several handles reading at once the rate of each depends

@@ -1139,10 +1139,10 @@ static uint32_t hp_take(void) {
   }
 }
 /* How long a helper looks for the next batch before it sleeps on the condition: PDMP3_STREAM_SPIN = pause instructions
- * (default 4000: ~50 us; rounds 3-5: 20000, 0.2-0.5 ms -- three cores at 100 % per streaming handle; the
+ * (default 1000: ~15 us; rounds 3-5: 20000, 0.2-0.5 ms -- three cores at 100 % per streaming handle; the
  * next batch of a caller that reads at the reference driver's cadence is 50-100 us away, measured with both:
  * profiles/r06_stream_api.json). */
-static int g_hp_spin = 4000;
+static int g_hp_spin = 1000;
 static void* hp_worker(void* arg) {
   (void)arg;
   uint32_t seen = 0;

@@ -98,7 +98,7 @@ def test_corpus_dealt_over_devices_from_c(oracle):
     entries, both device 0 on the test box -- with a decoder and a host thread each; an LSF file among them (PDMP3_ISO_LSF)"""
     from pdmp3_amd import api
     kinds = [dict(sfreq=0, mode=1, mode_ext=2, bitrate_index=14), dict(sfreq=1, mode=3, bitrate_index=7),
-             dict(sfreq=2, mode=0, mode_ext=0, vbr=True, block_pct=(40, 10, 40, 10), mixed_pct=50),
+             dict(sfreq=2, mode=0, mode_ext=0, vbr=True, vbr_hi=12, block_pct=(40, 10, 40, 10), mixed_pct=50),   # (32 kHz <= 224 kbps: SURVEY H10)
              dict(sfreq=0, mode=2, bitrate_index=12, block_pct=(10, 10, 70, 10))]
     files = [packer.generate(n_frames=300 + 131 * k, seed=700 + k, **kinds[k % 4]) for k in range(9)]
     files.append(packer.generate(n_frames=200, seed=77, sfreq=2, mode=1, mode_ext=2, bitrate_index=8, version=1, iso_strict=True))
