@@ -3432,6 +3432,10 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
       cpu_set_t before;
       const int rebind = gpu_local_cpus(ctx, &b->near_gpu) > 0 && sched_getaffinity(0, sizeof before, &before) == 0;
       if (rebind) (void)sched_setaffinity(0, sizeof b->near_gpu, &b->near_gpu);
+      /* (the scanners / hop threads / gather helpers are SIZED by the whole affinity mask and BOUND to the
+       *  GPU's node: on a host whose node holds half of the usable CPUs that oversubscribes the node.  Sizing them by the
+       *  node was tried in round 6 and not kept without a measurement on such a host: on the 16-CPU quota of the test boxes
+       *  it would cut the scanners from 8 to 2.  PDMP3_BULK_SCAN_THREADS / _PREPASS_THREADS / _GATHER_THREADS size them.) */
       made = pdmp3_hip_stream_create_slots(ctx, b->cap, BULK_SLOTS, &b->hs);
       if (rebind) (void)sched_setaffinity(0, sizeof before, &before);
     }
@@ -3469,7 +3473,7 @@ static struct bulk* bulk_new(int threads, int window_frames, int with_engine, in
   if (!b->th) { pdmp3_amd_bulk_delete(b); return NULL; }
   for (b->nth = 0; b->nth < threads; b->nth++)
     if (pthread_create(&b->th[b->nth], NULL, bulk_worker, b) != 0) break;
-    else bind_thread(b->th[b->nth], &b->near_gpu);
+    else if (bits_mode) bind_thread(b->th[b->nth], &b->near_gpu);   /* (a host-Huffman pool is compute: it takes every socket) */
   if (b->nth == 0) { pdmp3_amd_bulk_delete(b); return NULL; }
   return b;
 }

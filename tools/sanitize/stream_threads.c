@@ -8,6 +8,7 @@ static unsigned char* mp3; static size_t n;
 static void* run(void* arg) {
   size_t read_bytes = (size_t)arg;
   pdmp3_handle* id = pdmp3_amd_new_parse_only(); pdmp3_open_feed(id);
+  if (getenv("PDMP3_SAN_ISO")) pdmp3_amd_set_quirks(id, (unsigned)strtoul(getenv("PDMP3_SAN_ISO"), 0, 0));   /* e.g. 0x7f: the ISO switches + LSF */
   unsigned char* buf = malloc(read_bytes); size_t fed = 0, done, total = 0; int res;
   for (;;) {
     res = pdmp3_read(id, buf, read_bytes, &done); if (res == PDMP3_ERR) break; total += done;
