@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 # before HIP comes up (torch brings it up here): the whole-stream decoder of the `end_to_end` extra keeps six windows in
 # flight on their own HIP streams, which overlap only across hardware queues (default 4); the library sets the same
-# default when it initialises HIP itself (pdmp3_host.c shared_ctx_on).  No effect on the hot-path metric (one stream).
+# default when it initialises HIP itself (host/stream_api.c shared_ctx_on).  No effect on the hot-path metric (one stream).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 SEED_C2 = 0x5EED0000C2

@@ -3,7 +3,7 @@
 // the scalefactor / count1 state that the reference never clears.
 //
 // Replaces, for whole windows of frames at once, what the host stage does per
-// frame (pdmp3_host.c decode_main / apply_main / emit_records, themselves
+// frame (host/frame_parse.c decode_main / apply_main / emit_records, themselves
 // restatements of pdmp3.c:1376-1437 Read_Main_L3, P:2051-2115 Read_Huffman,
 // P:1593-1643 Huffman_Decode).  The input is what is left after the strictly
 // sequential part of the bitstream (ring, header sync, side info, bit
@@ -94,7 +94,7 @@ struct UnpackTables {
   uint32_t lut[kHuffLutMax];
 };
 
-// what one granule-channel's main data yields (cf. main_out in pdmp3_host.c)
+// what one granule-channel's main data yields (cf. main_out in host/frame_parse.c)
 struct alignas(16) GcRaw {
   uint16_t count1;
   uint8_t count1_set;            // 0 when part2_3_length == 0: count1 keeps its old value (H6)
@@ -147,7 +147,7 @@ PD_HD void row_chunk16(const pdmp3_row_desc* d, const uint8_t* pool, unsigned j,
 }
 
 // ---------------------------------------------------------------------------
-// bit reader over one reservoir row (same windows as pdmp3_host.c peek32 / peek64)
+// bit reader over one reservoir row (same windows as host/frame_parse.c peek32 / peek64)
 // ---------------------------------------------------------------------------
 struct BitPos {
   const uint8_t* buf;
@@ -331,7 +331,7 @@ PD_COLD unsigned unpack_quads_slow(const uint32_t* lut, BitPos& b, unsigned qbas
 }
 
 // ---------------------------------------------------------------------------
-// The symbols of one granule-channel (Read_Huffman P:2051-2115; cf. decode_pairs in pdmp3_host.c), in two stages.
+// The symbols of one granule-channel (Read_Huffman P:2051-2115; cf. decode_pairs in host/frame_parse.c), in two stages.
 //
 // What makes the loop sequential is only WHERE the next code word starts.  unpack_step() does just that much per
 // symbol -- the code book lookup and the bits the symbol takes in all: code word, linbits, sign bits, the last three

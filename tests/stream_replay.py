@@ -1,6 +1,6 @@
 """Random call sequences of the seven API functions, replayed on the product's handle and on the oracle's
 restatement of the reference's streaming API (oracle/pdmp3_oracle_stream.c, P:2351-2535): every return code and
-every byte count must agree call by call -- the read-ahead inside pdmp3_read (pdmp3_host.c: read_ahead) must be
+every byte count must agree call by call -- the read-ahead inside pdmp3_read (host/stream_api.c: read_ahead) must be
 invisible.  Used by the CPU suite (parse-only handle: codes and counts) and the GPU suite (PCM as well)."""
 import numpy as np
 

@@ -1,4 +1,4 @@
-"""Bulk pipeline, host stages (include/pdmp3_bulk.h; pdmp3_host.c stages A-C):
+"""Bulk pipeline, host stages (include/pdmp3_bulk.h; host/bulk.c stages A-C):
 the threaded scalefactor/Huffman fan-out with the sequential state merge must
 give the same gc records as the oracle's front end driven like the CLI, for any
 thread count and window size; the scan pass must give the CLI's byte count.

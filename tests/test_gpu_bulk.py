@@ -473,7 +473,7 @@ def test_compact_upload_equals_snapshot_rows(streams, monkeypatch):
 
 @pytest.mark.parametrize("scanners,window,sub", [(4, 16, 0), (3, 7, 0), (8, 64, 0), (4, 64, 8), (8, 256, 16), (3, 100, 7)])
 def test_split_scan_decodes_what_the_one_thread_scan_decodes(streams, monkeypatch, scanners, window, sub):
-    """pdmp3_host.c par_drive (round 4): pre-pass + scanner threads + stitch in window order, forced on for host
+    """host/split_scan.c par_drive (round 4): pre-pass + scanner threads + stitch in window order, forced on for host
     destinations too (by default it is taken for device destinations only).  Regular streams go the split way, irregular
     ones (resync, tags, truncation) are turned down before or half way -- then the windows that have gone up are let
     through and the stream is decoded again by the one-thread scan: either way the PCM is the one-thread decoder's, bit

@@ -1,4 +1,4 @@
-"""Host stage of the product (pdmp3_amd/host/pdmp3_host.c: ring, header sync,
+"""Host stage of the product (pdmp3_amd/host/frame_parse.c, stream_api.c: ring, header sync,
 side info, bit reservoir, scalefactors, table-driven Huffman, record
 emission) against the oracle's bitstream front end, on the real clip and on
 packer-made streams (pdmp3_amd/packer).  No GPU involved: the parse-only handle

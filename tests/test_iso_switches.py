@@ -37,7 +37,7 @@ def streams():
 
 @pytest.mark.parametrize("iso", [0, ISO_TABLE33, ISO_MS_BOUND, ISO_IS_SHORT, ISO_SF21, ISO_SF12, ISO_ALL])
 def test_host_stage_records_equal_the_oracles(oracle, streams, iso):
-    """pdmp3_host.c (header, side info, reservoir, table-driven Huffman, record builder) against the oracle's bit-serial
+    """host/frame_parse.c (header, side info, reservoir, table-driven Huffman, record builder) against the oracle's bit-serial
     restatement with the same switches: records byte-identical; mask 0 = the reference's records (test_host_stage.py pins
     those to oracle/_ref)"""
     from pdmp3_amd import api

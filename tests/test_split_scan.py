@@ -1,4 +1,4 @@
-"""The whole-stream decoder's split scan (pdmp3_host.c par_drive; round 4): a pre-pass that hops from header to header,
+"""The whole-stream decoder's split scan (host/split_scan.c par_drive; round 4): a pre-pass that hops from header to header,
 K scanner threads that start at window boundaries from the state the pre-pass leaves there, a stitch in stream order.
 The scanners run the unchanged stage-A code, so ONE scanner from frame 0 (K = 1) is the sequential scanner with private
 windows; what has to hold is that K = 2, 3, 4, 8 give the same windows byte for byte -- side-info records (the fields

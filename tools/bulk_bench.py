@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # before HIP starts (torch brings it up): see pdmp3_host.c shared_ctx_on
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # before HIP starts (torch brings it up): see host/stream_api.c shared_ctx_on
 
 
 def c4(args, api):

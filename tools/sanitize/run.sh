@@ -7,9 +7,11 @@ set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=${TMPDIR:-/tmp}/pdmp3_sanitize
 mkdir -p $OUT
+HOST=$ROOT/pdmp3_amd/host
+SRCS="$HOST/huffman_lut.c $HOST/frame_parse.c $HOST/stream_api.c $HOST/cpus.c $HOST/bulk.c $HOST/split_scan.c $HOST/bulk_api.c $HOST/corpus.c $HOST/wav_cli.c"
 for san in thread address,undefined; do
   for t in stream_threads bulk_threads split_scan; do
-    gcc -O1 -g -fsanitize=$san -I$ROOT/include -I$ROOT/pdmp3_amd/csrc -o $OUT/$t $ROOT/tools/sanitize/$t.c $ROOT/pdmp3_amd/host/pdmp3_host.c \
+    gcc -O1 -g -fsanitize=$san -I$ROOT/include -I$ROOT/pdmp3_amd/csrc -o $OUT/$t $ROOT/tools/sanitize/$t.c $SRCS \
         -L$ROOT/pdmp3_amd -lpdmp3_hip -lpthread -Wl,-rpath,$ROOT/pdmp3_amd -w     # (warnings off, errors shown: a failed build stops the script with its message)
     echo "== $san $t"
     ASAN_OPTIONS=detect_leaks=0 $OUT/$t "$1" 2>&1 | tail -4
