@@ -26,9 +26,10 @@
  * batch and uses helper threads for their scalefactors + Huffman data (started on first use, shared by all handles).
  * After a batch the helpers look for the next one for about 15 us (PDMP3_STREAM_SPIN pause instructions, default 1000: 101 k / 202 k frames/s at 25 / 13 us of CPU per frame against 109 k / 208 k at 37 / 19 with 20000, profiles/r06_stream_api.json;
  * 20000 = the 0.2-0.5 ms of rounds 3-5, which kept three more cores at 100 % under a caller that reads at the reference
- * driver's cadence) and then sleep on a condition; and only ONE handle at a time gets them (a handle that reads while
- * another one has the helpers decodes its batch alone), so with several handles reading at once the rate of each depends
- * on who got the helpers.  PDMP3_STREAM_THREADS=0 turns them off.
+ * driver's cadence) and then sleep on a condition.  Handles that read at the same time share them: each batch goes into one
+ * of four slots and a helper takes a frame from every slot that has one in turn (a handle that finds all four taken decodes
+ * its batch alone); three handles reading at once run within 3 % of each other (profiles/r06_stream_share.json).
+ * PDMP3_STREAM_THREADS=0 turns the helpers off.
  * Environment: PDMP3_STREAM_THREADS = number of helpers (default min(3, CPUs - 1); 0 = the
  * calling thread only), PDMP3_STREAM_SPIN (above), PDMP3_NO_READAHEAD = one frame per batch, PDMP3_DEVICE = HIP device of
  * new handles.

@@ -185,33 +185,45 @@ static int ra_rollback(pdmp3_handle* id) {
 /* stays sequential.  The helpers are per process, started on first use, spin */
 /* for a short while after a batch (the next one is usually 50-100 us away)   */
 /* and then sleep.  PDMP3_STREAM_THREADS = helpers (default min(3, CPUs - 1); */
-/* 0: none).  A second handle that reads while the helpers are busy decodes   */
-/* its batch alone.                                                           */
+/* 0: none).  Handles that read at the same time SHARE them (round 6): each   */
+/* batch goes into one of HP_SLOTS slots and a helper takes a frame from every */
+/* slot that has one in turn; a handle that finds all slots taken decodes its  */
+/* batch alone.                                                               */
 /* ------------------------------------------------------------------------ */
 #define HP_MAX 15
+#define HP_SLOTS 4
 typedef struct { const uint8_t* res; const frame_header* H; const side_info* S; main_out* out; } hp_job;
-static struct {
-  pthread_mutex_t own;             /* one batch at a time */
-  pthread_mutex_t m; pthread_cond_t cv;
-  int started, n, sleepers;
+typedef struct {
+  pthread_mutex_t own;             /* one batch at a time per slot */
   hp_job job[BATCH_MAX];
-  _Atomic uint64_t state;          /* batch number << 32 | frames of the batch << 16 | next frame: ONE word, so that a
+  _Alignas(64) _Atomic uint64_t state;   /* batch number << 32 | frames of the batch << 16 | next frame: ONE word, so that a
                                       helper that is late for a batch can never take a frame of it by the numbers of the next */
   _Atomic int done;
-} g_hp = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, {{0, 0, 0, 0}}, 0, 0};
+} hp_slot;
+static struct {
+  pthread_mutex_t start;           /* hp_start once */
+  pthread_mutex_t m; pthread_cond_t cv;
+  int started, n, sleepers;
+  _Atomic uint32_t bell;           /* batches posted so far, all slots: what an idle helper watches */
+  hp_slot slot[HP_SLOTS];
+} g_hp = {.start = PTHREAD_MUTEX_INITIALIZER, .m = PTHREAD_MUTEX_INITIALIZER, .cv = PTHREAD_COND_INITIALIZER,
+          .slot = {{.own = PTHREAD_MUTEX_INITIALIZER}, {.own = PTHREAD_MUTEX_INITIALIZER}, {.own = PTHREAD_MUTEX_INITIALIZER}, {.own = PTHREAD_MUTEX_INITIALIZER}}};
+_Static_assert(HP_SLOTS == 4, "g_hp's initialiser names four slots");
 
-/* Takes frames until the current batch has none left; returns that batch's number.  Whatever the fetch-and-add
- * returns IS a claim -- batch, frame count and index come out of one word -- also for a helper that arrives here
- * still thinking of the batch before: it must decode the frame it drew, nobody else will. */
-static uint32_t hp_take(void) {
-  for (;;) {
-    const uint64_t v = atomic_fetch_add_explicit(&g_hp.state, 1, memory_order_acq_rel);
-    const uint32_t k = (uint32_t)(v & 0xffff), n = (uint32_t)(v >> 16 & 0xffff);
-    if (k >= n) return (uint32_t)(v >> 32);
-    const hp_job* j = &g_hp.job[k];
-    decode_main(j->res, j->H, j->S, j->out);
-    atomic_fetch_add_explicit(&g_hp.done, 1, memory_order_release);
-  }
+/* Takes ONE frame of the slot's batch if it has one left.  Whatever the fetch-and-add returns IS a claim -- batch, frame
+ * count and index come out of one word -- also for a thread that arrives here still thinking of the batch before: it must
+ * decode the frame it drew, nobody else will.  (The look before the add keeps the index field from running over into the
+ * count: an idle slot is looked at, not added to.) */
+static inline int hp_take_one(hp_slot* sl) {
+  uint64_t v = atomic_load_explicit(&sl->state, memory_order_acquire);
+  if ((uint32_t)(v & 0xffff) >= (uint32_t)(v >> 16 & 0xffff)) return 0;
+  v = atomic_fetch_add_explicit(&sl->state, 1, memory_order_acq_rel);
+  const uint32_t k = (uint32_t)(v & 0xffff), n = (uint32_t)(v >> 16 & 0xffff);
+  if (k >= n) return 0;
+  const hp_job* j = &sl->job[k];
+  decode_main(j->res, j->H, j->S, j->out);
+  atomic_fetch_add_explicit(&sl->done, 1, memory_order_release);
+  return 1;
 }
 /* How long a helper looks for the next batch before it sleeps on the condition: PDMP3_STREAM_SPIN = pause instructions
  * (default 1000: ~15 us; rounds 3-5: 20000, 0.2-0.5 ms -- three cores at 100 % per streaming handle; the
@@ -219,25 +231,28 @@ static uint32_t hp_take(void) {
  * profiles/r06_stream_api.json). */
 static int g_hp_spin = 1000;
 static void* hp_worker(void* arg) {
-  (void)arg;
+  const unsigned me = (unsigned)(uintptr_t)arg;
   uint32_t seen = 0;
   for (;;) {
     int spins = 0;
-    while ((uint32_t)(atomic_load_explicit(&g_hp.state, memory_order_acquire) >> 32) == seen) {
+    while (atomic_load_explicit(&g_hp.bell, memory_order_acquire) == seen) {
       if (++spins < g_hp_spin) { hp_pause(); continue; }      /* a short look, then sleep */
       pthread_mutex_lock(&g_hp.m);
       g_hp.sleepers++;
-      while ((uint32_t)(atomic_load_explicit(&g_hp.state, memory_order_acquire) >> 32) == seen) pthread_cond_wait(&g_hp.cv, &g_hp.m);
+      while (atomic_load_explicit(&g_hp.bell, memory_order_acquire) == seen) pthread_cond_wait(&g_hp.cv, &g_hp.m);
       g_hp.sleepers--;
       pthread_mutex_unlock(&g_hp.m);
       spins = 0;
     }
-    seen = hp_take();
+    seen = atomic_load_explicit(&g_hp.bell, memory_order_acquire);   /* (a batch posted from here on rings again) */
+    for (int took = 1; took;) {                                      /* a frame from every slot that has one, in turn */
+      took = 0;
+      for (unsigned i = 0; i < HP_SLOTS; i++) took |= hp_take_one(&g_hp.slot[(me + i) % HP_SLOTS]);
+    }
   }
   return NULL;
 }
-static void hp_start(void) {                                   /* (g_hp.own held) */
-  g_hp.started = 1;
+static void hp_start(void) {                                   /* (g_hp.start held) */
   const char* e = getenv("PDMP3_STREAM_THREADS");
   int n = e ? atoi(e) : usable_cpus() - 1;
   if (!e && n > 3) n = 3;
@@ -246,29 +261,42 @@ static void hp_start(void) {                                   /* (g_hp.own held
   if (sp && atoi(sp) >= 0) g_hp_spin = atoi(sp);
   for (int i = 0; i < n; i++) {
     pthread_t t;
-    if (pthread_create(&t, NULL, hp_worker, NULL) != 0) break;
+    if (pthread_create(&t, NULL, hp_worker, (void*)(uintptr_t)i) != 0) break;
     pthread_detach(t);
     g_hp.n++;
   }
+  __atomic_store_n(&g_hp.started, 1, __ATOMIC_RELEASE);
 }
 /* decode_main of jobs[0..n) */
 static void hp_run(const hp_job* jobs, int n) {
-  if (n > 1 && pthread_mutex_trylock(&g_hp.own) == 0) {
-    if (!g_hp.started) hp_start();
-    if (g_hp.n > 0) {
-      memcpy(g_hp.job, jobs, (size_t)n * sizeof *jobs);
-      atomic_store_explicit(&g_hp.done, 0, memory_order_relaxed);
-      const uint32_t batch = (uint32_t)(atomic_load_explicit(&g_hp.state, memory_order_relaxed) >> 32) + 1;
-      atomic_store_explicit(&g_hp.state, (uint64_t)batch << 32 | (uint64_t)n << 16, memory_order_release);
+  if (n > 1) {
+    if (!__atomic_load_n(&g_hp.started, __ATOMIC_ACQUIRE)) {
+      pthread_mutex_lock(&g_hp.start);
+      if (!g_hp.started) hp_start();
+      pthread_mutex_unlock(&g_hp.start);
+    }
+    hp_slot* sl = NULL;
+    if (g_hp.n > 0)
+      for (int i = 0; i < HP_SLOTS && !sl; i++) if (pthread_mutex_trylock(&g_hp.slot[i].own) == 0) sl = &g_hp.slot[i];
+    if (sl) {
+      memcpy(sl->job, jobs, (size_t)n * sizeof *jobs);
+      atomic_store_explicit(&sl->done, 0, memory_order_relaxed);
+      const uint32_t batch = (uint32_t)(atomic_load_explicit(&sl->state, memory_order_relaxed) >> 32) + 1;
+      atomic_store_explicit(&sl->state, (uint64_t)batch << 32 | (uint64_t)n << 16, memory_order_release);
+      atomic_fetch_add_explicit(&g_hp.bell, 1, memory_order_release);
       pthread_mutex_lock(&g_hp.m);
       if (g_hp.sleepers) pthread_cond_broadcast(&g_hp.cv);
       pthread_mutex_unlock(&g_hp.m);
-      (void)hp_take();
-      while (atomic_load_explicit(&g_hp.done, memory_order_acquire) < n) hp_pause();
-      pthread_mutex_unlock(&g_hp.own);
+      while (hp_take_one(sl)) { }                                /* the caller works on its OWN batch only */
+      while (atomic_load_explicit(&sl->done, memory_order_acquire) < n) {   /* its last frames are in helpers' hands: a frame of
+                                                                               another handle's batch meanwhile, if there is one */
+        int took = 0;
+        for (int i = 0; i < HP_SLOTS && !took; i++) if (&g_hp.slot[i] != sl) took = hp_take_one(&g_hp.slot[i]);
+        if (!took) hp_pause();
+      }
+      pthread_mutex_unlock(&sl->own);
       return;
     }
-    pthread_mutex_unlock(&g_hp.own);
   }
   for (int i = 0; i < n; i++) decode_main(jobs[i].res, jobs[i].H, jobs[i].S, jobs[i].out);
 }

@@ -50,7 +50,8 @@ def test_batches_decoded_with_helpers_give_the_reference_parsers_records():
     """read-ahead batches of up to 16 frames, their main data decoded by several threads at once (hp_run): the records
     are those of the frame-by-frame parser (itself pinned to the oracle in test_host_stage.py) -- scalefactors that
     survive frames (scfsi, H4-H6), block switches and the reservoir included -- also with three handles reading at the
-    same time (only one gets the helpers, the others decode alone)"""
+    same time -- six handles over the four slots of the shared helper pool: batches side by side in the helpers' hands, and
+    a handle that finds every slot taken decodes alone"""
     import threading
     from pdmp3_amd import api
     from pdmp3_amd.packer import packer
