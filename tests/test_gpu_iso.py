@@ -64,6 +64,36 @@ def test_gpu_iso_pin(name):
         assert np.array_equal(got, s16), "whole-stream decoder (host_huffman=%s) != streaming API" % host_huffman
 
 
+def test_gpu_iso_pin_real_encoder_clip():
+    """the same on the one stream the packer did not make (tests/test_iso_pin.py load_clip_fixture): streaming API in float and
+    int16, whole-stream decoder with device and host Huffman, against FFmpeg's decode of the clip"""
+    from pdmp3_amd import api
+    from test_iso_pin import clip_error, load_clip_fixture
+    mp3, theirs, off = load_clip_fixture()
+    outs = {}
+    for enc, dt in ((api.PDMP3_ENC_FLOAT_32, np.float32), (api.PDMP3_ENC_SIGNED_16, np.int16)):
+        d = api.Decoder()
+        try:
+            d.set_quirks(ISO_ALL)
+            assert d.set_encoding(enc) == 0
+            outs[enc] = np.frombuffer(api.decode_like_cli(mp3, d), dtype=dt).reshape(-1, 2)
+        finally:
+            d.close()
+    f32, s16 = outs[api.PDMP3_ENC_FLOAT_32], outs[api.PDMP3_ENC_SIGNED_16]
+    mx, rms = clip_error(np.clip(f32.astype(np.float64) * 32768.0, -32768.0, 32767.0), theirs, off)
+    assert mx <= iso_streams.TOL_F32_LSB and rms <= iso_streams.RMS_LSB, "float PCM: max %.2f LSB, rms %.3f against FFmpeg" % (mx, rms)
+    mx16, _ = clip_error(s16.astype(np.float64) * (32768.0 / 32767.0), theirs, off)
+    assert mx16 <= iso_streams.TOL_S16_LSB, "int16 PCM: max %.2f LSB against FFmpeg" % mx16
+    for host_huffman in (False, True):
+        b = api.BulkDecoder(threads=2, window_frames=16, host_huffman=host_huffman)
+        try:
+            b.set_quirks(ISO_ALL)
+            got = b.decode(mp3).reshape(-1, 2)
+        finally:
+            b.close()
+        assert np.array_equal(got, s16), "whole-stream decoder (host_huffman=%s) != streaming API" % host_huffman
+
+
 @pytest.mark.parametrize("iso", [ISO_TABLE33, ISO_MS_BOUND | ISO_IS_SHORT, ISO_SF21 | ISO_SF12, ISO_MS_BOUND | ISO_IS_BOUND, ISO_ALL])
 def test_gpu_streams_with_quirks(oracle, iso):
     from pdmp3_amd import api

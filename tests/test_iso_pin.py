@@ -102,3 +102,35 @@ def test_host_stage_and_kernel_source_are_ffmpeg(emul, name):
     # the reference's int16 is trunc(sum * 32767) (P:2028); FFmpeg's is round(sum * 32768)
     mx, rms = ffmpeg_error(x.astype(np.float64) * (32768.0 / 32767.0), theirs)
     assert mx <= iso_streams.TOL_S16_LSB, "%s: max %.2f LSB against FFmpeg" % (name, mx)
+
+
+def load_clip_fixture():
+    """the one stream here that the packer did not make: a real encoder's clip (tests/golden/clip_invalid_keypress.mp3, MathJax's
+    accessibility click: 44.1 kHz stereo 64 kbps behind an ID3 tag, with an Info frame) -> (bytes, FFmpeg's int16 [samples][2], the
+    index of FFmpeg's first sample in ours: Chromium trims the Info frame and the encoder delay, 1152 + 1105)"""
+    z = np.load(os.path.join(GOLDEN, "iso_clip_real.npz"))
+    mp3 = open(os.path.join(GOLDEN, "clip_invalid_keypress.mp3"), "rb").read()
+    assert hashlib.sha256(mp3).hexdigest() == str(z["sha256"])
+    return mp3, z["pcm"], int(z["offset"])
+
+
+def clip_error(ours, theirs, off):
+    m = min(ours.shape[0] - off, theirs.shape[0])
+    assert m >= 17 * 1152
+    e = np.abs(ours[off:off + m].astype(np.float64) - theirs[:m])
+    return float(e.max()), float(np.sqrt((e ** 2).mean()))
+
+
+def test_a_real_encoders_stream_is_ffmpeg_too(oracle, emul):
+    """the packer's idea of a conforming stream is not what pins the decoder alone: a real encoder's clip through the oracle with
+    PDMP3_ISO_ALL is FFmpeg's output within the same bars (measured 1.07 LSB max, 0.30 rms), and so are the product's host stage +
+    the kernels' host build"""
+    from pdmp3_amd import api
+    mp3, theirs, off = load_clip_fixture()
+    assert off == 2257
+    mx, rms = clip_error(oracle_pcm(oracle, mp3, ISO_ALL, 2), theirs, off)
+    assert mx <= iso_streams.TOL_F32_LSB and rms <= iso_streams.RMS_LSB, "max %.2f LSB, rms %.3f against FFmpeg" % (mx, rms)
+    sp, sd = api.parse_like_cli(mp3, 4096, ISO_ALL)
+    pcm = emul_decode(emul, sp, sd, 0).reshape(-1, 2)
+    mx16, _ = clip_error(pcm.astype(np.float64) * (32768.0 / 32767.0), theirs, off)
+    assert mx16 <= iso_streams.TOL_S16_LSB, "max %.2f LSB against FFmpeg" % mx16

@@ -67,6 +67,26 @@ def main():
             np.savez_compressed(os.path.join(out_dir, name + ".npz"), kwargs=json.dumps(kw), sha256=hashlib.sha256(mp3).hexdigest(),
                                 rate=rate, channels=nch, offset=off, pcm=k.T.astype(np.int16))
             print(json.dumps(row))
+    # ---- a stream that is NOT the packer's: tests/golden/clip_invalid_keypress.mp3 (MathJax's accessibility click: a real encoder's
+    # 44.1 kHz stereo 64 kbps stream behind an ID3 tag, with an Info frame).  Chromium trims the Info frame and the encoder delay:
+    # `offset` = 1152 + 1105 = 2257 is found by the search, not assumed.
+    with FFmpegRef() as ff:
+        mp3 = open(os.path.join(out_dir, "clip_invalid_keypress.mp3"), "rb").read()
+        t = ff.decode(mp3, 44100, 2)[:2]
+        theirs = np.where(t < 0, t * 32768.0, t * 32767.0)
+        k = np.round(theirs)
+        assert np.abs(theirs - k).max() < 2e-3
+        row = {"stream": "iso_clip_real", "samples_ffmpeg": int(k.shape[1])}
+        for iso, label in ((0x3f, "all_on"), (0, "reference")):
+            ours = oracle_f32(orc, mp3, iso, 2)
+            off, e = align(ours / 32768.0, k / 32768.0, max_shift=3000)
+            m = min(ours.shape[1] - off, k.shape[1])
+            err = np.abs(ours[:, off:off + m] - k[:, :m])
+            row.update({label + "_offset": int(off), label + "_max": float(err.max()), label + "_rms": float(np.sqrt((err ** 2).mean())), "samples_compared": int(m)})
+        np.savez_compressed(os.path.join(out_dir, "iso_clip_real.npz"), sha256=hashlib.sha256(mp3).hexdigest(), rate=44100, channels=2,
+                            offset=row["all_on_offset"], pcm=k.T.astype(np.int16))
+        report.append(row)
+        print(json.dumps(row))
     json.dump(report, open(os.path.join(ROOT, "profiles", "r06_iso_pin.json"), "w"), indent=1)
     # ---- MPEG-2 LSF / MPEG-2.5: the same for tests/iso_streams.py LSF_STREAMS (PDMP3_ISO_LSF; the switches are implied) ----
     report = []
