@@ -51,6 +51,21 @@ def test_bench_two_ranks_gathered_pcm_equals_unsharded(engine, tmp_path):
     assert np.array_equal(got, pcm.cpu().numpy()), "sharded + gathered PCM differs from the unsharded decode"
 
 
+def test_bench_exchange_that_hangs_still_ends_with_a_line():
+    """the pipelined exchange is point-to-point traffic that only the driver's multi-GPU run ever issues over RCCL: a peer that
+    never sends (PDMP3_BENCH_TEST_HANG) must not cost the run its line -- the watchdog prints the decode-only measurement,
+    labelled, and every rank exits"""
+    env = dict(os.environ, PDMP3_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", PDMP3_BENCH_TEST_HANG="1", PDMP3_BENCH_WATCHDOG_S="4")
+    port = 29300 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "9000"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["value"] == d["value_decode_only"]
+    assert "watchdog" in d["pipelined_exchange_failed"] and d["roofline"]["frac"] > 0
+
+
 def test_bench_plain_command_starts_its_own_ranks():
     """`python bench.py --gpus 2 ...` with no launcher around it (the driver's N = 1 command with another N): bench.py
     starts the ranks itself as a fresh child torch.distributed.run and relays the one JSON line and the exit code"""
