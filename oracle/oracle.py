@@ -124,6 +124,7 @@ class Oracle:
         try:
             return s.decode_like_cli(mp3, tap_frames)
         finally:
+            self.last_undefined = s.undefined()      # the stream made the reference's line counter wrap: nothing it decodes to is defined
             s.close()
 
     def decode_buffer_like_cli(self, mp3: bytes, tap_frames=0):
@@ -195,6 +196,11 @@ class OracleStream:
     def set_quirks(self, iso_mask):
         self.L.orc_stream_set_quirks.argtypes = [_p, C.c_uint]
         self.L.orc_stream_set_quirks(self.s, iso_mask)
+
+    def undefined(self):
+        self.L.orc_stream_undefined.argtypes = [_p]
+        self.L.orc_stream_undefined.restype = C.c_int
+        return bool(self.L.orc_stream_undefined(self.s))
 
     def decode_like_cli(self, mp3: bytes, tap_frames=0):
         """tap_frames > 0: -> (pcm bytes, spectra, side) with the records of the first tap_frames frames"""

@@ -89,6 +89,9 @@ void orc_stream_set_tap(orc_stream*, orc_tap* tap);
 /* NOT the reference: the ISO-correct switches of include/pdmp3.h (PDMP3_ISO_*, same bit values) restated, so that the
  * library's modes have something to be compared with.  Nothing pins them ("parity unpinned"). */
 void orc_stream_set_quirks(orc_stream*, unsigned iso_mask);
+/* != 0 once a frame made the reference's line counter wrap (P:2106 on a counter below 4): the reference's behaviour from
+ * there on is undefined (it reads and writes past its arrays); the oracle clamps the counter and flags the stream */
+int orc_stream_undefined(const orc_stream*);
 /* tests only: the 24 kHz long band table with FFmpeg's / mpg123's entry 330 where the standard has 332 (pdmp3_oracle.c) */
 void orc_debug_24k_330(int on);
 

@@ -49,6 +49,7 @@ struct orc_stream {
   orc_synth synth;
   orc_tap* tap;
   unsigned iso;                      /* ORC_ISO_*: NOT the reference -- the standard's behaviour for SURVEY H1-H5 (unpinned) */
+  int undefined;                     /* sticky: the stream made the reference's line counter wrap (orc_stream_undefined) */
 };
 /* the ISO-correct switches of include/pdmp3.h (same bit values), restated for the oracle */
 #define ORC_ISO_TABLE33 0x01u
@@ -59,6 +60,7 @@ struct orc_stream {
 #define ORC_ISO_IS_BOUND 0x20u
 #define ORC_ISO_LSF 0x40u                /* accept MPEG-2 LSF / MPEG-2.5 frames (the reference returns an error: P:1293) */
 void orc_stream_set_quirks(orc_stream* s, unsigned iso_mask) { s->iso = iso_mask & 0x7fu; }
+int orc_stream_undefined(const orc_stream* s) { return s->undefined; }
 
 /* ---- MPEG-2 LSF / MPEG-2.5 (ISO/IEC 13818-3): NOT the reference.  Constants restated here independently of
  * pdmp3_amd/csrc/lsf_tables.h; what pins both is FFmpeg's decode of the same streams (tests/golden/lsf_*.npz). ---- */
@@ -417,6 +419,11 @@ static void read_huffman(orc_stream* s, unsigned part_2_start, unsigned gr, unsi
     PUT(is_pos, y);
   }
   if (main_pos(s) > (bit_pos_end + 1)) is_pos -= 4;
+  /* P:2106 on a line counter below 4 (a granule whose part2_3_length ends inside its scalefactors: corrupt input) wraps the
+   * reference's unsigned to 4 billion; its requantisation then runs off is[576] and every table: no defined output, here a
+   * crash.  The restatement stays memory-safe -- the counter stops at 576, as the product's does (host/frame_parse.c) -- and
+   * says so: what such a stream decodes to pins nothing (tests/fuzz_gpu.py skips it). */
+  if (is_pos > 576) { is_pos = 576; s->undefined = 1; }
   s->count1[gr][ch] = is_pos;
   for (; is_pos < 576; is_pos++) is[is_pos] = 0;
   set_main_pos(s, bit_pos_end + 1);

@@ -45,3 +45,23 @@ def test_clip_vs_reference(oracle, reference):
     assert np.array_equal(sp_r, sp_o)
     assert np.array_equal(sd_r.view(np.uint8), sd_o.view(np.uint8))
     assert reference.decode_buffer_like_cli(mp3) == p_ref   # through the real pdmp3_read
+
+
+def test_a_line_counter_that_wraps_is_flagged_not_followed(oracle):
+    """found by tests/fuzz_gpu.py (round 6): at 32-48 kbps the packer can make a granule whose part2_3_length ends inside its
+    scalefactors; the reference's overshoot rule (P:2106) then takes 4 from a line counter of 0, the unsigned wraps and its
+    requantisation runs off is[576] and every table -- the reference's behaviour is undefined from there on
+    and the oracle used to follow it into the heap.  Now: the oracle stops the counter at 576 like the product's host stage and
+    says that the stream pins nothing; the product's records stay inside their arrays."""
+    from pdmp3_amd import api
+    from pdmp3_amd.packer import packer
+    mp3 = packer.generate(n_frames=77, seed=271191999, sfreq=1, mode=2, mode_ext=0, crc=False, block_pct=(25, 25, 25, 25), mixed_pct=0,
+                          table33_pct=100, gain=(140, 165), version=0, vbr=True, vbr_lo=1, vbr_hi=10, iso_strict=True, is_cut_pct=60,
+                          narrow_scales=False)
+    pcm = oracle.decode_buffer_like_cli_iso(mp3, 0)
+    assert oracle.last_undefined and len(pcm) > 70 * 4608
+    sp, sd = api.parse_like_cli(mp3, 4096, 0)
+    assert sp.shape[0] >= 70 and int(sd["count1"].max()) <= 576
+    ok = packer.generate(n_frames=30, seed=5, sfreq=0, mode=1, mode_ext=2, bitrate_index=9)
+    oracle.decode_buffer_like_cli_iso(ok, 0)
+    assert not oracle.last_undefined
