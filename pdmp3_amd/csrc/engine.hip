@@ -484,6 +484,11 @@ struct ChainBuf {
   float* state;             // cap x 2 kGranFloats floats
   unsigned* flag;           // cap x 4 flags
   unsigned long long last_use;   // launch counter value of its latest use (the least recently used one is evicted)
+  // bare calls on this HIP stream (no stream object, which has its own): where the kernel leaves the closing state before it
+  // is copied over the caller's, and an LSF launch's regrouped records.  Stream-ordered like the rest: a call's launches are
+  // through with them before the next call's on the same stream start.
+  float* state_tmp;
+  int16_t* pair_sp; pdmp3_gc_side* pair_sd; int pair_cap;   // record-frames
 };
 // what a launch gets of it (a copy made under the lock: another thread's launch may replace the buffers right after)
 struct ChainUse { float* state; unsigned* flag; unsigned epoch; };
@@ -648,36 +653,74 @@ static int auto_chunk(int n_frames, int slots) {
 }
 
 // The scratch of a chained launch of n_frames frames on stream s; false: none to be had, the chunks stay independent.
-static bool chain_get(pdmp3_hip_ctx* c, const void* key, hipStream_t s, int n_frames, ChainUse* use) {
-  std::lock_guard<std::mutex> lock(c->chain_mu);
+// NO hipMallocAsync in here (until round 6 the scratch below, a bare call's state block and an LSF launch's regrouped records
+// were stream-ordered allocations).  On ROCm 7.0.2 / MI355X memory fresh from the stream-ordered allocator can lose the writes of
+// the first kernels that touch it, in a process's first moments: tools/ubench/malloc_async_probe.cpp -- allocate, one trivial
+// kernel writes, the next reads -- finds up to 2304 of 2560 16-byte words unwritten in 7 of 300 fresh processes (hipMalloc: 0 of
+// 300; a stream synchronise between allocation and use: 2 of 300).  It showed as an LSF stream's second batch through the
+// streaming API decoding single channels of single frames from zero spectra, in 3-30 % of fresh processes depending on the box
+// (tests/fuzz_gpu.py -> tests/test_gpu_lsf.py's CLI test).  Everything is hipMalloc'ed once now and kept: a free or a regrow
+// synchronises, which happens when a stream's launches grow, not per launch.
+static void chain_free(ChainBuf* b) {                      // (hipFree waits for whatever still uses the memory)
+  (void)hipFree(b->state); (void)hipFree(b->flag); (void)hipFree(b->state_tmp); (void)hipFree(b->pair_sp); (void)hipFree(b->pair_sd);
+  *b = ChainBuf{};
+}
+static ChainBuf* chain_entry(pdmp3_hip_ctx* c, const void* key) {   // (c->chain_mu held)
   ChainBuf* b = nullptr;
   for (ChainBuf& x : c->chain) if (x.used && x.key == key) { b = &x; break; }
   if (!b) for (ChainBuf& x : c->chain) if (!x.used) { b = &x; *b = ChainBuf{}; b->used = true; b->key = key; break; }
   if (!b) {
     // every slot is taken: the least recently used one goes (a HIP stream that bare calls once ran on may be long gone,
-    // and its scratch -- 17 KB per frame -- would otherwise stay until the engine is destroyed).  hipFree waits for
-    // whatever still uses it.
+    // and its scratch -- 17 KB per frame -- would otherwise stay until the engine is destroyed)
     ChainBuf* lru = &c->chain[0];
     for (ChainBuf& x : c->chain) if (x.last_use < lru->last_use) lru = &x;
-    (void)hipFree(lru->state); (void)hipFree(lru->flag);
-    *lru = ChainBuf{};
+    chain_free(lru);
     lru->used = true; lru->key = key;
     b = lru;
   }
   b->last_use = ++c->chain_clock;
+  return b;
+}
+// a bare call's state block / regrouped LSF records on stream `key` (see ChainBuf); false: no memory
+static bool bare_state_tmp(pdmp3_hip_ctx* c, const void* key, float** out) {
+  std::lock_guard<std::mutex> lock(c->chain_mu);
+  ChainBuf* b = chain_entry(c, key);
+  if (!b->state_tmp && hipMalloc((void**)&b->state_tmp, pdmp3_hip_state_bytes()) != hipSuccess) { (void)hipGetLastError(); b->state_tmp = nullptr; return false; }
+  *out = b->state_tmp;
+  return true;
+}
+static bool bare_pairs(pdmp3_hip_ctx* c, const void* key, int np, int16_t** sp, pdmp3_gc_side** sd) {
+  std::lock_guard<std::mutex> lock(c->chain_mu);
+  ChainBuf* b = chain_entry(c, key);
+  if (b->pair_cap < np) {
+    (void)hipFree(b->pair_sp); (void)hipFree(b->pair_sd);          // (synchronises: earlier launches are done with them)
+    b->pair_sp = nullptr; b->pair_sd = nullptr; b->pair_cap = 0;
+    const int cap = np < 64 ? 64 : np;
+    if (hipMalloc((void**)&b->pair_sp, (size_t)cap * PDMP3_FRAME_SPECTRA_BYTES) != hipSuccess ||
+        hipMalloc((void**)&b->pair_sd, (size_t)cap * PDMP3_FRAME_SIDE_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(b->pair_sp); b->pair_sp = nullptr; b->pair_sd = nullptr;
+      return false;
+    }
+    b->pair_cap = cap;
+  }
+  *sp = b->pair_sp; *sd = b->pair_sd;
+  return true;
+}
+static bool chain_get(pdmp3_hip_ctx* c, const void* key, hipStream_t s, int n_frames, ChainUse* use) {
+  std::lock_guard<std::mutex> lock(c->chain_mu);
+  ChainBuf* b = chain_entry(c, key);
   constexpr size_t kFloatsPerFrame = (size_t)2 * kGranFloats;
-  if (b->cap < n_frames) {                                 // (stream-ordered: earlier launches on s are done with the old one)
-    if (b->state) (void)hipFreeAsync(b->state, s);
-    if (b->flag) (void)hipFreeAsync(b->flag, s);
+  if (b->cap < n_frames) {
+    (void)hipFree(b->state); (void)hipFree(b->flag);       // (synchronises: earlier launches are done with the old ones)
     b->state = nullptr; b->flag = nullptr; b->cap = 0;
     const int cap = n_frames < 256 ? 256 : n_frames;
     const size_t flag_bytes = (size_t)cap * 4 * sizeof(unsigned);
-    if (hipMallocAsync((void**)&b->state, (size_t)cap * kFloatsPerFrame * sizeof(float), s) != hipSuccess ||
-        hipMallocAsync((void**)&b->flag, flag_bytes, s) != hipSuccess ||
+    if (hipMalloc((void**)&b->state, (size_t)cap * kFloatsPerFrame * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&b->flag, flag_bytes) != hipSuccess ||
         hipMemsetAsync(b->flag, 0, flag_bytes, s) != hipSuccess) {
       (void)hipGetLastError();
-      if (b->state) (void)hipFreeAsync(b->state, s);
-      if (b->flag) (void)hipFreeAsync(b->flag, s);
+      (void)hipFree(b->state); (void)hipFree(b->flag);
       b->state = nullptr; b->flag = nullptr;
       return false;
     }
@@ -698,19 +741,17 @@ static bool chain_get(pdmp3_hip_ctx* c, const void* key, hipStream_t s, int n_fr
 static void chain_release(pdmp3_hip_ctx* c, const void* key) {     // (its launches are complete)
   std::lock_guard<std::mutex> lock(c->chain_mu);
   for (ChainBuf& x : c->chain)
-    if (x.used && x.key == key) {
-      (void)hipFree(x.state); (void)hipFree(x.flag);
-      x = ChainBuf{};
-    }
+    if (x.used && x.key == key) chain_free(&x);
 }
 
 // d_state_tmp: where the kernel leaves the new state before it is copied over d_state (chunk 0 and the channel-1
 // pre-halo read the OLD state while the last chunk writes the new one).  Streams own one; a bare
-// pdmp3_hip_decode_frames call takes a stream-ordered allocation so that calls on different HIP streams never share it.
+// pdmp3_hip_decode_frames call takes the one kept for its HIP stream (bare_state_tmp), so that calls on different HIP streams never share it.
 static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3_gc_side* d_side, int n_frames,
                          void* d_state, int16_t* d_pcm, float* d_stages, int chunk_frames, void* stream,
                          unsigned long long* d_prof = nullptr, float* d_state_tmp = nullptr, float* d_pcm_f32 = nullptr,
-                         const void* owner = nullptr, bool leave_state_in_tmp = false, bool lsf = false) {
+                         const void* owner = nullptr, bool leave_state_in_tmp = false, bool lsf = false,
+                         int16_t* pair_sp = nullptr, pdmp3_gc_side* pair_sd = nullptr) {
   // owner: the stream object whose launches these are (they are ordered: one chain scratch for all of them);
   // leave_state_in_tmp: the caller swaps its two state buffers instead of having the new state copied back
   if (!c || n_frames < 0) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_frames: bad argument", hipSuccess);
@@ -732,8 +773,10 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   if (lsf) {
     if (d_stages || d_prof) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_decode_lsf_frames: no stage dumps / profiles of LSF launches", hipSuccess);
     const int np = (n_frames + 1) / 2;
-    HIP_TRY(hipMallocAsync((void**)&d_pair_sp, (size_t)np * PDMP3_FRAME_SPECTRA_BYTES, s), "hipMallocAsync LSF pairs");
-    if (hipMallocAsync((void**)&d_pair_sd, (size_t)np * PDMP3_FRAME_SIDE_BYTES, s) != hipSuccess) { (void)hipFreeAsync(d_pair_sp, s); return fail(PDMP3_HIP_ENOMEM, "hipMallocAsync LSF pairs", hipGetLastError()); }
+    // (a stream object brings its own buffers for the pairs, kept from batch to batch: pair_sp / pair_sd; a bare call's are the
+    //  stream-ordered allocator's)
+    if (pair_sp) { d_pair_sp = pair_sp; d_pair_sd = pair_sd; }
+    else if (!bare_pairs(c, owner ? owner : (const void*)s, np, &d_pair_sp, &d_pair_sd)) return fail(PDMP3_HIP_ENOMEM, "hipMalloc LSF pairs", hipSuccess);
     hipLaunchKernelGGL(k_lsf_pair, dim3(np), dim3(256), 0, s, d_spectra, d_side, n_frames, d_pair_sp, d_pair_sd);
     n_gran = n_frames;
     d_spectra = d_pair_sp; d_side = d_pair_sd; n_frames = np;
@@ -749,11 +792,7 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
   a.pcm_f32 = d_pcm_f32;
   a.state_in = (const float*)d_state;
   const void* chain_key = owner ? owner : (const void*)s;   // (a stream object, or the bare call's HIP stream)
-  bool own_tmp = false;
-  if (d_state && !d_state_tmp) {
-    HIP_TRY(hipMallocAsync((void**)&d_state_tmp, pdmp3_hip_state_bytes(), s), "hipMallocAsync state");
-    own_tmp = true;
-  }
+  if (d_state && !d_state_tmp && !bare_state_tmp(c, chain_key, &d_state_tmp)) return fail(PDMP3_HIP_ENOMEM, "hipMalloc state", hipSuccess);
   a.state_out = d_state ? d_state_tmp : nullptr;
   a.stages = d_stages;
   a.n_frames = n_frames;
@@ -770,7 +809,6 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
     ring = true;
 #if !defined(PDMP3_WITH_RING_KERNEL)
   if (ring && (chunk_frames_arg == PDMP3_HIP_CHUNK_PERSISTENT || ring_prof)) {
-    if (own_tmp) (void)hipFreeAsync(d_state_tmp, s);
     return fail(PDMP3_HIP_EINVAL, "this build of libpdmp3_hip.so does not carry the persistent kernel (make -C pdmp3_amd/csrc EXTRA=-DPDMP3_WITH_RING_KERNEL)", hipSuccess);
   }
   ring = false;
@@ -843,11 +881,6 @@ static int launch_decode(pdmp3_hip_ctx* c, const int16_t* d_spectra, const pdmp3
     what = "state copy";
     e = hipMemcpyAsync(d_state, d_state_tmp, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, s);
   }
-  if (own_tmp) {                                        // released on the failure paths too
-    const hipError_t ef = hipFreeAsync(d_state_tmp, s);
-    if (e == hipSuccess && ef != hipSuccess) { what = "hipFreeAsync state"; e = ef; }
-  }
-  if (d_pair_sp) { (void)hipFreeAsync(d_pair_sp, s); (void)hipFreeAsync(d_pair_sd, s); }
   if (e != hipSuccess) return fail(PDMP3_HIP_EDEVICE, what, e);
   return PDMP3_HIP_OK;
 }
@@ -904,6 +937,7 @@ struct StreamSlot {
   hipEvent_t done;
   int16_t* h_spectra; pdmp3_gc_side* h_side; int16_t* h_pcm;     // pinned
   int16_t* d_spectra; pdmp3_gc_side* d_side; int16_t* d_pcm;
+  int16_t* d_pair_sp; pdmp3_gc_side* d_pair_sd;                   // LSF launches: the regrouped records (allocated on first use, (max_frames + 1) / 2 frames)
   // bitstream-level input (allocated on first use)
   pdmp3_frame_bits* h_bits; uint8_t* h_res;                       // pinned
   pdmp3_frame_bits* d_bits; uint8_t* d_res; GcRaw* d_raw; uint32_t* d_outc; unsigned* d_mcnt;
@@ -936,7 +970,7 @@ extern "C" void pdmp3_hip_stream_destroy(pdmp3_hip_stream* hs) {
     if (t.stream) { (void)hipStreamSynchronize(t.stream); (void)hipStreamDestroy(t.stream); }
     if (t.done) (void)hipEventDestroy(t.done);
     (void)hipHostFree(t.h_spectra); (void)hipHostFree(t.h_side); (void)hipHostFree(t.h_pcm);
-    (void)hipFree(t.d_spectra); (void)hipFree(t.d_side); (void)hipFree(t.d_pcm);
+    (void)hipFree(t.d_spectra); (void)hipFree(t.d_side); (void)hipFree(t.d_pcm); (void)hipFree(t.d_pair_sp); (void)hipFree(t.d_pair_sd);
     (void)hipHostFree(t.h_in);
     (void)hipFree(t.d_in); (void)hipFree(t.d_res); (void)hipFree(t.d_raw); (void)hipFree(t.d_outc); (void)hipFree(t.d_mcnt);
   }
@@ -1105,6 +1139,14 @@ extern "C" int pdmp3_hip_stream_submit_to(pdmp3_hip_stream* hs, int slot, int n_
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_to: row_bytes must be 4608 or 2304", hipSuccess);
   return submit_records(hs, slot, n_frames, pinned_dst, row_bytes);
 }
+// the slot's buffers for an LSF launch's regrouped records (launch_decode pair_sp / pair_sd): allocated once, on the first LSF submit
+static int slot_pairs(pdmp3_hip_stream* hs, StreamSlot& t) {
+  if (!hs->lsf || t.d_pair_sp) return PDMP3_HIP_OK;
+  const size_t np = ((size_t)hs->max_frames + 1) / 2;
+  HIP_TRY(hipMalloc((void**)&t.d_pair_sp, np * PDMP3_FRAME_SPECTRA_BYTES), "hipMalloc LSF pairs");
+  if (hipMalloc((void**)&t.d_pair_sd, np * PDMP3_FRAME_SIDE_BYTES) != hipSuccess) { (void)hipFree(t.d_pair_sp); t.d_pair_sp = nullptr; return fail(PDMP3_HIP_ENOMEM, "hipMalloc LSF pairs", hipGetLastError()); }
+  return PDMP3_HIP_OK;
+}
 static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* host_dst, int row) {
   if (!SLOT_OK(hs, slot) || n_frames < 0 || n_frames > hs->max_frames)
     return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit: bad argument", hipSuccess);
@@ -1112,6 +1154,7 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
   if (t.busy) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit: slot still in flight (wait for it first)", hipSuccess);
   if (n_frames == 0) return PDMP3_HIP_OK;
   HIP_TRY(hipSetDevice(hs->ctx->device), "hipSetDevice");
+  { const int rcp = slot_pairs(hs, t); if (rcp != PDMP3_HIP_OK) return rcp; }
   const size_t n = (size_t)n_frames;
   if (hs->f32 && host_dst) return fail(PDMP3_HIP_EINVAL, "pdmp3_hip_stream_submit_to: not with float PCM", hipSuccess);
   // Small batches (the streaming API's read-ahead: a handful of frames per call): no copies at all.  The kernel reads the
@@ -1135,8 +1178,8 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
     if (!lone && hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
     void* dst = host_dst ? host_dst : (void*)t.h_pcm;
     int rc = hs->f32
-        ? launch_decode(hs->ctx, t.h_spectra, t.h_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)dst, hs, true, hs->lsf != 0)
-        : launch_decode(hs->ctx, t.h_spectra, t.h_side, n_frames, hs->d_state, (int16_t*)dst, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, true, hs->lsf != 0);
+        ? launch_decode(hs->ctx, t.h_spectra, t.h_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)dst, hs, true, hs->lsf != 0, t.d_pair_sp, t.d_pair_sd)
+        : launch_decode(hs->ctx, t.h_spectra, t.h_side, n_frames, hs->d_state, (int16_t*)dst, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, true, hs->lsf != 0, t.d_pair_sp, t.d_pair_sd);
     if (rc != PDMP3_HIP_OK) return rc;
     float* const was_prev = hs->d_state_prev;
     hs->d_state_prev = hs->d_state;            // (what pdmp3_hip_stream_rewind goes back to)
@@ -1156,8 +1199,8 @@ static int submit_records(pdmp3_hip_stream* hs, int slot, int n_frames, void* ho
   if (hs->have_state_ev) HIP_TRY(hipStreamWaitEvent(t.stream, hs->ev_state, 0), "wait for the previous batch's state");
   HIP_TRY(hipMemcpyAsync(hs->d_state_prev, hs->d_state, pdmp3_hip_state_bytes(), hipMemcpyDeviceToDevice, t.stream), "keep the state");
   int rc = hs->f32
-      ? launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs, false, hs->lsf != 0)
-      : launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, false, hs->lsf != 0);
+      ? launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs, false, hs->lsf != 0, t.d_pair_sp, t.d_pair_sd)
+      : launch_decode(hs->ctx, t.d_spectra, t.d_side, n_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, false, hs->lsf != 0, t.d_pair_sp, t.d_pair_sd);
   if (rc != PDMP3_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");
   hs->have_state_ev = 1;
@@ -1217,8 +1260,8 @@ extern "C" int pdmp3_hip_stream_rewind(pdmp3_hip_stream* hs, int slot, int keep_
     const int16_t* sp = t.direct ? t.h_spectra : t.d_spectra;
     const pdmp3_gc_side* sd = t.direct ? t.h_side : t.d_side;
     const int rc = hs->f32
-        ? launch_decode(hs->ctx, sp, sd, keep_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs, false, hs->lsf != 0)
-        : launch_decode(hs->ctx, sp, sd, keep_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, false, hs->lsf != 0);
+        ? launch_decode(hs->ctx, sp, sd, keep_frames, hs->d_state, nullptr, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, (float*)t.d_pcm, hs, false, hs->lsf != 0, t.d_pair_sp, t.d_pair_sd)
+        : launch_decode(hs->ctx, sp, sd, keep_frames, hs->d_state, t.d_pcm, nullptr, 0, t.stream, nullptr, hs->d_state_tmp, nullptr, hs, false, hs->lsf != 0, t.d_pair_sp, t.d_pair_sd);
     if (rc != PDMP3_HIP_OK) return rc;
   }
   HIP_TRY(hipEventRecord(hs->ev_state, t.stream), "record state event");

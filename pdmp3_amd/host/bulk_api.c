@@ -179,6 +179,8 @@ static void bulk_begin(struct bulk* b) {
   }
   id->pool_sink = b->pool_mode ? b : NULL;
   id->side_to_bits = b->bits_mode && !getenv("PDMP3_BULK_SLOW_SIDE_INFO");
+  id->bits_scan = b->bits_mode;
+  id->lsf_seen = 0;
   /* (windows, flights, a running copy job: the pipeline keeps going across streams) */
   b->win[b->cur].n = 0;
   b->frames = 0; b->pcm_emitted = 0; b->count_only = 0; b->failed = 0;
@@ -282,6 +284,18 @@ static long long bulk_decode_impl(struct bulk* b, const unsigned char* mp3, size
     }
   }
   if (total == PAR_NOT_TAKEN || total == PAR_GIVEN_UP) total = bulk_drive(b, mp3, n);
+  if (b->bits_mode && b->id->lsf_seen) {
+    /* an LSF frame somewhere behind the stream's first bytes (an ID3 tag in front, junk, an MPEG-1 stream that goes on as LSF): what
+     * has gone to the engine is let through and dropped, and the stream is decoded again by the host-Huffman decoder */
+    b->id->lsf_seen = 0;
+    (void)bits_close_window(b);
+    (void)bulk_drain(b);
+    b->failed = 0;
+    if (!b->lsf_alt) b->lsf_alt = bulk_new(b->nth, b->window_arg, 1, 0, b->device);
+    if (!b->lsf_alt) return -1;
+    b->lsf_alt->id->iso = b->id->iso;
+    return bulk_decode_impl(b->lsf_alt, mp3, n, pcm, pcm_cap, rate, channels, 1);
+  }
   const double t_driven = now_s();
   b->t_drive += t_driven - t_in;
   int ok = !b->failed;

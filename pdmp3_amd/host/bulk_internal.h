@@ -168,7 +168,7 @@ struct bulk {
 /* room for a segment start (2064 + 511), a frame's main data (< 2000) and an explicit image (2064) */
 #define POOL_ROOM 6700u
 _Static_assert(POOL_ROOM <= PDMP3_POOL_SLACK_BYTES, "a fresh window has room for its first frame");
-static inline int bulk_at_limit(const struct bulk* b) { return b->limit_frames && b->frames >= b->limit_frames; }
+static inline int bulk_at_limit(const struct bulk* b) { return (b->limit_frames && b->frames >= b->limit_frames) || b->id->lsf_seen; }
 
 typedef struct {              /* what a frame's header and side info say by themselves (hop_parse) */
   uint32_t x;

@@ -17,9 +17,11 @@ static int read_header(pdmp3_handle* id) {
   for (int i = 0; i < 4; i++) b[i] = ring_byte(id);
   if (b[0] == BYTE_EOF || b[1] == BYTE_EOF || b[2] == BYTE_EOF || b[3] == BYTE_EOF) return PDMP3_ERR;
   uint32_t h = (b[0] << 24) | (b[1] << 16) | (b[2] << 8) | b[3];
-  /* PDMP3_ISO_LSF (not the reference): eleven sync bits, so that MPEG-2.5's 0xFFE + ID 0 is a header too; never in bits
-   * mode (the device's Huffman stage reads MPEG-1 side info only: include/pdmp3_bulk.h) */
-  const int lsf_ok = (id->iso & PDMP3_ISO_LSF) && !id->side_to_bits;
+  /* PDMP3_ISO_LSF (not the reference): eleven sync bits, so that MPEG-2.5's 0xFFE + ID 0 is a header too.  In bits mode (the
+   * device's Huffman stage reads MPEG-1 side info only: include/pdmp3_bulk.h) an LSF frame ends the scan -- lsf_seen, below --
+   * and the stream goes to the decoder's host-Huffman twin from its first byte: what is a frame and what is junk must not
+   * depend on which stage decodes the Huffman data */
+  const int lsf_ok = (id->iso & PDMP3_ISO_LSF) != 0;
   const uint32_t sync = lsf_ok ? 0xffe00000u : 0xfff00000u;
   while ((h & sync) != sync) {                   /* byte-aligned 12-bit sync */
     unsigned nb = ring_byte(id);
@@ -40,6 +42,11 @@ static int read_header(pdmp3_handle* id) {
   if ((H->id != 1 && !H->ver) || H->bitrate_index == 0 || H->bitrate_index == 15 || H->sfreq == 3 || H->layer == 0)
     return PDMP3_ERR;
   H->layer = 4 - H->layer;
+  if (H->ver && id->bits_scan) {                  /* (only Layer III frames count: search_header goes on otherwise, as with any junk) */
+    if (H->layer == 3) id->lsf_seen = 1;
+    H->layer = 0;
+    return PDMP3_ERR;
+  }
   if (!id->new_header) id->new_header = 1;
   return PDMP3_OK;
 }

@@ -145,6 +145,9 @@ struct pdmp3_handle {
   /* whole-stream decoding in bits mode: the side info goes straight into the engine's record (read_side_info_bits);
    * fb_cur is valid for the frame just parsed when fb_valid is set */
   int side_to_bits, fb_valid;
+  int bits_scan;                   /* this handle scans for a device-Huffman decoder (bits mode) */
+  int lsf_seen;                    /* bits mode + PDMP3_ISO_LSF: the scan met an LSF frame, which the device's Huffman stage cannot take --
+                                      the whole stream goes to the host-Huffman decoder instead (bulk_api.c bulk_decode_impl) */
   pdmp3_frame_bits fb_cur;
   struct bulk* pool_sink;          /* bits mode with an engine: Get_Main_Data appends to the window's pool (fill_reservoir_pool) */
   /* Read-ahead of pdmp3_read (see read_ahead below).  The parser above may be AHEAD of the stream position the

@@ -463,7 +463,7 @@ static void* par_scanner(void* arg) {
     memset(wb, 0, sizeof *wb);
     id->host_only = 1;
     id->iso = P->b->id->iso;
-    id->side_to_bits = 1;
+    id->side_to_bits = 1; id->bits_scan = 1;
     id->pool_sink = wb;
     wb->id = id; wb->cap = P->sub; wb->bits_mode = 1; wb->pool_mode = 1; wb->win_sink = 1; wb->par = P; wb->pc = pc; wb->priv_pool = pool;
     wb->carry = P->b->carry;

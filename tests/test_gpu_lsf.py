@@ -104,6 +104,40 @@ def test_gpu_lsf_and_mpeg1_streams_through_one_handle(oracle):
     assert np.abs(got.astype(np.int32) - want).max() <= 1
 
 
+def test_gpu_whole_stream_decoder_meets_lsf_frames_behind_the_first_bytes(oracle):
+    """the whole-stream decoder's device Huffman stage reads MPEG-1 side info only: an LSF stream goes to the decoder's host-Huffman
+    twin -- also when it does not OPEN with an LSF header (found by tests/fuzz_gpu.py with a flipped bit in the first header: the
+    dispatch looked at the stream's first four bytes only, the device-Huffman scan then refused every LSF header and decoded
+    nothing while the count-only scan counted every frame).  A tag in front, and an MPEG-1 stream that goes on as LSF: device-
+    and host-Huffman decoders and the streaming API give the same PCM, the oracle's within 1 LSB"""
+    from pdmp3_amd import api
+    from pdmp3_amd.packer import packer
+    lsf, _, _ = load_lsf_fixture("lsf_22k_ms")
+    m1 = packer.generate(n_frames=20, seed=6, sfreq=1, mode=1, mode_ext=2, bitrate_index=9, iso_strict=True)
+    tag = b"ID3\x03\x00\x00\x00\x00\x00\x21" + bytes(33)                   # an (empty) ID3v2 tag: 43 bytes that are no frame
+    for name, mp3 in (("tag + LSF", tag + lsf), ("MPEG-1 then LSF", m1 + lsf), ("LSF then MPEG-1 then LSF", lsf + m1 + lsf)):
+        want = np.frombuffer(oracle.decode_buffer_like_cli_iso(mp3, 0x7f), dtype=np.int16)
+        outs = []
+        for host_huffman in (False, True):
+            b = api.BulkDecoder(threads=2, window_frames=16, host_huffman=host_huffman)
+            try:
+                b.set_quirks(0x7f)
+                outs.append(b.decode(mp3).reshape(-1))
+                plain = b.decode(m1).reshape(-1)              # and an MPEG-1 stream right after it through the same decoder
+            finally:
+                b.close()
+            assert np.abs(plain.astype(np.int32) - np.frombuffer(oracle.decode_buffer_like_cli_iso(m1, 0x7f), dtype=np.int16)).max() <= 1, name
+        d = api.Decoder()
+        try:
+            d.set_quirks(0x7f)
+            outs.append(np.frombuffer(api.decode_like_cli(mp3, d), dtype=np.int16))
+        finally:
+            d.close()
+        assert outs[0].shape == want.shape and want.size > 30 * 576 * 2, name
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), name
+        assert np.abs(outs[0].astype(np.int32) - want).max() <= 1, name
+
+
 def test_cli_decodes_lsf_with_the_env_switch(tmp_path):
     mp3, theirs, kw = load_lsf_fixture("lsf_22k_stereo")
     path = tmp_path / "l.mp3"
