@@ -93,8 +93,10 @@ int pdmp3_amd_bulk_set_quirks(pdmp3_amd_bulk* b, unsigned iso_mask);
 /* PDMP3_ISO_LSF (MPEG-2 LSF / MPEG-2.5 streams, which the reference rejects): the device's Huffman stage reads MPEG-1 side
  * info only, so LSF streams take the HOST Huffman stage -- a host_huffman decoder decodes them in its windows like any
  * stream (a window closes where the version, or an LSF stream's channel count, changes); a device-Huffman decoder
- * hands a stream that OPENS with an LSF header to a host-Huffman decoder it creates for the purpose (same device, threads,
- * window and switches; the call is synchronous then) and rejects LSF frames inside an MPEG-1 stream. */
+ * hands a stream that holds an LSF frame ANYWHERE to a host-Huffman decoder it creates for the purpose (same device,
+ * threads, window and switches; the call is synchronous then): at once when the stream opens with an LSF header, else when
+ * its scan meets the first one (what had gone to the GPU by then is dropped, the stream is decoded again from its first
+ * byte) -- what counts as a frame never depends on which stage decodes the Huffman data. */
 
 /* PCM bytes (return value) and frames pdmp3() would produce for this stream;
  * header / side-info / reservoir pass only, no Huffman, no GPU.  Use it to
