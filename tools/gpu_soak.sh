@@ -8,4 +8,6 @@ mkdir -p $OUT
   timeout 900 python3 tools/soak_bulk.py 60
   PDMP3_BULK_SCAN_THREADS=8 PDMP3_BULK_SUB_FRAMES=64 timeout 900 python3 tools/soak_bulk.py 40
   timeout 500 python3 tools/soak_device.py 240
+  timeout 500 python3 tests/fuzz_gpu.py 180 1
+  timeout 500 python3 tests/fuzz_gpu.py 180 2 corrupt
 } 2>&1 | grep -v amdgpu.ids | tee $OUT/soak.txt
