@@ -64,10 +64,8 @@ def random_cfg(rng):
     return kw
 
 
-def main():
-    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20261003)
-    corrupt = len(sys.argv) > 3 and sys.argv[3] == "corrupt"
+def run(seconds, seed, corrupt, result):
+    rng = random.Random(seed)
     orc = Oracle()
     log = open(os.environ.get("PDMP3_FUZZ_LOG", "/dev/null"), "w")
     t_end = time.time() + seconds
@@ -162,7 +160,30 @@ def main():
             dump = os.environ.get("PDMP3_FUZZ_DUMP")           # the stream's bytes as they were decoded (after the bit flips), to look at afterwards
             if dump and bad <= 40:
                 open(os.path.join(dump, "fail_%d_iso%02x.mp3" % (bad, iso)), "wb").write(mp3)
-    print("fuzz_gpu: %d streams (%d frames) in %.0f s, %s; failures: %d" % (n, frames, seconds, json.dumps(kinds, sort_keys=True), bad))
+    result.append((n, frames, kinds, bad))
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20261003
+    corrupt = len(sys.argv) > 3 and sys.argv[3] == "corrupt"
+    # $PDMP3_FUZZ_THREADS = N: N such loops at once in this process (seeds seed, seed + 1, ...): the decoders' pipelines, the
+    # streaming API's shared helper threads and the engines' streams side by side (ctypes calls run without the interpreter's lock)
+    nthreads = int(os.environ.get("PDMP3_FUZZ_THREADS", "1"))
+    Oracle().decode_buffer_like_cli_iso(packer.generate(n_frames=4, seed=1), 0)       # (the oracle's tables, built once, before any thread reads them)
+    results = []
+    import threading
+    ths = [threading.Thread(target=run, args=(seconds, seed + i, corrupt, results)) for i in range(nthreads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    n = sum(r[0] for r in results); frames = sum(r[1] for r in results); bad = sum(r[3] for r in results)
+    kinds = {}
+    for r in results:
+        for k, v in r[2].items():
+            kinds[k] = kinds.get(k, 0) + v
+    print("fuzz_gpu: %d streams (%d frames) in %.0f s on %d thread(s), %s; failures: %d" % (n, frames, seconds, nthreads, json.dumps(kinds, sort_keys=True), bad))
     return 1 if bad else 0
 
 
