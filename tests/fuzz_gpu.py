@@ -127,8 +127,42 @@ def run(seconds, seed, corrupt, result):
                 outs.append(np.frombuffer(api.decode_like_cli(mp3, d), dtype=np.int16))
             finally:
                 d.close()
+            # every few streams two more paths: the whole-stream decoder with the PCM left in device memory, and the streaming API's
+            # float PCM, whose int16 is by definition clip(trunc(float x 32767)) (include/pdmp3.h) -- but for sums beyond 2^31 / 32767,
+            # where the reference's conversion wraps (P:2028-2031)
+            extra = None
+            if n % 4 == 0 and outs[0].size:
+                import torch
+                b = api.BulkDecoder(threads=2, window_frames=rng.choice([32, 2048]))
+                try:
+                    b.set_quirks(iso)
+                    t = torch.zeros(outs[0].size, dtype=torch.int16, device="cuda")
+                    torch.cuda.synchronize()
+                    b.decode_into_device(mp3, t)
+                    dev = t.cpu().numpy()
+                finally:
+                    b.close()
+                d = api.Decoder()
+                try:
+                    d.set_quirks(iso)
+                    assert d.set_encoding(api.PDMP3_ENC_FLOAT_32) == 0
+                    f32 = np.frombuffer(api.decode_like_cli(mp3, d), dtype=np.float32)
+                finally:
+                    d.close()
+                if not np.array_equal(dev, outs[0]):
+                    extra = "PCM left in device memory differs from PCM in host memory"
+                elif f32.shape != outs[0].shape:
+                    extra = "float PCM has %d samples, int16 PCM %d" % (f32.size, outs[0].size)
+                else:
+                    x = f32.astype(np.float64) * 32767.0
+                    q = np.clip(np.trunc(x), -32767, 32767).astype(np.int32)
+                    off = (q != outs[0]) & (np.abs(x) < 2147483000.0)
+                    if off.any():
+                        extra = "int16 PCM is not clip(trunc(float PCM x 32767)) at %d samples" % int(off.sum())
             if undefined:
                 pass
+            elif extra:
+                why = extra
             elif not (outs[0].shape == outs[1].shape == outs[2].shape and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])):
                 why = "the product's paths differ: shapes %s" % [o.shape for o in outs]
             elif outs[0].shape != want.shape:
