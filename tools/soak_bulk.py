@@ -20,6 +20,7 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     mp3 = np.frombuffer(packer.generate(n_frames=20000, seed=91, vbr=True, block_pct=(40, 10, 40, 10), mixed_pct=30), dtype=np.uint8)
     ref = None
+    ref_pcm = [None]
     bad = 0
     lock = threading.Lock()
 
@@ -28,12 +29,17 @@ def main():
         b = api.BulkDecoder(threads=2, window_frames=window)
         try:
             for _ in range(reps):
-                h = hashlib.sha256(b.decode(mp3).tobytes()).hexdigest()
+                pcm = b.decode(mp3)
+                h = hashlib.sha256(pcm.tobytes()).hexdigest()
                 with lock:
                     if ref is None:
                         ref = h
+                        ref_pcm[0] = pcm.copy()
                     elif h != ref:
                         bad += 1
+                        w = np.argwhere(pcm.reshape(-1) != ref_pcm[0].reshape(-1)).reshape(-1) if pcm.size == ref_pcm[0].size else np.array([-1])
+                        print("soak_bulk: window %d: %d samples differ, frames %s ... %s, values %s / %s" % (
+                            window, w.size, sorted(set((w[:2000] // 2304).tolist()))[:8], int(w[-1]) // 2304, pcm.reshape(-1)[w[:4]].tolist(), ref_pcm[0].reshape(-1)[w[:4]].tolist()), flush=True)
         finally:
             b.close()
 
