@@ -1299,6 +1299,11 @@ static int ensure_bits(pdmp3_hip_stream* hs) {
   }
   HIP_TRY(hipMalloc((void**)&hs->d_sfstate, 2 * 256 * sizeof(uint16_t)), "hipMalloc sfstate");
   HIP_TRY(hipMemset(hs->d_sfstate, 0, 2 * 256 * sizeof(uint16_t)), "memset sfstate");
+  // hipMemset returns before the device has run it, and the slots' streams are non-blocking: they do not wait for the null
+  // stream.  Without this wait the zeroing of the scalefactor state could land AFTER the first window's k_merge_apply had
+  // written it -- the second window of a fresh decoder then started from zeros (round 6: one whole-stream decode in ~2000
+  // with fresh decoders differed by 1-3 LSB in frames 17-18; tools/ubench/malloc_async_probe.cpp mode M shows the mechanism)
+  HIP_TRY(hipDeviceSynchronize(), "device sync after the memsets");
   hs->have_bits = 1;
   return PDMP3_HIP_OK;
 }
