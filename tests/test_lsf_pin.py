@@ -142,3 +142,24 @@ def test_kernel_source_decodes_lsf_records_to_ffmpegs_pcm(emul, oracle, name):
     f = pairs_to_samples(emul_lsf(emul, sp[:9], sd[:9], f32=True), 9, nch)
     q = np.clip(np.trunc(f.astype(np.float64) * 32767.0), -32767, 32767)
     assert np.abs(q - got[:9 * 576]).max() <= 0
+
+
+def test_a_bits_mode_scan_stops_at_the_first_lsf_frame():
+    """the device Huffman stage reads MPEG-1 side info only: with PDMP3_ISO_LSF a bits-mode scan (host/frame_parse.c read_header:
+    lsf_seen) ends at the first LSF Layer III frame -- the whole-stream decoder then hands the stream to its host-Huffman twin
+    (host/bulk_api.c; GPU: tests/test_gpu_lsf.py) -- wherever that frame is; without the switch LSF frames are junk to every
+    scan, as they are to the reference; and the count-only scan, which the decoder's caller sizes its buffer by, counts them"""
+    from pdmp3_amd import api
+    from pdmp3_amd.packer import packer
+    lsf, _, _ = load_lsf_fixture("lsf_22k_ms")
+    m1 = packer.generate(n_frames=20, seed=6, sfreq=1, mode=1, mode_ext=2, bitrate_index=9, iso_strict=True)
+    only_m1, _, _ = api.parse_bits(m1, ISO_LSF)
+    assert only_m1.shape[0] >= 17                                          # (an MPEG-1 stream is not touched by the switch; H10: its last frames stay in the ring)
+    both, _, _ = api.parse_bits(m1 + lsf, ISO_LSF)
+    assert only_m1.shape[0] <= both.shape[0] <= 20                          # the scan ended where the LSF frames begin
+    tagged, _, _ = api.parse_bits(b"ID3" + bytes(40) + lsf, ISO_LSF)
+    assert tagged.shape[0] == 0
+    total, frames = api.scan_buffer(m1 + lsf, ISO_LSF)
+    assert frames >= 20 + 28 and total > 20 * 4608 + 28 * 2304
+    total0, frames0 = api.scan_buffer(m1 + lsf, 0)
+    assert frames0 == both.shape[0]                                        # the reference's view: LSF headers are no headers
